@@ -1,0 +1,172 @@
+"""Pins the CPU oracle (oracle/*.c) before anything trusts it:
+
+  * against the committed golden vectors captured from the unmodified reference
+    (tests/golden/hap_golden.json), and
+  * against the live reference (oracle/_ref/libhap_ref.so + libsnappy 1.1.8)
+    wherever that library exists, over swept formats / chunk counts / data kinds
+    and malformed frames.
+
+CPU only.
+"""
+import numpy as np
+import pytest
+
+import _data as D
+import _libs as L
+
+ORA = L.oracle_api()
+REF = L.ref_api()
+needs_ref = pytest.mark.skipif(REF is None, reason="oracle/_ref not built")
+
+
+# ---------------------------------------------------------------- golden ----
+@pytest.mark.parametrize("v", D.golden_vectors("frame"), ids=lambda v: v["name"])
+def test_golden_frames(v):
+    tex = [bytes.fromhex(t) for t in v["textures"]]
+    assert ORA.max_encoded_length([len(t) for t in tex], v["formats"], v["chunks"]) == v["max_encoded_length"]
+    r, frame = ORA.encode(tex, v["formats"], v["compressors"], v["chunks"])
+    assert r == v["result"]
+    if v["frame"] is None:
+        return
+    assert frame.hex() == v["frame"]
+    assert list(ORA.texture_count(frame)) == v["texture_count"]
+    for idx, d in enumerate(v["decode"]):
+        dr, out, fmt = ORA.decode(frame, idx, out_bytes=max(len(t) for t in tex) + 64)
+        assert (dr, fmt, ORA.callback_calls) == (d["result"], d["format"], d["callback_calls"])
+        assert (out == tex[idx]) == d["equals_input"]
+        assert list(ORA.chunk_count(frame, idx)) == d["chunk_count"]
+        assert list(ORA.texture_format(frame, idx)) == d["texture_format"]
+
+
+@pytest.mark.parametrize("v", D.golden_vectors("snappy"), ids=lambda v: v["name"])
+def test_golden_snappy_compress(v):
+    data = bytes.fromhex(v["input"])
+    comp = D.osnappy_compress(data)
+    assert comp.hex() == v["compressed"]
+    assert D.osnappy_uncompress(comp, len(data)) == (0, data)
+
+
+@pytest.mark.parametrize("v", D.golden_vectors("snappy_stream"), ids=lambda v: v["name"])
+def test_golden_snappy_streams(v):
+    r, out = D.osnappy_uncompress(bytes.fromhex(v["stream"]), v["capacity"])
+    assert r == v["result"]
+    assert (out.hex() if out is not None else None) == v["output"]
+
+
+# ------------------------------------------------------- live reference ----
+DATA_KINDS = ["zero", "random", "mixed", "runs"]
+
+
+@needs_ref
+@pytest.mark.parametrize("kind", DATA_KINDS)
+@pytest.mark.parametrize("n", [0, 1, 14, 15, 16, 17, 255, 4096, 65535, 65536, 65537, 200001])
+def test_snappy_compress_byte_identical(kind, n):
+    data = D.stream_bytes(n, kind, seed=n + 1)
+    assert D.osnappy_compress(data) == D.ref_snappy_compress(data)
+
+
+@needs_ref
+def test_snappy_compress_dxt_like_byte_identical():
+    img = D.rgba(256, 128)
+    for fmt in (L.FMT_DXT1, L.FMT_DXT5, L.FMT_YCOCG, L.FMT_RGTC1):
+        tex = D.oracle_bc_encode(img, fmt)
+        assert D.osnappy_compress(tex) == D.ref_snappy_compress(tex)
+
+
+@needs_ref
+def test_snappy_uncompress_agrees_on_corruption():
+    rng = np.random.default_rng(7)
+    base = D.ref_snappy_compress(D.stream_bytes(6000, "runs"))
+    for trial in range(300):
+        s = bytearray(base)
+        mode = trial % 3
+        if mode == 0:
+            s[rng.integers(0, len(s))] ^= 1 << rng.integers(0, 8)
+        elif mode == 1:
+            s = s[: rng.integers(0, len(s))]
+        else:
+            i = rng.integers(0, len(s))
+            s[i:i] = bytes(rng.integers(0, 256, 3, dtype=np.uint8))
+        assert D.osnappy_uncompress(s, 8192) == D.ref_snappy_uncompress(s, 8192), (trial, mode)
+
+
+def _frames_for_sweep():
+    cases = []
+    for fmt in L.ALL_FORMATS:
+        for chunks in (1, 2, 3, 7, 8):
+            for kind in DATA_KINDS:
+                cases.append((fmt, chunks, kind, 16 * 96))
+    cases += [(L.FMT_YCOCG, 24, "runs", 16 * 24 * 50), (L.FMT_DXT1, 64, "mixed", 8 * 64 * 300)]
+    return cases
+
+
+@needs_ref
+@pytest.mark.parametrize("fmt,chunks,kind,nbytes", _frames_for_sweep())
+def test_frames_byte_identical_to_reference(fmt, chunks, kind, nbytes):
+    tex = D.stream_bytes(nbytes, kind, seed=chunks * 131 + fmt)
+    for comp in (L.COMP_NONE, L.COMP_SNAPPY):
+        assert ORA.max_encoded_length([nbytes], [fmt], [chunks]) == REF.max_encoded_length([nbytes], [fmt], [chunks])
+        ro, fo = ORA.encode([tex], [fmt], [comp], [chunks])
+        rr, fr = REF.encode([tex], [fmt], [comp], [chunks])
+        assert (ro, fo) == (rr, fr)
+        assert ORA.decode(fr, 0, nbytes) == REF.decode(fr, 0, nbytes)
+        assert ORA.callback_calls == REF.callback_calls
+        assert ORA.chunk_count(fr, 0) == REF.chunk_count(fr, 0)
+        # output buffer one byte short
+        assert ORA.decode(fr, 0, nbytes - 1)[0] == REF.decode(fr, 0, nbytes - 1)[0]
+
+
+@needs_ref
+def test_dual_texture_and_inspectors():
+    a = D.stream_bytes(16 * 64, "runs")
+    b = D.stream_bytes(8 * 64, "mixed")
+    for comps in ([1, 1], [0, 1], [1, 0]):
+        for chunks in ([1, 1], [4, 2], [5, 64]):
+            ro, fo = ORA.encode([a, b], [L.FMT_YCOCG, L.FMT_RGTC1], comps, chunks)
+            rr, fr = REF.encode([a, b], [L.FMT_YCOCG, L.FMT_RGTC1], comps, chunks)
+            assert (ro, fo) == (rr, fr) and ro == 0
+            assert ORA.texture_count(fr) == REF.texture_count(fr) == (0, 2)
+            for idx in (0, 1, 2):
+                assert ORA.decode(fr, idx, 4096) == REF.decode(fr, idx, 4096)
+                assert ORA.texture_format(fr, idx) == REF.texture_format(fr, idx)
+                assert ORA.chunk_count(fr, idx) == REF.chunk_count(fr, idx)
+
+
+@needs_ref
+def test_bad_arguments_match():
+    tex = bytes(64)
+    for args in [([tex], [0x1234], [1], [1]), ([tex], [L.FMT_DXT1], [2], [1]), ([tex], [L.FMT_DXT1], [1], [0]),
+                 ([tex, tex, tex], [L.FMT_YCOCG] * 3, [1] * 3, [1] * 3)]:
+        assert ORA.encode(*args, out_bytes=4096)[0] == REF.encode(*args, out_bytes=4096)[0]
+    # output buffer below the worst case for the compressor -> Buffer_Too_Small before any work
+    assert ORA.encode([tex], [L.FMT_DXT1], [1], [1], out_bytes=80)[0] == REF.encode([tex], [L.FMT_DXT1], [1], [1], out_bytes=80)[0] == L.R_TOO_SMALL
+    assert ORA.max_encoded_length([64], [L.FMT_DXT1], [0]) == REF.max_encoded_length([64], [L.FMT_DXT1], [0]) == 0
+
+
+@needs_ref
+def test_malformed_frames_match():
+    """Truncations and payload corruptions. (Size-table corruptions that make the
+    reference read out of bounds -- hap.c:798-809 has no bounds check -- are
+    exercised only against the hardened product, not against the reference.)"""
+    rng = np.random.default_rng(3)
+    tex = D.stream_bytes(16 * 256, "runs")
+    _, frame = REF.encode([tex], [L.FMT_DXT5], [1], [4])
+    hdr = 4 + 4 + 5 * 4 + 8
+    for cut in list(range(0, hdr + 4)) + [len(frame) - 1, len(frame) - 7]:
+        f = frame[:cut]
+        assert ORA.decode(f, 0, 8192)[0] == REF.decode(f, 0, 8192)[0], cut
+        assert ORA.texture_count(f) == REF.texture_count(f)
+        assert ORA.chunk_count(f, 0) == REF.chunk_count(f, 0)
+    for trial in range(200):
+        f = bytearray(frame)
+        i = int(rng.integers(hdr, len(f)))
+        f[i] ^= 1 << int(rng.integers(0, 8))
+        assert ORA.decode(f, 0, 8192) == REF.decode(f, 0, 8192), (trial, i)
+    for byte3 in range(256):       # every top-level type byte
+        f = bytearray(frame)
+        f[3] = byte3
+        if (byte3 >> 4) == 0xB:    # reference would parse the tables as a raw Snappy stream: still in-bounds
+            pass
+        assert ORA.decode(f, 0, 8192)[0] == REF.decode(f, 0, 8192)[0], byte3
+        assert ORA.texture_format(f, 0) == REF.texture_format(f, 0)
+        assert ORA.chunk_count(f, 0) == REF.chunk_count(f, 0)
