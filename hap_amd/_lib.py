@@ -1,0 +1,51 @@
+"""ctypes binding of the C ABI declared in include/hap.h and include/hap_gpu.h.
+
+There is no Python or CPU implementation behind this module: if
+hap_amd/libhap_amd.so (the HIP build) is missing, importing fails loudly."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhap_amd.so")
+
+WORK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint)
+CALLBACK = C.CFUNCTYPE(None, WORK_FN, C.c_void_p, C.c_uint, C.c_void_p)
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "hap_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). hap_amd has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, u, ul = C.c_void_p, C.c_uint, C.c_ulong
+    P = C.POINTER
+    sig = {
+        "HapMaxEncodedLength": (ul, [u, P(ul), P(u), P(u)]),
+        "HapEncode": (u, [u, P(vp), P(ul), P(u), P(u), P(u), vp, ul, P(ul)]),
+        "HapDecode": (u, [vp, ul, u, CALLBACK, vp, vp, ul, P(ul), P(u)]),
+        "HapGetFrameTextureCount": (u, [vp, ul, P(u)]),
+        "HapGetFrameTextureFormat": (u, [vp, ul, u, P(u)]),
+        "HapGetFrameTextureChunkCount": (u, [vp, ul, u, P(C.c_int)]),
+        "HapGpuCreate": (u, [C.c_int, P(vp)]),
+        "HapGpuDestroy": (None, [vp]),
+        "HapGpuDefaultContext": (vp, []),
+        "HapGpuSetFragmentLog2": (u, [vp, u]),
+        "HapGpuSynchronize": (u, [vp]),
+        "HapGpuCompressRGBA": (u, [vp, vp, u, u, ul, u, vp, ul, P(ul)]),
+        "HapGpuEncodeFrames": (u, [vp, u, u, P(vp), P(ul), P(u), P(u), P(u), P(vp), P(ul), P(ul), P(u), u]),
+        "HapGpuEncodeFramesRGBA": (u, [vp, u, P(vp), u, u, ul, u, P(u), P(u), P(u), P(vp), P(ul), P(ul), P(u), u]),
+        "HapGpuDecodeFrames": (u, [vp, u, P(vp), P(ul), u, P(vp), P(ul), P(ul), P(u), P(u), u]),
+        "HapGpuSetProfiling": (u, [vp, u]),
+        "HapGpuCollectProfile": (u, [vp, P(ul), P(C.c_double)]),
+        "HapGpuTimerStart": (u, [vp]),
+        "HapGpuTimerStop": (u, [vp, P(C.c_double)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()

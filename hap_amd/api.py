@@ -1,0 +1,224 @@
+"""Python mirror of include/hap.h and include/hap_gpu.h (same names, argument
+meaning and result codes as /root/reference/source/hap.h:40-152).
+
+Buffers may be bytes / bytearray / numpy arrays (host) or objects exposing
+`data_ptr()` + `numel()`/`nbytes` (torch CUDA tensors -> used in place)."""
+import ctypes as C
+
+from ._lib import CALLBACK, WORK_FN, lib
+
+
+class HapTextureFormat:
+    RGB_DXT1 = 0x83F0
+    RGBA_DXT5 = 0x83F3
+    YCoCg_DXT5 = 0x01
+    A_RGTC1 = 0x8DBB
+    RGBA_BPTC_UNORM = 0x8E8C
+    RGB_BPTC_UNSIGNED_FLOAT = 0x8E8F
+    RGB_BPTC_SIGNED_FLOAT = 0x8E8E
+
+
+HapCompressorNone, HapCompressorSnappy = 0, 1
+
+
+class HapResult:
+    No_Error, Bad_Arguments, Buffer_Too_Small, Bad_Frame, Internal_Error = range(5)
+
+
+ENCODE_FRAGMENT_INDEX = 0x1
+DECODE_IGNORE_FRAGMENT_INDEX = 0x1
+KERNEL_CLASSES = ["block_encode", "snappy_compress", "frame_pack", "frame_gather", "decode_plan", "snappy_decode"]
+
+
+def _addr_len(buf):
+    """(address, nbytes, keepalive) of a host or device buffer."""
+    if buf is None:
+        return None, 0, None
+    if hasattr(buf, "data_ptr"):                      # torch tensor (host or device)
+        return buf.data_ptr(), buf.numel() * buf.element_size(), buf
+    if hasattr(buf, "ctypes") and hasattr(buf, "nbytes"):   # numpy
+        return buf.ctypes.data, buf.nbytes, buf
+    if isinstance(buf, (bytes, bytearray, memoryview)):
+        raw = (C.c_ubyte * max(1, len(buf))).from_buffer_copy(bytes(buf) or b"\0")
+        return C.addressof(raw), len(buf), raw
+    if isinstance(buf, C.Array):
+        return C.addressof(buf), C.sizeof(buf), buf
+    raise TypeError("unsupported buffer type %r" % type(buf))
+
+
+def HapMaxEncodedLength(lengths, textureFormats, chunkCounts):
+    n = len(lengths)
+    return lib.HapMaxEncodedLength(n, (C.c_ulong * n)(*lengths), (C.c_uint * n)(*textureFormats),
+                                   (C.c_uint * n)(*chunkCounts))
+
+
+def HapEncode(inputBuffers, textureFormats, compressors, chunkCounts, outputBuffer=None, outputBufferBytes=None):
+    """Returns (result, frame bytes | used). With outputBuffer=None a host buffer of
+    HapMaxEncodedLength() is allocated and the frame returned as bytes."""
+    n = len(inputBuffers)
+    infos = [_addr_len(b) for b in inputBuffers]
+    ptrs = (C.c_void_p * n)(*[i[0] for i in infos])
+    lens = (C.c_ulong * n)(*[i[1] for i in infos])
+    own = outputBuffer is None
+    if own:
+        if outputBufferBytes is None:
+            outputBufferBytes = HapMaxEncodedLength([i[1] for i in infos], textureFormats, chunkCounts)
+        outputBuffer = (C.c_ubyte * max(1, outputBufferBytes))()
+    oaddr, olen, _keep = _addr_len(outputBuffer)
+    if outputBufferBytes is None:
+        outputBufferBytes = olen
+    used = C.c_ulong(0)
+    r = lib.HapEncode(n, ptrs, lens, (C.c_uint * n)(*textureFormats), (C.c_uint * n)(*compressors),
+                      (C.c_uint * n)(*chunkCounts), oaddr, outputBufferBytes, C.byref(used))
+    if own:
+        return r, (bytes(outputBuffer[: used.value]) if r == 0 else None)
+    return r, used.value
+
+
+def _serial_callback():
+    def cb(fn, p, count, info):
+        for i in range(count):
+            fn(p, i)
+    return CALLBACK(cb)
+
+
+def HapDecode(inputBuffer, index=0, callback=None, outputBuffer=None, outputBufferBytes=1 << 20):
+    """Returns (result, decoded bytes | used, textureFormat)."""
+    iaddr, ilen, _k = _addr_len(inputBuffer)
+    own = outputBuffer is None
+    if own:
+        outputBuffer = (C.c_ubyte * max(1, outputBufferBytes))()
+    oaddr, olen, _k2 = _addr_len(outputBuffer)
+    if not own:
+        outputBufferBytes = olen
+    used = C.c_ulong(0)
+    fmt = C.c_uint(0)
+    cb = callback if callback is not None else _serial_callback()
+    r = lib.HapDecode(iaddr, ilen, index, cb, None, oaddr, outputBufferBytes, C.byref(used), C.byref(fmt))
+    if own:
+        return r, (bytes(outputBuffer[: used.value]) if r == 0 else None), fmt.value
+    return r, used.value, fmt.value
+
+
+def HapGetFrameTextureCount(frame):
+    a, n, _k = _addr_len(frame)
+    out = C.c_uint(0)
+    return lib.HapGetFrameTextureCount(a, n, C.byref(out)), out.value
+
+
+def HapGetFrameTextureFormat(frame, index):
+    a, n, _k = _addr_len(frame)
+    out = C.c_uint(0)
+    return lib.HapGetFrameTextureFormat(a, n, index, C.byref(out)), out.value
+
+
+def HapGetFrameTextureChunkCount(frame, index):
+    a, n, _k = _addr_len(frame)
+    out = C.c_int(-1)
+    return lib.HapGetFrameTextureChunkCount(a, n, index, C.byref(out)), out.value
+
+
+class Context:
+    """HapGpuContext: device + stream + scratch (include/hap_gpu.h)."""
+
+    def __init__(self, device=-1):
+        h = C.c_void_p()
+        r = lib.HapGpuCreate(device, C.byref(h))
+        if r != 0:
+            raise RuntimeError("HapGpuCreate failed with HapResult %d (no usable HIP device?)" % r)
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            lib.HapGpuDestroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_fragment_log2(self, v):
+        return lib.HapGpuSetFragmentLog2(self.handle, v)
+
+    def synchronize(self):
+        return lib.HapGpuSynchronize(self.handle)
+
+    def compress_rgba(self, rgba, width, height, row_bytes, texture_format, output=None):
+        block = 8 if texture_format in (HapTextureFormat.RGB_DXT1, HapTextureFormat.A_RGTC1) else 16
+        need = (width // 4) * (height // 4) * block
+        a, _n, _k = _addr_len(rgba)
+        own = output is None
+        if own:
+            output = (C.c_ubyte * max(1, need))()
+        oa, on, _k2 = _addr_len(output)
+        used = C.c_ulong(0)
+        r = lib.HapGpuCompressRGBA(self.handle, a, width, height, row_bytes, texture_format, oa, on, C.byref(used))
+        if own:
+            return r, (bytes(output[: used.value]) if r == 0 else None)
+        return r, used.value
+
+    @staticmethod
+    def _ptr_array(bufs):
+        infos = [_addr_len(b) for b in bufs]
+        return (C.c_void_p * len(bufs))(*[i[0] for i in infos]), infos
+
+    def encode_frames(self, textures, formats, compressors, chunk_counts, outputs, flags=0):
+        """textures: list (frames) of lists (count) of buffers; outputs: list of buffers.
+        Returns (result, used[], results[])."""
+        nf, count = len(textures), len(formats)
+        flat = [t for fr in textures for t in fr]
+        ptrs, infos = self._ptr_array(flat)
+        lens = (C.c_ulong * count)(*[infos[i][1] for i in range(count)])
+        optrs, oinfos = self._ptr_array(outputs)
+        olens = (C.c_ulong * nf)(*[i[1] for i in oinfos])
+        used = (C.c_ulong * nf)()
+        results = (C.c_uint * nf)()
+        r = lib.HapGpuEncodeFrames(self.handle, nf, count, ptrs, lens, (C.c_uint * count)(*formats),
+                                   (C.c_uint * count)(*compressors), (C.c_uint * count)(*chunk_counts),
+                                   optrs, olens, used, results, flags)
+        return r, list(used), list(results)
+
+    def encode_frames_rgba(self, rgba_frames, width, height, row_bytes, formats, compressors, chunk_counts,
+                           outputs, flags=0):
+        nf, count = len(rgba_frames), len(formats)
+        ptrs, _infos = self._ptr_array(rgba_frames)
+        optrs, oinfos = self._ptr_array(outputs)
+        olens = (C.c_ulong * nf)(*[i[1] for i in oinfos])
+        used = (C.c_ulong * nf)()
+        results = (C.c_uint * nf)()
+        r = lib.HapGpuEncodeFramesRGBA(self.handle, nf, ptrs, width, height, row_bytes, count,
+                                       (C.c_uint * count)(*formats), (C.c_uint * count)(*compressors),
+                                       (C.c_uint * count)(*chunk_counts), optrs, olens, used, results, flags)
+        return r, list(used), list(results)
+
+    def decode_frames(self, frames, frame_bytes, index, outputs, flags=0):
+        nf = len(frames)
+        ptrs, infos = self._ptr_array(frames)
+        lens = (C.c_ulong * nf)(*[fb if fb is not None else infos[i][1] for i, fb in enumerate(frame_bytes)])
+        optrs, oinfos = self._ptr_array(outputs)
+        olens = (C.c_ulong * nf)(*[i[1] for i in oinfos])
+        used = (C.c_ulong * nf)()
+        fmts = (C.c_uint * nf)()
+        results = (C.c_uint * nf)()
+        r = lib.HapGpuDecodeFrames(self.handle, nf, ptrs, lens, index, optrs, olens, used, fmts, results, flags)
+        return r, list(used), list(fmts), list(results)
+
+    def set_profiling(self, on):
+        return lib.HapGpuSetProfiling(self.handle, 1 if on else 0)
+
+    def collect_profile(self):
+        n = len(KERNEL_CLASSES)
+        launches = (C.c_ulong * n)()
+        ms = (C.c_double * n)()
+        lib.HapGpuCollectProfile(self.handle, launches, ms)
+        return {k: (launches[i], ms[i]) for i, k in enumerate(KERNEL_CLASSES)}
+
+    def timer_start(self):
+        return lib.HapGpuTimerStart(self.handle)
+
+    def timer_stop(self):
+        ms = C.c_double(0)
+        lib.HapGpuTimerStop(self.handle, C.byref(ms))
+        return ms.value

@@ -1,0 +1,268 @@
+// bc_encode.hip -- RGBA8 -> DXT1 / DXT5 / scaled YCoCg-DXT5 / RGTC1 block compression for gfx950.
+//
+// Replaces the "external squish/DXT encoder" stage that clients of the reference run in front
+// of HapEncode (the reference itself has none: hap.h:82-104 takes compressed texture bytes).
+// The integer algorithm is the one defined by oracle/bc_oracle.c; results are bit-identical.
+//
+// Mapping: one 4x4 block per lane.  Lane l of a wavefront loads the 16-byte pixel row segment
+// of block bx = base + l for each of the block's 4 rows, so every load instruction of a wave
+// covers 1 KiB of contiguous RGBA and every store 512 B / 1 KiB of contiguous blocks: fully
+// coalesced without an LDS stage.  Bounded by HBM: 64 B read + 8/16 B written per block.
+// Endpoint fitting uses per-lane min/max; index selection uses v_dot4_u32_u8 to get the
+// |p-c|^2 ordering of four palette entries in four instructions per pixel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace {
+
+constexpr int kFmtDXT1 = 0, kFmtDXT5 = 1, kFmtYCoCg = 2, kFmtRGTC1 = 3;
+
+__device__ __forceinline__ int quant5(int v) { int t = v * 31 + 128; return (t + (t >> 8)) >> 8; }
+__device__ __forceinline__ int quant6(int v) { int t = v * 63 + 128; return (t + (t >> 8)) >> 8; }
+__device__ __forceinline__ int expand5(int q) { return (q << 3) | (q >> 2); }
+__device__ __forceinline__ int expand6(int q) { return (q << 2) | (q >> 4); }
+__device__ __forceinline__ int clamp255(int v) { return min(max(v, 0), 255); }
+
+// 8-byte alpha-style block: a0, a1, 16 x 3-bit codes (S3TC alpha / RGTC1 layout).
+__device__ __forceinline__ uint2 alpha_block(const int (&a)[16])
+{
+    int lo = a[0], hi = a[0];
+#pragma unroll
+    for (int i = 1; i < 16; i++) {
+        lo = min(lo, a[i]);
+        hi = max(hi, a[i]);
+    }
+    const int inset = (hi - lo) >> 5;
+    const int a0 = hi - inset, a1 = lo + inset;
+    unsigned long long bits = 0;
+    if (a0 != a1) {
+        int t[7];
+        int prev = a0;
+#pragma unroll
+        for (int j = 1; j < 8; j++) {
+            const int q = ((7 - j) * a0 + j * a1) / 7;
+            t[j - 1] = prev + q;      // q_{j-1} + q_j
+            prev = q;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int v2 = 2 * a[i];
+            int r = 0;
+#pragma unroll
+            for (int j = 0; j < 7; j++)
+                r += (v2 < t[j]) ? 1 : 0;
+            const unsigned code = r == 0 ? 0u : (r == 7 ? 1u : (unsigned)(r + 1));
+            bits |= (unsigned long long)code << (3 * i);
+        }
+    }
+    const unsigned long long v = (unsigned long long)(unsigned)a0 | ((unsigned long long)(unsigned)a1 << 8) | (bits << 16);
+    return make_uint2((unsigned)v, (unsigned)(v >> 32));
+}
+
+// 2-bit index of the nearest of 4 palette entries for 16 pixels; px and pal are packed
+// bytes (c0 | c1<<8 | c2<<16), top byte zero.  Lowest index wins ties.
+__device__ __forceinline__ unsigned nearest4(const unsigned (&px)[16], const unsigned (&pal)[4])
+{
+    int n[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        n[k] = (int)__builtin_amdgcn_udot4(pal[k], pal[k], 0u, false);
+    unsigned idx = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        int best = n[0] - 2 * (int)__builtin_amdgcn_udot4(px[i], pal[0], 0u, false);
+        unsigned bk = 0;
+#pragma unroll
+        for (int k = 1; k < 4; k++) {
+            const int s = n[k] - 2 * (int)__builtin_amdgcn_udot4(px[i], pal[k], 0u, false);
+            const bool better = s < best;
+            best = better ? s : best;
+            bk = better ? (unsigned)k : bk;
+        }
+        idx |= bk << (2 * i);
+    }
+    return idx;
+}
+
+__device__ __forceinline__ unsigned pack3(int a, int b, int c) { return (unsigned)a | ((unsigned)b << 8) | ((unsigned)c << 16); }
+
+__device__ __forceinline__ void palette_from_565(unsigned c0, unsigned c1, bool blue, unsigned (&pal)[4])
+{
+    const int r0 = expand5(c0 >> 11), g0 = expand6((c0 >> 5) & 63), b0 = blue ? expand5(c0 & 31) : 0;
+    const int r1 = expand5(c1 >> 11), g1 = expand6((c1 >> 5) & 63), b1 = blue ? expand5(c1 & 31) : 0;
+    pal[0] = pack3(r0, g0, b0);
+    pal[1] = pack3(r1, g1, b1);
+    pal[2] = pack3((2 * r0 + r1) / 3, (2 * g0 + g1) / 3, (2 * b0 + b1) / 3);
+    pal[3] = pack3((r0 + 2 * r1) / 3, (g0 + 2 * g1) / 3, (b0 + 2 * b1) / 3);
+}
+
+// DXT1-style colour block from 16 packed RGB pixels (alpha byte already cleared).
+__device__ __forceinline__ uint2 colour_block(const unsigned (&px)[16])
+{
+    int lo[3] = {255, 255, 255}, hi[3] = {0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int v = (int)((px[i] >> (8 * c)) & 255u);
+            lo[c] = min(lo[c], v);
+            hi[c] = max(hi[c], v);
+        }
+    }
+    int cov_rg = 0, cov_bg = 0;
+    const int mr = lo[0] + hi[0], mg = lo[1] + hi[1], mb = lo[2] + hi[2];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int dr = 2 * (int)(px[i] & 255u) - mr;
+        const int dg = 2 * (int)((px[i] >> 8) & 255u) - mg;
+        const int db = 2 * (int)((px[i] >> 16) & 255u) - mb;
+        cov_rg += dr * dg;
+        cov_bg += db * dg;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int inset = (hi[c] - lo[c]) >> 4;
+        lo[c] += inset;
+        hi[c] -= inset;
+    }
+    const int ar = cov_rg < 0 ? lo[0] : hi[0], br = cov_rg < 0 ? hi[0] : lo[0];
+    const int ab = cov_bg < 0 ? lo[2] : hi[2], bb = cov_bg < 0 ? hi[2] : lo[2];
+    const unsigned qa = (unsigned)(quant5(ar) << 11 | quant6(hi[1]) << 5 | quant5(ab));
+    const unsigned qb = (unsigned)(quant5(br) << 11 | quant6(lo[1]) << 5 | quant5(bb));
+    const unsigned c0 = max(qa, qb), c1 = min(qa, qb);
+    unsigned idx = 0;
+    if (c0 != c1) {
+        unsigned pal[4];
+        palette_from_565(c0, c1, true, pal);
+        idx = nearest4(px, pal);
+    }
+    return make_uint2(c0 | (c1 << 16), idx);
+}
+
+// Colour half of a scaled YCoCg-DXT5 block; co/cg biased by 128.
+__device__ __forceinline__ uint2 ycocg_colour_block(const int (&co)[16], const int (&cg)[16])
+{
+    int lo_o = co[0], hi_o = co[0], lo_g = cg[0], hi_g = cg[0];
+#pragma unroll
+    for (int i = 1; i < 16; i++) {
+        lo_o = min(lo_o, co[i]); hi_o = max(hi_o, co[i]);
+        lo_g = min(lo_g, cg[i]); hi_g = max(hi_g, cg[i]);
+    }
+    const int m = max(max(128 - lo_o, hi_o - 128), max(128 - lo_g, hi_g - 128));
+    const int s = m <= 31 ? 4 : (m <= 63 ? 2 : 1);
+    int cov = 0;
+    const int mo = lo_o + hi_o, mg = lo_g + hi_g;
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        cov += (2 * co[i] - mo) * (2 * cg[i] - mg);
+    lo_o = (lo_o - 128) * s + 128; hi_o = (hi_o - 128) * s + 128;
+    lo_g = (lo_g - 128) * s + 128; hi_g = (hi_g - 128) * s + 128;
+    int ins = (hi_o - lo_o) >> 4; lo_o += ins; hi_o -= ins;
+    ins = (hi_g - lo_g) >> 4; lo_g += ins; hi_g -= ins;
+    const int ag = cov < 0 ? lo_g : hi_g, bg = cov < 0 ? hi_g : lo_g;
+    const unsigned qa = (unsigned)(quant5(hi_o) << 11 | quant6(ag) << 5 | (s - 1));
+    const unsigned qb = (unsigned)(quant5(lo_o) << 11 | quant6(bg) << 5 | (s - 1));
+    const unsigned c0 = max(qa, qb), c1 = min(qa, qb);
+    unsigned idx = 0;
+    if (c0 != c1) {
+        unsigned pal[4], px[16];
+        palette_from_565(c0, c1, false, pal);
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            px[i] = pack3((co[i] - 128) * s + 128, (cg[i] - 128) * s + 128, 0);
+        idx = nearest4(px, pal);
+    }
+    return make_uint2(c0 | (c1 << 16), idx);
+}
+
+template <int FMT, bool WIDE>
+__global__ __launch_bounds__(256) void bc_encode_kernel(const uint8_t *__restrict__ rgba, size_t row_bytes,
+                                                        unsigned blocks_x, unsigned blocks_total,
+                                                        uint8_t *__restrict__ out)
+{
+    const unsigned id = blockIdx.x * 256u + threadIdx.x;
+    if (id >= blocks_total)
+        return;
+    const unsigned by = id / blocks_x, bx = id - by * blocks_x;
+    const uint8_t *src = rgba + (size_t)(4u * by) * row_bytes + 16u * (size_t)bx;
+    unsigned p[16];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (WIDE) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(src + (size_t)r * row_bytes);
+            p[4 * r + 0] = v.x; p[4 * r + 1] = v.y; p[4 * r + 2] = v.z; p[4 * r + 3] = v.w;
+        } else {
+            const unsigned *q = reinterpret_cast<const unsigned *>(src + (size_t)r * row_bytes);
+            p[4 * r + 0] = q[0]; p[4 * r + 1] = q[1]; p[4 * r + 2] = q[2]; p[4 * r + 3] = q[3];
+        }
+    }
+    if (FMT == kFmtRGTC1) {
+        int a[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            a[i] = (int)(p[i] >> 24);
+        *reinterpret_cast<uint2 *>(out + (size_t)id * 8u) = alpha_block(a);
+    } else if (FMT == kFmtDXT1) {
+        unsigned px[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            px[i] = p[i] & 0x00FFFFFFu;
+        *reinterpret_cast<uint2 *>(out + (size_t)id * 8u) = colour_block(px);
+    } else if (FMT == kFmtDXT5) {
+        int a[16];
+        unsigned px[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            a[i] = (int)(p[i] >> 24);
+            px[i] = p[i] & 0x00FFFFFFu;
+        }
+        const uint2 ab = alpha_block(a), cb = colour_block(px);
+        *reinterpret_cast<uint4 *>(out + (size_t)id * 16u) = make_uint4(ab.x, ab.y, cb.x, cb.y);
+    } else {
+        int y[16], co[16], cg[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int r = (int)(p[i] & 255u), g = (int)((p[i] >> 8) & 255u), b = (int)((p[i] >> 16) & 255u);
+            y[i] = (r + 2 * g + b + 2) >> 2;
+            co[i] = clamp255(((r - b + 1) >> 1) + 128);
+            cg[i] = clamp255(((-r + 2 * g - b + 2) >> 2) + 128);
+        }
+        const uint2 ab = alpha_block(y), cb = ycocg_colour_block(co, cg);
+        *reinterpret_cast<uint4 *>(out + (size_t)id * 16u) = make_uint4(ab.x, ab.y, cb.x, cb.y);
+    }
+}
+
+template <int FMT>
+void launch(const void *rgba, size_t row_bytes, unsigned bx, unsigned by, void *out, bool wide, hipStream_t stream)
+{
+    const unsigned total = bx * by;
+    const dim3 grid((total + 255u) / 256u), block(256);
+    if (wide)
+        hipLaunchKernelGGL((bc_encode_kernel<FMT, true>), grid, block, 0, stream, (const uint8_t *)rgba, row_bytes, bx, total, (uint8_t *)out);
+    else
+        hipLaunchKernelGGL((bc_encode_kernel<FMT, false>), grid, block, 0, stream, (const uint8_t *)rgba, row_bytes, bx, total, (uint8_t *)out);
+}
+
+} // namespace
+
+// format: HapTextureFormat constant. Returns 0 when launched, 1 for bad arguments.
+extern "C" int hapgpu_launch_block_encode(const void *rgba, unsigned width, unsigned height, size_t row_bytes,
+                                          unsigned format, void *out, hipStream_t stream)
+{
+    if (!rgba || !out || width == 0 || height == 0 || (width & 3u) || (height & 3u) || row_bytes < (size_t)width * 4u)
+        return 1;
+    if (((uintptr_t)rgba & 3u) || (row_bytes & 3u))
+        return 1;
+    const unsigned bx = width / 4u, by = height / 4u;
+    if ((unsigned long long)bx * by > 0xFFFFFFFFull / 256u * 255u)
+        return 1;
+    const bool wide = (((uintptr_t)rgba | row_bytes) & 15u) == 0;
+    switch (format) {
+    case 0x83F0: if ((uintptr_t)out & 7u) return 1; launch<kFmtDXT1>(rgba, row_bytes, bx, by, out, wide, stream); break;
+    case 0x83F3: if ((uintptr_t)out & 15u) return 1; launch<kFmtDXT5>(rgba, row_bytes, bx, by, out, wide, stream); break;
+    case 0x01: if ((uintptr_t)out & 15u) return 1; launch<kFmtYCoCg>(rgba, row_bytes, bx, by, out, wide, stream); break;
+    case 0x8DBB: if ((uintptr_t)out & 7u) return 1; launch<kFmtRGTC1>(rgba, row_bytes, bx, by, out, wide, stream); break;
+    default: return 1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}

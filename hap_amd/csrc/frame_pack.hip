@@ -1,0 +1,278 @@
+// frame_pack.hip -- device-side Hap frame assembly for gfx950.
+//
+// The reference writes a frame while it compresses, chunk after chunk, because chunk i's
+// position depends on the compressed sizes of all chunks before it (hap.c:448-476,
+// `compressed_data += chunk_packed_length`).  On the GPU every fragment is compressed at once
+// into a worst-case slot, then:
+//
+//   frame_pack_kernel    one workgroup per frame: sums fragment sizes per chunk, decides per
+//                        chunk "store raw iff compressed >= chunk size" (hap.c:460-471) and per
+//                        texture "store the whole texture raw iff no gain" (hap.c:478-495),
+//                        prefix-sums the chunk positions, and writes every header and table of
+//                        the frame (hap.c:436-440, 497-501, 598) plus, optionally, the private
+//                        fragment-size section 0x46.  It also emits one move per fragment.
+//   frame_gather_kernel  one wavefront per move: slot (or raw texture bytes) -> final position.
+//
+// No host round trip: the only thing the host reads back is bytes_used / status per frame.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hapgpu_abi.h"
+
+namespace {
+
+__device__ __forceinline__ void put24(uint8_t *p, unsigned v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); }
+__device__ __forceinline__ void put32(uint8_t *p, unsigned v) { put24(p, v); p[3] = (uint8_t)(v >> 24); }
+
+// section header, reference hap.c:189-212
+__device__ void write_section(uint8_t *p, unsigned header_len, unsigned length, unsigned type)
+{
+    if (header_len == 4u) {
+        put24(p, length);
+    } else {
+        put24(p, 0u);
+        put32(p + 4, length);
+    }
+    p[3] = (uint8_t)type;
+}
+
+__device__ __forceinline__ unsigned varint_len(unsigned v) { return v < (1u << 7) ? 1u : v < (1u << 14) ? 2u : v < (1u << 21) ? 3u : v < (1u << 28) ? 4u : 5u; }
+
+__device__ void write_varint(uint8_t *p, unsigned v)
+{
+    while (v >= 0x80u) {
+        *p++ = (uint8_t)(v | 0x80u);
+        v >>= 7;
+    }
+    *p = (uint8_t)v;
+}
+
+// block-wide exclusive scan of one 64-bit value per thread (256 threads); returns the exclusive
+// prefix, *total receives the block sum.
+__device__ unsigned long long block_scan(unsigned long long v, unsigned long long *total, unsigned long long *lds)
+{
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long up = __shfl_up(incl, d);
+        if ((int)lane >= d)
+            incl += up;
+    }
+    __syncthreads();
+    if (lane == 63)
+        lds[wave] = incl;
+    __syncthreads();
+    unsigned long long before = 0, sum = 0;
+    for (unsigned w = 0; w < 4; w++) {
+        if (w < wave)
+            before += lds[w];
+        sum += lds[w];
+    }
+    *total = sum;
+    return before + incl - v;
+}
+
+__global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames, unsigned frag_log2,
+                                                         const uint8_t *__restrict__ slots, unsigned slot_stride,
+                                                         const uint32_t *__restrict__ frag_sizes,
+                                                         HapGpuCopyEntry *__restrict__ copies)
+{
+    __shared__ unsigned long long scan_lds[4];
+    __shared__ unsigned long long carry_lds;
+    HapGpuFrameEnc &frame = frames[blockIdx.x];
+    const unsigned tid = threadIdx.x;
+    const unsigned frag_bytes = 1u << frag_log2;
+    uint8_t *cursor = (uint8_t *)frame.dst + frame.outer_header_len;
+    unsigned long long sections_total = 0;
+
+    for (unsigned t = 0; t < frame.tex_count; t++) {
+        const HapGpuTexEnc tex = frame.tex[t];
+        uint8_t *sec = cursor;
+        const unsigned n = tex.chunk_count, fpc = tex.frags_per_chunk, cb = tex.chunk_bytes, hdr = tex.header_len;
+        const uint8_t *tsrc = (const uint8_t *)tex.src;
+        unsigned long long body = tex.bytes;
+        bool complex_frame = false;
+
+        if (tex.compressor == 1u) {
+            const unsigned vlen = varint_len(cb);
+            const unsigned index_len = tex.emit_index ? 8u + 4u * n * fpc : 0u;
+            const unsigned ilen = 5u * n + 8u + index_len;
+            // pass 1: total stored payload
+            unsigned long long total = 0;
+            for (unsigned base = 0; base < n; base += 256u) {
+                const unsigned i = base + tid;
+                unsigned long long stored = 0;
+                if (i < n) {
+                    unsigned long long c = vlen;
+                    const uint32_t *fs = frag_sizes + tex.frag_first + (size_t)i * fpc;
+                    for (unsigned k = 0; k < fpc; k++)
+                        c += fs[k];
+                    stored = c >= cb ? cb : c;                                   // hap.c:460-466
+                }
+                unsigned long long tile_total;
+                block_scan(stored, &tile_total, scan_lds);
+                total += tile_total;
+            }
+            const unsigned long long complex_body = 4ull + ilen + total;
+            complex_frame = complex_body < (unsigned long long)tex.bytes + hdr;   // hap.c:478
+            if (complex_frame) {
+                body = complex_body;
+                uint8_t *ctab = sec + hdr + 8u;
+                uint8_t *stab = ctab + n + 4u;
+                uint8_t *itab = stab + 4u * n;                                    // fragment section, if any
+                uint8_t *payload = sec + hdr + 4u + ilen;
+                if (tid == 0) {
+                    write_section(sec + hdr, 4u, ilen, HAP_SECTION_INSTRUCTIONS);      // hap.c:436
+                    write_section(sec + hdr + 4u, 4u, n, HAP_SECTION_COMPRESSORS);     // hap.c:438
+                    write_section(ctab + n, 4u, 4u * n, HAP_SECTION_SIZES);            // hap.c:440
+                    if (tex.emit_index) {
+                        write_section(itab, 4u, 4u + 4u * n * fpc, HAP_SECTION_FRAGMENTS);
+                        itab[4] = (uint8_t)HAP_FRAGMENT_TABLE_VERSION;
+                        itab[5] = (uint8_t)frag_log2;
+                        itab[6] = 0;
+                        itab[7] = 0;
+                    }
+                }
+                // pass 2: positions, tables, moves
+                unsigned long long run = 0;
+                for (unsigned base = 0; base < n; base += 256u) {
+                    const unsigned i = base + tid;
+                    unsigned long long csize = 0, stored = 0;
+                    const uint32_t *fs = frag_sizes + tex.frag_first + (size_t)i * fpc;
+                    if (i < n) {
+                        csize = vlen;
+                        for (unsigned k = 0; k < fpc; k++)
+                            csize += fs[k];
+                        stored = csize >= cb ? cb : csize;
+                    }
+                    unsigned long long tile_total;
+                    const unsigned long long off = run + block_scan(stored, &tile_total, scan_lds);
+                    run += tile_total;
+                    if (i < n) {
+                        const bool raw = csize >= cb;
+                        ctab[i] = raw ? (uint8_t)HAP_NIBBLE_NONE : (uint8_t)HAP_NIBBLE_SNAPPY;   // hap.c:465,470
+                        put32(stab + 4u * i, (unsigned)stored);                                  // hap.c:472
+                        uint8_t *at = payload + off;
+                        if (!raw) {
+                            write_varint(at, cb);
+                            at += vlen;
+                        }
+                        for (unsigned k = 0; k < fpc; k++) {
+                            const unsigned f = tex.frag_first + i * fpc + k;
+                            HapGpuCopyEntry e;
+                            e.reserved = 0;
+                            if (raw) {
+                                const unsigned begin = k << frag_log2;
+                                e.src = (uint64_t)(tsrc + (size_t)i * cb + begin);
+                                e.len = begin < cb ? min(frag_bytes, cb - begin) : 0u;
+                            } else {
+                                e.src = (uint64_t)(slots + (size_t)f * slot_stride);
+                                e.len = fs[k];
+                            }
+                            e.dst = (uint64_t)at;
+                            at += e.len;
+                            copies[f] = e;
+                            if (tex.emit_index)
+                                put32(itab + 8u + 4u * (i * fpc + k), raw ? 0u : fs[k]);
+                        }
+                    }
+                }
+            }
+        }
+        if (!complex_frame) {
+            // whole texture stored as-is, reference hap.c:490-495
+            const unsigned total_frags = n * fpc;
+            for (unsigned f = tid; f < total_frags; f += 256u) {
+                const unsigned i = f / fpc, k = f - i * fpc;
+                const unsigned begin = k << frag_log2;
+                HapGpuCopyEntry e;
+                e.reserved = 0;
+                e.len = begin < cb ? min(frag_bytes, cb - begin) : 0u;
+                if (f + 1u == total_frags)      // bytes not divisible by the chunk count: keep the tail
+                    e.len = tex.bytes - (i * cb + begin);
+                e.src = (uint64_t)(tsrc + (size_t)i * cb + begin);
+                e.dst = (uint64_t)(sec + hdr + (size_t)i * cb + begin);
+                copies[tex.frag_first + f] = e;
+            }
+        }
+        if (tid == 0) {
+            const unsigned type = ((complex_frame ? HAP_NIBBLE_COMPLEX : HAP_NIBBLE_NONE) << 4) | (tex.format_nibble & 0xFu);
+            write_section(sec, hdr, (unsigned)body, type);                         // hap.c:499
+        }
+        cursor += hdr + body;
+        sections_total += hdr + body;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (frame.outer_header_len)
+            write_section((uint8_t *)frame.dst, frame.outer_header_len, (unsigned)sections_total, HAP_SECTION_MULTI);   // hap.c:598
+        frame.bytes_used = frame.outer_header_len + sections_total;
+        frame.status = 0;
+    }
+    (void)carry_lds;
+}
+
+__global__ __launch_bounds__(64) void frame_gather_kernel(const HapGpuCopyEntry *__restrict__ copies, unsigned count)
+{
+    const unsigned lane = threadIdx.x;
+    if (blockIdx.x >= count)
+        return;
+    const HapGpuCopyEntry e = copies[blockIdx.x];
+    uint8_t *dst = (uint8_t *)e.dst;
+    const uint8_t *src = (const uint8_t *)e.src;
+    unsigned len = e.len;
+    if (len == 0)
+        return;
+    // head: bring dst to 16-byte alignment
+    const unsigned mis = (unsigned)((uintptr_t)dst & 15u);
+    if (mis) {
+        const unsigned head = min(16u - mis, len);
+        if (lane < head)
+            dst[lane] = src[lane];
+        dst += head;
+        src += head;
+        len -= head;
+    }
+    const unsigned wide = len >> 4;
+    const unsigned smis = (unsigned)((uintptr_t)src & 3u);
+    if (smis == 0) {
+        for (unsigned i = lane; i < wide; i += 64u) {
+            const uint32_t *s = reinterpret_cast<const uint32_t *>(src + ((size_t)i << 4));
+            *reinterpret_cast<uint4 *>(dst + ((size_t)i << 4)) = make_uint4(s[0], s[1], s[2], s[3]);
+        }
+    } else {
+        // source not dword aligned: read the 5 covering dwords and shift
+        const uint32_t *base = reinterpret_cast<const uint32_t *>(src - smis);
+        for (unsigned i = lane; i < wide; i += 64u) {
+            const uint32_t *s = base + ((size_t)i << 2);
+            const unsigned a = s[0], b = s[1], c = s[2], d = s[3], f = s[4];
+            *reinterpret_cast<uint4 *>(dst + ((size_t)i << 4)) =
+                make_uint4(__builtin_amdgcn_alignbyte(b, a, smis), __builtin_amdgcn_alignbyte(c, b, smis),
+                           __builtin_amdgcn_alignbyte(d, c, smis), __builtin_amdgcn_alignbyte(f, d, smis));
+        }
+    }
+    const unsigned done = wide << 4;
+    if (done + lane < len)
+        dst[done + lane] = src[done + lane];
+}
+
+} // namespace
+
+extern "C" int hapgpu_launch_frame_pack(HapGpuFrameEnc *frames, unsigned frame_count, unsigned frag_log2,
+                                        const void *slots, unsigned slot_stride, const uint32_t *frag_sizes,
+                                        HapGpuCopyEntry *copies, hipStream_t stream)
+{
+    if (frame_count == 0)
+        return 0;
+    hipLaunchKernelGGL(frame_pack_kernel, dim3(frame_count), dim3(256), 0, stream, frames, frag_log2,
+                       (const uint8_t *)slots, slot_stride, frag_sizes, copies);
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}
+
+extern "C" int hapgpu_launch_frame_gather(const HapGpuCopyEntry *copies, unsigned count, hipStream_t stream)
+{
+    if (count == 0)
+        return 0;
+    hipLaunchKernelGGL(frame_gather_kernel, dim3(count), dim3(64), 0, stream, copies, count);
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}

@@ -1,0 +1,355 @@
+/*
+ * hap_api.c -- the exported symbols: the six functions of include/hap.h (same
+ * names and signatures as the reference, /root/reference/source/hap.h:76-152)
+ * and the context / batch functions of include/hap_gpu.h.  Pure C99.
+ */
+#include "hap_batch.h"
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------ contexts -- */
+
+unsigned int HapGpuCreate(int device, HapGpuContext **context)
+{
+    HapGpuContext *c;
+    int rc;
+    if (!context)
+        return HapResult_Bad_Arguments;
+    *context = NULL;
+    c = (HapGpuContext *)calloc(1, sizeof(*c));
+    if (!c)
+        return HapResult_Internal_Error;
+    rc = hapgpu_rt_create(device, &c->rt);
+    if (rc) {
+        free(c);
+        return rc == 1 ? HapResult_Bad_Arguments : HapResult_Internal_Error;
+    }
+    c->frag_log2 = 14;
+    {
+        const char *e = getenv("HAP_AMD_FRAGMENT_LOG2");
+        if (e && atoi(e) >= 10 && atoi(e) <= 16)
+            c->frag_log2 = (unsigned)atoi(e);
+    }
+    *context = c;
+    return HapResult_No_Error;
+}
+
+void HapGpuDestroy(HapGpuContext *context)
+{
+    if (!context)
+        return;
+    hapgpu_rt_destroy(context->rt);
+    free(context);
+}
+
+static pthread_once_t g_default_once = PTHREAD_ONCE_INIT;
+static HapGpuContext *g_default;
+
+static void make_default(void)
+{
+    const char *e = getenv("HAP_AMD_DEVICE");
+    if (HapGpuCreate(e ? atoi(e) : -1, &g_default) != HapResult_No_Error) {
+        g_default = NULL;
+        fprintf(stderr, "hap_amd: cannot create a GPU context; HapEncode/HapDecode will fail "
+                        "(this library has no CPU path)\n");
+    }
+}
+
+HapGpuContext *HapGpuDefaultContext(void)
+{
+    pthread_once(&g_default_once, make_default);
+    return g_default;
+}
+
+unsigned int HapGpuSetFragmentLog2(HapGpuContext *context, unsigned int log2_bytes)
+{
+    if (!context || log2_bytes < 10 || log2_bytes > 16)
+        return HapResult_Bad_Arguments;
+    context->frag_log2 = log2_bytes;
+    return HapResult_No_Error;
+}
+
+unsigned int HapGpuSynchronize(HapGpuContext *context)
+{
+    unsigned r;
+    if (!context)
+        return HapResult_Bad_Arguments;
+    hapgpu_rt_lock(context->rt);
+    r = hapgpu_rt_sync(context->rt) ? HapResult_Internal_Error : HapResult_No_Error;
+    hapgpu_rt_unlock(context->rt);
+    return r;
+}
+
+/* --------------------------------------------------------------- hap.h -- */
+
+/* reference hap.c:324-353 */
+unsigned long HapMaxEncodedLength(unsigned int count, unsigned long *lengths,
+                                  unsigned int *textureFormats, unsigned int *chunkCounts)
+{
+    unsigned long total = 8;
+    unsigned i;
+    if (count == 0 || count > 2 || !lengths || !textureFormats || !chunkCounts)
+        return 0;
+    for (i = 0; i < count; i++) {
+        if (chunkCounts[i] == 0)
+            return 0;
+        total += (unsigned long)hapf_texture_bound(lengths[i], textureFormats[i], HapCompressorSnappy, chunkCounts[i]);
+    }
+    return total;
+}
+
+static unsigned env_encode_flags(void)
+{
+    const char *e = getenv("HAP_AMD_FRAGMENT_INDEX");
+    return (e && atoi(e) != 0) ? HAPGPU_ENCODE_FRAGMENT_INDEX : 0u;
+}
+
+/* reference hap.c:506-604 */
+unsigned int HapEncode(unsigned int count, const void **inputBuffers, unsigned long *inputBuffersBytes,
+                       unsigned int *textureFormats, unsigned int *compressors, unsigned int *chunkCounts,
+                       void *outputBuffer, unsigned long outputBufferBytes,
+                       unsigned long *outputBufferBytesUsed)
+{
+    HapGpuContext *ctx;
+    unsigned result = HapResult_Internal_Error, rc;
+    unsigned long used = 0;
+    void *out = outputBuffer;
+    if (count == 0 || count > 2 || !inputBuffers || !inputBuffersBytes || !textureFormats || !compressors ||
+        !chunkCounts || !outputBuffer || outputBufferBytes == 0 || !outputBufferBytesUsed)
+        return HapResult_Bad_Arguments;
+    ctx = HapGpuDefaultContext();
+    if (!ctx)
+        return HapResult_Internal_Error;
+    hapgpu_rt_lock(ctx->rt);
+    rc = hapb_encode(ctx, 1, count, (const void *const *)inputBuffers, inputBuffersBytes, textureFormats,
+                     compressors, chunkCounts, &out, &outputBufferBytes, &used, &result, env_encode_flags(), 0);
+    hapgpu_rt_unlock(ctx->rt);
+    if (rc == HapResult_No_Error)
+        *outputBufferBytesUsed = used;
+    return rc;
+}
+
+/* reference hap.c:993-1040 */
+unsigned int HapDecode(const void *inputBuffer, unsigned long inputBufferBytes, unsigned int index,
+                       HapDecodeCallback callback, void *info, void *outputBuffer,
+                       unsigned long outputBufferBytes, unsigned long *outputBufferBytesUsed,
+                       unsigned int *outputBufferTextureFormat)
+{
+    HapGpuContext *ctx;
+    unsigned result = HapResult_Internal_Error, rc, fmt = 0;
+    unsigned long used = 0;
+    if (!inputBuffer || index > 1 || !callback || !outputBuffer || !outputBufferTextureFormat)
+        return HapResult_Bad_Arguments;
+    ctx = HapGpuDefaultContext();
+    if (!ctx)
+        return HapResult_Internal_Error;
+    hapgpu_rt_lock(ctx->rt);
+    rc = hapb_decode(ctx, 1, &inputBuffer, &inputBufferBytes, index, &outputBuffer, &outputBufferBytes, &used,
+                     &fmt, &result, 0, callback, info);
+    hapgpu_rt_unlock(ctx->rt);
+    /* the reference stores the format as soon as the section type has been read (hap.c:754) */
+    *outputBufferTextureFormat = fmt;
+    if (rc == HapResult_No_Error && outputBufferBytesUsed)
+        *outputBufferBytesUsed = used;
+    return rc;
+}
+
+/* Inspectors read section headers only.  Host frames are parsed in place; for
+ * device-resident frames the few header bytes are copied back. */
+typedef struct inspect_fetch {
+    HapGpuContext *ctx;
+    const uint8_t *frame;
+} inspect_fetch;
+
+static int inspect_fetch_cb(void *user, uint64_t offset, uint64_t length, uint8_t *dst)
+{
+    inspect_fetch *f = (inspect_fetch *)user;
+    int rc;
+    hapgpu_rt_lock(f->ctx->rt);
+    rc = hapgpu_rt_d2h(f->ctx->rt, dst, f->frame + offset, (size_t)length);
+    if (!rc)
+        rc = hapgpu_rt_sync(f->ctx->rt);
+    hapgpu_rt_unlock(f->ctx->rt);
+    return rc;
+}
+
+static void open_reader(hapf_reader *r, inspect_fetch *f, const void *frame, unsigned long bytes)
+{
+    /* classify without forcing a context into existence for plain host memory users */
+    HapGpuContext *ctx = g_default;
+    if (ctx && hapgpu_rt_is_device_ptr(ctx->rt, frame)) {
+        hapf_reader_init_host(r, NULL, 0);
+        f->ctx = ctx;
+        f->frame = (const uint8_t *)frame;
+        r->fetch = inspect_fetch_cb;
+        r->user = f;
+    } else {
+        hapf_reader_init_host(r, frame, bytes);
+    }
+}
+
+/* reference hap.c:1042-1087 (no NULL checks there either) */
+unsigned int HapGetFrameTextureCount(const void *inputBuffer, unsigned long inputBufferBytes,
+                                     unsigned int *outputTextureCount)
+{
+    hapf_reader r;
+    inspect_fetch f;
+    unsigned rc;
+    open_reader(&r, &f, inputBuffer, inputBufferBytes);
+    rc = hapf_texture_count(&r, inputBufferBytes, outputTextureCount);
+    hapf_reader_free(&r);
+    return rc;
+}
+
+/* reference hap.c:1089-1126 */
+unsigned int HapGetFrameTextureFormat(const void *inputBuffer, unsigned long inputBufferBytes,
+                                      unsigned int index, unsigned int *outputBufferTextureFormat)
+{
+    hapf_reader r;
+    inspect_fetch f;
+    uint64_t off;
+    uint32_t len;
+    unsigned type = 0, rc;
+    if (!inputBuffer || index > 1 || !outputBufferTextureFormat)
+        return HapResult_Bad_Arguments;
+    open_reader(&r, &f, inputBuffer, inputBufferBytes);
+    rc = hapf_locate(&r, (uint32_t)inputBufferBytes, index, &off, &len, &type);
+    hapf_reader_free(&r);
+    if (rc != HapResult_No_Error)
+        return rc;
+    *outputBufferTextureFormat = hapf_format_from_nibble(type & 0xFu);
+    return *outputBufferTextureFormat ? HapResult_No_Error : HapResult_Bad_Frame;
+}
+
+/* reference hap.c:1128-1188 */
+unsigned int HapGetFrameTextureChunkCount(const void *inputBuffer, unsigned long inputBufferBytes,
+                                          unsigned int index, int *chunk_count)
+{
+    hapf_reader r;
+    inspect_fetch f;
+    hapf_texture_plan plan;
+    *chunk_count = 0;                     /* before validation, like hap.c:1134 */
+    if (!inputBuffer || index > 1)
+        return HapResult_Bad_Arguments;
+    open_reader(&r, &f, inputBuffer, inputBufferBytes);
+    hapf_plan_texture(&r, (uint32_t)inputBufferBytes, index, 0, &plan);
+    *chunk_count = plan.chunk_count;
+    hapf_plan_free(&plan);
+    hapf_reader_free(&r);
+    return plan.result;
+}
+
+/* ----------------------------------------------------------- hap_gpu.h -- */
+
+unsigned int HapGpuCompressRGBA(HapGpuContext *context, const void *rgba, unsigned int width,
+                                unsigned int height, unsigned long rowBytes, unsigned int textureFormat,
+                                void *output, unsigned long outputBytes, unsigned long *outputBytesUsed)
+{
+    unsigned r;
+    if (!context)
+        return HapResult_Bad_Arguments;
+    hapgpu_rt_lock(context->rt);
+    r = hapb_compress_rgba(context, rgba, width, height, rowBytes, textureFormat, output, outputBytes,
+                           outputBytesUsed, 1);
+    hapgpu_rt_unlock(context->rt);
+    return r;
+}
+
+unsigned int HapGpuEncodeFrames(HapGpuContext *context, unsigned int frameCount, unsigned int count,
+                                const void *const *inputBuffers, const unsigned long *inputBuffersBytes,
+                                const unsigned int *textureFormats, const unsigned int *compressors,
+                                const unsigned int *chunkCounts, void *const *outputBuffers,
+                                const unsigned long *outputBuffersBytes, unsigned long *outputBuffersBytesUsed,
+                                unsigned int *results, unsigned int flags)
+{
+    unsigned r;
+    if (!context)
+        return HapResult_Bad_Arguments;
+    hapgpu_rt_lock(context->rt);
+    r = hapb_encode(context, frameCount, count, inputBuffers, inputBuffersBytes, textureFormats, compressors,
+                    chunkCounts, outputBuffers, outputBuffersBytes, outputBuffersBytesUsed, results, flags, 0);
+    hapgpu_rt_unlock(context->rt);
+    return r;
+}
+
+unsigned int HapGpuEncodeFramesRGBA(HapGpuContext *context, unsigned int frameCount,
+                                    const void *const *rgbaFrames, unsigned int width, unsigned int height,
+                                    unsigned long rowBytes, unsigned int count,
+                                    const unsigned int *textureFormats, const unsigned int *compressors,
+                                    const unsigned int *chunkCounts, void *const *outputBuffers,
+                                    const unsigned long *outputBuffersBytes,
+                                    unsigned long *outputBuffersBytesUsed, unsigned int *results,
+                                    unsigned int flags)
+{
+    unsigned r;
+    if (!context)
+        return HapResult_Bad_Arguments;
+    hapgpu_rt_lock(context->rt);
+    r = hapb_encode_rgba(context, frameCount, rgbaFrames, width, height, rowBytes, count, textureFormats,
+                         compressors, chunkCounts, outputBuffers, outputBuffersBytes, outputBuffersBytesUsed,
+                         results, flags);
+    hapgpu_rt_unlock(context->rt);
+    return r;
+}
+
+unsigned int HapGpuDecodeFrames(HapGpuContext *context, unsigned int frameCount,
+                                const void *const *inputBuffers, const unsigned long *inputBuffersBytes,
+                                unsigned int index, void *const *outputBuffers,
+                                const unsigned long *outputBuffersBytes, unsigned long *outputBuffersBytesUsed,
+                                unsigned int *outputTextureFormats, unsigned int *results, unsigned int flags)
+{
+    unsigned r;
+    if (!context)
+        return HapResult_Bad_Arguments;
+    hapgpu_rt_lock(context->rt);
+    r = hapb_decode(context, frameCount, inputBuffers, inputBuffersBytes, index, outputBuffers,
+                    outputBuffersBytes, outputBuffersBytesUsed, outputTextureFormats, results, flags, NULL, NULL);
+    hapgpu_rt_unlock(context->rt);
+    return r;
+}
+
+unsigned int HapGpuSetProfiling(HapGpuContext *context, unsigned int enable)
+{
+    if (!context)
+        return HapResult_Bad_Arguments;
+    hapgpu_rt_lock(context->rt);
+    hapgpu_rt_set_profiling(context->rt, (int)enable);
+    hapgpu_rt_unlock(context->rt);
+    return HapResult_No_Error;
+}
+
+unsigned int HapGpuCollectProfile(HapGpuContext *context, unsigned long *launches, double *milliseconds)
+{
+    unsigned r;
+    if (!context || !launches || !milliseconds)
+        return HapResult_Bad_Arguments;
+    hapgpu_rt_lock(context->rt);
+    r = hapgpu_rt_collect_profile(context->rt, launches, milliseconds, HapGpuKernel_ClassCount)
+            ? HapResult_Internal_Error : HapResult_No_Error;
+    hapgpu_rt_unlock(context->rt);
+    return r;
+}
+
+unsigned int HapGpuTimerStart(HapGpuContext *context)
+{
+    unsigned r;
+    if (!context)
+        return HapResult_Bad_Arguments;
+    hapgpu_rt_lock(context->rt);
+    r = hapgpu_rt_timer_start(context->rt) ? HapResult_Internal_Error : HapResult_No_Error;
+    hapgpu_rt_unlock(context->rt);
+    return r;
+}
+
+unsigned int HapGpuTimerStop(HapGpuContext *context, double *milliseconds)
+{
+    unsigned r;
+    if (!context || !milliseconds)
+        return HapResult_Bad_Arguments;
+    hapgpu_rt_lock(context->rt);
+    r = hapgpu_rt_timer_stop(context->rt, milliseconds) ? HapResult_Internal_Error : HapResult_No_Error;
+    hapgpu_rt_unlock(context->rt);
+    return r;
+}

@@ -1,0 +1,760 @@
+/*
+ * hap_batch.c -- host-side orchestration of the GPU hot path (pure C99).
+ *
+ * Implements the batched entry points of include/hap_gpu.h; the six hap.h
+ * functions in hap_api.c are thin wrappers around the batch-of-one case.
+ * The host does only container arithmetic (header lengths, chunk-count
+ * limiting, section location, table parsing -- see hap_frame.c) and fills the
+ * descriptor arrays of hapgpu_abi.h; every byte of texture payload is moved,
+ * compressed or decompressed by HIP kernels.  There is no CPU fallback: when
+ * no HIP device is present the functions fail with HapResult_Internal_Error.
+ *
+ * Reference behaviour mirrored here: argument checks and result codes of
+ * HapEncode (hap.c:506-604, 355-504) and HapDecode (hap.c:993-1040, 732-930).
+ */
+#include "hap_batch.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum {
+    D_FRAMES = 0, D_SLOTS, D_FRAGSIZES, D_COPIES, D_TEX_STAGE, D_FRAME_STAGE, D_BC_TEX, D_RGBA_STAGE,
+    D_JOBS, D_CHUNKS, D_UNITS, D_IN_STAGE, D_OUT_STAGE
+};
+enum { P_FRAMES = 0, P_JOBS, P_CHUNKS, P_PREFIX };
+
+#define PREFIX_BYTES 16384u
+#define COPY_PIECE 65536u
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int is_dev(HapGpuContext *c, const void *p) { return hapgpu_rt_is_device_ptr(c->rt, p); }
+
+/* ================================================================== encode */
+
+typedef struct tex_geom {
+    unsigned format, compressor, chunk_count, chunk_bytes, header_len, fpc, nibble;
+    unsigned long bytes;
+    size_t bound;        /* hap_max_encoded_length for the requested compressor (hap.c:386) */
+} tex_geom;
+
+unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
+                     const void *const *inputs, const unsigned long *input_bytes,
+                     const unsigned *formats, const unsigned *compressors, const unsigned *chunk_counts,
+                     void *const *outputs, const unsigned long *output_bytes,
+                     unsigned long *output_used, unsigned *results, unsigned flags,
+                     int inputs_are_device)
+{
+    tex_geom g[2];
+    unsigned i, f, first_error = HapResult_No_Error;
+    unsigned outer_header = 0, frags_per_frame = 0, max_frags_per_tex = 0, live = 0;
+    unsigned frag_log2 = ctx->frag_log2, frag_bytes = 1u << frag_log2;
+    unsigned slot_stride;
+    int any_snappy = 0;
+    size_t stage_in_bytes = 0, stage_out_bytes = 0, frame_raw_bound = 0;
+    hapgpu_rt *rt = ctx->rt;
+    HapGpuFrameEnc *hframes, *dframes;
+    uint8_t *dslots, *tex_stage = NULL, *out_stage = NULL;
+    uint32_t *dfragsizes;
+    HapGpuCopyEntry *dcopies;
+    size_t *stage_off_in = NULL, *stage_off_out = NULL;
+    unsigned *live_index = NULL;
+
+    if (frame_count == 0)
+        return HapResult_No_Error;
+    if (!results)
+        return HapResult_Bad_Arguments;
+    /* frame-independent argument checks, reference hap.c:518-559 */
+    {
+        unsigned rc = HapResult_No_Error;
+        if (count == 0 || count > 2 || !inputs || !input_bytes || !formats || !compressors || !chunk_counts ||
+            !outputs || !output_bytes || !output_used)
+            rc = HapResult_Bad_Arguments;
+        for (i = 0; rc == HapResult_No_Error && i < count; i++)
+            if (chunk_counts[i] == 0)
+                rc = HapResult_Bad_Arguments;
+        if (rc == HapResult_No_Error && count == 2 &&
+            formats[0] != HapTextureFormat_YCoCg_DXT5 && formats[1] != HapTextureFormat_YCoCg_DXT5 &&
+            formats[0] != HapTextureFormat_A_RGTC1 && formats[1] != HapTextureFormat_A_RGTC1)
+            rc = HapResult_Bad_Arguments;
+        /* per-texture checks that do not depend on the frame, reference hap.c:367-385 */
+        for (i = 0; rc == HapResult_No_Error && i < count; i++)
+            if (input_bytes[i] == 0 || input_bytes[i] > 0xFFFFFFFFul || hapf_nibble_from_format(formats[i]) == 0 ||
+                (compressors[i] != HapCompressorNone && compressors[i] != HapCompressorSnappy))
+                rc = HapResult_Bad_Arguments;
+        if (rc != HapResult_No_Error) {
+            for (f = 0; f < frame_count; f++)
+                results[f] = rc;
+            return rc;
+        }
+    }
+    /* geometry shared by every frame of the batch */
+    if (count == 2) {
+        size_t worst = 0;                                             /* hap.c:563-576 */
+        for (i = 0; i < count; i++)
+            worst += input_bytes[i] + hapf_instructions_length(chunk_counts[i]) + 4u;
+        outer_header = worst > 0xFFFFFFu ? 8u : 4u;
+    }
+    for (i = 0; i < count; i++) {
+        tex_geom *t = &g[i];
+        t->format = formats[i];
+        t->nibble = hapf_nibble_from_format(formats[i]);
+        t->compressor = compressors[i];
+        t->bytes = input_bytes[i];
+        t->bound = hapf_texture_bound(t->bytes, t->format, t->compressor, chunk_counts[i]);
+        t->header_len = t->bytes > 0xFFFFFFu ? 8u : 4u;              /* hap.c:398-405 */
+        if (t->compressor == HapCompressorSnappy) {
+            t->chunk_count = hapf_limit_chunk_count(t->bytes, t->format, chunk_counts[i]);
+            t->chunk_bytes = (unsigned)(t->bytes / t->chunk_count);
+            any_snappy = 1;
+        } else {
+            t->chunk_count = 1;
+            t->chunk_bytes = (unsigned)t->bytes;
+        }
+        t->fpc = (t->chunk_bytes + frag_bytes - 1) / frag_bytes;
+        if (t->compressor == HapCompressorSnappy) {
+            /* header choice uses the layout that will actually be written (hap.c:425-428) */
+            size_t ilen = hapf_instructions_length(t->chunk_count);
+            if (flags & HAPGPU_ENCODE_FRAGMENT_INDEX)
+                ilen += 8u + 4u * (size_t)t->chunk_count * t->fpc;
+            if (ilen + 4u > 0xFFFFFFu)
+                return HapResult_Bad_Arguments;   /* instruction container must fit a 24-bit length */
+            if (t->bytes + ilen + 4u > 0xFFFFFFu)
+                t->header_len = 8u;
+        }
+        if ((size_t)t->chunk_count * t->fpc > max_frags_per_tex)
+            max_frags_per_tex = t->chunk_count * t->fpc;
+        frags_per_frame += t->chunk_count * t->fpc;
+        stage_in_bytes += align_up(t->bytes, 256);
+        frame_raw_bound += t->header_len + t->bytes;
+    }
+    frame_raw_bound += outer_header;
+    slot_stride = (unsigned)align_up(frag_bytes + frag_bytes / 32u + 64u, 16);
+
+    /* per-frame checks; frames that fail are left out of the launch */
+    live_index = (unsigned *)malloc(sizeof(unsigned) * frame_count);
+    stage_off_in = (size_t *)calloc(frame_count, sizeof(size_t));
+    stage_off_out = (size_t *)calloc(frame_count, sizeof(size_t));
+    if (!live_index || !stage_off_in || !stage_off_out) {
+        free(live_index); free(stage_off_in); free(stage_off_out);
+        return HapResult_Internal_Error;
+    }
+    {
+        size_t in_total = 0, out_total = 0;
+        for (f = 0; f < frame_count; f++) {
+            unsigned rc = HapResult_No_Error;
+            if (!outputs[f] || output_bytes[f] == 0)
+                rc = HapResult_Bad_Arguments;
+            for (i = 0; rc == HapResult_No_Error && i < count; i++)
+                if (!inputs[(size_t)f * count + i])
+                    rc = HapResult_Bad_Arguments;
+            if (rc == HapResult_No_Error) {
+                /* hap.c:386-389 for the first texture; later textures are re-checked against
+                   the space actually left once the sizes are known */
+                size_t avail = output_bytes[f] > outer_header ? output_bytes[f] - outer_header : 0;
+                if (avail < g[0].bound || output_bytes[f] < frame_raw_bound)
+                    rc = HapResult_Buffer_Too_Small;
+                /* second texture: the reference compares its bound with what is left after the
+                   first section's ACTUAL size (hap.c:589); that size is not known before the
+                   launch, so the first section's maximum (raw storage) is assumed */
+                else if (count == 2 && avail - (g[0].header_len + g[0].bytes) < g[1].bound)
+                    rc = HapResult_Buffer_Too_Small;
+            }
+            results[f] = rc;
+            output_used[f] = 0;
+            if (rc != HapResult_No_Error) {
+                if (first_error == HapResult_No_Error)
+                    first_error = rc;
+                continue;
+            }
+            live_index[live++] = f;
+            if (!inputs_are_device) {
+                int staged = 0;
+                for (i = 0; i < count; i++)
+                    if (!is_dev(ctx, inputs[(size_t)f * count + i]))
+                        staged = 1;
+                if (staged) {
+                    stage_off_in[f] = in_total + 1;         /* +1: 0 means "not staged" */
+                    in_total += stage_in_bytes;
+                }
+            }
+            if (!is_dev(ctx, outputs[f])) {
+                stage_off_out[f] = out_total + 1;
+                out_total += align_up(frame_raw_bound, 256);
+            }
+        }
+        stage_in_bytes = in_total;
+        stage_out_bytes = out_total;
+    }
+    if (live == 0) {
+        free(live_index); free(stage_off_in); free(stage_off_out);
+        return first_error;
+    }
+
+    /* scratch */
+    hframes = (HapGpuFrameEnc *)hapgpu_rt_pinned_scratch(rt, P_FRAMES, sizeof(HapGpuFrameEnc) * live);
+    dframes = (HapGpuFrameEnc *)hapgpu_rt_device_scratch(rt, D_FRAMES, sizeof(HapGpuFrameEnc) * live);
+    dslots = any_snappy ? (uint8_t *)hapgpu_rt_device_scratch(rt, D_SLOTS, (size_t)slot_stride * frags_per_frame * live) : NULL;
+    dfragsizes = (uint32_t *)hapgpu_rt_device_scratch(rt, D_FRAGSIZES, sizeof(uint32_t) * (size_t)frags_per_frame * live);
+    dcopies = (HapGpuCopyEntry *)hapgpu_rt_device_scratch(rt, D_COPIES, sizeof(HapGpuCopyEntry) * (size_t)frags_per_frame * live);
+    if (stage_in_bytes)
+        tex_stage = (uint8_t *)hapgpu_rt_device_scratch(rt, D_TEX_STAGE, stage_in_bytes);
+    if (stage_out_bytes)
+        out_stage = (uint8_t *)hapgpu_rt_device_scratch(rt, D_FRAME_STAGE, stage_out_bytes);
+    if (!hframes || !dframes || (any_snappy && !dslots) || !dfragsizes || !dcopies ||
+        (stage_in_bytes && !tex_stage) || (stage_out_bytes && !out_stage)) {
+        free(live_index); free(stage_off_in); free(stage_off_out);
+        for (f = 0; f < frame_count; f++)
+            if (results[f] == HapResult_No_Error)
+                results[f] = HapResult_Internal_Error;
+        return HapResult_Internal_Error;
+    }
+
+    /* descriptors (+ host->device staging of textures) */
+    {
+        unsigned k, rc = 0;
+        for (k = 0; k < live; k++) {
+            HapGpuFrameEnc *fe = &hframes[k];
+            size_t in_cursor = 0;
+            f = live_index[k];
+            memset(fe, 0, sizeof(*fe));
+            fe->dst = (uint64_t)(uintptr_t)(stage_off_out[f] ? out_stage + (stage_off_out[f] - 1) : (uint8_t *)outputs[f]);
+            fe->dst_cap = output_bytes[f];
+            fe->tex_count = count;
+            fe->outer_header_len = outer_header;
+            fe->status = HapResult_Internal_Error;   /* overwritten by the pack kernel */
+            for (i = 0; i < count; i++) {
+                HapGpuTexEnc *te = &fe->tex[i];
+                const void *src = inputs[(size_t)f * count + i];
+                if (stage_off_in[f] && !is_dev(ctx, src)) {
+                    uint8_t *d = tex_stage + (stage_off_in[f] - 1) + in_cursor;
+                    rc |= (unsigned)hapgpu_rt_h2d(rt, d, src, g[i].bytes);
+                    src = d;
+                }
+                in_cursor += align_up(g[i].bytes, 256);
+                te->src = (uint64_t)(uintptr_t)src;
+                te->bytes = (uint32_t)g[i].bytes;
+                te->format_nibble = g[i].nibble;
+                te->compressor = g[i].compressor;
+                te->chunk_count = g[i].chunk_count;
+                te->chunk_bytes = g[i].chunk_bytes;
+                te->header_len = g[i].header_len;
+                te->frags_per_chunk = g[i].fpc;
+                te->frag_first = k * frags_per_frame + (i ? g[0].chunk_count * g[0].fpc : 0u);
+                te->emit_index = (flags & HAPGPU_ENCODE_FRAGMENT_INDEX) ? 1u : 0u;
+            }
+        }
+        rc |= (unsigned)hapgpu_rt_h2d(rt, dframes, hframes, sizeof(HapGpuFrameEnc) * live);
+        if (any_snappy)
+            rc |= (unsigned)hapgpu_k_snappy_compress(rt, dframes, live, max_frags_per_tex, frag_log2, dslots, slot_stride, dfragsizes);
+        rc |= (unsigned)hapgpu_k_frame_pack(rt, dframes, live, frag_log2, dslots, slot_stride, dfragsizes, dcopies);
+        rc |= (unsigned)hapgpu_k_frame_gather(rt, dcopies, frags_per_frame * live);
+        rc |= (unsigned)hapgpu_rt_d2h(rt, hframes, dframes, sizeof(HapGpuFrameEnc) * live);
+        rc |= (unsigned)hapgpu_rt_sync(rt);
+        if (rc) {
+            for (k = 0; k < live; k++)
+                results[live_index[k]] = HapResult_Internal_Error;
+            free(live_index); free(stage_off_in); free(stage_off_out);
+            return HapResult_Internal_Error;
+        }
+        /* results (+ device->host copy of staged frames) */
+        {
+            int copied = 0;
+            for (k = 0; k < live; k++) {
+                HapGpuFrameEnc *fe = &hframes[k];
+                f = live_index[k];
+                results[f] = fe->status;
+                if (fe->status == HapResult_No_Error) {
+                    output_used[f] = (unsigned long)fe->bytes_used;
+                    if (stage_off_out[f]) {
+                        if (hapgpu_rt_d2h(rt, outputs[f], out_stage + (stage_off_out[f] - 1), (size_t)fe->bytes_used))
+                            results[f] = HapResult_Internal_Error;
+                        copied = 1;
+                    }
+                }
+                if (results[f] != HapResult_No_Error && first_error == HapResult_No_Error)
+                    first_error = results[f];
+            }
+            if (copied && hapgpu_rt_sync(rt))
+                first_error = HapResult_Internal_Error;
+        }
+    }
+    free(live_index); free(stage_off_in); free(stage_off_out);
+    return first_error;
+}
+
+unsigned hapb_compress_rgba(HapGpuContext *ctx, const void *rgba, unsigned width, unsigned height,
+                            unsigned long row_bytes, unsigned format, void *output,
+                            unsigned long output_bytes, unsigned long *used, int synchronise)
+{
+    hapgpu_rt *rt = ctx->rt;
+    size_t block = (format == HapTextureFormat_RGB_DXT1 || format == HapTextureFormat_A_RGTC1) ? 8u : 16u;
+    size_t need, rgba_bytes;
+    const void *src = rgba;
+    void *dst = output;
+    int rc = 0;
+    if (!rgba || !output || width == 0 || height == 0 || (width & 3u) || (height & 3u) ||
+        row_bytes < (unsigned long)width * 4ul ||
+        (format != HapTextureFormat_RGB_DXT1 && format != HapTextureFormat_RGBA_DXT5 &&
+         format != HapTextureFormat_YCoCg_DXT5 && format != HapTextureFormat_A_RGTC1))
+        return HapResult_Bad_Arguments;
+    need = (size_t)(width / 4u) * (height / 4u) * block;
+    if (output_bytes < need)
+        return HapResult_Buffer_Too_Small;
+    rgba_bytes = (size_t)row_bytes * (height - 1u) + (size_t)width * 4u;
+    if (!is_dev(ctx, rgba)) {
+        void *s = hapgpu_rt_device_scratch(rt, D_RGBA_STAGE, rgba_bytes);
+        if (!s || hapgpu_rt_h2d(rt, s, rgba, rgba_bytes))
+            return HapResult_Internal_Error;
+        src = s;
+    }
+    if (!is_dev(ctx, output)) {
+        dst = hapgpu_rt_device_scratch(rt, D_BC_TEX, need);
+        if (!dst)
+            return HapResult_Internal_Error;
+    }
+    rc = hapgpu_k_block_encode(rt, src, width, height, row_bytes, format, dst);
+    if (rc == 1)
+        return HapResult_Bad_Arguments;
+    if (rc)
+        return HapResult_Internal_Error;
+    if (dst != output && hapgpu_rt_d2h(rt, output, dst, need))
+        return HapResult_Internal_Error;
+    if ((synchronise || dst != output) && hapgpu_rt_sync(rt))
+        return HapResult_Internal_Error;
+    if (used)
+        *used = (unsigned long)need;
+    return HapResult_No_Error;
+}
+
+unsigned hapb_encode_rgba(HapGpuContext *ctx, unsigned frame_count, const void *const *rgba_frames,
+                          unsigned width, unsigned height, unsigned long row_bytes, unsigned count,
+                          const unsigned *formats, const unsigned *compressors, const unsigned *chunk_counts,
+                          void *const *outputs, const unsigned long *output_bytes,
+                          unsigned long *output_used, unsigned *results, unsigned flags)
+{
+    hapgpu_rt *rt = ctx->rt;
+    unsigned long tex_bytes[2] = {0, 0};
+    size_t per_frame = 0, rgba_bytes, tex_off[2] = {0, 0};
+    unsigned i, f, rc;
+    uint8_t *textures, *rgba_stage = NULL;
+    const void **tex_ptrs;
+    if (frame_count == 0)
+        return HapResult_No_Error;
+    if (!results || !rgba_frames || count == 0 || count > 2 || !formats || width == 0 || height == 0 ||
+        (width & 3u) || (height & 3u) || row_bytes < (unsigned long)width * 4ul) {
+        for (f = 0; results && f < frame_count; f++)
+            results[f] = HapResult_Bad_Arguments;
+        return HapResult_Bad_Arguments;
+    }
+    for (i = 0; i < count; i++) {
+        size_t block;
+        if (formats[i] != HapTextureFormat_RGB_DXT1 && formats[i] != HapTextureFormat_RGBA_DXT5 &&
+            formats[i] != HapTextureFormat_YCoCg_DXT5 && formats[i] != HapTextureFormat_A_RGTC1) {
+            for (f = 0; f < frame_count; f++)
+                results[f] = HapResult_Bad_Arguments;
+            return HapResult_Bad_Arguments;
+        }
+        block = (formats[i] == HapTextureFormat_RGB_DXT1 || formats[i] == HapTextureFormat_A_RGTC1) ? 8u : 16u;
+        tex_bytes[i] = (unsigned long)((size_t)(width / 4u) * (height / 4u) * block);
+        tex_off[i] = per_frame;
+        per_frame += align_up(tex_bytes[i], 256);
+    }
+    rgba_bytes = (size_t)row_bytes * (height - 1u) + (size_t)width * 4u;
+    textures = (uint8_t *)hapgpu_rt_device_scratch(rt, D_BC_TEX, per_frame * frame_count);
+    tex_ptrs = (const void **)malloc(sizeof(void *) * (size_t)frame_count * count);
+    if (!textures || !tex_ptrs) {
+        free(tex_ptrs);
+        for (f = 0; f < frame_count; f++)
+            results[f] = HapResult_Internal_Error;
+        return HapResult_Internal_Error;
+    }
+    for (f = 0; f < frame_count; f++) {
+        const void *src = rgba_frames[f];
+        for (i = 0; i < count; i++)
+            tex_ptrs[(size_t)f * count + i] = NULL;     /* NULL input => Bad_Arguments for that frame */
+        if (!src)
+            continue;
+        if (!is_dev(ctx, src)) {
+            /* one staging buffer per frame so that uploads and kernels can overlap on the stream */
+            if (!rgba_stage) {
+                rgba_stage = (uint8_t *)hapgpu_rt_device_scratch(rt, D_RGBA_STAGE, align_up(rgba_bytes, 256) * frame_count);
+                if (!rgba_stage)
+                    break;
+            }
+            if (hapgpu_rt_h2d(rt, rgba_stage + align_up(rgba_bytes, 256) * f, src, rgba_bytes))
+                break;
+            src = rgba_stage + align_up(rgba_bytes, 256) * f;
+        }
+        for (i = 0; i < count; i++) {
+            uint8_t *t = textures + per_frame * f + tex_off[i];
+            int k = hapgpu_k_block_encode(rt, src, width, height, row_bytes, formats[i], t);
+            if (k == 0)
+                tex_ptrs[(size_t)f * count + i] = t;
+        }
+    }
+    rc = hapb_encode(ctx, frame_count, count, tex_ptrs, tex_bytes, formats, compressors, chunk_counts, outputs,
+                     output_bytes, output_used, results, flags, 1);
+    free(tex_ptrs);
+    return rc;
+}
+
+/* ================================================================== decode */
+
+typedef struct fetch_ctx {
+    HapGpuContext *ctx;
+    const uint8_t *device_frame;
+} fetch_ctx;
+
+static int fetch_from_device(void *user, uint64_t offset, uint64_t length, uint8_t *dst)
+{
+    fetch_ctx *fc = (fetch_ctx *)user;
+    if (hapgpu_rt_d2h(fc->ctx->rt, dst, fc->device_frame + offset, (size_t)length))
+        return 1;
+    return hapgpu_rt_sync(fc->ctx->rt);
+}
+
+/* work function handed to the client's HapDecodeCallback: marks chunk `index` as requested */
+typedef struct request_marks {
+    unsigned count;
+    volatile unsigned char *requested;
+} request_marks;
+
+static void mark_chunk(void *p, unsigned index)
+{
+    request_marks *m = (request_marks *)p;
+    if (m && index < m->count)
+        m->requested[index] = 1;
+}
+
+unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const *inputs,
+                     const unsigned long *input_bytes, unsigned index, void *const *outputs,
+                     const unsigned long *output_bytes, unsigned long *output_used,
+                     unsigned *output_formats, unsigned *results, unsigned flags,
+                     HapDecodeCallback callback, void *callback_info)
+{
+    hapgpu_rt *rt = ctx->rt;
+    hapf_texture_plan *plans;
+    hapf_reader *readers;
+    fetch_ctx *fetchers;
+    unsigned f, live = 0, first_error = HapResult_No_Error, total_units = 0, total_chunks = 0;
+    unsigned frag_log2_seen = 0;
+    int any_stream = 0, need_retry = 0;
+    uint8_t *prefix = NULL, *in_stage = NULL, *out_stage = NULL;
+    size_t in_stage_bytes = 0, out_stage_bytes = 0;
+    size_t *in_off, *out_off;
+    HapGpuDecodeJob *hjobs, *djobs;
+    HapGpuChunkIn *hchunks, *dchunks;
+    HapGpuDecodeUnit *dunits;
+    unsigned *job_of_frame;
+    int rc = 0;
+
+    if (frame_count == 0)
+        return HapResult_No_Error;
+    if (!results)
+        return HapResult_Bad_Arguments;
+    if (!inputs || !input_bytes || !outputs || !output_bytes || index > 1) {
+        for (f = 0; f < frame_count; f++)
+            results[f] = HapResult_Bad_Arguments;
+        return HapResult_Bad_Arguments;
+    }
+    plans = (hapf_texture_plan *)calloc(frame_count, sizeof(*plans));
+    readers = (hapf_reader *)calloc(frame_count, sizeof(*readers));
+    fetchers = (fetch_ctx *)calloc(frame_count, sizeof(*fetchers));
+    in_off = (size_t *)calloc(frame_count, sizeof(size_t));
+    out_off = (size_t *)calloc(frame_count, sizeof(size_t));
+    job_of_frame = (unsigned *)calloc(frame_count, sizeof(unsigned));
+    if (!plans || !readers || !fetchers || !in_off || !out_off || !job_of_frame) {
+        rc = 1;
+        goto fail_alloc;
+    }
+
+    /* 1. make the container headers host-visible: device frames get a prefix copied back */
+    {
+        unsigned device_frames = 0;
+        for (f = 0; f < frame_count; f++) {
+            results[f] = HapResult_No_Error;
+            if (!inputs[f] || !outputs[f]) {
+                results[f] = HapResult_Bad_Arguments;
+                continue;
+            }
+            if (is_dev(ctx, inputs[f]))
+                device_frames++;
+        }
+        if (device_frames) {
+            prefix = (uint8_t *)hapgpu_rt_pinned_scratch(rt, P_PREFIX, (size_t)PREFIX_BYTES * frame_count);
+            if (!prefix) {
+                rc = 1;
+                goto fail_alloc;
+            }
+        }
+        for (f = 0; f < frame_count; f++) {
+            if (results[f] != HapResult_No_Error)
+                continue;
+            if (is_dev(ctx, inputs[f])) {
+                size_t n = input_bytes[f] < PREFIX_BYTES ? input_bytes[f] : PREFIX_BYTES;
+                rc |= hapgpu_rt_d2h(rt, prefix + (size_t)PREFIX_BYTES * f, inputs[f], n);
+                hapf_reader_init_host(&readers[f], prefix + (size_t)PREFIX_BYTES * f, n);
+                fetchers[f].ctx = ctx;
+                fetchers[f].device_frame = (const uint8_t *)inputs[f];
+                readers[f].fetch = fetch_from_device;
+                readers[f].user = &fetchers[f];
+            } else {
+                hapf_reader_init_host(&readers[f], inputs[f], input_bytes[f]);
+                in_off[f] = in_stage_bytes + 1;
+                in_stage_bytes += align_up(input_bytes[f], 256);
+            }
+        }
+        if (device_frames)
+            rc |= hapgpu_rt_sync(rt);
+        if (rc)
+            goto fail_alloc;
+    }
+
+    /* 2. plan on the host: sections and tables only (hap_frame.c) */
+    for (f = 0; f < frame_count; f++) {
+        hapf_texture_plan *p = &plans[f];
+        unsigned units = 0;
+        int c;
+        if (results[f] != HapResult_No_Error)
+            continue;
+        hapf_plan_texture(&readers[f], (uint32_t)input_bytes[f], index, 1, p);
+        if (output_formats && p->format)
+            output_formats[f] = p->format;
+        if (p->result != HapResult_No_Error) {
+            results[f] = p->result;
+            continue;
+        }
+        if (flags & HAPGPU_DECODE_IGNORE_FRAGMENT_INDEX)
+            p->frag_table_offset = 0;
+        if (p->mode == HAPGPU_JOB_COMPLEX) {
+            unsigned per_chunk = 0;
+            if (p->frag_table_offset && p->chunk_count > 0 && p->frag_entries % (unsigned)p->chunk_count == 0)
+                per_chunk = p->frag_entries / (unsigned)p->chunk_count;
+            else
+                p->frag_table_offset = 0;
+            for (c = 0; c < p->chunk_count; c++) {
+                HapGpuChunkIn *ch = &p->chunks[c];
+                unsigned codec = ch->codec & 0xFFu;
+                ch->unit_first = units;
+                ch->frag_first = per_chunk * (unsigned)c;
+                if (codec == HAP_NIBBLE_SNAPPY)
+                    ch->unit_count = per_chunk ? per_chunk : 1u;
+                else if (codec == HAP_NIBBLE_NONE)
+                    ch->unit_count = ch->src_len ? (ch->src_len + COPY_PIECE - 1) / COPY_PIECE : 1u;
+                else
+                    ch->unit_count = 1u;
+                units += ch->unit_count;
+                if (codec == HAP_NIBBLE_SNAPPY && !per_chunk)
+                    any_stream = 1;
+                if (codec == HAP_NIBBLE_NONE)
+                    any_stream = 1;
+            }
+            if (per_chunk) {
+                if (frag_log2_seen && frag_log2_seen != p->frag_log2) {
+                    /* one fragment size per launch: later frames fall back to whole-stream units */
+                    p->frag_table_offset = 0;
+                    units = 0;
+                    for (c = 0; c < p->chunk_count; c++) {
+                        HapGpuChunkIn *ch = &p->chunks[c];
+                        if ((ch->codec & 0xFFu) == HAP_NIBBLE_SNAPPY)
+                            ch->unit_count = 1u;
+                        ch->unit_first = units;
+                        units += ch->unit_count;
+                    }
+                    any_stream = 1;
+                } else {
+                    frag_log2_seen = p->frag_log2;
+                }
+            }
+            total_chunks += (unsigned)p->chunk_count;
+        } else if (p->mode == HAPGPU_JOB_RAW) {
+            units = p->section_length ? (p->section_length + COPY_PIECE - 1) / COPY_PIECE : 1u;
+            any_stream = 1;
+        } else {
+            units = 1;
+            any_stream = 1;
+        }
+        job_of_frame[f] = live++;
+        total_units += units;
+        p->frag_entries = p->frag_table_offset ? p->frag_entries : 0;
+        p->unit_count = units;
+        if (!is_dev(ctx, outputs[f])) {
+            out_off[f] = out_stage_bytes + 1;
+            out_stage_bytes += align_up(output_bytes[f], 256);
+        }
+    }
+    if (live == 0)
+        goto finish;
+
+    /* 3. device descriptors */
+    hjobs = (HapGpuDecodeJob *)hapgpu_rt_pinned_scratch(rt, P_JOBS, sizeof(HapGpuDecodeJob) * live);
+    hchunks = (HapGpuChunkIn *)hapgpu_rt_pinned_scratch(rt, P_CHUNKS, sizeof(HapGpuChunkIn) * (total_chunks + 1u));
+    djobs = (HapGpuDecodeJob *)hapgpu_rt_device_scratch(rt, D_JOBS, sizeof(HapGpuDecodeJob) * live);
+    dchunks = (HapGpuChunkIn *)hapgpu_rt_device_scratch(rt, D_CHUNKS, sizeof(HapGpuChunkIn) * (total_chunks + 1u));
+    dunits = (HapGpuDecodeUnit *)hapgpu_rt_device_scratch(rt, D_UNITS, sizeof(HapGpuDecodeUnit) * (total_units + 1u));
+    if (in_stage_bytes)
+        in_stage = (uint8_t *)hapgpu_rt_device_scratch(rt, D_IN_STAGE, in_stage_bytes);
+    if (out_stage_bytes)
+        out_stage = (uint8_t *)hapgpu_rt_device_scratch(rt, D_OUT_STAGE, out_stage_bytes);
+    if (!hjobs || !hchunks || !djobs || !dchunks || !dunits || (in_stage_bytes && !in_stage) ||
+        (out_stage_bytes && !out_stage)) {
+        rc = 1;
+        goto fail_alloc;
+    }
+    {
+        unsigned chunk_cursor = 0, unit_cursor = 0;
+        request_marks marks;
+        marks.count = 0;
+        marks.requested = NULL;
+        for (f = 0; f < frame_count; f++) {
+            hapf_texture_plan *p = &plans[f];
+            HapGpuDecodeJob *job;
+            const uint8_t *frame_dev;
+            unsigned units;
+            if (results[f] != HapResult_No_Error)
+                continue;
+            units = p->unit_count;
+            job = &hjobs[job_of_frame[f]];
+            memset(job, 0, sizeof(*job));
+            if (in_off[f]) {
+                uint8_t *d = in_stage + (in_off[f] - 1);
+                rc |= hapgpu_rt_h2d(rt, d, inputs[f], input_bytes[f]);
+                frame_dev = d;
+            } else {
+                frame_dev = (const uint8_t *)inputs[f];
+            }
+            job->dst = (uint64_t)(uintptr_t)(out_off[f] ? out_stage + (out_off[f] - 1) : (uint8_t *)outputs[f]);
+            job->dst_cap = output_bytes[f];
+            job->mode = p->mode;
+            job->unit_count = units;
+            job->units = (uint64_t)(uintptr_t)(dunits + unit_cursor);
+            job->status = HapResult_Internal_Error;
+            if (p->mode == HAPGPU_JOB_COMPLEX) {
+                job->payload = (uint64_t)(uintptr_t)(frame_dev + p->payload_offset);
+                job->payload_len = p->payload_length;
+                job->chunk_count = (uint32_t)p->chunk_count;
+                job->chunks = (uint64_t)(uintptr_t)(dchunks + chunk_cursor);
+                if (p->frag_table_offset) {
+                    job->frag_sizes = (uint64_t)(uintptr_t)(frame_dev + p->frag_table_offset);
+                    job->frag_log2 = p->frag_log2;
+                    job->frag_entries = p->frag_entries;
+                }
+                if (p->chunk_count > 0)
+                    memcpy(hchunks + chunk_cursor, p->chunks, sizeof(HapGpuChunkIn) * (size_t)p->chunk_count);
+                chunk_cursor += (unsigned)p->chunk_count;
+            } else {
+                job->payload = (uint64_t)(uintptr_t)(frame_dev + p->section_offset);
+                job->payload_len = p->section_length;
+            }
+            unit_cursor += units;
+        }
+        rc |= hapgpu_rt_h2d(rt, djobs, hjobs, sizeof(HapGpuDecodeJob) * live);
+        if (total_chunks)
+            rc |= hapgpu_rt_h2d(rt, dchunks, hchunks, sizeof(HapGpuChunkIn) * total_chunks);
+        rc |= hapgpu_k_decode_plan(rt, djobs, live, dunits, total_units);
+
+        /* hap.h callback contract (single-frame HapDecode only): the client is asked to "run" the
+           chunks once planning succeeded and there is more than one (reference hap.c:852-862) */
+        if (callback && frame_count == 1 && !rc && results[0] == HapResult_No_Error &&
+            plans[0].mode == HAPGPU_JOB_COMPLEX && plans[0].chunk_count > 1) {
+            unsigned char *req;
+            int c, all = 1;
+            rc |= hapgpu_rt_d2h(rt, hjobs, djobs, sizeof(HapGpuDecodeJob));
+            rc |= hapgpu_rt_sync(rt);
+            if (!rc && hjobs[0].status == HapResult_No_Error) {
+                req = (unsigned char *)calloc((size_t)plans[0].chunk_count, 1);
+                if (!req) {
+                    rc = 1;
+                } else {
+                    marks.count = (unsigned)plans[0].chunk_count;
+                    marks.requested = req;
+                    callback(mark_chunk, &marks, marks.count, callback_info);
+                    for (c = 0; c < plans[0].chunk_count; c++)
+                        if (!req[c])
+                            all = 0;
+                    if (!all) {
+                        /* chunks the client never asked for stay undecoded: blank their units */
+                        HapGpuDecodeUnit *blank = (HapGpuDecodeUnit *)calloc(1, sizeof(HapGpuDecodeUnit));
+                        for (c = 0; blank && c < plans[0].chunk_count; c++) {
+                            unsigned k;
+                            if (req[c])
+                                continue;
+                            for (k = 0; k < plans[0].chunks[c].unit_count; k++)
+                                rc |= hapgpu_rt_h2d(rt, dunits + plans[0].chunks[c].unit_first + k, blank, sizeof(*blank));
+                        }
+                        rc |= hapgpu_rt_sync(rt);
+                        free(blank);
+                    }
+                    free(req);
+                }
+            }
+        }
+        rc |= hapgpu_k_snappy_decode(rt, dunits, total_units, djobs, frag_log2_seen, any_stream);
+        rc |= hapgpu_rt_d2h(rt, hjobs, djobs, sizeof(HapGpuDecodeJob) * live);
+        rc |= hapgpu_rt_sync(rt);
+        if (rc)
+            goto fail_alloc;
+    }
+
+    /* 4. results */
+    {
+        int copied = 0;
+        for (f = 0; f < frame_count; f++) {
+            HapGpuDecodeJob *job;
+            if (results[f] != HapResult_No_Error)
+                continue;
+            job = &hjobs[job_of_frame[f]];
+            if (job->status == HAPGPU_STATUS_INDEX_MISMATCH) {
+                need_retry = 1;
+                results[f] = HAPGPU_STATUS_INDEX_MISMATCH;
+                continue;
+            }
+            results[f] = job->status;
+            if (job->status == HapResult_No_Error) {
+                if (output_used)
+                    output_used[f] = (unsigned long)job->bytes_used;
+                if (out_off[f]) {
+                    rc |= hapgpu_rt_d2h(rt, outputs[f], out_stage + (out_off[f] - 1), (size_t)job->bytes_used);
+                    copied = 1;
+                }
+            }
+        }
+        if (copied)
+            rc |= hapgpu_rt_sync(rt);
+        if (rc)
+            goto fail_alloc;
+    }
+
+    /* 5. frames whose fragment table did not describe their streams: decode them the generic way */
+    if (need_retry) {
+        for (f = 0; f < frame_count; f++) {
+            if (results[f] != HAPGPU_STATUS_INDEX_MISMATCH)
+                continue;
+            results[f] = HapResult_No_Error;
+            hapb_decode(ctx, 1, &inputs[f], &input_bytes[f], index, &outputs[f], &output_bytes[f],
+                        output_used ? &output_used[f] : NULL, output_formats ? &output_formats[f] : NULL,
+                        &results[f], flags | HAPGPU_DECODE_IGNORE_FRAGMENT_INDEX, NULL, NULL);
+        }
+    }
+
+finish:
+    for (f = 0; f < frame_count; f++) {
+        if (results[f] != HapResult_No_Error && first_error == HapResult_No_Error)
+            first_error = results[f];
+        hapf_plan_free(&plans[f]);
+        hapf_reader_free(&readers[f]);
+    }
+    free(plans); free(readers); free(fetchers); free(in_off); free(out_off); free(job_of_frame);
+    return first_error;
+
+fail_alloc:
+    for (f = 0; f < frame_count; f++) {
+        if (results[f] == HapResult_No_Error || results[f] == HAPGPU_STATUS_INDEX_MISMATCH)
+            results[f] = HapResult_Internal_Error;
+        if (plans) hapf_plan_free(&plans[f]);
+        if (readers) hapf_reader_free(&readers[f]);
+    }
+    free(plans); free(readers); free(fetchers); free(in_off); free(out_off); free(job_of_frame);
+    return HapResult_Internal_Error;
+}

@@ -1,0 +1,39 @@
+/*
+ * hap_batch.h -- internal interface between hap_api.c (public symbols) and
+ * hap_batch.c (GPU orchestration).  Pure C.
+ */
+#ifndef HAP_BATCH_H
+#define HAP_BATCH_H
+
+#include "../../include/hap_gpu.h"
+#include "hap_frame.h"
+#include "hapgpu_abi.h"
+
+struct HapGpuContext {
+    hapgpu_rt *rt;
+    unsigned frag_log2;
+};
+
+/* inputs_are_device != 0: every input pointer is known to be device memory (skips classification) */
+unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
+                     const void *const *inputs, const unsigned long *input_bytes,
+                     const unsigned *formats, const unsigned *compressors, const unsigned *chunk_counts,
+                     void *const *outputs, const unsigned long *output_bytes,
+                     unsigned long *output_used, unsigned *results, unsigned flags,
+                     int inputs_are_device);
+unsigned hapb_compress_rgba(HapGpuContext *ctx, const void *rgba, unsigned width, unsigned height,
+                            unsigned long row_bytes, unsigned format, void *output,
+                            unsigned long output_bytes, unsigned long *used, int synchronise);
+unsigned hapb_encode_rgba(HapGpuContext *ctx, unsigned frame_count, const void *const *rgba_frames,
+                          unsigned width, unsigned height, unsigned long row_bytes, unsigned count,
+                          const unsigned *formats, const unsigned *compressors, const unsigned *chunk_counts,
+                          void *const *outputs, const unsigned long *output_bytes,
+                          unsigned long *output_used, unsigned *results, unsigned flags);
+/* callback/callback_info: only honoured for frame_count == 1 (the hap.h HapDecode path) */
+unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const *inputs,
+                     const unsigned long *input_bytes, unsigned index, void *const *outputs,
+                     const unsigned long *output_bytes, unsigned long *output_used,
+                     unsigned *output_formats, unsigned *results, unsigned flags,
+                     HapDecodeCallback callback, void *callback_info);
+
+#endif

@@ -1,0 +1,172 @@
+/*
+ * hapgpu_abi.h -- the thin C ABI between the host-side C code (hap_api.c,
+ * hap_batch.c, hap_frame.c: pure C99, no HIP headers) and the HIP translation
+ * unit (hapgpu_runtime.hip + kernels).  Plain pointers, integers and PODs
+ * only.  Structures marked [device] are laid out identically for gcc/clang
+ * host code and hipcc device code (fixed-width members, natural alignment).
+ */
+#ifndef HAPGPU_ABI_H
+#define HAPGPU_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- container constants (reference hap.c:41-51, 84-88) ---- */
+#define HAP_NIBBLE_NONE 0xAu
+#define HAP_NIBBLE_SNAPPY 0xBu
+#define HAP_NIBBLE_COMPLEX 0xCu
+#define HAP_SECTION_MULTI 0x0Du
+#define HAP_SECTION_INSTRUCTIONS 0x01u
+#define HAP_SECTION_COMPRESSORS 0x02u
+#define HAP_SECTION_SIZES 0x03u
+#define HAP_SECTION_OFFSETS 0x04u
+#define HAP_SECTION_FRAGMENTS 0x46u   /* private: hap_gpu.h */
+#define HAP_FRAGMENT_TABLE_VERSION 1u
+
+/* internal status codes beyond HapResult (never returned to API callers) */
+#define HAPGPU_STATUS_INDEX_MISMATCH 100u /* fragment index inconsistent: redo without it */
+
+/* ------------------------------------------------------------------ */
+/* encode side                                                          */
+/* ------------------------------------------------------------------ */
+
+/* [device] one texture of one frame */
+typedef struct HapGpuTexEnc {
+    uint64_t src;            /* device address of the block-compressed texture */
+    uint32_t bytes;          /* texture bytes */
+    uint32_t format_nibble;  /* low nibble of the section type (hap.c:45-51) */
+    uint32_t compressor;     /* 0 none, 1 snappy (hap.h:50-53) */
+    uint32_t chunk_count;    /* already limited (hap.c:277-300) */
+    uint32_t chunk_bytes;    /* bytes / chunk_count */
+    uint32_t header_len;     /* 4 or 8 (hap.c:398-405, 425-428) */
+    uint32_t frags_per_chunk;
+    uint32_t frag_first;     /* global index of this texture's first fragment */
+    uint32_t emit_index;     /* write the fragment-size section */
+    uint32_t reserved;
+} HapGpuTexEnc;
+
+/* [device] one frame */
+typedef struct HapGpuFrameEnc {
+    uint64_t dst;            /* device address of the frame buffer */
+    uint64_t dst_cap;
+    uint32_t tex_count;      /* 1 or 2 */
+    uint32_t outer_header_len; /* 0 (single texture), 4 or 8 (hap.c:562-576) */
+    HapGpuTexEnc tex[2];
+    /* results */
+    uint64_t bytes_used;
+    uint32_t status;
+    uint32_t reserved;
+} HapGpuFrameEnc;
+
+/* [device] one byte-range move of the gather pass (one per fragment) */
+typedef struct HapGpuCopyEntry {
+    uint64_t src;
+    uint64_t dst;
+    uint32_t len;
+    uint32_t reserved;
+} HapGpuCopyEntry;
+
+/* ------------------------------------------------------------------ */
+/* decode side                                                          */
+/* ------------------------------------------------------------------ */
+
+/* [device] one chunk as listed by the frame's tables (hap.c:794-809) */
+typedef struct HapGpuChunkIn {
+    uint32_t src_off;        /* from the start of the payload ("frame_data") */
+    uint32_t src_len;
+    uint32_t codec;          /* compressor table byte; bit 31 set = not requested by the client */
+    uint32_t unit_first;     /* first unit slot of this chunk (relative to the job) */
+    uint32_t unit_count;     /* slots reserved for it */
+    uint32_t frag_first;     /* first fragment-table entry of this chunk, if the frame has one */
+} HapGpuChunkIn;
+
+#define HAPGPU_JOB_COMPLEX 0u
+#define HAPGPU_JOB_SNAPPY 1u  /* 0xB_: one Snappy stream (hap.c:885-904) */
+#define HAPGPU_JOB_RAW 2u     /* 0xA_ (hap.c:905-916) */
+
+/* [device] one texture to decode */
+typedef struct HapGpuDecodeJob {
+    uint64_t payload;        /* device address of the first chunk's bytes */
+    uint64_t payload_len;    /* bytes from payload to the end of the texture section */
+    uint64_t dst;
+    uint64_t dst_cap;
+    uint64_t chunks;         /* device address of HapGpuChunkIn[chunk_count] */
+    uint64_t frag_sizes;     /* device address of the u32 fragment-size entries inside the frame, or 0 */
+    uint64_t units;          /* device address of this job's HapGpuDecodeUnit[unit_count] */
+    uint32_t chunk_count;
+    uint32_t mode;           /* HAPGPU_JOB_* */
+    uint32_t frag_log2;
+    uint32_t frag_entries;   /* number of fragment-size entries */
+    uint32_t unit_count;
+    uint32_t reserved;
+    /* results */
+    uint64_t bytes_used;
+    uint32_t status;         /* HapResult or HAPGPU_STATUS_* */
+    uint32_t reserved2;
+} HapGpuDecodeJob;
+
+#define HAPGPU_UNIT_SKIP 0u
+#define HAPGPU_UNIT_SNAPPY_STREAM 1u   /* varint header + elements */
+#define HAPGPU_UNIT_SNAPPY_FRAGMENT 2u /* bare elements producing exactly dst_len bytes */
+#define HAPGPU_UNIT_COPY 3u
+
+/* [device] one wavefront's worth of decode work */
+typedef struct HapGpuDecodeUnit {
+    uint64_t src;
+    uint64_t dst;
+    uint32_t src_len;
+    uint32_t dst_len;
+    uint32_t kind;           /* HAPGPU_UNIT_* */
+    uint32_t job;            /* index of the owning job (status word) */
+} HapGpuDecodeUnit;
+
+/* ------------------------------------------------------------------ */
+/* runtime + launchers (implemented in hapgpu_runtime.hip)              */
+/* ------------------------------------------------------------------ */
+typedef struct hapgpu_rt hapgpu_rt;
+
+int hapgpu_rt_create(int device, hapgpu_rt **rt);
+void hapgpu_rt_destroy(hapgpu_rt *rt);
+/* 1: HIP device memory (usable by kernels in place), 0: host memory */
+int hapgpu_rt_is_device_ptr(hapgpu_rt *rt, const void *p);
+/* grow-only scratch arenas, slot 0..15; contents undefined after growth */
+void *hapgpu_rt_device_scratch(hapgpu_rt *rt, int slot, size_t bytes);
+void *hapgpu_rt_pinned_scratch(hapgpu_rt *rt, int slot, size_t bytes);
+int hapgpu_rt_h2d(hapgpu_rt *rt, void *dst, const void *src, size_t bytes);
+int hapgpu_rt_d2h(hapgpu_rt *rt, void *dst, const void *src, size_t bytes);
+int hapgpu_rt_d2d(hapgpu_rt *rt, void *dst, const void *src, size_t bytes);
+int hapgpu_rt_sync(hapgpu_rt *rt);
+void hapgpu_rt_lock(hapgpu_rt *rt);
+void hapgpu_rt_unlock(hapgpu_rt *rt);
+
+/* kernels: all asynchronous on the runtime's stream; 0 = launched */
+int hapgpu_k_block_encode(hapgpu_rt *rt, const void *rgba, unsigned width, unsigned height,
+                          size_t row_bytes, unsigned hap_texture_format, void *out);
+int hapgpu_k_snappy_compress(hapgpu_rt *rt, const HapGpuFrameEnc *frames, unsigned frame_count,
+                             unsigned max_frags_per_texture, unsigned frag_log2,
+                             void *slots, unsigned slot_stride, uint32_t *frag_sizes);
+int hapgpu_k_frame_pack(hapgpu_rt *rt, HapGpuFrameEnc *frames, unsigned frame_count,
+                        unsigned frag_log2, const void *slots, unsigned slot_stride,
+                        const uint32_t *frag_sizes, HapGpuCopyEntry *copies);
+int hapgpu_k_frame_gather(hapgpu_rt *rt, const HapGpuCopyEntry *copies, unsigned count);
+/* clears `units` (all SKIP) then plans every job */
+int hapgpu_k_decode_plan(hapgpu_rt *rt, HapGpuDecodeJob *jobs, unsigned job_count,
+                         HapGpuDecodeUnit *units, unsigned unit_count);
+/* frag_log2: fragment size of the batch's FRAGMENT units (0: none present) */
+int hapgpu_k_snappy_decode(hapgpu_rt *rt, const HapGpuDecodeUnit *units, unsigned unit_count,
+                           HapGpuDecodeJob *jobs, unsigned frag_log2, int any_stream_or_copy_units);
+
+/* measurement */
+void hapgpu_rt_set_profiling(hapgpu_rt *rt, int enable);
+int hapgpu_rt_collect_profile(hapgpu_rt *rt, unsigned long *launches, double *ms, unsigned classes);
+int hapgpu_rt_timer_start(hapgpu_rt *rt);
+int hapgpu_rt_timer_stop(hapgpu_rt *rt, double *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

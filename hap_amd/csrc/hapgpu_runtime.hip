@@ -1,0 +1,335 @@
+// hapgpu_runtime.hip -- the HIP side of the C ABI in hapgpu_abi.h: device/stream ownership,
+// grow-only scratch arenas, host<->device staging, kernel launchers and the HIP-event
+// instrumentation bench.py reads.  Everything here is plumbing; the kernels live in
+// bc_encode.hip, snappy_compress.hip, frame_pack.hip and snappy_decode.hip.
+#include <hip/hip_runtime.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "hapgpu_abi.h"
+
+extern "C" {
+int hapgpu_launch_block_encode(const void *rgba, unsigned width, unsigned height, size_t row_bytes,
+                               unsigned format, void *out, hipStream_t stream);
+int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsigned frame_count, unsigned max_frags_per_texture,
+                                  unsigned frag_log2, void *slots, unsigned slot_stride, uint32_t *frag_sizes,
+                                  hipStream_t stream);
+int hapgpu_launch_frame_pack(HapGpuFrameEnc *frames, unsigned frame_count, unsigned frag_log2, const void *slots,
+                             unsigned slot_stride, const uint32_t *frag_sizes, HapGpuCopyEntry *copies,
+                             hipStream_t stream);
+int hapgpu_launch_frame_gather(const HapGpuCopyEntry *copies, unsigned count, hipStream_t stream);
+int hapgpu_launch_decode_plan(HapGpuDecodeJob *jobs, unsigned job_count, hipStream_t stream);
+int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsigned unit_count, HapGpuDecodeJob *jobs,
+                                unsigned frag_log2, int any_stream_or_copy_units, hipStream_t stream);
+}
+
+namespace {
+constexpr int kSlots = 16;
+constexpr int kClasses = 6;
+
+struct timed_launch {
+    int cls;
+    hipEvent_t start, stop;
+};
+}
+
+struct hapgpu_rt {
+    int device;
+    hipStream_t stream;
+    void *dev[kSlots];
+    size_t dev_cap[kSlots];
+    void *pin[kSlots];
+    size_t pin_cap[kSlots];
+    pthread_mutex_t lock;
+    int profiling;
+    std::vector<timed_launch> pending;
+    std::vector<hipEvent_t> free_events;
+    hipEvent_t t0, t1;
+};
+
+#define HIP_OK(expr) ((expr) == hipSuccess)
+
+static void complain(const char *what, hipError_t e)
+{
+    fprintf(stderr, "hap_amd: %s failed: %s\n", what, hipGetErrorString(e));
+}
+
+extern "C" int hapgpu_rt_create(int device, hapgpu_rt **out)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        fprintf(stderr, "hap_amd: no HIP device available (%s); the Hap hot path has no CPU fallback\n",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return 4;
+    }
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess)
+            device = 0;
+    }
+    if (device >= count)
+        return 1;
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        complain("hipSetDevice", e);
+        return 4;
+    }
+    hapgpu_rt *rt = new hapgpu_rt();
+    rt->device = device;
+    memset(rt->dev, 0, sizeof(rt->dev));
+    memset(rt->dev_cap, 0, sizeof(rt->dev_cap));
+    memset(rt->pin, 0, sizeof(rt->pin));
+    memset(rt->pin_cap, 0, sizeof(rt->pin_cap));
+    rt->profiling = 0;
+    pthread_mutex_init(&rt->lock, NULL);
+    if ((e = hipStreamCreateWithFlags(&rt->stream, hipStreamNonBlocking)) != hipSuccess) {
+        complain("hipStreamCreate", e);
+        delete rt;
+        return 4;
+    }
+    if (hipEventCreate(&rt->t0) != hipSuccess || hipEventCreate(&rt->t1) != hipSuccess) {
+        delete rt;
+        return 4;
+    }
+    *out = rt;
+    return 0;
+}
+
+extern "C" void hapgpu_rt_destroy(hapgpu_rt *rt)
+{
+    if (!rt)
+        return;
+    (void)hipSetDevice(rt->device);
+    (void)hipStreamSynchronize(rt->stream);
+    for (int i = 0; i < kSlots; i++) {
+        if (rt->dev[i]) (void)hipFree(rt->dev[i]);
+        if (rt->pin[i]) (void)hipHostFree(rt->pin[i]);
+    }
+    for (auto &p : rt->pending) {
+        (void)hipEventDestroy(p.start);
+        (void)hipEventDestroy(p.stop);
+    }
+    for (auto &ev : rt->free_events)
+        (void)hipEventDestroy(ev);
+    (void)hipEventDestroy(rt->t0);
+    (void)hipEventDestroy(rt->t1);
+    (void)hipStreamDestroy(rt->stream);
+    pthread_mutex_destroy(&rt->lock);
+    delete rt;
+}
+
+extern "C" void hapgpu_rt_lock(hapgpu_rt *rt)
+{
+    pthread_mutex_lock(&rt->lock);
+    (void)hipSetDevice(rt->device);
+}
+
+extern "C" void hapgpu_rt_unlock(hapgpu_rt *rt) { pthread_mutex_unlock(&rt->lock); }
+
+extern "C" int hapgpu_rt_is_device_ptr(hapgpu_rt *rt, const void *p)
+{
+    (void)rt;
+    hipPointerAttribute_t attr;
+    memset(&attr, 0, sizeof(attr));
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();      // unregistered host memory: clear the sticky error
+        return 0;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged || attr.type == hipMemoryTypeArray;
+}
+
+extern "C" void *hapgpu_rt_device_scratch(hapgpu_rt *rt, int slot, size_t bytes)
+{
+    if (slot < 0 || slot >= kSlots)
+        return NULL;
+    if (bytes == 0)
+        bytes = 256;
+    if (rt->dev_cap[slot] < bytes) {
+        // contents are not preserved; wait for work that may still use the old block
+        (void)hipStreamSynchronize(rt->stream);
+        if (rt->dev[slot])
+            (void)hipFree(rt->dev[slot]);
+        rt->dev[slot] = NULL;
+        rt->dev_cap[slot] = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipMalloc(&rt->dev[slot], want);
+        if (e != hipSuccess) {
+            complain("hipMalloc(scratch)", e);
+            return NULL;
+        }
+        rt->dev_cap[slot] = want;
+    }
+    return rt->dev[slot];
+}
+
+extern "C" void *hapgpu_rt_pinned_scratch(hapgpu_rt *rt, int slot, size_t bytes)
+{
+    if (slot < 0 || slot >= kSlots)
+        return NULL;
+    if (bytes == 0)
+        bytes = 256;
+    if (rt->pin_cap[slot] < bytes) {
+        (void)hipStreamSynchronize(rt->stream);
+        if (rt->pin[slot])
+            (void)hipHostFree(rt->pin[slot]);
+        rt->pin[slot] = NULL;
+        rt->pin_cap[slot] = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipHostMalloc(&rt->pin[slot], want, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            complain("hipHostMalloc(scratch)", e);
+            return NULL;
+        }
+        rt->pin_cap[slot] = want;
+    }
+    return rt->pin[slot];
+}
+
+extern "C" int hapgpu_rt_h2d(hapgpu_rt *rt, void *dst, const void *src, size_t bytes)
+{
+    if (!bytes) return 0;
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, rt->stream);
+    if (e != hipSuccess) { complain("hipMemcpyAsync(H2D)", e); return 4; }
+    return 0;
+}
+
+extern "C" int hapgpu_rt_d2h(hapgpu_rt *rt, void *dst, const void *src, size_t bytes)
+{
+    if (!bytes) return 0;
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, rt->stream);
+    if (e != hipSuccess) { complain("hipMemcpyAsync(D2H)", e); return 4; }
+    return 0;
+}
+
+extern "C" int hapgpu_rt_d2d(hapgpu_rt *rt, void *dst, const void *src, size_t bytes)
+{
+    if (!bytes) return 0;
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, rt->stream);
+    if (e != hipSuccess) { complain("hipMemcpyAsync(D2D)", e); return 4; }
+    return 0;
+}
+
+extern "C" int hapgpu_rt_sync(hapgpu_rt *rt)
+{
+    hipError_t e = hipStreamSynchronize(rt->stream);
+    if (e != hipSuccess) { complain("hipStreamSynchronize", e); return 4; }
+    return 0;
+}
+
+// ---- instrumentation -----------------------------------------------------------------------
+
+static hipEvent_t take_event(hapgpu_rt *rt)
+{
+    if (!rt->free_events.empty()) {
+        hipEvent_t ev = rt->free_events.back();
+        rt->free_events.pop_back();
+        return ev;
+    }
+    hipEvent_t ev = nullptr;
+    (void)hipEventCreate(&ev);
+    return ev;
+}
+
+struct scoped_timing {
+    hapgpu_rt *rt;
+    timed_launch t;
+    bool on;
+    scoped_timing(hapgpu_rt *r, int cls) : rt(r), on(r->profiling != 0)
+    {
+        if (on) {
+            t.cls = cls;
+            t.start = take_event(rt);
+            t.stop = take_event(rt);
+            (void)hipEventRecord(t.start, rt->stream);
+        }
+    }
+    ~scoped_timing()
+    {
+        if (on) {
+            (void)hipEventRecord(t.stop, rt->stream);
+            rt->pending.push_back(t);
+        }
+    }
+};
+
+extern "C" void hapgpu_rt_set_profiling(hapgpu_rt *rt, int enable) { rt->profiling = enable; }
+
+extern "C" int hapgpu_rt_collect_profile(hapgpu_rt *rt, unsigned long *launches, double *ms, unsigned classes)
+{
+    if (hipStreamSynchronize(rt->stream) != hipSuccess)
+        return 4;
+    for (auto &p : rt->pending) {
+        float dt = 0.f;
+        if (hipEventElapsedTime(&dt, p.start, p.stop) == hipSuccess && (unsigned)p.cls < classes) {
+            launches[p.cls] += 1;
+            ms[p.cls] += (double)dt;
+        }
+        rt->free_events.push_back(p.start);
+        rt->free_events.push_back(p.stop);
+    }
+    rt->pending.clear();
+    return 0;
+}
+
+extern "C" int hapgpu_rt_timer_start(hapgpu_rt *rt) { return HIP_OK(hipEventRecord(rt->t0, rt->stream)) ? 0 : 4; }
+
+extern "C" int hapgpu_rt_timer_stop(hapgpu_rt *rt, double *ms)
+{
+    float dt = 0.f;
+    if (!HIP_OK(hipEventRecord(rt->t1, rt->stream)) || !HIP_OK(hipEventSynchronize(rt->t1)) ||
+        !HIP_OK(hipEventElapsedTime(&dt, rt->t0, rt->t1)))
+        return 4;
+    *ms = (double)dt;
+    return 0;
+}
+
+// ---- launchers -----------------------------------------------------------------------------
+
+extern "C" int hapgpu_k_block_encode(hapgpu_rt *rt, const void *rgba, unsigned width, unsigned height,
+                                     size_t row_bytes, unsigned hap_texture_format, void *out)
+{
+    scoped_timing st(rt, 0);
+    return hapgpu_launch_block_encode(rgba, width, height, row_bytes, hap_texture_format, out, rt->stream);
+}
+
+extern "C" int hapgpu_k_snappy_compress(hapgpu_rt *rt, const HapGpuFrameEnc *frames, unsigned frame_count,
+                                        unsigned max_frags_per_texture, unsigned frag_log2, void *slots,
+                                        unsigned slot_stride, uint32_t *frag_sizes)
+{
+    scoped_timing st(rt, 1);
+    return hapgpu_launch_snappy_compress(frames, frame_count, max_frags_per_texture, frag_log2, slots, slot_stride,
+                                         frag_sizes, rt->stream);
+}
+
+extern "C" int hapgpu_k_frame_pack(hapgpu_rt *rt, HapGpuFrameEnc *frames, unsigned frame_count, unsigned frag_log2,
+                                   const void *slots, unsigned slot_stride, const uint32_t *frag_sizes,
+                                   HapGpuCopyEntry *copies)
+{
+    scoped_timing st(rt, 2);
+    return hapgpu_launch_frame_pack(frames, frame_count, frag_log2, slots, slot_stride, frag_sizes, copies, rt->stream);
+}
+
+extern "C" int hapgpu_k_frame_gather(hapgpu_rt *rt, const HapGpuCopyEntry *copies, unsigned count)
+{
+    scoped_timing st(rt, 3);
+    return hapgpu_launch_frame_gather(copies, count, rt->stream);
+}
+
+extern "C" int hapgpu_k_decode_plan(hapgpu_rt *rt, HapGpuDecodeJob *jobs, unsigned job_count,
+                                    HapGpuDecodeUnit *units, unsigned unit_count)
+{
+    // unit slots the planner does not reach (it stops at the first malformed chunk) must read as SKIP
+    if (unit_count && hipMemsetAsync(units, 0, (size_t)unit_count * sizeof(HapGpuDecodeUnit), rt->stream) != hipSuccess)
+        return 4;
+    scoped_timing st(rt, 4);
+    return hapgpu_launch_decode_plan(jobs, job_count, rt->stream);
+}
+
+extern "C" int hapgpu_k_snappy_decode(hapgpu_rt *rt, const HapGpuDecodeUnit *units, unsigned unit_count,
+                                      HapGpuDecodeJob *jobs, unsigned frag_log2, int any_stream_or_copy_units)
+{
+    scoped_timing st(rt, 5);
+    return hapgpu_launch_snappy_decode(units, unit_count, jobs, frag_log2, any_stream_or_copy_units, rt->stream);
+}

@@ -1,0 +1,257 @@
+// snappy_compress.hip -- per-fragment Snappy compressor for gfx950.
+//
+// Replaces the snappy_compress call-out of the reference's chunk loop (hap.c:448-476, call at
+// hap.c:453).  libsnappy itself compresses independent 64 KiB fragments with a per-fragment
+// hash table; here a fragment is 2^frag_log2 bytes (default 16 KiB) so that
+// fragment + hash table fit in LDS several times per CU, and one wavefront compresses one
+// fragment.  Output is ordinary Snappy elements (literal / copy-1 / copy-2); a chunk's stream is
+// varint(chunk bytes) followed by its fragments' element runs, concatenated by the pack/gather
+// kernels (frame_pack.hip).  The produced bytes differ from libsnappy's (Snappy encoding is not
+// unique); parity is defined as: the reference decoder reproduces the input exactly.
+//
+// Per 64-byte tile, lane l owns input position p = tile*64 + l:
+//   1. match finding, all lanes at once: (a) hash of the 4 bytes at p -> most recent earlier
+//      position with that hash (LDS u16 table, updated after the lookup), verified and extended
+//      up to 64 bytes; (b) fixed distances 8 and 16 (the block pitch of DXT data) through wave
+//      ballots: equality bit per position, run length = count-trailing-ones of the shifted mask.
+//   2. greedy selection: the scalar unit walks the ballot of "match >= 4" left to right,
+//      skipping the bytes each chosen copy covers (v_readlane for the length).
+//   3. emission, all lanes at once: uncovered positions are literal bytes; every lane knows the
+//      number of bytes it emits (0..3), offsets come from two ballots + mbcnt, and each lane
+//      stores its own tag/data bytes.
+// HBM traffic: fragment read once, compressed bytes written once.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hapgpu_abi.h"
+
+namespace {
+
+constexpr unsigned kHashBits = 12;
+constexpr unsigned kHashEntries = 1u << kHashBits;
+
+__device__ __forceinline__ unsigned uniform(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
+{
+    return ((unsigned long long)uniform((unsigned)(v >> 32)) << 32) | uniform((unsigned)v);
+}
+
+// 4 bytes at an arbitrary LDS byte offset (two aligned dword reads + byte align)
+__device__ __forceinline__ unsigned lds_load32(const uint32_t *words, unsigned byte_off)
+{
+    const unsigned w = byte_off >> 2;
+    return __builtin_amdgcn_alignbyte(words[w + 1], words[w], byte_off & 3u);
+}
+
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ unsigned bits_below(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// run of consecutive 1 bits starting at bit `lane` of the 128-bit value next:cur, capped at 64
+__device__ __forceinline__ unsigned run_from(unsigned long long cur, unsigned long long next, unsigned lane)
+{
+    const unsigned long long a = ~(cur >> lane);
+    const unsigned avail = 64u - lane;
+    unsigned r = a ? (unsigned)__builtin_ctzll(a) : 64u;
+    if (r >= avail) {
+        const unsigned long long b = ~next;
+        r = avail + (b ? (unsigned)__builtin_ctzll(b) : 64u);
+    }
+    return min(r, 64u);
+}
+
+__global__ __launch_bounds__(64) void snappy_compress_kernel(const HapGpuFrameEnc *__restrict__ frames,
+                                                             unsigned frag_log2, uint8_t *__restrict__ slots,
+                                                             unsigned slot_stride, uint32_t *__restrict__ frag_sizes)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const unsigned frag_bytes = 1u << frag_log2;
+    uint32_t *dataw = reinterpret_cast<uint32_t *>(smem);                 // frag_bytes + 16
+    const uint8_t *data = smem;
+    uint16_t *table = reinterpret_cast<uint16_t *>(smem + frag_bytes + 16);
+
+    const unsigned lane = threadIdx.x;
+    const HapGpuFrameEnc &frame = frames[blockIdx.z];
+    if (blockIdx.y >= frame.tex_count)
+        return;
+    const HapGpuTexEnc &tex = frame.tex[blockIdx.y];
+    if (tex.compressor != 1u)
+        return;
+    const unsigned x = blockIdx.x;
+    if (x >= tex.chunk_count * tex.frags_per_chunk)
+        return;
+    const unsigned chunk = x / tex.frags_per_chunk, j = x - chunk * tex.frags_per_chunk;
+    const unsigned begin = j << frag_log2;
+    const unsigned n = min(frag_bytes, tex.chunk_bytes - begin);
+    const uint8_t *src = (const uint8_t *)tex.src + (size_t)chunk * tex.chunk_bytes + begin;
+    const unsigned f = tex.frag_first + x;
+    uint8_t *out = slots + (size_t)f * slot_stride;
+
+    // ---- stage the fragment and clear the hash table ----
+    if (((uintptr_t)src & 15u) == 0) {
+        for (unsigned i = lane * 16u; i < n + 16u; i += 1024u) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (i + 16u <= n) {
+                v = *reinterpret_cast<const uint4 *>(src + i);
+            } else if (i < n) {
+                unsigned w[4] = {0, 0, 0, 0};
+                for (unsigned k = 0; i + k < n; k++)
+                    w[k >> 2] |= (unsigned)src[i + k] << (8 * (k & 3));
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            *reinterpret_cast<uint4 *>(smem + i) = v;
+        }
+    } else {
+        for (unsigned i = lane; i < n + 16u; i += 64u)
+            smem[i] = i < n ? src[i] : (uint8_t)0;
+    }
+    for (unsigned i = lane; i < kHashEntries / 2; i += 64u)
+        reinterpret_cast<uint32_t *>(table)[i] = 0u;
+    __syncthreads();
+
+    const unsigned tiles = (n + 63u) / 64u;
+    unsigned out_pos = 0;       // bytes emitted so far
+    unsigned skip = 0;          // leading positions of the current tile covered by an earlier copy
+
+    // equality ballots for the fixed distances, one tile ahead
+    auto eq_mask = [&](unsigned tile, unsigned d) -> unsigned long long {
+        const unsigned p = tile * 64u + lane;
+        const bool e = tile < tiles && p >= d && p < n && data[p] == data[p - d];
+        return __ballot(e);
+    };
+    unsigned long long m8 = eq_mask(0, 8), m16 = eq_mask(0, 16);
+
+    for (unsigned t = 0; t < tiles; t++) {
+        const unsigned p = t * 64u + lane;
+        const bool in_range = p < n;
+        const unsigned room = in_range ? min(64u, n - p) : 0u;      // longest match allowed here
+        const unsigned long long n8 = eq_mask(t + 1, 8), n16 = eq_mask(t + 1, 16);
+
+        // ---- (a) hash candidate ----
+        unsigned best_len = 0, best_off = 0;
+        if (p + 4u <= n) {
+            const unsigned cur = lds_load32(dataw, p);
+            const unsigned h = (cur * 0x1e35a7bdu) >> (32u - kHashBits);
+            const unsigned cand = table[h];
+            table[h] = (uint16_t)p;
+            if (cand < p && lds_load32(dataw, cand) == cur) {
+                unsigned l = 4;
+                while (l < room) {
+                    const unsigned diff = lds_load32(dataw, cand + l) ^ lds_load32(dataw, p + l);
+                    if (diff) {
+                        l += (unsigned)__builtin_ctz(diff) >> 3;
+                        break;
+                    }
+                    l += 4;
+                }
+                best_len = min(l, room);
+                best_off = p - cand;
+            }
+        }
+        // ---- (b) fixed distances ----
+        {
+            const unsigned l8 = min(run_from(m8, n8, lane), room);
+            const unsigned l16 = min(run_from(m16, n16, lane), room);
+            if (l16 > best_len) { best_len = l16; best_off = 16; }
+            if (l8 >= best_len && l8 >= 4) { best_len = l8; best_off = 8; }
+        }
+        m8 = n8;
+        m16 = n16;
+
+        // ---- greedy selection on the scalar unit ----
+        const unsigned long long cand_mask = __ballot(in_range && best_len >= 4u);
+        unsigned long long sel = 0, covered = skip >= 64u ? ~0ull : ((1ull << skip) - 1ull);
+        unsigned cursor = min(skip, 64u);
+        unsigned carry = skip >= 64u ? skip - 64u : 0u;
+        while (cursor < 64u) {
+            const unsigned long long rest = cand_mask >> cursor;
+            if (!rest)
+                break;
+            const unsigned s = cursor + (unsigned)__builtin_ctzll(rest);
+            const unsigned len = (unsigned)__builtin_amdgcn_readlane((int)best_len, (int)s);
+            sel |= 1ull << s;
+            const unsigned e = s + len;
+            covered |= (e >= 64u ? ~0ull : ((1ull << e) - 1ull)) & ~((1ull << s) - 1ull);
+            cursor = e;
+            if (e >= 64u) {
+                carry = e - 64u;
+                break;
+            }
+        }
+        skip = carry;
+        sel = uniform64(sel);
+        covered = uniform64(covered);
+
+        // ---- emission ----
+        const unsigned long long valid = n - t * 64u >= 64u ? ~0ull : ((1ull << (n - t * 64u)) - 1ull);
+        const unsigned long long lit = ~covered & valid;
+        const unsigned long long starts = lit & ~(lit << 1);
+        const bool is_lit = (lit >> lane) & 1ull;
+        const bool is_start = (starts >> lane) & 1ull;
+        const bool is_copy = (sel >> lane) & 1ull;
+        unsigned run = 0;
+        if (is_start) {
+            const unsigned long long a = ~(lit >> lane);
+            run = a ? (unsigned)__builtin_ctzll(a) : 64u;
+        }
+        const bool copy1 = best_len < 12u && best_off < 2048u;
+        unsigned emit = 0;
+        if (is_lit)
+            emit = 1u + (is_start ? (run > 60u ? 2u : 1u) : 0u);
+        else if (is_copy)
+            emit = copy1 ? 2u : 3u;
+        const unsigned long long e0 = __ballot(emit & 1u), e1 = __ballot(emit & 2u);
+        unsigned at = out_pos + bits_below(e0) + 2u * bits_below(e1);
+        if (is_lit) {
+            if (is_start) {
+                if (run > 60u) {
+                    out[at++] = (uint8_t)(60u << 2);
+                    out[at++] = (uint8_t)(run - 1u);
+                } else {
+                    out[at++] = (uint8_t)((run - 1u) << 2);
+                }
+            }
+            out[at] = data[p];
+        } else if (is_copy) {
+            if (copy1) {
+                out[at] = (uint8_t)(1u | ((best_len - 4u) << 2) | ((best_off >> 8) << 5));
+                out[at + 1] = (uint8_t)best_off;
+            } else {
+                out[at] = (uint8_t)(2u | ((best_len - 1u) << 2));
+                out[at + 1] = (uint8_t)best_off;
+                out[at + 2] = (uint8_t)(best_off >> 8);
+            }
+        }
+        out_pos += (unsigned)__popcll(e0) + 2u * (unsigned)__popcll(e1);
+    }
+    if (lane == 0)
+        frag_sizes[f] = out_pos;
+}
+
+} // namespace
+
+// LDS bytes needed per workgroup for a fragment size
+static unsigned compress_lds_bytes(unsigned frag_log2) { return (1u << frag_log2) + 16u + kHashEntries * 2u; }
+
+extern "C" int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsigned frame_count,
+                                             unsigned max_frags_per_texture, unsigned frag_log2, void *slots,
+                                             unsigned slot_stride, uint32_t *frag_sizes, hipStream_t stream)
+{
+    if (frame_count == 0 || max_frags_per_texture == 0)
+        return 0;
+    if (frag_log2 < 10 || frag_log2 > 16)
+        return 1;
+    const unsigned lds = compress_lds_bytes(frag_log2);
+    if (lds > 65536u) {
+        static bool once = false;
+        if (!once) {
+            if (hipFuncSetAttribute((const void *)snappy_compress_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return 4;
+            once = true;
+        }
+    }
+    hipLaunchKernelGGL(snappy_compress_kernel, dim3(max_frags_per_texture, 2, frame_count), dim3(64), lds, stream,
+                       frames, frag_log2, (uint8_t *)slots, slot_stride, frag_sizes);
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}

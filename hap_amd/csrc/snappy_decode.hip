@@ -1,0 +1,525 @@
+// snappy_decode.hip -- decode planner + per-unit Snappy decoder for gfx950.
+//
+// Replaces, for HapDecode, the reference's planning loop (hap.c:794-838: per-chunk
+// snappy_uncompressed_length + running output offsets), its HapDecodeCallback fan-out
+// (hap.c:852-862), and the worker hap_decode_chunk (hap.c:606-642: snappy_uncompress | memcpy).
+//
+//   decode_plan_kernel   one wavefront per texture: reads every chunk's varint, prefix-sums the
+//                        output offsets, applies the reference's error precedence, and expands
+//                        chunks into decode units (whole stream, independent fragment, raw copy).
+//   snappy_decode_kernel one wavefront per unit.  The element chain of a Snappy stream is serial,
+//                        so a wave walks it element by element (tag parsed from an LDS staging
+//                        window with broadcast reads, wave-uniform control flow) and all 64 lanes
+//                        move the element's bytes.  The most recent RING bytes of output live in
+//                        LDS, so back-references are LDS->LDS; finished 4 KiB segments are written
+//                        to HBM with 16-byte-per-lane stores.  HBM traffic = compressed bytes read
+//                        once + output written once.
+//
+// Parallelism comes from the number of units: chunks x frames for foreign frames, and
+// fragments (16 KiB of output each) x chunks x frames for frames carrying hap_amd's fragment
+// table (section 0x46, see include/hap_gpu.h).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hapgpu_abi.h"
+
+namespace {
+
+constexpr unsigned kResBadFrame = 3, kResTooSmall = 2, kResInternal = 4;
+constexpr unsigned kCopyPiece = 65536;   // raw chunks are copied in pieces of this size
+
+// ------------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------------
+
+// varint32 length prefix (<= 5 bytes, fifth byte < 16). Returns header bytes, 0 if malformed.
+__device__ unsigned parse_varint(const uint8_t *p, unsigned avail, unsigned *value)
+{
+    unsigned v = 0;
+    for (unsigned i = 0; i < 5; i++) {
+        if (i >= avail)
+            return 0;
+        const unsigned b = p[i];
+        if (i == 4 && b >= 16)
+            return 0;
+        v |= (b & 0x7fu) << (7 * i);
+        if (!(b & 0x80u)) {
+            *value = v;
+            return i + 1;
+        }
+    }
+    return 0;
+}
+
+__device__ void emit_copy_units(HapGpuDecodeUnit *u, unsigned slots, const uint8_t *src, uint8_t *dst,
+                                unsigned len, unsigned job)
+{
+    for (unsigned k = 0; k < slots; k++) {
+        const unsigned long long at = (unsigned long long)k * kCopyPiece;
+        HapGpuDecodeUnit w;
+        w.src = (uint64_t)(src + at);
+        w.dst = (uint64_t)(dst + at);
+        w.src_len = at < len ? min(kCopyPiece, (unsigned)(len - at)) : 0u;
+        w.dst_len = w.src_len;
+        w.kind = w.src_len ? HAPGPU_UNIT_COPY : HAPGPU_UNIT_SKIP;
+        w.job = job;
+        u[k] = w;
+    }
+}
+
+__global__ __launch_bounds__(64) void decode_plan_kernel(HapGpuDecodeJob *jobs, unsigned job_count)
+{
+    const unsigned j = blockIdx.x, lane = threadIdx.x;
+    if (j >= job_count)
+        return;
+    HapGpuDecodeJob *job = &jobs[j];
+    HapGpuDecodeUnit *units = (HapGpuDecodeUnit *)job->units;
+    const uint8_t *payload = (const uint8_t *)job->payload;
+    uint8_t *dst = (uint8_t *)job->dst;
+
+    if (job->mode != HAPGPU_JOB_COMPLEX) {
+        if (lane != 0)
+            return;
+        unsigned status = 0;
+        unsigned long long used = 0;
+        for (unsigned k = 0; k < job->unit_count; k++)
+            units[k].kind = HAPGPU_UNIT_SKIP;
+        if (job->mode == HAPGPU_JOB_RAW) {                 // reference hap.c:905-916
+            used = job->payload_len;
+            if (used > job->dst_cap)
+                status = kResTooSmall;
+            else
+                emit_copy_units(units, job->unit_count, payload, dst, (unsigned)used, j);
+        } else {                                           // reference hap.c:885-904
+            unsigned n = 0;
+            const unsigned h = parse_varint(payload, (unsigned)min(job->payload_len, (uint64_t)5), &n);
+            if (!h)
+                status = kResInternal;
+            else if (n > job->dst_cap)
+                status = kResTooSmall;
+            else {
+                HapGpuDecodeUnit w;
+                w.src = (uint64_t)payload; w.dst = (uint64_t)dst;
+                w.src_len = (unsigned)job->payload_len; w.dst_len = n;
+                w.kind = HAPGPU_UNIT_SNAPPY_STREAM; w.job = j;
+                units[0] = w;
+                used = n;
+            }
+        }
+        job->bytes_used = used;
+        job->status = status;
+        return;
+    }
+
+    // complex: reference hap.c:794-843
+    const HapGpuChunkIn *chunks = (const HapGpuChunkIn *)job->chunks;
+    const unsigned n = job->chunk_count;
+    const uint32_t *frag_sizes = (const uint32_t *)job->frag_sizes;
+    const unsigned frag_bytes = 1u << job->frag_log2;
+    const unsigned per_chunk = (frag_sizes && n) ? job->frag_entries / n : 0u;
+    unsigned long long run = 0;
+    bool bad_varint = false, bad_codec = false;
+    for (unsigned base = 0; base < n; base += 64) {
+        const unsigned i = base + lane;
+        unsigned out_len = 0, hdr = 0, codec = 0;
+        bool bad = false, wanted = false;
+        HapGpuChunkIn c = {};
+        if (i < n) {
+            c = chunks[i];
+            codec = c.codec & 0xFFu;
+            wanted = (c.codec >> 31) == 0;
+            if (codec == HAP_NIBBLE_SNAPPY) {
+                hdr = parse_varint(payload + c.src_off, c.src_len, &out_len);
+                bad = hdr == 0;
+            } else {
+                out_len = c.src_len;
+                if (codec != HAP_NIBBLE_NONE && wanted)
+                    bad_codec = true;
+            }
+        }
+        // the reference stops at the first chunk whose length prefix is malformed
+        const unsigned long long badmask = __ballot(bad);
+        if (badmask) {
+            bad_varint = true;
+            break;
+        }
+        // inclusive scan of out_len across the wave
+        unsigned long long incl = out_len;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long up = __shfl_up(incl, d);
+            if ((int)lane >= d)
+                incl += up;
+        }
+        const unsigned long long my_off = run + incl - out_len;
+        run += __shfl(incl, 63);
+        if (i < n) {
+            HapGpuDecodeUnit *u = units + c.unit_first;
+            for (unsigned k = 0; k < c.unit_count; k++)
+                u[k].kind = HAPGPU_UNIT_SKIP;
+            if (!wanted || my_off + out_len > job->dst_cap) {
+                // not requested by the client / will be rejected as Buffer_Too_Small below
+            } else if (codec == HAP_NIBBLE_NONE) {
+                emit_copy_units(u, c.unit_count, payload + c.src_off, dst + my_off, c.src_len, j);
+            } else if (codec == HAP_NIBBLE_SNAPPY) {
+                bool indexed = false;
+                if (per_chunk && c.unit_count == per_chunk &&
+                    (unsigned long long)per_chunk * frag_bytes >= out_len &&
+                    (unsigned long long)(per_chunk - 1) * frag_bytes < out_len) {
+                    const uint32_t *fs = frag_sizes + c.frag_first;
+                    unsigned long long total = hdr;
+                    for (unsigned k = 0; k < per_chunk; k++)
+                        total += fs[k];
+                    if (total == c.src_len) {
+                        unsigned at = hdr;
+                        for (unsigned k = 0; k < per_chunk; k++) {
+                            HapGpuDecodeUnit w;
+                            w.src = (uint64_t)(payload + c.src_off + at);
+                            w.dst = (uint64_t)(dst + my_off + (unsigned long long)k * frag_bytes);
+                            w.src_len = fs[k];
+                            w.dst_len = min(frag_bytes, out_len - k * frag_bytes);
+                            w.kind = HAPGPU_UNIT_SNAPPY_FRAGMENT;
+                            w.job = j;
+                            u[k] = w;
+                            at += fs[k];
+                        }
+                        indexed = true;
+                    }
+                }
+                if (!indexed) {
+                    HapGpuDecodeUnit w;
+                    w.src = (uint64_t)(payload + c.src_off);
+                    w.dst = (uint64_t)(dst + my_off);
+                    w.src_len = c.src_len;
+                    w.dst_len = out_len;
+                    w.kind = HAPGPU_UNIT_SNAPPY_STREAM;
+                    w.job = j;
+                    u[0] = w;
+                }
+            }
+        }
+    }
+    bad_codec = __ballot(bad_codec) != 0;
+    if (lane == 0) {
+        unsigned status = 0;
+        if (bad_varint)
+            status = kResBadFrame;
+        else if (run > job->dst_cap)
+            status = kResTooSmall;
+        else if (bad_codec)
+            status = kResBadFrame;             // reference hap.c:637-640 via 867-875
+        job->bytes_used = run;
+        job->status = status;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// decode
+// ------------------------------------------------------------------------------------------
+
+constexpr unsigned kInBytes = 2048, kInGranule = 1024, kSegment = 4096;
+
+__device__ __forceinline__ unsigned uniform(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Cooperative byte-range copy global->global for raw chunks.
+__device__ void wave_copy(uint8_t *dst, const uint8_t *src, unsigned len, unsigned lane)
+{
+    if ((((uintptr_t)dst | (uintptr_t)src) & 15u) == 0) {
+        const unsigned wide = len >> 4;
+        for (unsigned i = lane; i < wide; i += 64)
+            reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
+        for (unsigned i = (wide << 4) + lane; i < len; i += 64)
+            dst[i] = src[i];
+    } else if ((((uintptr_t)dst | (uintptr_t)src) & 3u) == 0) {
+        const unsigned words = len >> 2;
+        for (unsigned i = lane; i < words; i += 64)
+            reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(src)[i];
+        for (unsigned i = (words << 2) + lane; i < len; i += 64)
+            dst[i] = src[i];
+    } else {
+        for (unsigned i = lane; i < len; i += 64)
+            dst[i] = src[i];
+    }
+}
+
+// Writes ring positions [from, to) to global memory; `to - from` <= RING.
+template <unsigned RING>
+__device__ void flush_ring(const uint8_t *ring, uint8_t *dst, unsigned from, unsigned to, unsigned lane)
+{
+    // head up to 16-byte alignment of the global address, then 16 B per lane, then tail
+    unsigned at = from;
+    const unsigned mis = (unsigned)((uintptr_t)(dst + at) & 15u);
+    if (mis) {
+        const unsigned head = min(16u - mis, to - at);
+        if (lane < head)
+            dst[at + lane] = ring[(at + lane) & (RING - 1)];
+        at += head;
+    }
+    const unsigned wide = (to - at) >> 4;
+    if (((at & 15u) == 0)) {
+        for (unsigned i = lane; i < wide; i += 64) {
+            const unsigned x = at + (i << 4);
+            *reinterpret_cast<uint4 *>(dst + x) = *reinterpret_cast<const uint4 *>(ring + (x & (RING - 1)));
+        }
+    } else {
+        // ring offset not 16-aligned relative to the global address: assemble from bytes
+        for (unsigned i = lane; i < wide; i += 64) {
+            const unsigned x = at + (i << 4);
+            unsigned w[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned y = x + 4 * k;
+                w[k] = (unsigned)ring[y & (RING - 1)] | ((unsigned)ring[(y + 1) & (RING - 1)] << 8) |
+                       ((unsigned)ring[(y + 2) & (RING - 1)] << 16) | ((unsigned)ring[(y + 3) & (RING - 1)] << 24);
+            }
+            *reinterpret_cast<uint4 *>(dst + x) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+    at += wide << 4;
+    if (at + lane < to)
+        dst[at + lane] = ring[(at + lane) & (RING - 1)];
+}
+
+template <unsigned RING, bool FRAGMENT>
+__global__ __launch_bounds__(64) void snappy_decode_kernel(const HapGpuDecodeUnit *__restrict__ units,
+                                                           unsigned unit_count, HapGpuDecodeJob *jobs)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *ring = smem;
+    uint32_t *inw = reinterpret_cast<uint32_t *>(smem + RING);
+    const uint8_t *inb = smem + RING;
+
+    const unsigned lane = threadIdx.x;
+    if (blockIdx.x >= unit_count)
+        return;
+    const HapGpuDecodeUnit u = units[blockIdx.x];
+    if (u.kind == HAPGPU_UNIT_SKIP)
+        return;
+    HapGpuDecodeJob *job = &jobs[u.job];
+    if (job->status != 0)
+        return;
+    if (u.kind == HAPGPU_UNIT_COPY) {
+        if (!FRAGMENT)      // raw copies ride with the stream-kernel launch
+            wave_copy((uint8_t *)u.dst, (const uint8_t *)u.src, u.src_len, lane);
+        return;
+    }
+    if ((u.kind == HAPGPU_UNIT_SNAPPY_FRAGMENT) != FRAGMENT)
+        return;
+
+    const uint8_t *src = (const uint8_t *)u.src;
+    uint8_t *dst = (uint8_t *)u.dst;
+    // stream coordinates are relative to the 16-byte aligned address at or below src
+    const unsigned shift = (unsigned)((uintptr_t)src & 15u);
+    const uint8_t *src_al = src - shift;
+    const unsigned in_end = shift + u.src_len;          // one past the last valid coordinate
+    const unsigned out_len = u.dst_len;
+
+    // Loads one 1 KiB granule (coordinate g*1024) into registers; bytes outside the unit read as 0.
+    auto load_granule = [&](unsigned g) -> uint4 {
+        const unsigned x = g * kInGranule + lane * 16u;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (x >= shift && x + 16u <= in_end) {
+            v = *reinterpret_cast<const uint4 *>(src_al + x);
+        } else if (x + 16u > shift && x < in_end) {
+            unsigned w[4] = {0, 0, 0, 0};
+            for (unsigned k = 0; k < 16; k++) {
+                const unsigned y = x + k;
+                if (y >= shift && y < in_end)
+                    w[k >> 2] |= (unsigned)src_al[y] << (8 * (k & 3));
+            }
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        return v;
+    };
+    auto store_granule = [&](unsigned g, uint4 v) {
+        *reinterpret_cast<uint4 *>(smem + RING + ((g & 1u) * kInGranule) + lane * 16u) = v;
+    };
+
+    unsigned ip = shift;
+    const unsigned granules = (in_end + kInGranule - 1) / kInGranule;
+    // staged window: granules next_g-2 and next_g-1, i.e. coordinates [in_hi-2048, in_hi)
+    store_granule(0, load_granule(0));
+    store_granule(1, load_granule(1));
+    unsigned next_g = 2, in_hi = 2 * kInGranule;
+    uint4 pend = make_uint4(0, 0, 0, 0);
+    bool pend_valid = false;
+    __syncthreads();
+
+    bool failed = false;
+    unsigned op = 0, flushed = 0;
+
+    if (!FRAGMENT) {
+        // skip the length prefix (validated by the plan kernel)
+        unsigned b;
+        do {
+            b = inb[ip & (kInBytes - 1)];
+            ip++;
+        } while ((b & 0x80u) && ip < in_end);
+        ip = uniform(ip);
+    }
+
+    while (ip < in_end) {
+        // ---- keep >= 256 staged bytes ahead of ip (or everything up to the end of the unit) ----
+        if (!pend_valid && next_g < granules && ip + 3 * (kInGranule / 2) >= in_hi) {
+            pend = load_granule(next_g);          // prefetch: consumed when the window slides
+            pend_valid = true;
+        }
+        if (ip + 256u > in_hi && next_g < granules + 1 && in_hi < granules * kInGranule) {
+            const unsigned g = ip / kInGranule;
+            if (g + 1 == next_g) {                // ip is in the newer staged granule: slide by one
+                store_granule(next_g, pend_valid ? pend : load_granule(next_g));
+                next_g += 1;
+            } else if (g >= next_g) {             // a long literal jumped past the window
+                store_granule(g, load_granule(g));
+                store_granule(g + 1, load_granule(g + 1));
+                next_g = g + 2;
+            }
+            pend_valid = false;
+            in_hi = next_g * kInGranule;
+            __syncthreads();
+        }
+        // ---- 8 bytes at ip, broadcast from LDS ----
+        const unsigned wi = ip >> 2;
+        const unsigned w0 = inw[wi & 511u], w1 = inw[(wi + 1) & 511u], w2 = inw[(wi + 2) & 511u];
+        const unsigned sh = (ip & 3u) * 8u;
+        const unsigned lo = uniform(sh ? (w0 >> sh) | (w1 << (32 - sh)) : w0);
+        const unsigned hi = uniform(sh ? (w1 >> sh) | (w2 << (32 - sh)) : w1);
+        const unsigned tag = lo & 0xFFu;
+        const unsigned kind = tag & 3u;
+        if (kind == 0) {
+            unsigned len = (tag >> 2) + 1u, hdr = 1;
+            if (len > 60u) {
+                const unsigned extra = len - 60u;                    // 1..4 length bytes
+                const unsigned long long field = (((unsigned long long)hi << 32) | lo) >> 8;
+                const unsigned v = (unsigned)(extra == 4 ? field : (field & ((1ull << (8 * extra)) - 1ull)));
+                hdr = 1 + extra;
+                if (hdr > in_end - ip || v == 0xFFFFFFFFu) { failed = true; break; }
+                len = v + 1u;
+            }
+            if (len > in_end - ip - hdr || len > out_len - op) { failed = true; break; }
+            ip += hdr;
+            // literal payload: from the staging window when it is inside, else straight from memory
+            for (unsigned done = 0; done < len; done += 64u) {
+                const unsigned n = min(64u, len - done);
+                const bool staged = ip + done + n <= in_hi;
+                if (lane < n) {
+                    const unsigned x = ip + done + lane;
+                    const uint8_t b = staged ? inb[x & (kInBytes - 1)] : src_al[x];
+                    ring[(op + lane) & (RING - 1)] = b;
+                }
+                op += n;
+                if (!FRAGMENT && op - flushed >= 2 * kSegment) {
+                    const unsigned upto = op & ~(kSegment - 1);
+                    flush_ring<RING>(ring, dst, flushed, upto, lane);
+                    flushed = upto;
+                }
+            }
+            ip += len;
+        } else {
+            unsigned len, off, hdr;
+            if (kind == 1) {
+                len = 4u + ((tag >> 2) & 7u);
+                off = ((tag >> 5) << 8) | ((lo >> 8) & 0xFFu);
+                hdr = 2;
+            } else if (kind == 2) {
+                len = (tag >> 2) + 1u;
+                off = (lo >> 8) & 0xFFFFu;
+                hdr = 3;
+            } else {
+                len = (tag >> 2) + 1u;
+                off = (lo >> 8) | (hi << 24);
+                hdr = 5;
+            }
+            if (hdr > in_end - ip || off == 0 || off > op || len > out_len - op) { failed = true; break; }
+            ip += hdr;
+            const unsigned from = op - off;
+            if (FRAGMENT || off + 64u <= RING) {
+                // source bytes live in the LDS ring (a fragment never wraps it)
+                if (lane < len) {
+                    unsigned rel = lane;
+                    if (off < len) {
+                        const unsigned q = (lane * ((65536u / off) + 1u)) >> 16;   // lane / off, exact for lane < 64
+                        rel = lane - q * off;
+                    }
+                    const uint8_t b = ring[(from + rel) & (RING - 1)];
+                    ring[(op + lane) & (RING - 1)] = b;
+                }
+            } else {
+                // far back-reference (> ring): the source bytes are in memory once everything
+                // produced so far is flushed; bypass this CU's L1 for the read-back
+                if (op > flushed) {
+                    flush_ring<RING>(ring, dst, flushed, op, lane);
+                    flushed = op;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (lane < len) {
+                    const uint8_t b = __hip_atomic_load(dst + from + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ring[(op + lane) & (RING - 1)] = b;
+                }
+            }
+            op += len;
+            if (!FRAGMENT && op - flushed >= 2 * kSegment) {
+                const unsigned upto = op & ~(kSegment - 1);
+                flush_ring<RING>(ring, dst, flushed, upto, lane);
+                flushed = upto;
+            }
+        }
+    }
+    if (!failed && op != out_len)
+        failed = true;
+    if (failed) {
+        if (lane == 0) {
+            const unsigned code = FRAGMENT ? HAPGPU_STATUS_INDEX_MISMATCH
+                                           : (job->mode == HAPGPU_JOB_SNAPPY ? kResInternal : kResBadFrame);
+            atomicCAS(&job->status, 0u, code);
+        }
+        return;
+    }
+    if (op > flushed)
+        flush_ring<RING>(ring, dst, flushed, op, lane);
+}
+
+} // namespace
+
+extern "C" int hapgpu_launch_decode_plan(HapGpuDecodeJob *jobs, unsigned job_count, hipStream_t stream)
+{
+    if (job_count == 0)
+        return 0;
+    hipLaunchKernelGGL(decode_plan_kernel, dim3(job_count), dim3(64), 0, stream, jobs, job_count);
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}
+
+// frag_log2: fragment size of FRAGMENT units in this batch (0 = none present).
+extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsigned unit_count, HapGpuDecodeJob *jobs,
+                                           unsigned frag_log2, int any_stream_or_copy_units, hipStream_t stream)
+{
+    if (unit_count == 0)
+        return 0;
+    if (any_stream_or_copy_units) {
+        static bool once = false;
+        if (!once) {
+            hipFuncSetAttribute((const void *)snappy_decode_kernel<65536u, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes);
+            once = true;
+        }
+        hipLaunchKernelGGL((snappy_decode_kernel<65536u, false>), dim3(unit_count), dim3(64), 65536 + kInBytes, stream, units, unit_count, jobs);
+    }
+    switch (frag_log2) {
+    case 0: break;
+    case 10: case 11: case 12: case 13:
+        hipLaunchKernelGGL((snappy_decode_kernel<8192u, true>), dim3(unit_count), dim3(64), 8192 + kInBytes, stream, units, unit_count, jobs); break;
+    case 14:
+        hipLaunchKernelGGL((snappy_decode_kernel<16384u, true>), dim3(unit_count), dim3(64), 16384 + kInBytes, stream, units, unit_count, jobs); break;
+    case 15:
+        hipLaunchKernelGGL((snappy_decode_kernel<32768u, true>), dim3(unit_count), dim3(64), 32768 + kInBytes, stream, units, unit_count, jobs); break;
+    case 16: {
+        static bool once = false;
+        if (!once) {
+            hipFuncSetAttribute((const void *)snappy_decode_kernel<65536u, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes);
+            once = true;
+        }
+        hipLaunchKernelGGL((snappy_decode_kernel<65536u, true>), dim3(unit_count), dim3(64), 65536 + kInBytes, stream, units, unit_count, jobs); break;
+    }
+    default: return 1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}

@@ -1,0 +1,155 @@
+/*
+ * hap_gpu.h -- device-resident, batched and RGBA entry points of hap_amd.
+ *
+ * hap.h (the reference API) takes one frame of already block-compressed
+ * texture bytes at a time and has no RGBA input (reference hap.h:82-104).
+ * The functions here cover what a GPU pipeline needs on top of that, without
+ * touching hap.h:
+ *
+ *   - RGBA -> DXT1 / DXT5 / scaled YCoCg-DXT5 / RGTC1 block compression
+ *     (the "external squish/DXT encoder" stage that reference clients run
+ *     before HapEncode; absent from the reference tree),
+ *   - whole batches of frames per call, all work enqueued on one HIP stream
+ *     with a single host synchronisation at the end,
+ *   - explicit contexts (device, stream, scratch) instead of the implicit
+ *     per-process context hap.h uses.
+ *
+ * Plain C ABI: no HIP or C++ types appear in any signature.  Every pointer
+ * argument documented as "host or device" is classified at run time
+ * (hipPointerGetAttributes); device pointers are used in place, host pointers
+ * are staged through pinned memory.
+ *
+ * Frames produced here are ordinary Hap frames: the reference decoder
+ * (hap.c:993-1040) decodes them byte-identically.  With
+ * HAPGPU_ENCODE_FRAGMENT_INDEX the Decode Instructions Container additionally
+ * carries a private section (type 0x46) listing the compressed size of every
+ * independently compressed Snappy fragment; decoders that do not know it skip
+ * it (reference hap.c:701-703, HapVideoDRAFT.md:34), hap_amd's decoder uses it
+ * to decode one chunk with many wavefronts.
+ */
+#ifndef HAP_AMD_HAP_GPU_H
+#define HAP_AMD_HAP_GPU_H
+
+#include "hap.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct HapGpuContext HapGpuContext;
+
+/* Encode flags */
+#define HAPGPU_ENCODE_FRAGMENT_INDEX 0x1u   /* emit the private fragment-size section (type 0x46) */
+
+/* Decode flags */
+#define HAPGPU_DECODE_IGNORE_FRAGMENT_INDEX 0x1u /* decode as a decoder unaware of section 0x46 would */
+
+/* Creates a context on HIP device `device` (-1: the current device) with its
+ * own non-blocking stream and growable scratch.  Returns a HapResult. */
+unsigned int HapGpuCreate(int device, HapGpuContext **context);
+void HapGpuDestroy(HapGpuContext *context);
+
+/* The process-wide context used by the hap.h functions (created on first
+ * use on the current device; HAP_AMD_DEVICE overrides). NULL if no GPU. */
+HapGpuContext *HapGpuDefaultContext(void);
+
+/* Log2 of the Snappy fragment size used by the compressor (12..16, default
+ * 14 = 16 KiB).  Fragments are compressed independently of each other. */
+unsigned int HapGpuSetFragmentLog2(HapGpuContext *context, unsigned int log2_bytes);
+
+/* Blocks until everything enqueued on the context's stream has finished. */
+unsigned int HapGpuSynchronize(HapGpuContext *context);
+
+/* RGBA8 (row-major, rowBytes stride, width/height multiples of 4) -> block
+ * compressed texture.  textureFormat is one of RGB_DXT1, RGBA_DXT5,
+ * YCoCg_DXT5, A_RGTC1 (A_RGTC1 compresses the alpha channel).  rgba and
+ * output: host or device.  *outputBytesUsed = width/4 * height/4 * 8 or 16. */
+unsigned int HapGpuCompressRGBA(HapGpuContext *context,
+                                const void *rgba, unsigned int width, unsigned int height,
+                                unsigned long rowBytes, unsigned int textureFormat,
+                                void *output, unsigned long outputBytes,
+                                unsigned long *outputBytesUsed);
+
+/* Batched HapEncode: frame f is made of `count` textures
+ * inputBuffers[f*count + i] of inputBuffersBytes[i] bytes each (every frame of
+ * a batch has the same geometry).  Semantics, frame layout, chunk-count
+ * limiting, store-raw decisions and result codes per frame follow HapEncode.
+ * outputBuffers[f] must hold HapMaxEncodedLength() bytes.
+ * results[f] receives the HapResult of frame f; the function result is the
+ * first non-zero of them. */
+unsigned int HapGpuEncodeFrames(HapGpuContext *context, unsigned int frameCount,
+                                unsigned int count,
+                                const void *const *inputBuffers,
+                                const unsigned long *inputBuffersBytes,
+                                const unsigned int *textureFormats,
+                                const unsigned int *compressors,
+                                const unsigned int *chunkCounts,
+                                void *const *outputBuffers,
+                                const unsigned long *outputBuffersBytes,
+                                unsigned long *outputBuffersBytesUsed,
+                                unsigned int *results,
+                                unsigned int flags);
+
+/* Batched RGBA -> Hap frame: block-compresses every frame into `count`
+ * textures of textureFormats[] (e.g. {YCoCg_DXT5} for Hap Q, {YCoCg_DXT5,
+ * A_RGTC1} for Hap Q Alpha, {RGB_DXT1} for Hap, {RGBA_DXT5} for Hap Alpha)
+ * and packs them exactly as HapGpuEncodeFrames does; the intermediate
+ * textures never leave HBM.  rgbaFrames[f]: host or device. */
+unsigned int HapGpuEncodeFramesRGBA(HapGpuContext *context, unsigned int frameCount,
+                                    const void *const *rgbaFrames,
+                                    unsigned int width, unsigned int height,
+                                    unsigned long rowBytes,
+                                    unsigned int count,
+                                    const unsigned int *textureFormats,
+                                    const unsigned int *compressors,
+                                    const unsigned int *chunkCounts,
+                                    void *const *outputBuffers,
+                                    const unsigned long *outputBuffersBytes,
+                                    unsigned long *outputBuffersBytesUsed,
+                                    unsigned int *results,
+                                    unsigned int flags);
+
+/* Batched HapDecode of texture `index` of every frame.  No callback: all
+ * chunks of all frames are decoded by the GPU.  Per-frame result codes,
+ * bytes used and texture formats follow HapDecode (including the hardening
+ * noted in INTEGRATION.md: out-of-range chunk tables are Bad_Frame instead of
+ * an out-of-bounds read).  outputBytesUsed / outputTextureFormats may be NULL. */
+unsigned int HapGpuDecodeFrames(HapGpuContext *context, unsigned int frameCount,
+                                const void *const *inputBuffers,
+                                const unsigned long *inputBuffersBytes,
+                                unsigned int index,
+                                void *const *outputBuffers,
+                                const unsigned long *outputBuffersBytes,
+                                unsigned long *outputBuffersBytesUsed,
+                                unsigned int *outputTextureFormats,
+                                unsigned int *results,
+                                unsigned int flags);
+
+/* --- measurement hooks (used by bench.py; see DESIGN.md "Measurement") --- */
+
+/* Kernel classes whose launches are bracketed with HIP events on the
+ * context's stream while profiling is enabled. */
+enum HapGpuKernelClass {
+    HapGpuKernel_BlockEncode = 0,
+    HapGpuKernel_SnappyCompress = 1,
+    HapGpuKernel_FramePack = 2,
+    HapGpuKernel_FrameGather = 3,
+    HapGpuKernel_DecodePlan = 4,
+    HapGpuKernel_SnappyDecode = 5,
+    HapGpuKernel_ClassCount = 6
+};
+
+/* enable != 0: record a start/stop event pair around every kernel launch. */
+unsigned int HapGpuSetProfiling(HapGpuContext *context, unsigned int enable);
+/* Drains recorded events: launches[k] and milliseconds[k] are ADDED to for
+ * every class k (arrays of HapGpuKernel_ClassCount). Synchronises. */
+unsigned int HapGpuCollectProfile(HapGpuContext *context, unsigned long *launches, double *milliseconds);
+/* Wall-clock bracket on the context's stream with HIP events. */
+unsigned int HapGpuTimerStart(HapGpuContext *context);
+unsigned int HapGpuTimerStop(HapGpuContext *context, double *milliseconds);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* HAP_AMD_HAP_GPU_H */

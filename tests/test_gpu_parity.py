@@ -1,0 +1,459 @@
+"""GPU parity tests: the HIP path (through the C ABI of include/hap.h / hap_gpu.h)
+against the CPU oracle, the live reference (when oracle/_ref exists) and the
+committed golden vectors.  Bit-exact everywhere: this is byte/integer work."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _data as D
+import _libs as L
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def hap():
+    import hap_amd
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return hap_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(hap):
+    c = hap.Context(0)
+    yield c
+    c.close()
+
+
+ORA = L.oracle_api()
+REF = L.ref_api()
+CHECKERS = [("oracle", ORA)] + ([("reference", REF)] if REF is not None else [])
+BC_FORMATS = [L.FMT_DXT1, L.FMT_DXT5, L.FMT_YCOCG, L.FMT_RGTC1]
+
+
+# ------------------------------------------------------------ block encode --
+@pytest.mark.parametrize("fmt", BC_FORMATS)
+@pytest.mark.parametrize("size", [(4, 4), (8, 4), (64, 64), (260, 36), (1024, 256), (1920, 1080)])
+def test_block_encode_bit_exact(ctx, fmt, size):
+    w, h = size
+    img = D.rgba(w, h, frame=3)
+    want = D.oracle_bc_encode(img, fmt)
+    r, got = ctx.compress_rgba(img, w, h, w * 4, fmt)
+    assert r == 0
+    assert got == want
+    # device-resident input and output
+    dimg = torch.from_numpy(img).cuda()
+    dout = torch.zeros(len(want), dtype=torch.uint8, device="cuda")
+    r, used = ctx.compress_rgba(dimg, w, h, w * 4, fmt, dout)
+    assert (r, used) == (0, len(want))
+    assert dout.cpu().numpy().tobytes() == want
+
+
+@pytest.mark.parametrize("fmt", BC_FORMATS)
+def test_block_encode_row_stride_and_random(ctx, fmt):
+    rng = np.random.default_rng(11)
+    w, h, stride = 252, 64, 1024 + 16
+    buf = rng.integers(0, 256, (h, stride), dtype=np.uint8)
+    img = np.lib.stride_tricks.as_strided(buf, shape=(h, w, 4), strides=(stride, 4, 1))
+    want = D.oracle_bc_encode(np.ascontiguousarray(img), fmt)
+    r, got = ctx.compress_rgba(buf, w, h, stride, fmt)
+    assert r == 0 and got == want
+    # dword-aligned but not 16-byte aligned stride takes the narrow-load kernel
+    stride2 = w * 4 + 4
+    buf2 = rng.integers(0, 256, (h, stride2), dtype=np.uint8)
+    img2 = np.lib.stride_tricks.as_strided(buf2, shape=(h, w, 4), strides=(stride2, 4, 1))
+    want2 = D.oracle_bc_encode(np.ascontiguousarray(img2), fmt)
+    r, got2 = ctx.compress_rgba(buf2, w, h, stride2, fmt)
+    assert r == 0 and got2 == want2
+
+
+def test_block_encode_extremes_and_quality(ctx):
+    # flat, black, white, two-colour and alpha-edge blocks
+    img = np.zeros((16, 16, 4), dtype=np.uint8)
+    img[:4] = 255
+    img[4:8, :8] = (255, 0, 0, 0)
+    img[4:8, 8:] = (0, 0, 255, 255)
+    img[8:12, ::2] = (10, 200, 30, 128)
+    img[12:, :, 3] = np.arange(16, dtype=np.uint8) * 17
+    for fmt in BC_FORMATS:
+        r, got = ctx.compress_rgba(img, 16, 16, 64, fmt)
+        assert r == 0 and got == D.oracle_bc_encode(img, fmt)
+    # PSNR sanity of the algorithm itself on a smooth image (oracle decoders)
+    pic = D.rgba(512, 512, frame=1)
+    for fmt, floor in ((L.FMT_DXT1, 30.0), (L.FMT_DXT5, 30.0), (L.FMT_YCOCG, 33.0)):
+        r, blocks = ctx.compress_rgba(pic, 512, 512, 2048, fmt)
+        dec = D.oracle_bc_decode(blocks, fmt, 512, 512)
+        assert D.psnr(dec[..., :3], pic[..., :3]) > floor, fmt
+    r, blocks = ctx.compress_rgba(pic, 512, 512, 2048, L.FMT_RGTC1)
+    assert D.psnr(D.oracle_bc_decode(blocks, L.FMT_RGTC1, 512, 512), pic[..., 3]) > 40.0
+
+
+def test_block_encode_bad_arguments(ctx, hap):
+    img = np.zeros((8, 8, 4), dtype=np.uint8)
+    assert ctx.compress_rgba(img, 7, 8, 32, L.FMT_DXT1)[0] == hap.HapResult.Bad_Arguments
+    assert ctx.compress_rgba(img, 8, 8, 16, L.FMT_DXT1)[0] == hap.HapResult.Bad_Arguments
+    assert ctx.compress_rgba(img, 8, 8, 32, L.FMT_BC7)[0] == hap.HapResult.Bad_Arguments
+    small = (C.c_ubyte * 8)()
+    assert ctx.compress_rgba(img, 8, 8, 32, L.FMT_DXT1, small)[0] == hap.HapResult.Buffer_Too_Small
+
+
+# ------------------------------------------------------------------ decode --
+@pytest.mark.parametrize("v", D.golden_vectors("frame"), ids=lambda v: v["name"])
+def test_decode_golden_frames(hap, v):
+    if v["frame"] is None:
+        return
+    frame = bytes.fromhex(v["frame"])
+    tex = [bytes.fromhex(t) for t in v["textures"]]
+    assert list(hap.HapGetFrameTextureCount(frame)) == v["texture_count"]
+    for idx, d in enumerate(v["decode"]):
+        calls = [0]
+
+        def cb(fn, p, count, info):
+            calls[0] += 1
+            for i in range(count):
+                fn(p, i)
+        from hap_amd._lib import CALLBACK
+        r, out, fmt = hap.HapDecode(frame, idx, callback=CALLBACK(cb), outputBufferBytes=max(len(t) for t in tex) + 64)
+        assert (r, fmt, calls[0]) == (d["result"], d["format"], d["callback_calls"])
+        assert (out == tex[idx]) == d["equals_input"]
+        assert list(hap.HapGetFrameTextureChunkCount(frame, idx)) == d["chunk_count"]
+        assert list(hap.HapGetFrameTextureFormat(frame, idx)) == d["texture_format"]
+
+
+@pytest.mark.parametrize("v", D.golden_vectors("snappy_stream"), ids=lambda v: v["name"])
+def test_decode_golden_snappy_streams(hap, v):
+    """Hand-written element streams, wrapped as a whole-texture Snappy section (0xB_) and as a
+    one-chunk complex frame; result codes follow hap.c:885-904 and 606-642."""
+    stream = bytes.fromhex(v["stream"])
+    if v["capacity"] != 256:
+        return
+    want = bytes.fromhex(v["output"]) if v["output"] is not None else None
+    sec = (len(stream)).to_bytes(3, "little") + bytes([0xBB]) + stream
+    r, out, fmt = hap.HapDecode(sec, 0, outputBufferBytes=256)
+    assert fmt == L.FMT_DXT1
+    ro, oo, _ = ORA.decode(sec, 0, 256)
+    assert (r, out) == (ro, oo)
+    if want is not None:
+        assert (r, out) == (0, want)
+    else:
+        assert r == hap.HapResult.Internal_Error
+    tables = bytes([1, 0, 0, 2, 0x0B, 4, 0, 0, 3]) + len(stream).to_bytes(4, "little")
+    body = len(tables).to_bytes(3, "little") + bytes([1]) + tables + stream
+    cplx = len(body).to_bytes(3, "little") + bytes([0xCB]) + body
+    r, out, fmt = hap.HapDecode(cplx, 0, outputBufferBytes=256)
+    assert (r, out) == ORA.decode(cplx, 0, 256)[:2]
+    if want is None:
+        assert r == hap.HapResult.Bad_Frame
+
+
+DATA_KINDS = ["zero", "random", "mixed", "runs"]
+
+
+def _encode_with(api, tex, fmt, comp, chunks):
+    r, frame = api.encode([tex], [fmt], [comp], [chunks])
+    assert r == 0
+    return frame
+
+
+@pytest.mark.parametrize("name,api", CHECKERS)
+@pytest.mark.parametrize("kind", DATA_KINDS)
+@pytest.mark.parametrize("fmt,chunks,nbytes", [
+    (L.FMT_DXT1, 1, 8 * 777), (L.FMT_DXT5, 8, 16 * 8 * 999), (L.FMT_YCOCG, 24, 16 * 24 * 300),
+    (L.FMT_RGTC1, 3, 8 * 3 * 5000), (L.FMT_BC7, 5, 16 * 5 * 8200), (L.FMT_BC6U, 64, 16 * 64 * 70)])
+def test_decode_frames_from_checker(hap, name, api, kind, fmt, chunks, nbytes):
+    """G1: ours.HapDecode(F) == checker.HapDecode(F) for frames F made by the reference encoder."""
+    tex = D.stream_bytes(nbytes, kind, seed=nbytes)
+    for comp in (L.COMP_NONE, L.COMP_SNAPPY):
+        frame = _encode_with(api, tex, fmt, comp, chunks)
+        r, out, f = hap.HapDecode(frame, 0, outputBufferBytes=nbytes)
+        assert (r, f) == (0, fmt)
+        assert out == tex
+        assert hap.HapGetFrameTextureChunkCount(frame, 0) == api.chunk_count(frame, 0)
+        assert hap.HapDecode(frame, 0, outputBufferBytes=nbytes - 1)[0] == api.decode(frame, 0, nbytes - 1)[0]
+        assert hap.HapDecode(frame, 1, outputBufferBytes=nbytes)[0] == api.decode(frame, 1, nbytes)[0]
+
+
+def test_decode_dxt_textures_all_offsets(hap):
+    """Real block-compressed textures (long back-references: one block row up)."""
+    img = D.rgba(2048, 256, frame=2)
+    for fmt in BC_FORMATS:
+        tex = D.oracle_bc_encode(img, fmt)
+        for chunks in (1, 4):
+            frame = _encode_with(ORA, tex, fmt, L.COMP_SNAPPY, chunks)
+            r, out, f = hap.HapDecode(frame, 0, outputBufferBytes=len(tex))
+            assert (r, f) == (0, fmt) and out == tex
+
+
+def test_decode_far_back_references(hap):
+    """Offsets beyond the 64 KiB LDS ring (copy-4 elements): only a foreign encoder emits them."""
+    rng = np.random.default_rng(5)
+    head = rng.integers(0, 256, 70000, dtype=np.uint8).tobytes()
+    n = len(head)
+    stream = bytearray()
+    total = n + 64 + 40
+    v = total
+    while v >= 0x80:
+        stream.append((v & 0x7F) | 0x80)
+        v >>= 7
+    stream.append(v)
+    stream += bytes([62 << 2]) + (n - 1).to_bytes(3, "little") + head          # literal, 3 length bytes
+    stream += bytes([(63 << 2) | 3]) + (n).to_bytes(4, "little")               # copy-4 len 64 off n  -> head[0:64]
+    stream += bytes([(39 << 2) | 3]) + (66000 + 64).to_bytes(4, "little")      # copy-4 len 40 off 66064
+    want = head + head[:64] + head[n + 64 - 66064: n + 64 - 66064 + 40]
+    assert D.osnappy_uncompress(bytes(stream), total) == (0, want)
+    tables = bytes([1, 0, 0, 2, 0x0B, 4, 0, 0, 3]) + len(stream).to_bytes(4, "little")
+    body = len(tables).to_bytes(3, "little") + bytes([1]) + tables + bytes(stream)
+    frame = len(body).to_bytes(3, "little") + bytes([0xCE]) + body
+    r, out, fmt = hap.HapDecode(frame, 0, outputBufferBytes=total)
+    assert (r, fmt) == (0, L.FMT_DXT5) and out == want
+
+
+def test_decode_dual_texture(hap):
+    a = D.stream_bytes(16 * 64 * 9, "runs")
+    b = D.stream_bytes(8 * 64 * 9, "mixed")
+    for name, api in CHECKERS:
+        r, frame = api.encode([a, b], [L.FMT_YCOCG, L.FMT_RGTC1], [1, 1], [4, 2])
+        assert r == 0
+        assert hap.HapGetFrameTextureCount(frame) == (0, 2)
+        assert hap.HapDecode(frame, 0, outputBufferBytes=len(a)) == (0, a, L.FMT_YCOCG)
+        assert hap.HapDecode(frame, 1, outputBufferBytes=len(b)) == (0, b, L.FMT_RGTC1)
+
+
+def test_decode_malformed_frames_match_oracle(hap):
+    rng = np.random.default_rng(3)
+    tex = D.stream_bytes(16 * 256, "runs")
+    _, frame = ORA.encode([tex], [L.FMT_DXT5], [1], [4])
+    hdr = 4 + 4 + 5 * 4 + 8
+    for cut in list(range(0, hdr + 4)) + [len(frame) - 1, len(frame) - 7]:
+        f = frame[:cut]
+        if len(f) == 0:
+            continue
+        assert hap.HapDecode(f, 0, outputBufferBytes=8192)[0] == ORA.decode(f, 0, 8192)[0], cut
+        assert hap.HapGetFrameTextureCount(f) == ORA.texture_count(f)
+        assert hap.HapGetFrameTextureChunkCount(f, 0) == ORA.chunk_count(f, 0)
+    for trial in range(120):
+        f = bytearray(frame)
+        i = int(rng.integers(hdr, len(f)))
+        f[i] ^= 1 << int(rng.integers(0, 8))
+        r, out, fmt = hap.HapDecode(bytes(f), 0, outputBufferBytes=8192)
+        ro, oo, fo = ORA.decode(bytes(f), 0, 8192)
+        assert (r, fmt) == (ro, fo), (trial, i)
+        if r == 0:
+            assert out == oo
+    for byte3 in range(256):
+        f = bytearray(frame)
+        f[3] = byte3
+        assert hap.HapDecode(bytes(f), 0, outputBufferBytes=8192)[0] == ORA.decode(bytes(f), 0, 8192)[0], byte3
+        assert hap.HapGetFrameTextureFormat(bytes(f), 0) == ORA.texture_format(bytes(f), 0)
+        assert hap.HapGetFrameTextureChunkCount(bytes(f), 0) == ORA.chunk_count(bytes(f), 0)
+    # hardening: a size table pointing outside the frame is Bad_Frame (the reference reads out of bounds)
+    f = bytearray(frame)
+    f[4 + 4 + 4 + 4 + 4: 4 + 4 + 4 + 4 + 8] = (1 << 30).to_bytes(4, "little")
+    assert hap.HapDecode(bytes(f), 0, outputBufferBytes=8192)[0] == hap.HapResult.Bad_Frame
+
+
+def test_decode_bad_arguments(hap):
+    from hap_amd._lib import lib
+    out = (C.c_ubyte * 64)()
+    fmt = C.c_uint(0)
+    f = bytes.fromhex("400000ab") + bytes(64)
+    buf = (C.c_ubyte * len(f)).from_buffer_copy(f)
+    assert lib.HapDecode(buf, len(f), 0, hap.api._serial_callback(), None, out, 64, None, C.byref(fmt)) == 0
+    assert lib.HapDecode(None, len(f), 0, hap.api._serial_callback(), None, out, 64, None, C.byref(fmt)) == 1
+    assert lib.HapDecode(buf, len(f), 2, hap.api._serial_callback(), None, out, 64, None, C.byref(fmt)) == 1
+    assert lib.HapDecode(buf, len(f), 0, hap.api._serial_callback(), None, None, 64, None, C.byref(fmt)) == 1
+    assert lib.HapDecode(buf, len(f), 0, hap.api._serial_callback(), None, out, 64, None, None) == 1
+    null_cb = C.cast(0, hap._lib.CALLBACK)
+    assert lib.HapDecode(buf, len(f), 0, null_cb, None, out, 64, None, C.byref(fmt)) == 1
+
+
+def test_decode_partial_callback(hap):
+    """A client that asks for only some chunks gets only those decoded (others left untouched)."""
+    from hap_amd._lib import CALLBACK
+    tex = D.stream_bytes(16 * 4 * 600, "runs")
+    _, frame = ORA.encode([tex], [L.FMT_DXT5], [1], [4])
+
+    def cb(fn, p, count, info):
+        assert count == 4
+        fn(p, 1)
+        fn(p, 3)
+    out = np.full(len(tex), 0xEE, dtype=np.uint8)
+    r, used, fmt = hap.HapDecode(frame, 0, callback=CALLBACK(cb), outputBuffer=out)
+    assert (r, used, fmt) == (0, len(tex), L.FMT_DXT5)
+    q = len(tex) // 4
+    got = out.tobytes()
+    assert got[q:2 * q] == tex[q:2 * q] and got[3 * q:] == tex[3 * q:]
+    assert got[:q] == b"\xEE" * q and got[2 * q:3 * q] == b"\xEE" * q
+
+
+# ------------------------------------------------------------------ encode --
+def _check_frame_structure(frame, tex, fmt, chunks_expected):
+    """Header/table layout rules of hap.c:425-501 on a frame we produced."""
+    first = int.from_bytes(frame[0:3], "little")
+    hdr = 4 if first else 8
+    length = first if first else int.from_bytes(frame[4:8], "little")
+    assert hdr + length == len(frame)
+    kind = frame[3] >> 4
+    assert kind in (0xA, 0xC)
+    if kind == 0xA:
+        assert frame[hdr:] == tex
+        return None
+    p = hdr
+    assert frame[p + 3] == 0x01
+    ilen = int.from_bytes(frame[p:p + 3], "little")
+    p += 4
+    assert frame[p + 3] == 0x02 and int.from_bytes(frame[p:p + 3], "little") == chunks_expected
+    codecs = frame[p + 4:p + 4 + chunks_expected]
+    p += 4 + chunks_expected
+    assert frame[p + 3] == 0x03 and int.from_bytes(frame[p:p + 3], "little") == 4 * chunks_expected
+    sizes = [int.from_bytes(frame[p + 4 + 4 * i:p + 8 + 4 * i], "little") for i in range(chunks_expected)]
+    payload = hdr + 4 + ilen
+    assert payload + sum(sizes) == len(frame)
+    cb = len(tex) // chunks_expected
+    at = payload
+    for i, (c, s) in enumerate(zip(codecs, sizes)):
+        assert c in (0x0A, 0x0B)
+        if c == 0x0A:
+            assert s == cb and frame[at:at + s] == tex[i * cb:(i + 1) * cb]     # hap.c:460-466
+        else:
+            assert s < cb
+        at += s
+    return codecs
+
+
+@pytest.mark.parametrize("flags_env", [0, 1])
+@pytest.mark.parametrize("kind", DATA_KINDS)
+@pytest.mark.parametrize("fmt,chunks,nbytes", [
+    (L.FMT_DXT1, 1, 8 * 777), (L.FMT_DXT5, 8, 16 * 8 * 999), (L.FMT_YCOCG, 24, 16 * 24 * 300),
+    (L.FMT_RGTC1, 3, 8 * 3 * 5000), (L.FMT_BC7, 7, 16 * 5 * 8200), (L.FMT_BC6S, 64, 16 * 64 * 70)])
+def test_encode_round_trips_through_checkers(ctx, hap, kind, fmt, chunks, nbytes, flags_env):
+    """G2: checker.HapDecode(ours.HapEncode(x)) == x, with and without the private fragment table."""
+    tex = D.stream_bytes(nbytes, kind, seed=nbytes + 7)
+    cap = hap.HapMaxEncodedLength([nbytes], [fmt], [chunks])
+    assert cap == ORA.max_encoded_length([nbytes], [fmt], [chunks])
+    out = np.zeros(cap, dtype=np.uint8)
+    r, used, results = ctx.encode_frames([[tex]], [fmt], [L.COMP_SNAPPY], [chunks], [out],
+                                         flags=hap.ENCODE_FRAGMENT_INDEX if flags_env else 0)
+    assert (r, results) == (0, [0])
+    frame = out[: used[0]].tobytes()
+    for name, api in CHECKERS:
+        assert api.decode(frame, 0, nbytes) == (0, tex, fmt), name
+    limited = ORA.chunk_count(_encode_with(ORA, tex, fmt, L.COMP_SNAPPY, chunks), 0)[1]
+    if not flags_env:
+        codecs = _check_frame_structure(frame, tex, fmt, limited)
+        if kind == "random":
+            assert codecs is None                      # no gain -> whole texture raw (hap.c:478-495)
+        if kind == "zero":
+            assert codecs is not None and set(codecs) == {0x0B}
+    assert hap.HapDecode(frame, 0, outputBufferBytes=nbytes) == (0, tex, fmt)
+    # compressor None: byte-identical to the reference encoder
+    r, f_none = hap.HapEncode([tex], [fmt], [L.COMP_NONE], [chunks])
+    assert (r, f_none) == ORA.encode([tex], [fmt], [L.COMP_NONE], [chunks])
+
+
+def test_encode_compression_ratio_close_to_libsnappy(ctx, hap):
+    img = D.rgba(2048, 512, frame=0)
+    for fmt in BC_FORMATS:
+        tex = D.oracle_bc_encode(img, fmt)
+        ours = len(hap.HapEncode([tex], [fmt], [1], [8])[1])
+        theirs = len(ORA.encode([tex], [fmt], [1], [8])[1])
+        assert ours < len(tex)
+        assert ours <= theirs * 1.35 + 64, (fmt, ours, theirs)
+
+
+def test_encode_dual_texture_and_errors(ctx, hap):
+    a = D.stream_bytes(16 * 64 * 9, "runs")
+    b = D.stream_bytes(8 * 64 * 9, "mixed")
+    r, frame = hap.HapEncode([a, b], [L.FMT_YCOCG, L.FMT_RGTC1], [1, 1], [4, 2])
+    assert r == 0
+    for name, api in CHECKERS:
+        assert api.texture_count(frame) == (0, 2)
+        assert api.decode(frame, 0, len(a)) == (0, a, L.FMT_YCOCG)
+        assert api.decode(frame, 1, len(b)) == (0, b, L.FMT_RGTC1)
+    # mixed compressors
+    r, frame = hap.HapEncode([a, b], [L.FMT_YCOCG, L.FMT_RGTC1], [0, 1], [1, 2])
+    assert r == 0 and ORA.decode(frame, 0, len(a))[1] == a and ORA.decode(frame, 1, len(b))[1] == b
+    # argument errors as the reference reports them
+    tex = bytes(64)
+    for args in [([tex], [0x1234], [1], [1]), ([tex], [L.FMT_DXT1], [2], [1]), ([tex], [L.FMT_DXT1], [1], [0]),
+                 ([tex, tex], [L.FMT_DXT1, L.FMT_DXT5], [1, 1], [1, 1])]:
+        assert hap.HapEncode(*args, outputBufferBytes=4096)[0] == ORA.encode(*args, out_bytes=4096)[0]
+    assert hap.HapEncode([tex], [L.FMT_DXT1], [1], [1], outputBufferBytes=80)[0] == hap.HapResult.Buffer_Too_Small
+    assert hap.HapMaxEncodedLength([64], [L.FMT_DXT1], [0]) == 0
+
+
+# ----------------------------------------------------- device-resident path --
+def test_device_resident_batch_round_trip(ctx, hap):
+    """RGBA frames in HBM -> Hap Q Alpha frames in HBM -> textures in HBM; no host staging."""
+    w, h, nf = 512, 256, 5
+    fmts = [L.FMT_YCOCG, L.FMT_RGTC1]
+    sizes = [(w // 4) * (h // 4) * 16, (w // 4) * (h // 4) * 8]
+    cap = hap.HapMaxEncodedLength(sizes, fmts, [8, 8])
+    from hap_amd import synth
+    frames_rgba = [synth.rgba_frame(w, h, i, device="cuda") for i in range(nf)]
+    outs = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(nf)]
+    for flags in (0, hap.ENCODE_FRAGMENT_INDEX):
+        r, used, results = ctx.encode_frames_rgba(frames_rgba, w, h, w * 4, fmts, [1, 1], [8, 8], outs, flags=flags)
+        assert r == 0 and results == [0] * nf
+        for idx in (0, 1):
+            dec = [torch.zeros(sizes[idx], dtype=torch.uint8, device="cuda") for _ in range(nf)]
+            r, dused, dfmts, dres = ctx.decode_frames(outs, used, idx, dec)
+            assert r == 0 and dres == [0] * nf and dused == [sizes[idx]] * nf and dfmts == [fmts[idx]] * nf
+            for i in range(nf):
+                want = D.oracle_bc_encode(frames_rgba[i].cpu().numpy(), fmts[idx])
+                assert dec[i].cpu().numpy().tobytes() == want
+                frame = outs[i][: used[i]].cpu().numpy().tobytes()
+                assert ORA.decode(frame, idx, sizes[idx]) == (0, want, fmts[idx])
+            # ignoring the fragment table gives the same bytes
+            dec2 = [torch.zeros(sizes[idx], dtype=torch.uint8, device="cuda") for _ in range(nf)]
+            r, _, _, dres = ctx.decode_frames(outs, used, idx, dec2, flags=hap.DECODE_IGNORE_FRAGMENT_INDEX)
+            assert r == 0 and all(torch.equal(x, y) for x, y in zip(dec, dec2))
+
+
+def test_corrupt_fragment_table_falls_back(ctx, hap):
+    tex = D.stream_bytes(16 * 4 * 3000, "runs")
+    cap = hap.HapMaxEncodedLength([len(tex)], [L.FMT_DXT5], [4])
+    out = np.zeros(cap, dtype=np.uint8)
+    r, used, _ = ctx.encode_frames([[tex]], [L.FMT_DXT5], [1], [4], [out], flags=hap.ENCODE_FRAGMENT_INDEX)
+    frame = bytearray(out[: used[0]].tobytes())
+    pos = frame.find(bytes([0x46, 1, 14, 0, 0]), 0, 200) + 5
+    assert pos > 5
+    e0 = int.from_bytes(frame[pos:pos + 4], "little")
+    e1 = int.from_bytes(frame[pos + 4:pos + 8], "little")
+    frame[pos:pos + 4] = (e0 + 1).to_bytes(4, "little")       # still sums to the chunk size,
+    frame[pos + 4:pos + 8] = (e1 - 1).to_bytes(4, "little")   # but splits in the wrong place
+    assert ORA.decode(bytes(frame), 0, len(tex)) == (0, tex, L.FMT_DXT5)
+    assert hap.HapDecode(bytes(frame), 0, outputBufferBytes=len(tex)) == (0, tex, L.FMT_DXT5)
+
+
+@pytest.mark.parametrize("cfg", ["C2", "C3", "C4"])
+def test_full_size_configs_round_trip(ctx, hap, cfg):
+    """BASELINE.json configs at full size on the device: encode -> decode round trip, the
+    decoded texture equals the block encoder's output (checked by checksum-free tensor equality)
+    and one frame is cross-checked against the CPU oracle decoder."""
+    from hap_amd import synth
+    w, h, fmts, chunks, nf = {"C2": (3840, 2160, [L.FMT_DXT1], [1], 1),
+                              "C3": (3840, 2160, [L.FMT_DXT5], [8], 1),
+                              "C4": (7680, 4320, [L.FMT_YCOCG], [24], 3)}[cfg]
+    sizes = [(w // 4) * (h // 4) * D.BLOCK_BYTES[f] for f in fmts]
+    cap = hap.HapMaxEncodedLength(sizes, fmts, chunks)
+    rgba = [synth.rgba_frame(w, h, i, device="cuda") for i in range(nf)]
+    outs = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(nf)]
+    tex = [torch.zeros(sizes[0], dtype=torch.uint8, device="cuda") for _ in range(nf)]
+    for i in range(nf):
+        assert ctx.compress_rgba(rgba[i], w, h, w * 4, fmts[0], tex[i]) == (0, sizes[0])
+    for flags in (0, hap.ENCODE_FRAGMENT_INDEX):
+        r, used, results = ctx.encode_frames_rgba(rgba, w, h, w * 4, fmts, [1], chunks, outs, flags=flags)
+        assert r == 0 and results == [0] * nf
+        dec = [torch.zeros(sizes[0], dtype=torch.uint8, device="cuda") for _ in range(nf)]
+        r, dused, dfmts, dres = ctx.decode_frames(outs, used, 0, dec)
+        assert r == 0 and dres == [0] * nf and dused == [sizes[0]] * nf
+        for i in range(nf):
+            assert torch.equal(dec[i], tex[i])
+        frame = outs[0][: used[0]].cpu().numpy().tobytes()
+        ro, oo, fo = ORA.decode(frame, 0, sizes[0])
+        assert (ro, fo) == (0, fmts[0]) and oo == tex[0].cpu().numpy().tobytes()
+        assert hap.HapGetFrameTextureChunkCount(frame, 0) == (0, chunks[0])
