@@ -13,6 +13,14 @@ CALLBACK = C.CFUNCTYPE(None, WORK_FN, C.c_void_p, C.c_uint, C.c_void_p)
 
 
 def _load():
+    # PyTorch wheels bundle their own libamdhip64/libhsa-runtime64 (same SONAMEs as /opt/rocm's).
+    # Two HIP runtimes in one process fight over the device, so when torch is installed let it
+    # load its runtime first; libhap_amd.so then binds to that already-loaded copy.  Plain C
+    # clients link /opt/rocm directly and are unaffected.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "hap_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "

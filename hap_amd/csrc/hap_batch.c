@@ -676,6 +676,10 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                     if (!all) {
                         /* chunks the client never asked for stay undecoded: blank their units */
                         HapGpuDecodeUnit *blank = (HapGpuDecodeUnit *)calloc(1, sizeof(HapGpuDecodeUnit));
+                        /* a staged (host) output must come back unchanged where nothing is decoded */
+                        if (out_off[0])
+                            rc |= hapgpu_rt_h2d(rt, out_stage + (out_off[0] - 1), outputs[0],
+                                                output_bytes[0] < hjobs[0].bytes_used ? output_bytes[0] : (size_t)hjobs[0].bytes_used);
                         for (c = 0; blank && c < plans[0].chunk_count; c++) {
                             unsigned k;
                             if (req[c])

@@ -26,7 +26,10 @@
 
 namespace {
 
-constexpr unsigned kHashBits = 12;
+#ifndef HAP_HASH_BITS
+#define HAP_HASH_BITS 12
+#endif
+constexpr unsigned kHashBits = HAP_HASH_BITS;
 constexpr unsigned kHashEntries = 1u << kHashBits;
 
 __device__ __forceinline__ unsigned uniform(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -129,12 +132,12 @@ __global__ __launch_bounds__(64) void snappy_compress_kernel(const HapGpuFrameEn
         const unsigned long long n8 = eq_mask(t + 1, 8), n16 = eq_mask(t + 1, 16);
 
         // ---- (a) hash candidate ----
-        unsigned best_len = 0, best_off = 0;
+        unsigned best_len = 0, best_off = 0, my_hash = 0xFFFFFFFFu;
         if (p + 4u <= n) {
             const unsigned cur = lds_load32(dataw, p);
             const unsigned h = (cur * 0x1e35a7bdu) >> (32u - kHashBits);
             const unsigned cand = table[h];
-            table[h] = (uint16_t)p;
+            my_hash = h;
             if (cand < p && lds_load32(dataw, cand) == cur) {
                 unsigned l = 4;
                 while (l < room) {
@@ -224,6 +227,10 @@ __global__ __launch_bounds__(64) void snappy_compress_kernel(const HapGpuFrameEn
             }
         }
         out_pos += (unsigned)__popcll(e0) + 2u * (unsigned)__popcll(e1);
+        // remember only positions where an element starts (as libsnappy does): bytes inside a
+        // copy would otherwise evict the older, still useful entries of a small table
+        if ((is_lit || is_copy) && my_hash != 0xFFFFFFFFu)
+            table[my_hash] = (uint16_t)p;
     }
     if (lane == 0)
         frag_sizes[f] = out_pos;
