@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--config", default="C4", choices=sorted(CONFIGS))
     ap.add_argument("--frames", type=int, default=0, help="frames per batch (default: the config's)")
     ap.add_argument("--no-fragment-index", action="store_true")
+    ap.add_argument("--frag-log2", type=int, default=0, help="Snappy fragment size (log2 bytes); 0 = library default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
@@ -72,6 +73,8 @@ def main():
     w, h, fmts, chunks, nf_default = CONFIGS[args.config]
     nf = args.frames or nf_default
     ctx = hap_amd.Context(local_rank)
+    if args.frag_log2:
+        ctx.set_fragment_log2(args.frag_log2)
     flags = 0 if args.no_fragment_index else hap_amd.ENCODE_FRAGMENT_INDEX
     tex_bytes = [(w // 4) * (h // 4) * BLOCK_BYTES[f] for f in fmts]
     cap = hap_amd.HapMaxEncodedLength(tex_bytes, fmts, chunks)
