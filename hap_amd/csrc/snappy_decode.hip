@@ -20,6 +20,7 @@
 // table (section 0x46, see include/hap_gpu.h).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "hapgpu_abi.h"
 
 namespace {
@@ -479,6 +480,310 @@ __global__ __launch_bounds__(64) void snappy_decode_kernel(const HapGpuDecodeUni
         flush_ring<RING>(ring, dst, flushed, op, lane);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// window-parallel fragment decoder
+// ------------------------------------------------------------------------------------------
+//
+// The element-by-element kernel above spends ~40 scalar instructions and several dependent LDS
+// round trips per element.  This one works on a 64-byte window of compressed bytes at a time:
+//
+//   1. every lane parses "the element that would start at my byte" (speculatively, in parallel);
+//   2. which of those are real is a chain from lane 0: two rounds of pointer doubling with
+//      ds_bpermute give each lane the set of its next 4 chain members, and the scalar unit then
+//      hops 4 elements per iteration;
+//   3. a DPP prefix sum over the real elements gives every element its output position;
+//   4. the window's output is produced 64 bytes per step, one byte per lane: lanes find their
+//      element through an owner map in LDS, compute their source (literal byte in the staging
+//      window, or an earlier output byte in the LDS ring) and sources that fall inside the same
+//      64-byte step are chased with pointer jumping in registers (<= 6 rounds) before one LDS
+//      gather + one LDS store.
+//
+// Same results and failure semantics as the serial kernel: any malformed element, bad offset or
+// length mismatch fails the unit.  Used for FRAGMENT units (output never wraps the ring).
+
+constexpr unsigned kOwnerBytes = 1024;      // output bytes handled per window pass
+
+__device__ __forceinline__ int dpp_row_shr(int identity, int v, int n)
+{
+    switch (n) {
+    case 1: return __builtin_amdgcn_update_dpp(identity, v, 0x111, 0xF, 0xF, false);
+    case 2: return __builtin_amdgcn_update_dpp(identity, v, 0x112, 0xF, 0xF, false);
+    case 4: return __builtin_amdgcn_update_dpp(identity, v, 0x114, 0xF, 0xF, false);
+    default: return __builtin_amdgcn_update_dpp(identity, v, 0x118, 0xF, 0xF, false);
+    }
+}
+
+// wave64 inclusive scans with DPP (row shifts inside each 16-lane row, then row broadcasts)
+__device__ __forceinline__ int wave_scan_add(int v)
+{
+    v += dpp_row_shr(0, v, 1);
+    v += dpp_row_shr(0, v, 2);
+    v += dpp_row_shr(0, v, 4);
+    v += dpp_row_shr(0, v, 8);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+__device__ __forceinline__ int wave_scan_max(int v)
+{
+    v = max(v, dpp_row_shr(0, v, 1));
+    v = max(v, dpp_row_shr(0, v, 2));
+    v = max(v, dpp_row_shr(0, v, 4));
+    v = max(v, dpp_row_shr(0, v, 8));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false));
+    return v;
+}
+
+__device__ __forceinline__ int lane_gather(int v, unsigned src_lane)
+{
+    return __builtin_amdgcn_ds_bpermute((int)(src_lane << 2), v);
+}
+
+template <unsigned RING>
+__global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpuDecodeUnit *__restrict__ units,
+                                                                    unsigned unit_count, HapGpuDecodeJob *jobs)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *ring = smem;                                          // [0, RING): output
+    uint32_t *inw = reinterpret_cast<uint32_t *>(smem + RING);     // [RING, RING+2048): staged input
+    uint8_t *owner = smem + RING + kInBytes;                       // [.., +1024+64): owner map
+    const unsigned lane = threadIdx.x;
+    if (blockIdx.x >= unit_count)
+        return;
+    const HapGpuDecodeUnit u = units[blockIdx.x];
+    if (u.kind != HAPGPU_UNIT_SNAPPY_FRAGMENT)
+        return;
+    HapGpuDecodeJob *job = &jobs[u.job];
+    if (job->status != 0)
+        return;
+
+    const uint8_t *src = (const uint8_t *)u.src;
+    uint8_t *dst = (uint8_t *)u.dst;
+    const unsigned shift = (unsigned)((uintptr_t)src & 15u);
+    const uint8_t *src_al = src - shift;
+    const unsigned in_end = shift + u.src_len;
+    const unsigned out_len = u.dst_len;
+
+    auto load_granule = [&](unsigned g) -> uint4 {
+        const unsigned x = g * kInGranule + lane * 16u;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (x >= shift && x + 16u <= in_end) {
+            v = *reinterpret_cast<const uint4 *>(src_al + x);
+        } else if (x + 16u > shift && x < in_end) {
+            unsigned w[4] = {0, 0, 0, 0};
+            for (unsigned k = 0; k < 16; k++) {
+                const unsigned y = x + k;
+                if (y >= shift && y < in_end)
+                    w[k >> 2] |= (unsigned)src_al[y] << (8 * (k & 3));
+            }
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        return v;
+    };
+    auto store_granule = [&](unsigned g, uint4 v) {
+        *reinterpret_cast<uint4 *>(smem + RING + ((g & 1u) * kInGranule) + lane * 16u) = v;
+    };
+
+    unsigned ip = shift;
+    const unsigned granules = (in_end + kInGranule - 1) / kInGranule;
+    store_granule(0, load_granule(0));
+    store_granule(1, load_granule(1));
+    unsigned next_g = 2, in_hi = 2 * kInGranule;
+    uint4 pend = make_uint4(0, 0, 0, 0);
+    bool pend_valid = false;
+    __syncthreads();
+
+    bool failed = out_len > RING;
+    unsigned op = 0;
+
+    while (!failed && ip < in_end) {
+        // ---- staging window: keep >= 256 bytes ahead of ip ----
+        if (!pend_valid && next_g < granules && ip + 3 * (kInGranule / 2) >= in_hi) {
+            pend = load_granule(next_g);
+            pend_valid = true;
+        }
+        if (ip + 256u > in_hi && in_hi < granules * kInGranule) {
+            const unsigned g = ip / kInGranule;
+            if (g + 1 == next_g) {
+                store_granule(next_g, pend_valid ? pend : load_granule(next_g));
+                next_g += 1;
+            } else if (g >= next_g) {
+                store_granule(g, load_granule(g));
+                store_granule(g + 1, load_granule(g + 1));
+                next_g = g + 2;
+            }
+            pend_valid = false;
+            in_hi = next_g * kInGranule;
+            __syncthreads();
+        }
+
+        // ---- 1. speculative parse: the element that would start at coordinate ip + lane ----
+        const unsigned x = ip + lane;
+        const unsigned wi = x >> 2, sh = x & 3u;
+        const unsigned w0 = inw[wi & 511u], w1 = inw[(wi + 1) & 511u], w2 = inw[(wi + 2) & 511u];
+        const unsigned lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
+        const unsigned hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+        const unsigned tag = lo & 0xFFu, kind = tag & 3u;
+        unsigned len, off = 0, hdr;
+        bool special = false;                   // long literal: taken alone by the slow path
+        if (kind == 0) {
+            len = (tag >> 2) + 1u;
+            hdr = 1;
+            if (len > 60u) {
+                special = true;
+                hdr = 1u + (len - 60u);
+            }
+        } else if (kind == 1) {
+            len = 4u + ((tag >> 2) & 7u);
+            off = ((tag >> 5) << 8) | ((lo >> 8) & 0xFFu);
+            hdr = 2;
+        } else if (kind == 2) {
+            len = (tag >> 2) + 1u;
+            off = (lo >> 8) & 0xFFFFu;
+            hdr = 3;
+        } else {
+            len = (tag >> 2) + 1u;
+            off = (lo >> 8) | (hi << 24);
+            hdr = 5;
+        }
+        const unsigned tokbytes = hdr + (kind == 0 ? len : 0u);
+        // an element that does not fit the input, or a long literal, ends the window before it
+        const bool stopper = special || x >= in_end || tokbytes > in_end - x;
+        const unsigned nxt = stopper ? 64u : min(lane + tokbytes, 64u);
+
+        // ---- 2. chain membership from lane 0 ----
+        unsigned long long mask1 = stopper ? 0ull : (1ull << lane);
+        unsigned j1 = nxt;
+        // round 1: two elements per hop
+        unsigned g_j = (unsigned)lane_gather((int)j1, j1 & 63u);
+        unsigned g_lo = (unsigned)lane_gather((int)(unsigned)mask1, j1 & 63u);
+        unsigned g_hi = (unsigned)lane_gather((int)(unsigned)(mask1 >> 32), j1 & 63u);
+        unsigned long long mask2 = mask1 | (j1 < 64u ? (((unsigned long long)g_hi << 32) | g_lo) : 0ull);
+        unsigned j2 = j1 < 64u ? g_j : 64u;
+        // round 2: four elements per hop
+        g_j = (unsigned)lane_gather((int)j2, j2 & 63u);
+        g_lo = (unsigned)lane_gather((int)(unsigned)mask2, j2 & 63u);
+        g_hi = (unsigned)lane_gather((int)(unsigned)(mask2 >> 32), j2 & 63u);
+        const unsigned long long mask4 = mask2 | (j2 < 64u ? (((unsigned long long)g_hi << 32) | g_lo) : 0ull);
+        const unsigned j4 = j2 < 64u ? g_j : 64u;
+        unsigned long long T = 0;
+        for (unsigned s = 0; s < 64u;) {
+            const unsigned m_lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mask4, (int)s);
+            const unsigned m_hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mask4 >> 32), (int)s);
+            T |= ((unsigned long long)m_hi << 32) | m_lo;
+            s = (unsigned)__builtin_amdgcn_readlane((int)j4, (int)s);
+        }
+
+        if (T == 0) {
+            // the element at ip is a long literal (or malformed): serial path, one element
+            const unsigned lo0 = uniform(lo), hi0 = uniform(hi);
+            const unsigned tag0 = lo0 & 0xFFu;
+            if ((tag0 & 3u) != 0 || (tag0 >> 2) < 60u) { failed = true; break; }
+            const unsigned extra = (tag0 >> 2) - 59u;
+            const unsigned long long field = (((unsigned long long)hi0 << 32) | lo0) >> 8;
+            const unsigned v = (unsigned)(extra == 4 ? field : (field & ((1ull << (8 * extra)) - 1ull)));
+            const unsigned h = 1u + extra;
+            if (h > in_end - ip || v == 0xFFFFFFFFu) { failed = true; break; }
+            const unsigned llen = v + 1u;
+            if (llen > in_end - ip - h || llen > out_len - op) { failed = true; break; }
+            ip += h;
+            for (unsigned done = 0; done < llen; done += 64u) {
+                const unsigned n = min(64u, llen - done);
+                const bool staged = ip + done + n <= in_hi;
+                if (lane < n) {
+                    const unsigned y = ip + done + lane;
+                    ring[op + lane] = staged ? smem[RING + (y & (kInBytes - 1))] : src_al[y];
+                }
+                op += n;
+            }
+            ip += llen;
+            continue;
+        }
+
+        // ---- 3. output positions ----
+        bool is_tok = (T >> lane) & 1ull;
+        int incl = wave_scan_add(is_tok ? (int)len : 0);
+        unsigned o_t = (unsigned)incl - (is_tok ? len : 0u);
+        // keep at most kOwnerBytes of output per pass (prefix-closed because o_t is monotone)
+        const unsigned long long keep = __ballot(is_tok && o_t + len <= kOwnerBytes);
+        T = keep;
+        is_tok = (T >> lane) & 1ull;
+        const unsigned last = 63u - (unsigned)__builtin_clzll(T);
+        const unsigned N = (unsigned)__builtin_amdgcn_readlane(incl, (int)last);
+        const unsigned adv = last + (unsigned)__builtin_amdgcn_readlane((int)tokbytes, (int)last);
+        // validity of every element of the pass
+        const bool bad = is_tok && ((kind != 0 && (off == 0 || off > op + o_t)) || len > out_len - op - o_t ||
+                                    o_t > out_len - op);
+        if (__ballot(bad) != 0) { failed = true; break; }
+
+        // ---- 4. owner map + per-byte production ----
+        for (unsigned i = lane * 4u; i < N; i += 256u)
+            *reinterpret_cast<uint32_t *>(owner + i) = 0u;
+        if (is_tok)
+            owner[o_t] = (uint8_t)(lane + 1u);
+        // element attributes, fetched by the byte lanes with ds_bpermute
+        const int a0 = (int)(o_t | (len << 16) | (kind == 0 ? 0x80000000u : 0u));
+        const int a1 = (int)(kind == 0 ? x + hdr : op + o_t - off);    // literal: input coordinate; copy: source position
+        const int a2 = (int)off;
+        unsigned carry = 0;
+        for (unsigned B = 0; B < N; B += 64u) {
+            const unsigned b = B + lane;
+            const bool active = b < N;
+            int m = active ? (int)owner[b] : 0;
+            m = wave_scan_max(m);
+            m = max(m, (int)carry);
+            carry = (unsigned)__builtin_amdgcn_readlane(m, 63);
+            const unsigned sl = (unsigned)(m - 1) & 63u;
+            const unsigned g0 = (unsigned)lane_gather(a0, sl);
+            const unsigned g1 = (unsigned)lane_gather(a1, sl);
+            const unsigned g2 = (unsigned)lane_gather(a2, sl);
+            const unsigned rel = b - (g0 & 0xFFFFu);
+            const unsigned elen = (g0 >> 16) & 0x7Fu;
+            const bool lit = (g0 >> 31) != 0;
+            unsigned desc;                       // bit 31: resolved (LDS byte address), else output position
+            if (lit) {
+                desc = 0x80000000u | (RING + ((g1 + rel) & (kInBytes - 1)));
+            } else {
+                unsigned r = rel;
+                if (g2 < elen) {                                 // overlapping copy: periodic pattern
+                    const unsigned q = (rel * ((65536u / g2) + 1u)) >> 16;
+                    r = rel - q * g2;
+                }
+                const unsigned q = g1 + r;                       // output position of the source byte
+                desc = q < op + B ? (0x80000000u | q) : q;
+            }
+            if (!active)
+                desc = 0x80000000u;
+            // sources inside this 64-byte step: pointer jumping
+            for (int round = 0; round < 7; round++) {
+                const bool pending = (desc >> 31) == 0;
+                if (__ballot(pending) == 0)
+                    break;
+                const unsigned from = (desc - (op + B)) & 63u;
+                const unsigned g = (unsigned)lane_gather((int)desc, from);
+                if (pending)
+                    desc = g;
+            }
+            const uint8_t value = smem[desc & 0x7FFFFFFFu];
+            if (active)
+                ring[op + b] = value;
+        }
+        op += N;
+        ip += adv;
+    }
+    if (!failed && op != out_len)
+        failed = true;
+    if (failed) {
+        if (lane == 0)
+            atomicCAS(&job->status, 0u, HAPGPU_STATUS_INDEX_MISMATCH);
+        return;
+    }
+    flush_ring<RING>(ring, dst, 0, op, lane);
+}
+
 } // namespace
 
 extern "C" int hapgpu_launch_decode_plan(HapGpuDecodeJob *jobs, unsigned job_count, hipStream_t stream)
@@ -498,26 +803,37 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
     if (any_stream_or_copy_units) {
         static bool once = false;
         if (!once) {
-            hipFuncSetAttribute((const void *)snappy_decode_kernel<65536u, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes);
+            (void)hipFuncSetAttribute((const void *)snappy_decode_kernel<65536u, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes);
             once = true;
         }
         hipLaunchKernelGGL((snappy_decode_kernel<65536u, false>), dim3(unit_count), dim3(64), 65536 + kInBytes, stream, units, unit_count, jobs);
     }
+    static const bool use_v1 = getenv("HAP_AMD_DECODE_V1") != nullptr;
+    const unsigned extra = kInBytes + (use_v1 ? 0u : kOwnerBytes + 64u);
     switch (frag_log2) {
     case 0: break;
     case 10: case 11: case 12: case 13:
-        hipLaunchKernelGGL((snappy_decode_kernel<8192u, true>), dim3(unit_count), dim3(64), 8192 + kInBytes, stream, units, unit_count, jobs); break;
+        if (use_v1) hipLaunchKernelGGL((snappy_decode_kernel<8192u, true>), dim3(unit_count), dim3(64), 8192 + extra, stream, units, unit_count, jobs);
+        else hipLaunchKernelGGL((snappy_decode_fragment_kernel<8192u>), dim3(unit_count), dim3(64), 8192 + extra, stream, units, unit_count, jobs);
+        break;
     case 14:
-        hipLaunchKernelGGL((snappy_decode_kernel<16384u, true>), dim3(unit_count), dim3(64), 16384 + kInBytes, stream, units, unit_count, jobs); break;
+        if (use_v1) hipLaunchKernelGGL((snappy_decode_kernel<16384u, true>), dim3(unit_count), dim3(64), 16384 + extra, stream, units, unit_count, jobs);
+        else hipLaunchKernelGGL((snappy_decode_fragment_kernel<16384u>), dim3(unit_count), dim3(64), 16384 + extra, stream, units, unit_count, jobs);
+        break;
     case 15:
-        hipLaunchKernelGGL((snappy_decode_kernel<32768u, true>), dim3(unit_count), dim3(64), 32768 + kInBytes, stream, units, unit_count, jobs); break;
+        if (use_v1) hipLaunchKernelGGL((snappy_decode_kernel<32768u, true>), dim3(unit_count), dim3(64), 32768 + extra, stream, units, unit_count, jobs);
+        else hipLaunchKernelGGL((snappy_decode_fragment_kernel<32768u>), dim3(unit_count), dim3(64), 32768 + extra, stream, units, unit_count, jobs);
+        break;
     case 16: {
         static bool once = false;
         if (!once) {
-            hipFuncSetAttribute((const void *)snappy_decode_kernel<65536u, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes);
+            (void)hipFuncSetAttribute((const void *)snappy_decode_kernel<65536u, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes);
+            (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes + kOwnerBytes + 64);
             once = true;
         }
-        hipLaunchKernelGGL((snappy_decode_kernel<65536u, true>), dim3(unit_count), dim3(64), 65536 + kInBytes, stream, units, unit_count, jobs); break;
+        if (use_v1) hipLaunchKernelGGL((snappy_decode_kernel<65536u, true>), dim3(unit_count), dim3(64), 65536 + extra, stream, units, unit_count, jobs);
+        else hipLaunchKernelGGL((snappy_decode_fragment_kernel<65536u>), dim3(unit_count), dim3(64), 65536 + extra, stream, units, unit_count, jobs);
+        break;
     }
     default: return 1;
     }
