@@ -22,6 +22,7 @@
 // HBM traffic: fragment read once, compressed bytes written once.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "hapgpu_abi.h"
 
 namespace {
@@ -236,6 +237,268 @@ __global__ __launch_bounds__(64) void snappy_compress_kernel(const HapGpuFrameEn
         frag_sizes[f] = out_pos;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// workgroup-per-fragment compressor
+// ------------------------------------------------------------------------------------------
+//
+// Same element stream rules as the kernel above, restructured for throughput:
+//   * 4 wavefronts share one fragment (data + hash table in LDS once, 4x the waves per CU);
+//     in every ROUND wave w takes the 128-byte supertile 4*round + w (two 64-byte tiles).
+//   * rounds are synchronous: all lookups of a round read the hash table as it was after the
+//     previous round, then all waves insert with LDS atomicMax (u32 entries, the most recent
+//     position wins) -- the output does not depend on wave timing (deterministic).
+//   * copies never cross a supertile boundary, so supertiles are independent; their sizes are
+//     exchanged through LDS at the round barrier and every wave writes its bytes straight to
+//     their final position (no staging, no compaction pass).
+//   * match extension compares 16 bytes per step (<= 4 steps), the covered-by-a-copy mask comes
+//     from a DPP max-scan instead of 64-bit scalar arithmetic in the selection loop.
+
+constexpr unsigned kWgWaves = 4;
+#ifndef HAP_FIXED_DISTANCES
+#define HAP_FIXED_DISTANCES 8, 16, 24, 32, 48, 64
+#endif
+__device__ constexpr unsigned kFixedDist[] = {HAP_FIXED_DISTANCES};
+constexpr int kFixed = (int)(sizeof(kFixedDist) / sizeof(kFixedDist[0]));
+constexpr unsigned kWgHashBits = 12;
+constexpr unsigned kWgHashEntries = 1u << kWgHashBits;
+
+__device__ __forceinline__ int cdpp_row_shr(int v, int n)
+{
+    switch (n) {
+    case 1: return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);
+    case 2: return __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
+    case 4: return __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
+    default: return __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
+    }
+}
+
+__device__ __forceinline__ int cwave_scan_max(int v)   // inclusive, values >= 0
+{
+    v = max(v, cdpp_row_shr(v, 1));
+    v = max(v, cdpp_row_shr(v, 2));
+    v = max(v, cdpp_row_shr(v, 4));
+    v = max(v, cdpp_row_shr(v, 8));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false));
+    return v;
+}
+
+// equal bytes of data[a..] and data[b..], 16 per step, at most `limit`
+__device__ __forceinline__ unsigned match_extend16(const uint32_t *dw, unsigned a, unsigned b, unsigned limit)
+{
+    unsigned l = 0;
+    while (l < limit) {
+        const unsigned wa = (a + l) >> 2, sa = (a + l) & 3u, wb = (b + l) >> 2, sb = (b + l) & 3u;
+        const unsigned a0 = dw[wa], a1 = dw[wa + 1], a2 = dw[wa + 2], a3 = dw[wa + 3], a4 = dw[wa + 4];
+        const unsigned b0 = dw[wb], b1 = dw[wb + 1], b2 = dw[wb + 2], b3 = dw[wb + 3], b4 = dw[wb + 4];
+        const unsigned d0 = __builtin_amdgcn_alignbyte(a1, a0, sa) ^ __builtin_amdgcn_alignbyte(b1, b0, sb);
+        const unsigned d1 = __builtin_amdgcn_alignbyte(a2, a1, sa) ^ __builtin_amdgcn_alignbyte(b2, b1, sb);
+        const unsigned d2 = __builtin_amdgcn_alignbyte(a3, a2, sa) ^ __builtin_amdgcn_alignbyte(b3, b2, sb);
+        const unsigned d3 = __builtin_amdgcn_alignbyte(a4, a3, sa) ^ __builtin_amdgcn_alignbyte(b4, b3, sb);
+        if (d0 | d1 | d2 | d3) {
+            l += d0 ? ((unsigned)__builtin_ctz(d0) >> 3)
+               : d1 ? 4u + ((unsigned)__builtin_ctz(d1) >> 3)
+               : d2 ? 8u + ((unsigned)__builtin_ctz(d2) >> 3)
+                    : 12u + ((unsigned)__builtin_ctz(d3) >> 3);
+            break;
+        }
+        l += 16u;
+    }
+    return min(l, limit);
+}
+
+__global__ __launch_bounds__(256) void snappy_compress_wg_kernel(const HapGpuFrameEnc *__restrict__ frames,
+                                                                unsigned frag_log2, uint8_t *__restrict__ slots,
+                                                                unsigned slot_stride, uint32_t *__restrict__ frag_sizes)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const unsigned frag_bytes = 1u << frag_log2;
+    uint32_t *dataw = reinterpret_cast<uint32_t *>(smem);                        // frag_bytes + 32
+    const uint8_t *data = smem;
+    uint32_t *table = reinterpret_cast<uint32_t *>(smem + frag_bytes + 32);      // kWgHashEntries
+    uint32_t *roundsz = table + kWgHashEntries;                                  // kWgWaves
+
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const HapGpuFrameEnc &frame = frames[blockIdx.z];
+    if (blockIdx.y >= frame.tex_count)
+        return;
+    const HapGpuTexEnc &tex = frame.tex[blockIdx.y];
+    if (tex.compressor != 1u)
+        return;
+    const unsigned x = blockIdx.x;
+    if (x >= tex.chunk_count * tex.frags_per_chunk)
+        return;
+    const unsigned chunk = x / tex.frags_per_chunk, j = x - chunk * tex.frags_per_chunk;
+    const unsigned begin = j << frag_log2;
+    const unsigned n = min(frag_bytes, tex.chunk_bytes - begin);
+    const uint8_t *src = (const uint8_t *)tex.src + (size_t)chunk * tex.chunk_bytes + begin;
+    const unsigned f = tex.frag_first + x;
+    uint8_t *out = slots + (size_t)f * slot_stride;
+
+    if (((uintptr_t)src & 15u) == 0) {
+        for (unsigned i = tid * 16u; i < n + 32u; i += 4096u) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (i + 16u <= n) {
+                v = *reinterpret_cast<const uint4 *>(src + i);
+            } else if (i < n) {
+                unsigned w[4] = {0, 0, 0, 0};
+                for (unsigned k = 0; i + k < n; k++)
+                    w[k >> 2] |= (unsigned)src[i + k] << (8 * (k & 3));
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            *reinterpret_cast<uint4 *>(smem + i) = v;
+        }
+    } else {
+        for (unsigned i = tid; i < n + 32u; i += 256u)
+            smem[i] = i < n ? src[i] : (uint8_t)0;
+    }
+    for (unsigned i = tid; i < kWgHashEntries; i += 256u)
+        table[i] = 0u;
+    __syncthreads();
+
+    const unsigned tiles = (n + 63u) / 64u, supers = (tiles + 1u) / 2u;
+    unsigned round_base = 0;
+
+    for (unsigned base = 0; base < supers; base += kWgWaves) {
+        const unsigned k = base + wave;
+        const bool have = k < supers;
+        // per-tile emission plan, kept in registers across the round barrier
+        unsigned p_len[2] = {0, 0}, p_off[2] = {0, 0}, p_hash[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+        unsigned p_at[2] = {0, 0}, p_run[2] = {0, 0}, p_flags[2] = {0, 0}, p_byte[2] = {0, 0};
+        unsigned total = 0;
+        if (have) {
+            const unsigned super_end = min(n, (2u * k + 2u) * 64u);
+            // equality ballots for the fixed distances (block pitches of DXT data)
+            unsigned long long eq[kFixed][2];
+#pragma unroll
+            for (int sub = 0; sub < 2; sub++) {
+                const unsigned p = (2u * k + sub) * 64u + lane;
+                const bool in = p < n;
+                const uint8_t here = data[p];
+#pragma unroll
+                for (int d = 0; d < kFixed; d++) {
+                    const unsigned dist = kFixedDist[d];
+                    eq[d][sub] = __ballot(in && p >= dist && here == data[p >= dist ? p - dist : 0u]);
+                }
+            }
+            unsigned skip = 0;
+#pragma unroll
+            for (int sub = 0; sub < 2; sub++) {
+                const unsigned p = (2u * k + sub) * 64u + lane;
+                const bool in_range = p < n;
+                const unsigned room = in_range ? min(64u, super_end - p) : 0u;
+                unsigned best_len = 0, best_off = 0, my_hash = 0xFFFFFFFFu;
+                const unsigned cur = lds_load32(dataw, p);
+                if (p + 4u <= n) {
+                    const unsigned h = (cur * 0x1e35a7bdu) >> (32u - kWgHashBits);
+                    const unsigned cand = table[h];
+                    my_hash = h;
+                    if (cand < p && room >= 4u && lds_load32(dataw, cand) == cur) {
+                        best_len = 4u + match_extend16(dataw, cand + 4u, p + 4u, room - 4u);
+                        best_off = p - cand;
+                    }
+                }
+#pragma unroll
+                for (int d = kFixed - 1; d >= 0; d--) {          // nearer distances win ties
+                    const unsigned l = min(run_from(eq[d][sub], sub == 0 ? eq[d][1] : 0ull, lane), room);
+                    if (l >= best_len && l >= 4u) { best_len = l; best_off = kFixedDist[d]; }
+                }
+                // greedy selection: the scalar unit hops from chosen copy to chosen copy
+                const unsigned long long cand_mask = __ballot(in_range && best_len >= 4u);
+                unsigned long long sel = 0;
+                unsigned cursor = min(skip, 64u);
+                unsigned carry = skip > 64u ? skip - 64u : 0u;
+                while (cursor < 64u) {
+                    const unsigned long long rest = cand_mask >> cursor;
+                    if (!rest)
+                        break;
+                    const unsigned s = cursor + (unsigned)__builtin_ctzll(rest);
+                    sel |= 1ull << s;
+                    cursor = s + (unsigned)__builtin_amdgcn_readlane((int)best_len, (int)s);
+                    if (cursor > 64u)
+                        carry = cursor - 64u;
+                }
+                const bool is_copy = (sel >> lane) & 1ull;
+                // covered[l] <=> some chosen copy (or the carry-in) spans position l
+                const int reach = cwave_scan_max(is_copy ? (int)(lane + best_len) : 0);
+                const bool covered = (unsigned)reach > lane || lane < skip;
+                skip = carry;
+                const unsigned long long lit = __ballot(in_range && !covered);
+                const unsigned long long starts = lit & ~(lit << 1);
+                const bool is_lit = (lit >> lane) & 1ull;
+                const bool is_start = (starts >> lane) & 1ull;
+                unsigned run = 0;
+                if (is_start) {
+                    const unsigned long long a = ~(lit >> lane);
+                    run = a ? (unsigned)__builtin_ctzll(a) : 64u;
+                }
+                const bool copy1 = best_len < 12u && best_off < 2048u;
+                unsigned emit = 0;
+                if (is_lit)
+                    emit = 1u + (is_start ? (run > 60u ? 2u : 1u) : 0u);
+                else if (is_copy)
+                    emit = copy1 ? 2u : 3u;
+                const unsigned long long e0 = __ballot(emit & 1u), e1 = __ballot(emit & 2u);
+                p_at[sub] = total + bits_below(e0) + 2u * bits_below(e1);
+                total += (unsigned)__popcll(e0) + 2u * (unsigned)__popcll(e1);
+                p_len[sub] = best_len;
+                p_off[sub] = best_off;
+                p_hash[sub] = my_hash;
+                p_run[sub] = run;
+                p_byte[sub] = cur & 0xFFu;
+                p_flags[sub] = (is_lit ? 1u : 0u) | (is_start ? 2u : 0u) | (is_copy ? 4u : 0u) | (copy1 ? 8u : 0u);
+            }
+        }
+        if (lane == 0)
+            roundsz[wave] = total;
+        __syncthreads();
+        unsigned my_base = round_base, all = 0;
+#pragma unroll
+        for (unsigned w = 0; w < kWgWaves; w++) {
+            const unsigned sz = roundsz[w];
+            if (w < wave)
+                my_base += sz;
+            all += sz;
+        }
+        round_base += all;
+        if (have) {
+#pragma unroll
+            for (int sub = 0; sub < 2; sub++) {
+                const unsigned p = (2u * k + sub) * 64u + lane;
+                unsigned at = my_base + p_at[sub];
+                const unsigned fl = p_flags[sub];
+                if (fl & 1u) {
+                    if (fl & 2u) {
+                        if (p_run[sub] > 60u) {
+                            out[at++] = (uint8_t)(60u << 2);
+                            out[at++] = (uint8_t)(p_run[sub] - 1u);
+                        } else {
+                            out[at++] = (uint8_t)((p_run[sub] - 1u) << 2);
+                        }
+                    }
+                    out[at] = (uint8_t)p_byte[sub];
+                } else if (fl & 4u) {
+                    if (fl & 8u) {
+                        out[at] = (uint8_t)(1u | ((p_len[sub] - 4u) << 2) | ((p_off[sub] >> 8) << 5));
+                        out[at + 1] = (uint8_t)p_off[sub];
+                    } else {
+                        out[at] = (uint8_t)(2u | ((p_len[sub] - 1u) << 2));
+                        out[at + 1] = (uint8_t)p_off[sub];
+                        out[at + 2] = (uint8_t)(p_off[sub] >> 8);
+                    }
+                }
+                // only element starts are remembered (see the single-wave kernel)
+                if ((fl & 5u) && p_hash[sub] != 0xFFFFFFFFu)
+                    atomicMax(&table[p_hash[sub]], p);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0)
+        frag_sizes[f] = round_base;
+}
+
 } // namespace
 
 // LDS bytes needed per workgroup for a fragment size
@@ -249,6 +512,21 @@ extern "C" int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsig
         return 0;
     if (frag_log2 < 10 || frag_log2 > 16)
         return 1;
+    static const bool use_v1 = getenv("HAP_AMD_COMPRESS_V1") != nullptr;
+    if (!use_v1) {
+        const unsigned lds2 = (1u << frag_log2) + 32u + kWgHashEntries * 4u + kWgWaves * 4u;
+        if (lds2 > 65536u) {
+            static bool once2 = false;
+            if (!once2) {
+                if (hipFuncSetAttribute((const void *)snappy_compress_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+                    return 4;
+                once2 = true;
+            }
+        }
+        hipLaunchKernelGGL(snappy_compress_wg_kernel, dim3(max_frags_per_texture, 2, frame_count), dim3(256), lds2, stream,
+                           frames, frag_log2, (uint8_t *)slots, slot_stride, frag_sizes);
+        return hipGetLastError() == hipSuccess ? 0 : 4;
+    }
     const unsigned lds = compress_lds_bytes(frag_log2);
     if (lds > 65536u) {
         static bool once = false;
