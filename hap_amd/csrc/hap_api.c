@@ -26,7 +26,7 @@ unsigned int HapGpuCreate(int device, HapGpuContext **context)
         free(c);
         return rc == 1 ? HapResult_Bad_Arguments : HapResult_Internal_Error;
     }
-    c->frag_log2 = 14;
+    c->frag_log2 = 13;   /* 8 KiB: best decode occupancy for ~1 % more bytes than 16 KiB */
     {
         const char *e = getenv("HAP_AMD_FRAGMENT_LOG2");
         if (e && atoi(e) >= 10 && atoi(e) <= 16)

@@ -53,8 +53,8 @@ void HapGpuDestroy(HapGpuContext *context);
  * use on the current device; HAP_AMD_DEVICE overrides). NULL if no GPU. */
 HapGpuContext *HapGpuDefaultContext(void);
 
-/* Log2 of the Snappy fragment size used by the compressor (12..16, default
- * 14 = 16 KiB).  Fragments are compressed independently of each other. */
+/* Log2 of the Snappy fragment size used by the compressor (10..16, default
+ * 13 = 8 KiB).  Fragments are compressed independently of each other. */
 unsigned int HapGpuSetFragmentLog2(HapGpuContext *context, unsigned int log2_bytes);
 
 /* Blocks until everything enqueued on the context's stream has finished. */

@@ -362,9 +362,9 @@ def test_encode_compression_ratio_close_to_libsnappy(ctx, hap):
         ours = len(hap.HapEncode([tex], [fmt], [1], [8])[1])
         theirs = len(ORA.encode([tex], [fmt], [1], [8])[1])
         assert ours < len(tex)
-        # 16 KiB fragments see less history than libsnappy's 64 KiB ones; RGTC1's matches are
-        # almost all one block-row up, so it pays the most
-        slack = 2.5 if fmt == L.FMT_RGTC1 else 1.30
+        # 8 KiB fragments see less history than libsnappy's 64 KiB ones; RGTC1's matches are
+        # almost all one block-row up (4096 B here), so it pays the most
+        slack = 4.0 if fmt == L.FMT_RGTC1 else 1.40
         assert ours <= theirs * slack + 64, (fmt, ours, theirs)
 
 
@@ -426,7 +426,7 @@ def test_corrupt_fragment_table_falls_back(ctx, hap):
     out = np.zeros(cap, dtype=np.uint8)
     r, used, _ = ctx.encode_frames([[tex]], [L.FMT_DXT5], [1], [4], [out], flags=hap.ENCODE_FRAGMENT_INDEX)
     frame = bytearray(out[: used[0]].tobytes())
-    pos = frame.find(bytes([0x46, 1, 14, 0, 0]), 0, 200) + 5
+    pos = frame.find(bytes([0x46, 1, 13, 0, 0]), 0, 200) + 5
     assert pos > 5
     e0 = int.from_bytes(frame[pos:pos + 4], "little")
     e1 = int.from_bytes(frame[pos + 4:pos + 8], "little")
