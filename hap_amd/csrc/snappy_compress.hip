@@ -255,11 +255,7 @@ __global__ __launch_bounds__(64) void snappy_compress_kernel(const HapGpuFrameEn
 //     from a DPP max-scan instead of 64-bit scalar arithmetic in the selection loop.
 
 constexpr unsigned kWgWaves = 4;
-#ifndef HAP_FIXED_DISTANCES
-#define HAP_FIXED_DISTANCES 8, 16, 24, 32, 48, 64
-#endif
-__device__ constexpr unsigned kFixedDist[] = {HAP_FIXED_DISTANCES};
-constexpr int kFixed = (int)(sizeof(kFixedDist) / sizeof(kFixedDist[0]));
+constexpr int kFixed = 4;      // candidates at 1..4 block pitches (8-byte or 16-byte blocks)
 constexpr unsigned kWgHashBits = 12;
 constexpr unsigned kWgHashEntries = 1u << kWgHashBits;
 
@@ -359,6 +355,8 @@ __global__ __launch_bounds__(256) void snappy_compress_wg_kernel(const HapGpuFra
 
     const unsigned tiles = (n + 63u) / 64u, supers = (tiles + 1u) / 2u;
     unsigned round_base = 0;
+    // DXT1 / RGTC1 textures are arrays of 8-byte blocks, everything else 16-byte blocks (hap.c:287-294)
+    const unsigned pitch = (tex.format_nibble == 0xBu || tex.format_nibble == 0x1u) ? 8u : 16u;
 
     for (unsigned base = 0; base < supers; base += kWgWaves) {
         const unsigned k = base + wave;
@@ -378,7 +376,7 @@ __global__ __launch_bounds__(256) void snappy_compress_wg_kernel(const HapGpuFra
                 const uint8_t here = data[p];
 #pragma unroll
                 for (int d = 0; d < kFixed; d++) {
-                    const unsigned dist = kFixedDist[d];
+                    const unsigned dist = (unsigned)(d + 1) * pitch;
                     eq[d][sub] = __ballot(in && p >= dist && here == data[p >= dist ? p - dist : 0u]);
                 }
             }
@@ -391,7 +389,11 @@ __global__ __launch_bounds__(256) void snappy_compress_wg_kernel(const HapGpuFra
                 unsigned best_len = 0, best_off = 0, my_hash = 0xFFFFFFFFu;
                 const unsigned cur = lds_load32(dataw, p);
                 if (p + 4u <= n) {
+#ifdef HAP_MUL24_HASH
+                    const unsigned h = (__umul24(cur & 0xFFFFFFu, 0x9E3779u) + __umul24(cur >> 8, 0x85EBCBu)) >> (32u - kWgHashBits);
+#else
                     const unsigned h = (cur * 0x1e35a7bdu) >> (32u - kWgHashBits);
+#endif
                     const unsigned cand = table[h];
                     my_hash = h;
                     if (cand < p && room >= 4u && lds_load32(dataw, cand) == cur) {
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(256) void snappy_compress_wg_kernel(const HapGpuFra
 #pragma unroll
                 for (int d = kFixed - 1; d >= 0; d--) {          // nearer distances win ties
                     const unsigned l = min(run_from(eq[d][sub], sub == 0 ? eq[d][1] : 0ull, lane), room);
-                    if (l >= best_len && l >= 4u) { best_len = l; best_off = kFixedDist[d]; }
+                    if (l >= best_len && l >= 4u) { best_len = l; best_off = (unsigned)(d + 1) * pitch; }
                 }
                 // greedy selection: the scalar unit hops from chosen copy to chosen copy
                 const unsigned long long cand_mask = __ballot(in_range && best_len >= 4u);

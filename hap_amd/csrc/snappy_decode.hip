@@ -749,8 +749,8 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
             } else {
                 unsigned r = rel;
                 if (g2 < elen) {                                 // overlapping copy: periodic pattern
-                    const unsigned q = (rel * ((65536u / g2) + 1u)) >> 16;
-                    r = rel - q * g2;
+                    const unsigned q = __umul24(rel, (65536u / g2) + 1u) >> 16;      // rel / g2, exact for rel < 64
+                    r = rel - __umul24(q, g2);
                 }
                 const unsigned q = g1 + r;                       // output position of the source byte
                 desc = q < op + B ? (0x80000000u | q) : q;

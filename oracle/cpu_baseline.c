@@ -92,6 +92,64 @@ double SYM(decode)(const void *const *frames, const unsigned long *frame_bytes, 
     return now_s() - t0;
 }
 
+/* ---- decode: whole frames per thread (serial callback inside) -------------- */
+typedef struct {
+    const void *const *frames; const unsigned long *frame_bytes; unsigned nframes, index, tid, threads, reps, rc;
+    unsigned char *out; unsigned long out_stride;
+} dec_t;
+
+static void serial_callback(work_fn fn, void *p, unsigned count, void *info)
+{
+    unsigned i;
+    (void)info;
+    for (i = 0; i < count; i++)
+        fn(p, i);
+}
+
+static void *dec_main(void *arg)
+{
+    dec_t *d = (dec_t *)arg;
+    unsigned r, f;
+    for (r = 0; r < d->reps; r++)
+        for (f = d->tid; f < d->nframes; f += d->threads) {
+            unsigned long used = 0;
+            unsigned fmt = 0;
+            unsigned rc = API_DECODE(d->frames[f], d->frame_bytes[f], d->index, serial_callback, NULL,
+                                     d->out + (size_t)d->tid * d->out_stride, d->out_stride, &used, &fmt);
+            if (rc != 0)
+                d->rc = rc;
+        }
+    return NULL;
+}
+
+/* out must hold threads * out_stride bytes */
+double SYM(decode_parallel)(const void *const *frames, const unsigned long *frame_bytes, unsigned nframes,
+                            unsigned index, void *out, unsigned long out_stride, unsigned threads, unsigned reps)
+{
+    pthread_t th[256];
+    dec_t job[256];
+    unsigned t;
+    double t0;
+    if (threads == 0) threads = 1;
+    if (threads > 256) threads = 256;
+    t0 = now_s();
+    for (t = 0; t < threads; t++) {
+        dec_t *d = &job[t];
+        d->frames = frames; d->frame_bytes = frame_bytes; d->nframes = nframes; d->index = index;
+        d->tid = t; d->threads = threads; d->reps = reps; d->rc = 0;
+        d->out = (unsigned char *)out; d->out_stride = out_stride;
+        if (t + 1 < threads)
+            pthread_create(&th[t], NULL, dec_main, d);
+    }
+    dec_main(&job[threads - 1]);
+    for (t = 0; t + 1 < threads; t++)
+        pthread_join(th[t], NULL);
+    for (t = 0; t < threads; t++)
+        if (job[t].rc)
+            return -(double)job[t].rc;
+    return now_s() - t0;
+}
+
 /* ---- encode: one frame per thread ---------------------------------------- */
 typedef struct {
     unsigned count, nframes, tid, threads, reps, rc;
