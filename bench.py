@@ -165,7 +165,7 @@ def main():
     dom = max((k for k in kernels if algo.get(k)), key=lambda k: kernels[k]["ms_total"])
     achieved = kernels[dom]["algorithmic_GBps"]
     roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": measured_traffic(args.config, dom, nf),
                 "algorithmic_bytes_per_launch": int(algo[dom]), "avg_launch_ms": kernels[dom]["ms_avg"]}
 
     cpu = None
@@ -194,6 +194,21 @@ def main():
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def measured_traffic(config, kernel, frames):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC pass (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs by tools/prof_traffic.sh; FETCH doubled as the MI355X
+    guide prescribes for wide streaming reads).  None when no measurement exists for this config."""
+    path = os.path.join(ROOT, "profiles", "traffic_%s.json" % config.lower())
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        k = t["kernels"][kernel]
+    except (OSError, KeyError, ValueError):
+        return None
+    scale = 1.0 if k["per"] == "frame" else frames / float(t["frames_per_launch"])
+    return int((2.0 * k["fetch"] + k["write"]) * 1024 * scale)
 
 
 def cpu_baseline(w, h, fmts, chunks, rgba, dec, tex_bytes, cap, budget_s):
