@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--frag-log2", type=int, default=0, help="Snappy fragment size (log2 bytes); 0 = library default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--foreign-frames", type=int, default=8,
+                    help="also time decoding of N frames made by the CPU reference encoder (no fragment table); 0 = skip")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -168,6 +170,12 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": measured_traffic(args.config, dom, nf),
                 "algorithmic_bytes_per_launch": int(algo[dom]), "avg_launch_ms": kernels[dom]["ms_avg"]}
 
+    foreign = None
+    if args.foreign_frames and not args.no_cpu_baseline:
+        try:
+            foreign = decode_foreign(ctx, dev, fmts, chunks, dec, tex_bytes, cap, min(args.foreign_frames, nf), rgba_bytes)
+        except Exception as exc:
+            foreign = {"error": repr(exc)}
     cpu = None
     if not args.no_cpu_baseline:
         try:
@@ -189,11 +197,44 @@ def main():
         "encode_only": {"rgba_GBps": round(nf * rgba_bytes / (enc_ms * 1e-3) / 1e9, 2), "ms": round(enc_ms, 3)},
         "decode_only": {"rgba_GBps": round(nf * rgba_bytes / (dec_ms * 1e-3) / 1e9, 2), "ms": round(dec_ms, 3),
                         "texture_GBps": round(nf * bsum / (dec_ms * 1e-3) / 1e9, 2)},
+        "decode_of_reference_encoded_frames": foreign,
         "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
     }
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def decode_foreign(ctx, dev, fmts, chunks, dec, tex_bytes, cap, n, rgba_bytes):
+    """Frames produced by the CPU reference encoder (libsnappy streams, no fragment table) decoded by
+    the GPU: the generic one-wave-per-chunk path.  Reported beside the headline, never part of it."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import _libs as L
+    ref = L.ref_lib()
+    lib, prefix = (ref, "refbase") if ref is not None else (L.oracle_lib(), "oraclebase")
+    enc = getattr(lib, prefix + "_encode"); enc.restype = C.c_double
+    count = len(fmts)
+    tex_host = [[dec[i][f].cpu().numpy() for i in range(count)] for f in range(n)]
+    ptrs = (C.c_void_p * (n * count))(*[tex_host[f][i].ctypes.data for f in range(n) for i in range(count)])
+    lens = (C.c_ulong * count)(*tex_bytes)
+    cf = (C.c_uint * count)(*fmts); cc = (C.c_uint * count)(*([1] * count)); ck = (C.c_uint * count)(*chunks)
+    out = np.zeros(cap * n, dtype=np.uint8)
+    used = (C.c_ulong * n)()
+    if enc(C.c_uint(count), ptrs, lens, cf, cc, ck, C.c_uint(n), out.ctypes.data_as(C.c_void_p), C.c_ulong(cap), used,
+           C.c_uint(n), C.c_uint(1)) < 0:
+        raise RuntimeError("reference encode failed")
+    frames = [torch.from_numpy(out[i * cap: i * cap + used[i]].copy()).to(dev) for i in range(n)]
+    outs = [torch.empty(tex_bytes[0], dtype=torch.uint8, device=dev) for _ in range(n)]
+    torch.cuda.synchronize()
+    ctx.decode_frames(frames, [int(u) for u in used], 0, outs)          # warm-up
+    ctx.timer_start()
+    r, dused, _f, dres = ctx.decode_frames(frames, [int(u) for u in used], 0, outs)
+    ms = ctx.timer_stop()
+    ok = r == 0 and all(torch.equal(outs[i], dec[0][i]) for i in range(n))
+    return {"frames": n, "ms": round(ms, 3), "rgba_GBps": round(n * rgba_bytes / (ms * 1e-3) / 1e9, 2),
+            "texture_GBps": round(n * tex_bytes[0] / (ms * 1e-3) / 1e9, 2), "bit_exact": bool(ok),
+            "encoder": "reference hap.c + libsnappy 1.1.8" if ref is not None else "oracle/ C port"}
 
 
 def measured_traffic(config, kernel, frames):

@@ -542,7 +542,7 @@ __device__ __forceinline__ int lane_gather(int v, unsigned src_lane)
     return __builtin_amdgcn_ds_bpermute((int)(src_lane << 2), v);
 }
 
-template <unsigned RING>
+template <unsigned RING, bool STREAM>
 __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpuDecodeUnit *__restrict__ units,
                                                                     unsigned unit_count, HapGpuDecodeJob *jobs)
 {
@@ -554,10 +554,17 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
     if (blockIdx.x >= unit_count)
         return;
     const HapGpuDecodeUnit u = units[blockIdx.x];
-    if (u.kind != HAPGPU_UNIT_SNAPPY_FRAGMENT)
+    if (u.kind == HAPGPU_UNIT_SKIP)
         return;
     HapGpuDecodeJob *job = &jobs[u.job];
     if (job->status != 0)
+        return;
+    if (u.kind == HAPGPU_UNIT_COPY) {
+        if (STREAM)      // raw chunks ride with the stream launch
+            wave_copy((uint8_t *)u.dst, (const uint8_t *)u.src, u.src_len, lane);
+        return;
+    }
+    if ((u.kind == HAPGPU_UNIT_SNAPPY_STREAM) != STREAM)
         return;
 
     const uint8_t *src = (const uint8_t *)u.src;
@@ -596,8 +603,17 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
     bool pend_valid = false;
     __syncthreads();
 
-    bool failed = out_len > RING;
-    unsigned op = 0;
+    bool failed = !STREAM && out_len > RING;
+    unsigned op = 0, flushed = 0;
+    if (STREAM) {
+        // skip the length prefix (validated by the plan kernel)
+        unsigned b;
+        do {
+            b = smem[RING + (ip & (kInBytes - 1))];
+            ip++;
+        } while ((b & 0x80u) && ip < in_end);
+        ip = uniform(ip);
+    }
 
     while (!failed && ip < in_end) {
         // ---- staging window: keep >= 256 bytes ahead of ip ----
@@ -695,9 +711,14 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
                 const bool staged = ip + done + n <= in_hi;
                 if (lane < n) {
                     const unsigned y = ip + done + lane;
-                    ring[op + lane] = staged ? smem[RING + (y & (kInBytes - 1))] : src_al[y];
+                    ring[(op + lane) & (RING - 1)] = staged ? smem[RING + (y & (kInBytes - 1))] : src_al[y];
                 }
                 op += n;
+                if (STREAM && op - flushed >= 2 * kSegment) {
+                    const unsigned upto = op & ~(kSegment - 1);
+                    flush_ring<RING>(ring, dst, flushed, upto, lane);
+                    flushed = upto;
+                }
             }
             ip += llen;
             continue;
@@ -744,6 +765,8 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
             const unsigned elen = (g0 >> 16) & 0x7Fu;
             const bool lit = (g0 >> 31) != 0;
             unsigned desc;                       // bit 31: resolved (LDS byte address), else output position
+            bool far = false;
+            unsigned far_pos = 0;
             if (lit) {
                 desc = 0x80000000u | (RING + ((g1 + rel) & (kInBytes - 1)));
             } else {
@@ -753,10 +776,15 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
                     r = rel - __umul24(q, g2);
                 }
                 const unsigned q = g1 + r;                       // output position of the source byte
-                desc = q < op + B ? (0x80000000u | q) : q;
+                desc = q < op + B ? (0x80000000u | (q & (RING - 1))) : q;
+                // a stream's ring holds only the last RING bytes: older sources come back from memory
+                far = STREAM && q + RING < op + kOwnerBytes + 64u;
+                far_pos = q;
             }
-            if (!active)
+            if (!active) {
                 desc = 0x80000000u;
+                far = false;
+            }
             // sources inside this 64-byte step: pointer jumping
             for (int round = 0; round < 7; round++) {
                 const bool pending = (desc >> 31) == 0;
@@ -767,21 +795,38 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
                 if (pending)
                     desc = g;
             }
-            const uint8_t value = smem[desc & 0x7FFFFFFFu];
+            uint8_t value = smem[desc & 0x7FFFFFFFu];
+            if (STREAM && __ballot(far) != 0) {
+                // far sources were flushed long ago by this wave; make those stores visible and
+                // bypass this CU's L1 for the read-back
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (far)
+                    value = __hip_atomic_load(dst + far_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (active)
-                ring[op + b] = value;
+                ring[(op + b) & (RING - 1)] = value;
         }
         op += N;
         ip += adv;
+        if (STREAM && op - flushed >= 2 * kSegment) {
+            const unsigned upto = op & ~(kSegment - 1);
+            flush_ring<RING>(ring, dst, flushed, upto, lane);
+            flushed = upto;
+        }
     }
     if (!failed && op != out_len)
         failed = true;
     if (failed) {
-        if (lane == 0)
-            atomicCAS(&job->status, 0u, HAPGPU_STATUS_INDEX_MISMATCH);
+        if (lane == 0) {
+            const unsigned code = !STREAM ? HAPGPU_STATUS_INDEX_MISMATCH
+                                          : (job->mode == HAPGPU_JOB_SNAPPY ? kResInternal : kResBadFrame);
+            atomicCAS(&job->status, 0u, code);
+        }
         return;
     }
-    flush_ring<RING>(ring, dst, 0, op, lane);
+    if (op > flushed)
+        flush_ring<RING>(ring, dst, flushed, op, lane);
 }
 
 } // namespace
@@ -800,39 +845,43 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
 {
     if (unit_count == 0)
         return 0;
+    static const bool use_v1 = getenv("HAP_AMD_DECODE_V1") != nullptr;
     if (any_stream_or_copy_units) {
         static bool once = false;
         if (!once) {
             (void)hipFuncSetAttribute((const void *)snappy_decode_kernel<65536u, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes);
+            (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes + kOwnerBytes + 64);
             once = true;
         }
-        hipLaunchKernelGGL((snappy_decode_kernel<65536u, false>), dim3(unit_count), dim3(64), 65536 + kInBytes, stream, units, unit_count, jobs);
+        if (use_v1)
+            hipLaunchKernelGGL((snappy_decode_kernel<65536u, false>), dim3(unit_count), dim3(64), 65536 + kInBytes, stream, units, unit_count, jobs);
+        else
+            hipLaunchKernelGGL((snappy_decode_fragment_kernel<65536u, true>), dim3(unit_count), dim3(64), 65536 + kInBytes + kOwnerBytes + 64, stream, units, unit_count, jobs);
     }
-    static const bool use_v1 = getenv("HAP_AMD_DECODE_V1") != nullptr;
     const unsigned extra = kInBytes + (use_v1 ? 0u : kOwnerBytes + 64u);
     switch (frag_log2) {
     case 0: break;
     case 10: case 11: case 12: case 13:
         if (use_v1) hipLaunchKernelGGL((snappy_decode_kernel<8192u, true>), dim3(unit_count), dim3(64), 8192 + extra, stream, units, unit_count, jobs);
-        else hipLaunchKernelGGL((snappy_decode_fragment_kernel<8192u>), dim3(unit_count), dim3(64), 8192 + extra, stream, units, unit_count, jobs);
+        else hipLaunchKernelGGL((snappy_decode_fragment_kernel<8192u, false>), dim3(unit_count), dim3(64), 8192 + extra, stream, units, unit_count, jobs);
         break;
     case 14:
         if (use_v1) hipLaunchKernelGGL((snappy_decode_kernel<16384u, true>), dim3(unit_count), dim3(64), 16384 + extra, stream, units, unit_count, jobs);
-        else hipLaunchKernelGGL((snappy_decode_fragment_kernel<16384u>), dim3(unit_count), dim3(64), 16384 + extra, stream, units, unit_count, jobs);
+        else hipLaunchKernelGGL((snappy_decode_fragment_kernel<16384u, false>), dim3(unit_count), dim3(64), 16384 + extra, stream, units, unit_count, jobs);
         break;
     case 15:
         if (use_v1) hipLaunchKernelGGL((snappy_decode_kernel<32768u, true>), dim3(unit_count), dim3(64), 32768 + extra, stream, units, unit_count, jobs);
-        else hipLaunchKernelGGL((snappy_decode_fragment_kernel<32768u>), dim3(unit_count), dim3(64), 32768 + extra, stream, units, unit_count, jobs);
+        else hipLaunchKernelGGL((snappy_decode_fragment_kernel<32768u, false>), dim3(unit_count), dim3(64), 32768 + extra, stream, units, unit_count, jobs);
         break;
     case 16: {
         static bool once = false;
         if (!once) {
             (void)hipFuncSetAttribute((const void *)snappy_decode_kernel<65536u, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes);
-            (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes + kOwnerBytes + 64);
+            (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes + kOwnerBytes + 64);
             once = true;
         }
         if (use_v1) hipLaunchKernelGGL((snappy_decode_kernel<65536u, true>), dim3(unit_count), dim3(64), 65536 + extra, stream, units, unit_count, jobs);
-        else hipLaunchKernelGGL((snappy_decode_fragment_kernel<65536u>), dim3(unit_count), dim3(64), 65536 + extra, stream, units, unit_count, jobs);
+        else hipLaunchKernelGGL((snappy_decode_fragment_kernel<65536u, false>), dim3(unit_count), dim3(64), 65536 + extra, stream, units, unit_count, jobs);
         break;
     }
     default: return 1;
