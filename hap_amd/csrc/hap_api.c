@@ -32,6 +32,10 @@ unsigned int HapGpuCreate(int device, HapGpuContext **context)
         if (e && atoi(e) >= 10 && atoi(e) <= 16)
             c->frag_log2 = (unsigned)atoi(e);
     }
+    {
+        const char *e = getenv("HAP_AMD_BYTE_GRANULAR");
+        c->byte_granular = ((e && atoi(e) != 0) || getenv("HAP_AMD_COMPRESS_V1")) ? 1u : 0u;
+    }
     *context = c;
     return HapResult_No_Error;
 }

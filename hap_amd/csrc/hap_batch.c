@@ -33,7 +33,7 @@ static int is_dev(HapGpuContext *c, const void *p) { return hapgpu_rt_is_device_
 /* ================================================================== encode */
 
 typedef struct tex_geom {
-    unsigned format, compressor, chunk_count, chunk_bytes, header_len, fpc, nibble;
+    unsigned format, compressor, chunk_count, chunk_bytes, header_len, fpc, nibble, gran_log2;
     unsigned long bytes;
     size_t bound;        /* hap_max_encoded_length for the requested compressor (hap.c:386) */
 } tex_geom;
@@ -51,6 +51,7 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
     unsigned frag_log2 = ctx->frag_log2, frag_bytes = 1u << frag_log2;
     unsigned slot_stride;
     int any_snappy = 0;
+    unsigned gran_mask = 0;
     size_t stage_in_bytes = 0, stage_out_bytes = 0, frame_raw_bound = 0;
     hapgpu_rt *rt = ctx->rt;
     HapGpuFrameEnc *hframes, *dframes;
@@ -112,6 +113,10 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
             t->chunk_bytes = (unsigned)t->bytes;
         }
         t->fpc = (t->chunk_bytes + frag_bytes - 1) / frag_bytes;
+        /* 16-bit granular element streams need even chunk sizes (always true for block textures) */
+        t->gran_log2 = (t->compressor == HapCompressorSnappy && (t->chunk_bytes & 1u) == 0 && !ctx->byte_granular) ? 1u : 0u;
+        if (t->compressor == HapCompressorSnappy)
+            gran_mask |= 1u << t->gran_log2;
         if (t->compressor == HapCompressorSnappy) {
             /* header choice uses the layout that will actually be written (hap.c:425-428) */
             size_t ilen = hapf_instructions_length(t->chunk_count);
@@ -242,11 +247,12 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
                 te->frags_per_chunk = g[i].fpc;
                 te->frag_first = k * frags_per_frame + (i ? g[0].chunk_count * g[0].fpc : 0u);
                 te->emit_index = (flags & HAPGPU_ENCODE_FRAGMENT_INDEX) ? 1u : 0u;
+                te->reserved = g[i].gran_log2;
             }
         }
         rc |= (unsigned)hapgpu_rt_h2d(rt, dframes, hframes, sizeof(HapGpuFrameEnc) * live);
         if (any_snappy)
-            rc |= (unsigned)hapgpu_k_snappy_compress(rt, dframes, live, max_frags_per_tex, frag_log2, dslots, slot_stride, dfragsizes);
+            rc |= (unsigned)hapgpu_k_snappy_compress(rt, dframes, live, max_frags_per_tex, frag_log2, dslots, slot_stride, dfragsizes, gran_mask);
         rc |= (unsigned)hapgpu_k_frame_pack(rt, dframes, live, frag_log2, dslots, slot_stride, dfragsizes, dcopies);
         rc |= (unsigned)hapgpu_k_frame_gather(rt, dcopies, frags_per_frame * live);
         rc |= (unsigned)hapgpu_rt_d2h(rt, hframes, dframes, sizeof(HapGpuFrameEnc) * live);

@@ -12,6 +12,7 @@
 struct HapGpuContext {
     hapgpu_rt *rt;
     unsigned frag_log2;
+    unsigned byte_granular;   /* HAP_AMD_BYTE_GRANULAR=1: never emit 16-bit granular element streams */
 };
 
 /* inputs_are_device != 0: every input pointer is known to be device memory (skips classification) */

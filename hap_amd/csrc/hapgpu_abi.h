@@ -46,7 +46,8 @@ typedef struct HapGpuTexEnc {
     uint32_t frags_per_chunk;
     uint32_t frag_first;     /* global index of this texture's first fragment */
     uint32_t emit_index;     /* write the fragment-size section */
-    uint32_t reserved;
+    uint32_t reserved;       /* granularity_log2 of the element stream: 0 = bytes, 1 = every position, offset
+                                and length even (lets the decoder move 16 bits per lane) */
 } HapGpuTexEnc;
 
 /* [device] one frame */
@@ -148,7 +149,8 @@ int hapgpu_k_block_encode(hapgpu_rt *rt, const void *rgba, unsigned width, unsig
                           size_t row_bytes, unsigned hap_texture_format, void *out);
 int hapgpu_k_snappy_compress(hapgpu_rt *rt, const HapGpuFrameEnc *frames, unsigned frame_count,
                              unsigned max_frags_per_texture, unsigned frag_log2,
-                             void *slots, unsigned slot_stride, uint32_t *frag_sizes);
+                             void *slots, unsigned slot_stride, uint32_t *frag_sizes,
+                             unsigned granularity_mask /* bit g set: some texture has granularity_log2 == g */);
 int hapgpu_k_frame_pack(hapgpu_rt *rt, HapGpuFrameEnc *frames, unsigned frame_count,
                         unsigned frag_log2, const void *slots, unsigned slot_stride,
                         const uint32_t *frag_sizes, HapGpuCopyEntry *copies);

@@ -16,7 +16,7 @@ int hapgpu_launch_block_encode(const void *rgba, unsigned width, unsigned height
                                unsigned format, void *out, hipStream_t stream);
 int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsigned frame_count, unsigned max_frags_per_texture,
                                   unsigned frag_log2, void *slots, unsigned slot_stride, uint32_t *frag_sizes,
-                                  hipStream_t stream);
+                                  unsigned granularity_mask, hipStream_t stream);
 int hapgpu_launch_frame_pack(HapGpuFrameEnc *frames, unsigned frame_count, unsigned frag_log2, const void *slots,
                              unsigned slot_stride, const uint32_t *frag_sizes, HapGpuCopyEntry *copies,
                              hipStream_t stream);
@@ -296,11 +296,11 @@ extern "C" int hapgpu_k_block_encode(hapgpu_rt *rt, const void *rgba, unsigned w
 
 extern "C" int hapgpu_k_snappy_compress(hapgpu_rt *rt, const HapGpuFrameEnc *frames, unsigned frame_count,
                                         unsigned max_frags_per_texture, unsigned frag_log2, void *slots,
-                                        unsigned slot_stride, uint32_t *frag_sizes)
+                                        unsigned slot_stride, uint32_t *frag_sizes, unsigned granularity_mask)
 {
     scoped_timing st(rt, 1);
     return hapgpu_launch_snappy_compress(frames, frame_count, max_frags_per_texture, frag_log2, slots, slot_stride,
-                                         frag_sizes, rt->stream);
+                                         frag_sizes, granularity_mask, rt->stream);
 }
 
 extern "C" int hapgpu_k_frame_pack(hapgpu_rt *rt, HapGpuFrameEnc *frames, unsigned frame_count, unsigned frag_log2,

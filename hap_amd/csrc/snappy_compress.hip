@@ -304,6 +304,7 @@ __device__ __forceinline__ unsigned match_extend16(const uint32_t *dw, unsigned 
     return min(l, limit);
 }
 
+template <unsigned GRAN>     // bytes per lane: 1, or 2 (positions, offsets and lengths all even)
 __global__ __launch_bounds__(256) void snappy_compress_wg_kernel(const HapGpuFrameEnc *__restrict__ frames,
                                                                 unsigned frag_log2, uint8_t *__restrict__ slots,
                                                                 unsigned slot_stride, uint32_t *__restrict__ frag_sizes)
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256) void snappy_compress_wg_kernel(const HapGpuFra
     if (blockIdx.y >= frame.tex_count)
         return;
     const HapGpuTexEnc &tex = frame.tex[blockIdx.y];
-    if (tex.compressor != 1u)
+    if (tex.compressor != 1u || (1u << tex.reserved) != GRAN)
         return;
     const unsigned x = blockIdx.x;
     if (x >= tex.chunk_count * tex.frags_per_chunk)
@@ -353,7 +354,9 @@ __global__ __launch_bounds__(256) void snappy_compress_wg_kernel(const HapGpuFra
         table[i] = 0u;
     __syncthreads();
 
-    const unsigned tiles = (n + 63u) / 64u, supers = (tiles + 1u) / 2u;
+    constexpr unsigned TB = 64u * GRAN;                 // bytes per tile
+    const uint16_t *data16 = reinterpret_cast<const uint16_t *>(smem);
+    const unsigned tiles = (n + TB - 1u) / TB, supers = (tiles + 1u) / 2u;
     unsigned round_base = 0;
     // DXT1 / RGTC1 textures are arrays of 8-byte blocks, everything else 16-byte blocks (hap.c:287-294)
     const unsigned pitch = (tex.format_nibble == 0xBu || tex.format_nibble == 0x1u) ? 8u : 16u;
@@ -364,28 +367,31 @@ __global__ __launch_bounds__(256) void snappy_compress_wg_kernel(const HapGpuFra
         // per-tile emission plan, kept in registers across the round barrier
         unsigned p_len[2] = {0, 0}, p_off[2] = {0, 0}, p_hash[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
         unsigned p_at[2] = {0, 0}, p_run[2] = {0, 0}, p_flags[2] = {0, 0}, p_byte[2] = {0, 0};
+        (void)data16;
         unsigned total = 0;
         if (have) {
-            const unsigned super_end = min(n, (2u * k + 2u) * 64u);
+            const unsigned super_end = min(n, (2u * k + 2u) * TB);
             // equality ballots for the fixed distances (block pitches of DXT data)
             unsigned long long eq[kFixed][2];
 #pragma unroll
             for (int sub = 0; sub < 2; sub++) {
-                const unsigned p = (2u * k + sub) * 64u + lane;
+                const unsigned p = (2u * k + sub) * TB + GRAN * lane;
                 const bool in = p < n;
-                const uint8_t here = data[p];
+                const unsigned here = GRAN == 2 ? (unsigned)data16[p >> 1] : (unsigned)data[p];
 #pragma unroll
                 for (int d = 0; d < kFixed; d++) {
                     const unsigned dist = (unsigned)(d + 1) * pitch;
-                    eq[d][sub] = __ballot(in && p >= dist && here == data[p >= dist ? p - dist : 0u]);
+                    const unsigned back = p >= dist ? p - dist : 0u;
+                    const unsigned there = GRAN == 2 ? (unsigned)data16[back >> 1] : (unsigned)data[back];
+                    eq[d][sub] = __ballot(in && p >= dist && here == there);
                 }
             }
             unsigned skip = 0;
 #pragma unroll
             for (int sub = 0; sub < 2; sub++) {
-                const unsigned p = (2u * k + sub) * 64u + lane;
+                const unsigned p = (2u * k + sub) * TB + GRAN * lane;
                 const bool in_range = p < n;
-                const unsigned room = in_range ? min(64u, super_end - p) : 0u;
+                const unsigned room = in_range ? (min(64u, super_end - p) & ~(GRAN - 1u)) : 0u;
                 unsigned best_len = 0, best_off = 0, my_hash = 0xFFFFFFFFu;
                 const unsigned cur = lds_load32(dataw, p);
                 if (p + 4u <= n) {
@@ -397,13 +403,13 @@ __global__ __launch_bounds__(256) void snappy_compress_wg_kernel(const HapGpuFra
                     const unsigned cand = table[h];
                     my_hash = h;
                     if (cand < p && room >= 4u && lds_load32(dataw, cand) == cur) {
-                        best_len = 4u + match_extend16(dataw, cand + 4u, p + 4u, room - 4u);
+                        best_len = (4u + match_extend16(dataw, cand + 4u, p + 4u, room - 4u)) & ~(GRAN - 1u);
                         best_off = p - cand;
                     }
                 }
 #pragma unroll
                 for (int d = kFixed - 1; d >= 0; d--) {          // nearer distances win ties
-                    const unsigned l = min(run_from(eq[d][sub], sub == 0 ? eq[d][1] : 0ull, lane), room);
+                    const unsigned l = min(GRAN * run_from(eq[d][sub], sub == 0 ? eq[d][1] : 0ull, lane), room);
                     if (l >= best_len && l >= 4u) { best_len = l; best_off = (unsigned)(d + 1) * pitch; }
                 }
                 // greedy selection: the scalar unit hops from chosen copy to chosen copy
@@ -417,38 +423,39 @@ __global__ __launch_bounds__(256) void snappy_compress_wg_kernel(const HapGpuFra
                         break;
                     const unsigned s = cursor + (unsigned)__builtin_ctzll(rest);
                     sel |= 1ull << s;
-                    cursor = s + (unsigned)__builtin_amdgcn_readlane((int)best_len, (int)s);
+                    cursor = s + (unsigned)__builtin_amdgcn_readlane((int)best_len, (int)s) / GRAN;
                     if (cursor > 64u)
                         carry = cursor - 64u;
                 }
                 const bool is_copy = (sel >> lane) & 1ull;
                 // covered[l] <=> some chosen copy (or the carry-in) spans position l
-                const int reach = cwave_scan_max(is_copy ? (int)(lane + best_len) : 0);
+                const int reach = cwave_scan_max(is_copy ? (int)(lane + best_len / GRAN) : 0);
                 const bool covered = (unsigned)reach > lane || lane < skip;
                 skip = carry;
                 const unsigned long long lit = __ballot(in_range && !covered);
                 const unsigned long long starts = lit & ~(lit << 1);
                 const bool is_lit = (lit >> lane) & 1ull;
                 const bool is_start = (starts >> lane) & 1ull;
-                unsigned run = 0;
+                unsigned run = 0;                          // literal run length in BYTES
                 if (is_start) {
                     const unsigned long long a = ~(lit >> lane);
-                    run = a ? (unsigned)__builtin_ctzll(a) : 64u;
+                    run = GRAN * (a ? (unsigned)__builtin_ctzll(a) : 64u);
                 }
                 const bool copy1 = best_len < 12u && best_off < 2048u;
                 unsigned emit = 0;
                 if (is_lit)
-                    emit = 1u + (is_start ? (run > 60u ? 2u : 1u) : 0u);
+                    emit = GRAN + (is_start ? (run > 60u ? 2u : 1u) : 0u);
                 else if (is_copy)
                     emit = copy1 ? 2u : 3u;
                 const unsigned long long e0 = __ballot(emit & 1u), e1 = __ballot(emit & 2u);
-                p_at[sub] = total + bits_below(e0) + 2u * bits_below(e1);
-                total += (unsigned)__popcll(e0) + 2u * (unsigned)__popcll(e1);
+                const unsigned long long e2 = GRAN == 2 ? __ballot(emit & 4u) : 0ull;
+                p_at[sub] = total + bits_below(e0) + 2u * bits_below(e1) + (GRAN == 2 ? 4u * bits_below(e2) : 0u);
+                total += (unsigned)__popcll(e0) + 2u * (unsigned)__popcll(e1) + 4u * (unsigned)__popcll(e2);
                 p_len[sub] = best_len;
                 p_off[sub] = best_off;
                 p_hash[sub] = my_hash;
                 p_run[sub] = run;
-                p_byte[sub] = cur & 0xFFu;
+                p_byte[sub] = cur & (GRAN == 2 ? 0xFFFFu : 0xFFu);
                 p_flags[sub] = (is_lit ? 1u : 0u) | (is_start ? 2u : 0u) | (is_copy ? 4u : 0u) | (copy1 ? 8u : 0u);
             }
         }
@@ -467,7 +474,7 @@ __global__ __launch_bounds__(256) void snappy_compress_wg_kernel(const HapGpuFra
         if (have) {
 #pragma unroll
             for (int sub = 0; sub < 2; sub++) {
-                const unsigned p = (2u * k + sub) * 64u + lane;
+                const unsigned p = (2u * k + sub) * TB + GRAN * lane;
                 unsigned at = my_base + p_at[sub];
                 const unsigned fl = p_flags[sub];
                 if (fl & 1u) {
@@ -480,6 +487,8 @@ __global__ __launch_bounds__(256) void snappy_compress_wg_kernel(const HapGpuFra
                         }
                     }
                     out[at] = (uint8_t)p_byte[sub];
+                    if (GRAN == 2)
+                        out[at + 1] = (uint8_t)(p_byte[sub] >> 8);
                 } else if (fl & 4u) {
                     if (fl & 8u) {
                         out[at] = (uint8_t)(1u | ((p_len[sub] - 4u) << 2) | ((p_off[sub] >> 8) << 5));
@@ -508,7 +517,8 @@ static unsigned compress_lds_bytes(unsigned frag_log2) { return (1u << frag_log2
 
 extern "C" int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsigned frame_count,
                                              unsigned max_frags_per_texture, unsigned frag_log2, void *slots,
-                                             unsigned slot_stride, uint32_t *frag_sizes, hipStream_t stream)
+                                             unsigned slot_stride, uint32_t *frag_sizes, unsigned granularity_mask,
+                                             hipStream_t stream)
 {
     if (frame_count == 0 || max_frags_per_texture == 0)
         return 0;
@@ -520,13 +530,17 @@ extern "C" int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsig
         if (lds2 > 65536u) {
             static bool once2 = false;
             if (!once2) {
-                if (hipFuncSetAttribute((const void *)snappy_compress_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+                if (hipFuncSetAttribute((const void *)snappy_compress_wg_kernel<1u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess ||
+                    hipFuncSetAttribute((const void *)snappy_compress_wg_kernel<2u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
                     return 4;
                 once2 = true;
             }
         }
-        hipLaunchKernelGGL(snappy_compress_wg_kernel, dim3(max_frags_per_texture, 2, frame_count), dim3(256), lds2, stream,
-                           frames, frag_log2, (uint8_t *)slots, slot_stride, frag_sizes);
+        const dim3 grid(max_frags_per_texture, 2, frame_count);
+        if (granularity_mask & 1u)
+            hipLaunchKernelGGL(snappy_compress_wg_kernel<1u>, grid, dim3(256), lds2, stream, frames, frag_log2, (uint8_t *)slots, slot_stride, frag_sizes);
+        if (granularity_mask & 2u)
+            hipLaunchKernelGGL(snappy_compress_wg_kernel<2u>, grid, dim3(256), lds2, stream, frames, frag_log2, (uint8_t *)slots, slot_stride, frag_sizes);
         return hipGetLastError() == hipSuccess ? 0 : 4;
     }
     const unsigned lds = compress_lds_bytes(frag_log2);

@@ -426,7 +426,7 @@ def test_corrupt_fragment_table_falls_back(ctx, hap):
     out = np.zeros(cap, dtype=np.uint8)
     r, used, _ = ctx.encode_frames([[tex]], [L.FMT_DXT5], [1], [4], [out], flags=hap.ENCODE_FRAGMENT_INDEX)
     frame = bytearray(out[: used[0]].tobytes())
-    pos = frame.find(bytes([0x46, 1, 13, 0, 0]), 0, 200) + 5
+    pos = frame.find(bytes([0x46, 1, 13]), 0, 200) + 5      # type, version, log2 fragment, granularity, 0
     assert pos > 5
     e0 = int.from_bytes(frame[pos:pos + 4], "little")
     e1 = int.from_bytes(frame[pos + 4:pos + 8], "little")
