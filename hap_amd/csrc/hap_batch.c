@@ -444,7 +444,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     hapf_reader *readers;
     fetch_ctx *fetchers;
     unsigned f, live = 0, first_error = HapResult_No_Error, total_units = 0, total_chunks = 0;
-    unsigned frag_log2_seen = 0;
+    unsigned frag_log2_seen = 0, frag_kinds = 0;
     int any_stream = 0, need_retry = 0;
     uint8_t *prefix = NULL, *in_stage = NULL, *out_stage = NULL;
     size_t in_stage_bytes = 0, out_stage_bytes = 0;
@@ -645,6 +645,8 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                     job->frag_sizes = (uint64_t)(uintptr_t)(frame_dev + p->frag_table_offset);
                     job->frag_log2 = p->frag_log2;
                     job->frag_entries = p->frag_entries;
+                    job->reserved = p->frag_gran_log2;
+                    frag_kinds |= 1u << p->frag_gran_log2;
                 }
                 if (p->chunk_count > 0)
                     memcpy(hchunks + chunk_cursor, p->chunks, sizeof(HapGpuChunkIn) * (size_t)p->chunk_count);
@@ -700,7 +702,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                 }
             }
         }
-        rc |= hapgpu_k_snappy_decode(rt, dunits, total_units, djobs, frag_log2_seen, any_stream);
+        rc |= hapgpu_k_snappy_decode(rt, dunits, total_units, djobs, frag_log2_seen, frag_kinds, any_stream);
         rc |= hapgpu_rt_d2h(rt, hjobs, djobs, sizeof(HapGpuDecodeJob) * live);
         rc |= hapgpu_rt_sync(rt);
         if (rc)

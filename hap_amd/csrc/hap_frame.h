@@ -47,6 +47,7 @@ typedef struct hapf_texture_plan {
     uint64_t frag_table_offset; /* frame offset of the u32 fragment sizes, 0 if absent */
     uint32_t frag_entries;
     uint32_t frag_log2;
+    uint32_t frag_gran_log2;/* 1: the table promises 16-bit granular element streams */
     unsigned unit_count;    /* filled by the batch layer: GPU work units reserved for this texture */
 } hapf_texture_plan;
 

@@ -23,7 +23,8 @@ int hapgpu_launch_frame_pack(HapGpuFrameEnc *frames, unsigned frame_count, unsig
 int hapgpu_launch_frame_gather(const HapGpuCopyEntry *copies, unsigned count, hipStream_t stream);
 int hapgpu_launch_decode_plan(HapGpuDecodeJob *jobs, unsigned job_count, hipStream_t stream);
 int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsigned unit_count, HapGpuDecodeJob *jobs,
-                                unsigned frag_log2, int any_stream_or_copy_units, hipStream_t stream);
+                                unsigned frag_log2, unsigned fragment_kinds, int any_stream_or_copy_units,
+                                hipStream_t stream);
 }
 
 namespace {
@@ -328,8 +329,10 @@ extern "C" int hapgpu_k_decode_plan(hapgpu_rt *rt, HapGpuDecodeJob *jobs, unsign
 }
 
 extern "C" int hapgpu_k_snappy_decode(hapgpu_rt *rt, const HapGpuDecodeUnit *units, unsigned unit_count,
-                                      HapGpuDecodeJob *jobs, unsigned frag_log2, int any_stream_or_copy_units)
+                                      HapGpuDecodeJob *jobs, unsigned frag_log2, unsigned fragment_kinds,
+                                      int any_stream_or_copy_units)
 {
     scoped_timing st(rt, 5);
-    return hapgpu_launch_snappy_decode(units, unit_count, jobs, frag_log2, any_stream_or_copy_units, rt->stream);
+    return hapgpu_launch_snappy_decode(units, unit_count, jobs, frag_log2, fragment_kinds, any_stream_or_copy_units,
+                                       rt->stream);
 }

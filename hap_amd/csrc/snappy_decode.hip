@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64) void decode_plan_kernel(HapGpuDecodeJob *jobs, 
                             w.dst = (uint64_t)(dst + my_off + (unsigned long long)k * frag_bytes);
                             w.src_len = fs[k];
                             w.dst_len = min(frag_bytes, out_len - k * frag_bytes);
-                            w.kind = HAPGPU_UNIT_SNAPPY_FRAGMENT;
+                            w.kind = job->reserved ? HAPGPU_UNIT_SNAPPY_FRAGMENT16 : HAPGPU_UNIT_SNAPPY_FRAGMENT;
                             w.job = j;
                             u[k] = w;
                             at += fs[k];
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(64) void snappy_decode_kernel(const HapGpuDecodeUni
             wave_copy((uint8_t *)u.dst, (const uint8_t *)u.src, u.src_len, lane);
         return;
     }
-    if ((u.kind == HAPGPU_UNIT_SNAPPY_FRAGMENT) != FRAGMENT)
+    if ((u.kind == HAPGPU_UNIT_SNAPPY_FRAGMENT || u.kind == HAPGPU_UNIT_SNAPPY_FRAGMENT16) != FRAGMENT)
         return;
 
     const uint8_t *src = (const uint8_t *)u.src;
@@ -542,7 +542,9 @@ __device__ __forceinline__ int lane_gather(int v, unsigned src_lane)
     return __builtin_amdgcn_ds_bpermute((int)(src_lane << 2), v);
 }
 
-template <unsigned RING, bool STREAM>
+// GRAN = 2: every element of the unit has even length and (copies) even offset, so one lane moves
+// 16 bits (FRAGMENT16 units, produced by hap_amd's 16-bit granular compressor).
+template <unsigned RING, bool STREAM, unsigned GRAN>
 __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpuDecodeUnit *__restrict__ units,
                                                                     unsigned unit_count, HapGpuDecodeJob *jobs)
 {
@@ -564,7 +566,8 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
             wave_copy((uint8_t *)u.dst, (const uint8_t *)u.src, u.src_len, lane);
         return;
     }
-    if ((u.kind == HAPGPU_UNIT_SNAPPY_STREAM) != STREAM)
+    if (STREAM ? u.kind != HAPGPU_UNIT_SNAPPY_STREAM
+               : u.kind != (GRAN == 2 ? HAPGPU_UNIT_SNAPPY_FRAGMENT16 : HAPGPU_UNIT_SNAPPY_FRAGMENT))
         return;
 
     const uint8_t *src = (const uint8_t *)u.src;
@@ -704,7 +707,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
             const unsigned h = 1u + extra;
             if (h > in_end - ip || v == 0xFFFFFFFFu) { failed = true; break; }
             const unsigned llen = v + 1u;
-            if (llen > in_end - ip - h || llen > out_len - op) { failed = true; break; }
+            if (llen > in_end - ip - h || llen > out_len - op || (llen & (GRAN - 1u))) { failed = true; break; }
             ip += h;
             for (unsigned done = 0; done < llen; done += 64u) {
                 const unsigned n = min(64u, llen - done);
@@ -737,22 +740,24 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
         const unsigned adv = last + (unsigned)__builtin_amdgcn_readlane((int)tokbytes, (int)last);
         // validity of every element of the pass
         const bool bad = is_tok && ((kind != 0 && (off == 0 || off > op + o_t)) || len > out_len - op - o_t ||
-                                    o_t > out_len - op);
+                                    o_t > out_len - op || ((len | off) & (GRAN - 1u)));
         if (__ballot(bad) != 0) { failed = true; break; }
 
         // ---- 4. owner map + per-byte production ----
-        for (unsigned i = lane * 4u; i < N; i += 256u)
+        const unsigned NU = N / GRAN;                 // production units (bytes or 16-bit words)
+        for (unsigned i = lane * 4u; i < NU; i += 256u)
             *reinterpret_cast<uint32_t *>(owner + i) = 0u;
         if (is_tok)
-            owner[o_t] = (uint8_t)(lane + 1u);
+            owner[o_t / GRAN] = (uint8_t)(lane + 1u);
         // element attributes, fetched by the byte lanes with ds_bpermute
         const int a0 = (int)(o_t | (len << 16) | (kind == 0 ? 0x80000000u : 0u));
         const int a1 = (int)(kind == 0 ? x + hdr : op + o_t - off);    // literal: input coordinate; copy: source position
         const int a2 = (int)off;
         unsigned carry = 0;
-        for (unsigned B = 0; B < N; B += 64u) {
+        const unsigned opu = op / GRAN;
+        for (unsigned B = 0; B < NU; B += 64u) {
             const unsigned b = B + lane;
-            const bool active = b < N;
+            const bool active = b < NU;
             int m = active ? (int)owner[b] : 0;
             m = wave_scan_max(m);
             m = max(m, (int)carry);
@@ -761,22 +766,23 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
             const unsigned g0 = (unsigned)lane_gather(a0, sl);
             const unsigned g1 = (unsigned)lane_gather(a1, sl);
             const unsigned g2 = (unsigned)lane_gather(a2, sl);
-            const unsigned rel = b - (g0 & 0xFFFFu);
-            const unsigned elen = (g0 >> 16) & 0x7Fu;
+            const unsigned rel = b - (g0 & 0xFFFFu) / GRAN;
+            const unsigned elen = ((g0 >> 16) & 0x7Fu) / GRAN;
             const bool lit = (g0 >> 31) != 0;
             unsigned desc;                       // bit 31: resolved (LDS byte address), else output position
             bool far = false;
             unsigned far_pos = 0;
             if (lit) {
-                desc = 0x80000000u | (RING + ((g1 + rel) & (kInBytes - 1)));
+                desc = 0x80000000u | (GRAN == 2 ? 0x40000000u : 0u) | (RING + ((g1 + GRAN * rel) & (kInBytes - 1)));
             } else {
                 unsigned r = rel;
-                if (g2 < elen) {                                 // overlapping copy: periodic pattern
-                    const unsigned q = __umul24(rel, (65536u / g2) + 1u) >> 16;      // rel / g2, exact for rel < 64
-                    r = rel - __umul24(q, g2);
+                const unsigned offu = g2 / GRAN;
+                if (offu < elen) {                               // overlapping copy: periodic pattern
+                    const unsigned q = __umul24(rel, (65536u / offu) + 1u) >> 16;    // rel / offu, exact for rel < 64
+                    r = rel - __umul24(q, offu);
                 }
-                const unsigned q = g1 + r;                       // output position of the source byte
-                desc = q < op + B ? (0x80000000u | (q & (RING - 1))) : q;
+                const unsigned q = g1 / GRAN + r;                // output position (in units) of the source
+                desc = q < opu + B ? (0x80000000u | ((GRAN * q) & (RING - 1))) : q;
                 // a stream's ring holds only the last RING bytes: older sources come back from memory
                 far = STREAM && q + RING < op + kOwnerBytes + 64u;
                 far_pos = q;
@@ -790,12 +796,18 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
                 const bool pending = (desc >> 31) == 0;
                 if (__ballot(pending) == 0)
                     break;
-                const unsigned from = (desc - (op + B)) & 63u;
+                const unsigned from = (desc - (opu + B)) & 63u;
                 const unsigned g = (unsigned)lane_gather((int)desc, from);
                 if (pending)
                     desc = g;
             }
-            uint8_t value = smem[desc & 0x7FFFFFFFu];
+            const unsigned a0 = desc & 0x3FFFFFFFu;
+            unsigned value = smem[a0];
+            if (GRAN == 2) {
+                // second byte: literals live in the 2 KiB staging ring (may wrap), copies are contiguous
+                const unsigned a1 = (desc & 0x40000000u) ? RING + ((a0 - RING + 1u) & (kInBytes - 1)) : a0 + 1u;
+                value |= (unsigned)smem[a1] << 8;
+            }
             if (STREAM && __ballot(far) != 0) {
                 // far sources were flushed long ago by this wave; make those stores visible and
                 // bypass this CU's L1 for the read-back
@@ -804,8 +816,12 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
                 if (far)
                     value = __hip_atomic_load(dst + far_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (active)
-                ring[(op + b) & (RING - 1)] = value;
+            if (active) {
+                if (GRAN == 2)
+                    *reinterpret_cast<uint16_t *>(ring + ((op + 2u * b) & (RING - 1))) = (uint16_t)value;
+                else
+                    ring[(op + b) & (RING - 1)] = (uint8_t)value;
+            }
         }
         op += N;
         ip += adv;
@@ -841,7 +857,8 @@ extern "C" int hapgpu_launch_decode_plan(HapGpuDecodeJob *jobs, unsigned job_cou
 
 // frag_log2: fragment size of FRAGMENT units in this batch (0 = none present).
 extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsigned unit_count, HapGpuDecodeJob *jobs,
-                                           unsigned frag_log2, int any_stream_or_copy_units, hipStream_t stream)
+                                           unsigned frag_log2, unsigned fragment_kinds, int any_stream_or_copy_units,
+                                           hipStream_t stream)
 {
     if (unit_count == 0)
         return 0;
@@ -850,41 +867,44 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
         static bool once = false;
         if (!once) {
             (void)hipFuncSetAttribute((const void *)snappy_decode_kernel<65536u, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes);
-            (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes + kOwnerBytes + 64);
+            (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, true, 1u>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes + kOwnerBytes + 64);
             once = true;
         }
         if (use_v1)
             hipLaunchKernelGGL((snappy_decode_kernel<65536u, false>), dim3(unit_count), dim3(64), 65536 + kInBytes, stream, units, unit_count, jobs);
         else
-            hipLaunchKernelGGL((snappy_decode_fragment_kernel<65536u, true>), dim3(unit_count), dim3(64), 65536 + kInBytes + kOwnerBytes + 64, stream, units, unit_count, jobs);
+            hipLaunchKernelGGL((snappy_decode_fragment_kernel<65536u, true, 1u>), dim3(unit_count), dim3(64), 65536 + kInBytes + kOwnerBytes + 64, stream, units, unit_count, jobs);
     }
     const unsigned extra = kInBytes + (use_v1 ? 0u : kOwnerBytes + 64u);
+    static bool once16 = false;
+    if (!once16 && frag_log2 == 16) {
+        (void)hipFuncSetAttribute((const void *)snappy_decode_kernel<65536u, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes);
+        (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, false, 1u>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes + kOwnerBytes + 64);
+        (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, false, 2u>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes + kOwnerBytes + 64);
+        once16 = true;
+    }
+#define HAP_LAUNCH_FRAGMENT(RINGBYTES)                                                                                          \
+    do {                                                                                                                        \
+        if (use_v1) {                                                                                                           \
+            hipLaunchKernelGGL((snappy_decode_kernel<RINGBYTES, true>), dim3(unit_count), dim3(64), RINGBYTES + extra, stream,  \
+                               units, unit_count, jobs);                                                                        \
+        } else {                                                                                                                \
+            if (fragment_kinds & 1u)                                                                                            \
+                hipLaunchKernelGGL((snappy_decode_fragment_kernel<RINGBYTES, false, 1u>), dim3(unit_count), dim3(64),           \
+                                   RINGBYTES + extra, stream, units, unit_count, jobs);                                         \
+            if (fragment_kinds & 2u)                                                                                            \
+                hipLaunchKernelGGL((snappy_decode_fragment_kernel<RINGBYTES, false, 2u>), dim3(unit_count), dim3(64),           \
+                                   RINGBYTES + extra, stream, units, unit_count, jobs);                                         \
+        }                                                                                                                       \
+    } while (0)
     switch (frag_log2) {
     case 0: break;
-    case 10: case 11: case 12: case 13:
-        if (use_v1) hipLaunchKernelGGL((snappy_decode_kernel<8192u, true>), dim3(unit_count), dim3(64), 8192 + extra, stream, units, unit_count, jobs);
-        else hipLaunchKernelGGL((snappy_decode_fragment_kernel<8192u, false>), dim3(unit_count), dim3(64), 8192 + extra, stream, units, unit_count, jobs);
-        break;
-    case 14:
-        if (use_v1) hipLaunchKernelGGL((snappy_decode_kernel<16384u, true>), dim3(unit_count), dim3(64), 16384 + extra, stream, units, unit_count, jobs);
-        else hipLaunchKernelGGL((snappy_decode_fragment_kernel<16384u, false>), dim3(unit_count), dim3(64), 16384 + extra, stream, units, unit_count, jobs);
-        break;
-    case 15:
-        if (use_v1) hipLaunchKernelGGL((snappy_decode_kernel<32768u, true>), dim3(unit_count), dim3(64), 32768 + extra, stream, units, unit_count, jobs);
-        else hipLaunchKernelGGL((snappy_decode_fragment_kernel<32768u, false>), dim3(unit_count), dim3(64), 32768 + extra, stream, units, unit_count, jobs);
-        break;
-    case 16: {
-        static bool once = false;
-        if (!once) {
-            (void)hipFuncSetAttribute((const void *)snappy_decode_kernel<65536u, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes);
-            (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes + kOwnerBytes + 64);
-            once = true;
-        }
-        if (use_v1) hipLaunchKernelGGL((snappy_decode_kernel<65536u, true>), dim3(unit_count), dim3(64), 65536 + extra, stream, units, unit_count, jobs);
-        else hipLaunchKernelGGL((snappy_decode_fragment_kernel<65536u, false>), dim3(unit_count), dim3(64), 65536 + extra, stream, units, unit_count, jobs);
-        break;
-    }
+    case 10: case 11: case 12: case 13: HAP_LAUNCH_FRAGMENT(8192u); break;
+    case 14: HAP_LAUNCH_FRAGMENT(16384u); break;
+    case 15: HAP_LAUNCH_FRAGMENT(32768u); break;
+    case 16: HAP_LAUNCH_FRAGMENT(65536u); break;
     default: return 1;
     }
+#undef HAP_LAUNCH_FRAGMENT
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }

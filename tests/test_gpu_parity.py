@@ -436,6 +436,34 @@ def test_corrupt_fragment_table_falls_back(ctx, hap):
     assert hap.HapDecode(bytes(frame), 0, outputBufferBytes=len(tex)) == (0, tex, L.FMT_DXT5)
 
 
+def test_byte_granular_streams_and_a_lying_table(hap):
+    """Fragments are flagged 16-bit granular only when every element is; byte-granular streams take the
+    byte kernel, and a table that promises more than the stream keeps falls back to the generic path."""
+    import os
+    os.environ["HAP_AMD_BYTE_GRANULAR"] = "1"
+    try:
+        bctx = hap.Context(0)
+    finally:
+        del os.environ["HAP_AMD_BYTE_GRANULAR"]
+    img = D.rgba(512, 256, frame=5)
+    tex = D.oracle_bc_encode(img, L.FMT_YCOCG)
+    cap = hap.HapMaxEncodedLength([len(tex)], [L.FMT_YCOCG], [4])
+    out = np.zeros(cap, dtype=np.uint8)
+    r, used, res = bctx.encode_frames([[tex]], [L.FMT_YCOCG], [1], [4], [out], flags=hap.ENCODE_FRAGMENT_INDEX)
+    assert (r, res) == (0, [0])
+    frame = bytearray(out[: used[0]].tobytes())
+    pos = frame.find(bytes([0x46, 1, 13, 0, 0]), 0, 200)
+    assert pos > 0                                           # granularity byte 0 = bytes
+    assert ORA.decode(bytes(frame), 0, len(tex)) == (0, tex, L.FMT_YCOCG)
+    assert hap.HapDecode(bytes(frame), 0, outputBufferBytes=len(tex)) == (0, tex, L.FMT_YCOCG)
+    frame[pos + 3] = 1                                       # claim 16-bit granularity (false: odd lengths exist)
+    assert hap.HapDecode(bytes(frame), 0, outputBufferBytes=len(tex)) == (0, tex, L.FMT_YCOCG)
+    bctx.close()
+    # the default context does emit 16-bit granular streams for block textures
+    r, f16 = hap.HapEncode([tex], [L.FMT_YCOCG], [1], [4])
+    assert r == 0 and ORA.decode(f16, 0, len(tex)) == (0, tex, L.FMT_YCOCG)
+
+
 @pytest.mark.parametrize("cfg", ["C2", "C3", "C4"])
 def test_full_size_configs_round_trip(ctx, hap, cfg):
     """BASELINE.json configs at full size on the device: encode -> decode round trip, the
