@@ -34,7 +34,7 @@ __device__ __forceinline__ uint2 alpha_block(const int (&a)[16])
     }
     const int inset = (hi - lo) >> 5;
     const int a0 = hi - inset, a1 = lo + inset;
-    unsigned long long bits = 0;
+    unsigned lo24 = 0, hi24 = 0;       // 3-bit codes of pixels 0..7 and 8..15
     if (a0 != a1) {
         int t[7];
         int prev = a0;
@@ -47,14 +47,19 @@ __device__ __forceinline__ uint2 alpha_block(const int (&a)[16])
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const int v2 = 2 * a[i];
-            int r = 0;
+            unsigned r = 0;
 #pragma unroll
             for (int j = 0; j < 7; j++)
-                r += (v2 < t[j]) ? 1 : 0;
-            const unsigned code = r == 0 ? 0u : (r == 7 ? 1u : (unsigned)(r + 1));
-            bits |= (unsigned long long)code << (3 * i);
+                r += (v2 < t[j]) ? 1u : 0u;
+            // ramp position -> S3TC code: 0->0, 7->1, r->r+1 (nibble table)
+            const unsigned code = (0x17654320u >> (4u * r)) & 7u;
+            if (i < 8)
+                lo24 |= code << (3 * i);
+            else
+                hi24 |= code << (3 * (i - 8));
         }
     }
+    const unsigned long long bits = (unsigned long long)lo24 | ((unsigned long long)hi24 << 24);
     const unsigned long long v = (unsigned long long)(unsigned)a0 | ((unsigned long long)(unsigned)a1 << 8) | (bits << 16);
     return make_uint2((unsigned)v, (unsigned)(v >> 32));
 }
@@ -63,23 +68,21 @@ __device__ __forceinline__ uint2 alpha_block(const int (&a)[16])
 // bytes (c0 | c1<<8 | c2<<16), top byte zero.  Lowest index wins ties.
 __device__ __forceinline__ unsigned nearest4(const unsigned (&px)[16], const unsigned (&pal)[4])
 {
-    int n[4];
+    // |p - c_k|^2 orders like |c_k|^2 - 2 p.c_k; scale by 4 and put k in the low bits so that one
+    // signed min picks the smallest distance with the smallest index on ties
+    int base[4];
 #pragma unroll
     for (int k = 0; k < 4; k++)
-        n[k] = (int)__builtin_amdgcn_udot4(pal[k], pal[k], 0u, false);
+        base[k] = 4 * (int)__builtin_amdgcn_udot4(pal[k], pal[k], 0u, false) + k;
     unsigned idx = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        int best = n[0] - 2 * (int)__builtin_amdgcn_udot4(px[i], pal[0], 0u, false);
-        unsigned bk = 0;
-#pragma unroll
-        for (int k = 1; k < 4; k++) {
-            const int s = n[k] - 2 * (int)__builtin_amdgcn_udot4(px[i], pal[k], 0u, false);
-            const bool better = s < best;
-            best = better ? s : best;
-            bk = better ? (unsigned)k : bk;
-        }
-        idx |= bk << (2 * i);
+        const int s0 = base[0] - 8 * (int)__builtin_amdgcn_udot4(px[i], pal[0], 0u, false);
+        const int s1 = base[1] - 8 * (int)__builtin_amdgcn_udot4(px[i], pal[1], 0u, false);
+        const int s2 = base[2] - 8 * (int)__builtin_amdgcn_udot4(px[i], pal[2], 0u, false);
+        const int s3 = base[3] - 8 * (int)__builtin_amdgcn_udot4(px[i], pal[3], 0u, false);
+        const int best = min(min(s0, s1), min(s2, s3));
+        idx |= ((unsigned)best & 3u) << (2 * i);
     }
     return idx;
 }
@@ -222,10 +225,12 @@ __global__ __launch_bounds__(256) void bc_encode_kernel(const uint8_t *__restric
         int y[16], co[16], cg[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const int r = (int)(p[i] & 255u), g = (int)((p[i] >> 8) & 255u), b = (int)((p[i] >> 16) & 255u);
-            y[i] = (r + 2 * g + b + 2) >> 2;
-            co[i] = clamp255(((r - b + 1) >> 1) + 128);
-            cg[i] = clamp255(((-r + 2 * g - b + 2) >> 2) + 128);
+            // Y = (R+2G+B+2)>>2 ; Co = ((R-B+1)>>1)+128 = (R+(255-B)+2)>>1 ; Cg = ((-R+2G-B+2)>>2)+128 =
+            // ((255-R)+2G+(255-B)+4)>>2 -- three byte dot products (alpha weight 0), upper clamp only
+            const unsigned q = p[i];
+            y[i] = (int)(__builtin_amdgcn_udot4(q, 0x00010201u, 2u, false) >> 2);
+            co[i] = (int)min(__builtin_amdgcn_udot4(q ^ 0x00FF0000u, 0x00010001u, 2u, false) >> 1, 255u);
+            cg[i] = (int)min(__builtin_amdgcn_udot4(q ^ 0x00FF00FFu, 0x00010201u, 4u, false) >> 2, 255u);
         }
         const uint2 ab = alpha_block(y), cb = ycocg_colour_block(co, cg);
         *reinterpret_cast<uint4 *>(out + (size_t)id * 16u) = make_uint4(ab.x, ab.y, cb.x, cb.y);
