@@ -267,7 +267,7 @@ def cpu_baseline(w, h, fmts, chunks, rgba, dec, tex_bytes, cap, budget_s):
 
     sample = min(len(rgba), 4)                 # distinct frames copied to the host
     threads = min(cores, 256)
-    nwork = max(sample, min(threads, 64))      # frames in flight: pointers cycle over the sample
+    nwork = max(sample, min(threads, 128))     # frames in flight: pointers cycle over the sample
     count = len(fmts)
     tex_host = [[dec[i][f].cpu().numpy() for i in range(count)] for f in range(sample)]
     rgba_host = rgba[0].cpu().numpy()
@@ -316,6 +316,7 @@ def cpu_baseline(w, h, fmts, chunks, rgba, dec, tex_bytes, cap, budget_s):
     rgba_bytes = w * h * 4
     per_frame = t_bc + t_enc / sample + t_dec / sample
     return {"value": round(rgba_bytes / per_frame / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": kind,
+            "threads": {"block_encode": threads, "hap_encode": enc_threads, "hap_decode": enc_threads},
             "sample": "%d frames in flight (%d distinct) of this workload: RGBA->DXT by oracle/bc_oracle.c (the reference "
                       "has no block encoder) + HapEncode + HapDecode by %s, %d threads, amortised per frame" % (
                           nwork, sample_n, "unmodified reference hap.c + libsnappy 1.1.8" if kind == "reference" else "oracle/ C port", threads),
