@@ -58,7 +58,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or "RANK" in os.environ:     # launched by torch.distributed.run
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
@@ -133,6 +133,16 @@ def main():
         ctx.decode_frames(frames, used, idx, dec[idx])
     dec_ms = ctx.timer_stop()
 
+    # DXT -> RGBA, untimed extra: what a player without texture units needs after HapDecode
+    rgba_out = torch.empty(w * h * 4, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx.set_profiling(True)
+    ctx.collect_profile()
+    for i in range(min(nf, 16)):
+        ctx.decompress_rgba(dec[0][i], fmts[0], w, h, rgba=rgba_out, alpha=(dec[1][i] if len(fmts) > 1 else None))
+    prof_bd = ctx.collect_profile().get("block_decode", (0, 0.0))
+    ctx.set_profiling(False)
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -197,6 +207,9 @@ def main():
         "encode_only": {"rgba_GBps": round(nf * rgba_bytes / (enc_ms * 1e-3) / 1e9, 2), "ms": round(enc_ms, 3)},
         "decode_only": {"rgba_GBps": round(nf * rgba_bytes / (dec_ms * 1e-3) / 1e9, 2), "ms": round(dec_ms, 3),
                         "texture_GBps": round(nf * bsum / (dec_ms * 1e-3) / 1e9, 2)},
+        "texture_to_rgba": ({"us_per_frame": round(prof_bd[1] / prof_bd[0] * 1e3, 2),
+                             "algorithmic_GBps": round((sum(tex_bytes) + rgba_bytes) / (prof_bd[1] / prof_bd[0] * 1e-3) / 1e9, 1)}
+                            if prof_bd[0] else None),
         "decode_of_reference_encoded_frames": foreign,
         "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
     }

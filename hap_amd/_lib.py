@@ -41,6 +41,7 @@ def _load():
         "HapGpuSetFragmentLog2": (u, [vp, u]),
         "HapGpuSynchronize": (u, [vp]),
         "HapGpuCompressRGBA": (u, [vp, vp, u, u, ul, u, vp, ul, P(ul)]),
+        "HapGpuDecompressRGBA": (u, [vp, vp, ul, u, vp, ul, u, u, vp, ul]),
         "HapGpuEncodeFrames": (u, [vp, u, u, P(vp), P(ul), P(u), P(u), P(u), P(vp), P(ul), P(ul), P(u), u]),
         "HapGpuEncodeFramesRGBA": (u, [vp, u, P(vp), u, u, ul, u, P(u), P(u), P(u), P(vp), P(ul), P(ul), P(u), u]),
         "HapGpuDecodeFrames": (u, [vp, u, P(vp), P(ul), u, P(vp), P(ul), P(ul), P(u), P(u), u]),

@@ -27,7 +27,8 @@ class HapResult:
 
 ENCODE_FRAGMENT_INDEX = 0x1
 DECODE_IGNORE_FRAGMENT_INDEX = 0x1
-KERNEL_CLASSES = ["block_encode", "snappy_compress", "frame_pack", "frame_gather", "decode_plan", "snappy_decode"]
+KERNEL_CLASSES = ["block_encode", "snappy_compress", "frame_pack", "frame_gather", "decode_plan", "snappy_decode",
+                  "block_decode"]
 
 
 def _addr_len(buf):
@@ -158,6 +159,24 @@ class Context:
         if own:
             return r, (bytes(output[: used.value]) if r == 0 else None)
         return r, used.value
+
+    def decompress_rgba(self, texture, texture_format, width, height, rgba=None, alpha=None, row_bytes=None):
+        """Texture (+ optional RGTC1 alpha plane) -> RGBA8. Returns (result, bytes | None)."""
+        ta, tn, _k = _addr_len(texture)
+        aa, an, _k2 = _addr_len(alpha) if alpha is not None else (None, 0, None)
+        row_bytes = row_bytes or width * 4
+        own = rgba is None
+        if own:
+            rgba = (C.c_ubyte * (row_bytes * height + 16))()
+            base = C.addressof(rgba)
+            pad = (-base) % 16
+            oa = base + pad
+        else:
+            oa, _on, _k3 = _addr_len(rgba)
+        r = lib.HapGpuDecompressRGBA(self.handle, ta, tn, texture_format, aa, an, width, height, oa, row_bytes)
+        if own:
+            return r, (C.string_at(oa, row_bytes * height) if r == 0 else None)
+        return r, None
 
     @staticmethod
     def _ptr_array(bufs):

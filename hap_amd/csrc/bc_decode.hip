@@ -1,0 +1,157 @@
+// bc_decode.hip -- DXT1 / DXT5 / scaled YCoCg-DXT5 (+ RGTC1 alpha plane) -> RGBA8 for gfx950.
+//
+// The reference stops at block-compressed texture bytes because its clients hand them to GPU
+// texture units (README.md:4); CDNA has none, so a pipeline that wants pixels needs this kernel
+// (SURVEY.md section 8f, rank 1).  Mirror image of bc_encode.hip: one 4x4 block per lane, 8/16-byte
+// block load per lane (512 B / 1 KiB contiguous per wave), four 16-byte row stores per lane
+// (1 KiB contiguous per wave-instruction).  Bounded by HBM: b read + 64 B written per block.
+// Arithmetic follows oracle/bc_oracle.c (obc_decode_*) exactly; results are bit-identical.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace {
+
+__device__ __forceinline__ int expand5(int q) { return (q << 3) | (q >> 2); }
+__device__ __forceinline__ int expand6(int q) { return (q << 2) | (q >> 4); }
+__device__ __forceinline__ int clamp255(int v) { return min(max(v, 0), 255); }
+
+// 16 alpha-style values of an 8-byte block (S3TC alpha / RGTC1)
+__device__ __forceinline__ void decode_alpha(uint2 blk, int (&out)[16])
+{
+    const int a0 = (int)(blk.x & 255u), a1 = (int)((blk.x >> 8) & 255u);
+    int v[8];
+    v[0] = a0;
+    v[1] = a1;
+    if (a0 > a1) {
+#pragma unroll
+        for (int i = 1; i < 7; i++)
+            v[i + 1] = ((7 - i) * a0 + i * a1) / 7;
+    } else {
+#pragma unroll
+        for (int i = 1; i < 5; i++)
+            v[i + 1] = ((5 - i) * a0 + i * a1) / 5;
+        v[6] = 0;
+        v[7] = 255;
+    }
+    const unsigned long long bits = (((unsigned long long)blk.y << 32) | blk.x) >> 16;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const unsigned code = (unsigned)(bits >> (3 * i)) & 7u;
+        int r = v[0];
+#pragma unroll
+        for (int k = 1; k < 8; k++)
+            r = code == (unsigned)k ? v[k] : r;
+        out[i] = r;
+    }
+}
+
+__device__ __forceinline__ void decode_palette(uint2 blk, bool dxt1_modes, int (&pal)[4][3])
+{
+    const unsigned c0 = blk.x & 0xFFFFu, c1 = blk.x >> 16;
+    pal[0][0] = expand5(c0 >> 11); pal[0][1] = expand6((c0 >> 5) & 63); pal[0][2] = expand5(c0 & 31);
+    pal[1][0] = expand5(c1 >> 11); pal[1][1] = expand6((c1 >> 5) & 63); pal[1][2] = expand5(c1 & 31);
+    const bool four = !dxt1_modes || c0 > c1;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        pal[2][c] = four ? (2 * pal[0][c] + pal[1][c]) / 3 : (pal[0][c] + pal[1][c]) / 2;
+        pal[3][c] = four ? (pal[0][c] + 2 * pal[1][c]) / 3 : 0;
+    }
+}
+
+// FMT: 0 DXT1, 1 DXT5, 2 YCoCg-DXT5; HAS_ALPHA: separate RGTC1 plane supplies A (Hap Q Alpha)
+template <int FMT, bool HAS_ALPHA>
+__global__ __launch_bounds__(256) void bc_decode_kernel(const uint8_t *__restrict__ blocks,
+                                                        const uint8_t *__restrict__ alpha_blocks,
+                                                        unsigned blocks_x, unsigned blocks_total,
+                                                        uint8_t *__restrict__ rgba, size_t row_bytes)
+{
+    const unsigned id = blockIdx.x * 256u + threadIdx.x;
+    if (id >= blocks_total)
+        return;
+    const unsigned by = id / blocks_x, bx = id - by * blocks_x;
+    int a[16];
+    uint2 colour;
+    if (FMT == 0) {
+        colour = *reinterpret_cast<const uint2 *>(blocks + (size_t)id * 8u);
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            a[i] = 255;
+    } else {
+        const uint4 v = *reinterpret_cast<const uint4 *>(blocks + (size_t)id * 16u);
+        decode_alpha(make_uint2(v.x, v.y), a);          // DXT5: alpha; YCoCg: luma
+        colour = make_uint2(v.z, v.w);
+    }
+    int pal[4][3];
+    decode_palette(colour, FMT == 0, pal);
+    int plane[16];
+    if (HAS_ALPHA)
+        decode_alpha(*reinterpret_cast<const uint2 *>(alpha_blocks + (size_t)id * 8u), plane);
+    uint8_t *dst = rgba + (size_t)(4u * by) * row_bytes + 16u * (size_t)bx;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        unsigned px[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int i = 4 * r + c;
+            const unsigned k = (colour.y >> (2 * i)) & 3u;
+            int cr = pal[0][0], cg = pal[0][1], cb = pal[0][2];
+#pragma unroll
+            for (int q = 1; q < 4; q++) {
+                cr = k == (unsigned)q ? pal[q][0] : cr;
+                cg = k == (unsigned)q ? pal[q][1] : cg;
+                cb = k == (unsigned)q ? pal[q][2] : cb;
+            }
+            int R, G, B, A;
+            if (FMT == 2) {
+                const int s = (cb >> 3) + 1;
+                int co = cr - 128, cgg = cg - 128;
+                co = co >= 0 ? co / s : -((-co) / s);
+                cgg = cgg >= 0 ? cgg / s : -((-cgg) / s);
+                const int y = a[i];
+                R = clamp255(y + co - cgg);
+                G = clamp255(y + cgg);
+                B = clamp255(y - co - cgg);
+                A = HAS_ALPHA ? plane[i] : 255;
+            } else {
+                R = cr; G = cg; B = cb;
+                A = HAS_ALPHA ? plane[i] : a[i];
+            }
+            px[c] = (unsigned)R | ((unsigned)G << 8) | ((unsigned)B << 16) | ((unsigned)A << 24);
+        }
+        *reinterpret_cast<uint4 *>(dst + (size_t)r * row_bytes) = make_uint4(px[0], px[1], px[2], px[3]);
+    }
+}
+
+template <int FMT>
+void launch(const void *blocks, const void *alpha, unsigned bx, unsigned by, void *rgba, size_t row_bytes, hipStream_t stream)
+{
+    const unsigned total = bx * by;
+    const dim3 grid((total + 255u) / 256u), block(256);
+    if (alpha)
+        hipLaunchKernelGGL((bc_decode_kernel<FMT, true>), grid, block, 0, stream, (const uint8_t *)blocks, (const uint8_t *)alpha, bx, total, (uint8_t *)rgba, row_bytes);
+    else
+        hipLaunchKernelGGL((bc_decode_kernel<FMT, false>), grid, block, 0, stream, (const uint8_t *)blocks, (const uint8_t *)nullptr, bx, total, (uint8_t *)rgba, row_bytes);
+}
+
+} // namespace
+
+// format: HapTextureFormat of `blocks` (DXT1, DXT5, YCoCg-DXT5); alpha: optional RGTC1 plane.
+// Returns 0 launched, 1 bad arguments.
+extern "C" int hapgpu_launch_block_decode(const void *blocks, const void *alpha, unsigned width, unsigned height,
+                                          unsigned format, void *rgba, size_t row_bytes, hipStream_t stream)
+{
+    if (!blocks || !rgba || width == 0 || height == 0 || (width & 3u) || (height & 3u) || row_bytes < (size_t)width * 4u)
+        return 1;
+    if (((uintptr_t)rgba | row_bytes) & 15u)
+        return 1;
+    if (((uintptr_t)blocks & (format == 0x83F0 ? 7u : 15u)) || ((uintptr_t)alpha & 7u))
+        return 1;
+    const unsigned bx = width / 4u, by = height / 4u;
+    switch (format) {
+    case 0x83F0: launch<0>(blocks, alpha, bx, by, rgba, row_bytes, stream); break;
+    case 0x83F3: launch<1>(blocks, alpha, bx, by, rgba, row_bytes, stream); break;
+    case 0x01: launch<2>(blocks, alpha, bx, by, rgba, row_bytes, stream); break;
+    default: return 1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}

@@ -261,6 +261,20 @@ unsigned int HapGpuCompressRGBA(HapGpuContext *context, const void *rgba, unsign
     return r;
 }
 
+unsigned int HapGpuDecompressRGBA(HapGpuContext *context, const void *texture, unsigned long textureBytes,
+                                  unsigned int textureFormat, const void *alphaTexture, unsigned long alphaBytes,
+                                  unsigned int width, unsigned int height, void *rgba, unsigned long rowBytes)
+{
+    unsigned r;
+    if (!context)
+        return HapResult_Bad_Arguments;
+    hapgpu_rt_lock(context->rt);
+    r = hapb_decompress_rgba(context, texture, textureBytes, textureFormat, alphaTexture, alphaBytes, width, height,
+                             rgba, rowBytes);
+    hapgpu_rt_unlock(context->rt);
+    return r;
+}
+
 unsigned int HapGpuEncodeFrames(HapGpuContext *context, unsigned int frameCount, unsigned int count,
                                 const void *const *inputBuffers, const unsigned long *inputBuffersBytes,
                                 const unsigned int *textureFormats, const unsigned int *compressors,

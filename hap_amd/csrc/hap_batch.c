@@ -333,6 +333,60 @@ unsigned hapb_compress_rgba(HapGpuContext *ctx, const void *rgba, unsigned width
     return HapResult_No_Error;
 }
 
+unsigned hapb_decompress_rgba(HapGpuContext *ctx, const void *texture, unsigned long texture_bytes, unsigned format,
+                              const void *alpha, unsigned long alpha_bytes, unsigned width, unsigned height,
+                              void *rgba, unsigned long row_bytes)
+{
+    hapgpu_rt *rt = ctx->rt;
+    size_t block = format == HapTextureFormat_RGB_DXT1 ? 8u : 16u;
+    size_t need, alpha_need, rgba_bytes;
+    const void *src = texture, *asrc = alpha;
+    void *dst = rgba;
+    int rc;
+    if (!texture || !rgba || width == 0 || height == 0 || (width & 3u) || (height & 3u) ||
+        row_bytes < (unsigned long)width * 4ul ||
+        (format != HapTextureFormat_RGB_DXT1 && format != HapTextureFormat_RGBA_DXT5 &&
+         format != HapTextureFormat_YCoCg_DXT5))
+        return HapResult_Bad_Arguments;
+    need = (size_t)(width / 4u) * (height / 4u) * block;
+    alpha_need = (size_t)(width / 4u) * (height / 4u) * 8u;
+    if (texture_bytes < need || (alpha && alpha_bytes < alpha_need))
+        return HapResult_Bad_Arguments;
+    rgba_bytes = (size_t)row_bytes * (height - 1u) + (size_t)width * 4u;
+    if (!is_dev(ctx, texture)) {
+        void *s = hapgpu_rt_device_scratch(rt, D_BC_TEX, need + alpha_need + 256);
+        if (!s || hapgpu_rt_h2d(rt, s, texture, need))
+            return HapResult_Internal_Error;
+        src = s;
+        if (alpha && !is_dev(ctx, alpha)) {
+            uint8_t *a = (uint8_t *)s + align_up(need, 256);
+            if (hapgpu_rt_h2d(rt, a, alpha, alpha_need))
+                return HapResult_Internal_Error;
+            asrc = a;
+        }
+    } else if (alpha && !is_dev(ctx, alpha)) {
+        void *a = hapgpu_rt_device_scratch(rt, D_BC_TEX, alpha_need);
+        if (!a || hapgpu_rt_h2d(rt, a, alpha, alpha_need))
+            return HapResult_Internal_Error;
+        asrc = a;
+    }
+    if (!is_dev(ctx, rgba)) {
+        dst = hapgpu_rt_device_scratch(rt, D_RGBA_STAGE, rgba_bytes);
+        if (!dst)
+            return HapResult_Internal_Error;
+    }
+    rc = hapgpu_k_block_decode(rt, src, asrc, width, height, format, dst, row_bytes);
+    if (rc == 1)
+        return HapResult_Bad_Arguments;
+    if (rc)
+        return HapResult_Internal_Error;
+    if (dst != rgba && hapgpu_rt_d2h(rt, rgba, dst, rgba_bytes))
+        return HapResult_Internal_Error;
+    if (hapgpu_rt_sync(rt))
+        return HapResult_Internal_Error;
+    return HapResult_No_Error;
+}
+
 unsigned hapb_encode_rgba(HapGpuContext *ctx, unsigned frame_count, const void *const *rgba_frames,
                           unsigned width, unsigned height, unsigned long row_bytes, unsigned count,
                           const unsigned *formats, const unsigned *compressors, const unsigned *chunk_counts,

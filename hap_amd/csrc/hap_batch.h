@@ -25,6 +25,9 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
 unsigned hapb_compress_rgba(HapGpuContext *ctx, const void *rgba, unsigned width, unsigned height,
                             unsigned long row_bytes, unsigned format, void *output,
                             unsigned long output_bytes, unsigned long *used, int synchronise);
+unsigned hapb_decompress_rgba(HapGpuContext *ctx, const void *texture, unsigned long texture_bytes, unsigned format,
+                              const void *alpha, unsigned long alpha_bytes, unsigned width, unsigned height,
+                              void *rgba, unsigned long row_bytes);
 unsigned hapb_encode_rgba(HapGpuContext *ctx, unsigned frame_count, const void *const *rgba_frames,
                           unsigned width, unsigned height, unsigned long row_bytes, unsigned count,
                           const unsigned *formats, const unsigned *compressors, const unsigned *chunk_counts,

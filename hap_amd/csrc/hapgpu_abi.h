@@ -148,6 +148,8 @@ void hapgpu_rt_unlock(hapgpu_rt *rt);
 /* kernels: all asynchronous on the runtime's stream; 0 = launched */
 int hapgpu_k_block_encode(hapgpu_rt *rt, const void *rgba, unsigned width, unsigned height,
                           size_t row_bytes, unsigned hap_texture_format, void *out);
+int hapgpu_k_block_decode(hapgpu_rt *rt, const void *blocks, const void *alpha, unsigned width, unsigned height,
+                          unsigned hap_texture_format, void *rgba, size_t row_bytes);
 int hapgpu_k_snappy_compress(hapgpu_rt *rt, const HapGpuFrameEnc *frames, unsigned frame_count,
                              unsigned max_frags_per_texture, unsigned frag_log2,
                              void *slots, unsigned slot_stride, uint32_t *frag_sizes,

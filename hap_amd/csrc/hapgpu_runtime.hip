@@ -14,6 +14,8 @@
 extern "C" {
 int hapgpu_launch_block_encode(const void *rgba, unsigned width, unsigned height, size_t row_bytes,
                                unsigned format, void *out, hipStream_t stream);
+int hapgpu_launch_block_decode(const void *blocks, const void *alpha, unsigned width, unsigned height,
+                               unsigned format, void *rgba, size_t row_bytes, hipStream_t stream);
 int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsigned frame_count, unsigned max_frags_per_texture,
                                   unsigned frag_log2, void *slots, unsigned slot_stride, uint32_t *frag_sizes,
                                   unsigned granularity_mask, hipStream_t stream);
@@ -29,7 +31,7 @@ int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsigned unit_cou
 
 namespace {
 constexpr int kSlots = 16;
-constexpr int kClasses = 6;
+constexpr int kClasses = 7;
 
 struct timed_launch {
     int cls;
@@ -293,6 +295,13 @@ extern "C" int hapgpu_k_block_encode(hapgpu_rt *rt, const void *rgba, unsigned w
 {
     scoped_timing st(rt, 0);
     return hapgpu_launch_block_encode(rgba, width, height, row_bytes, hap_texture_format, out, rt->stream);
+}
+
+extern "C" int hapgpu_k_block_decode(hapgpu_rt *rt, const void *blocks, const void *alpha, unsigned width,
+                                     unsigned height, unsigned hap_texture_format, void *rgba, size_t row_bytes)
+{
+    scoped_timing st(rt, 6);
+    return hapgpu_launch_block_decode(blocks, alpha, width, height, hap_texture_format, rgba, row_bytes, rt->stream);
 }
 
 extern "C" int hapgpu_k_snappy_compress(hapgpu_rt *rt, const HapGpuFrameEnc *frames, unsigned frame_count,

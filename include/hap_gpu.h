@@ -70,6 +70,16 @@ unsigned int HapGpuCompressRGBA(HapGpuContext *context,
                                 void *output, unsigned long outputBytes,
                                 unsigned long *outputBytesUsed);
 
+/* Block-compressed texture -> RGBA8 (the stage a GPU's texture unit performs for the reference's
+ * clients; CDNA has none).  textureFormat: RGB_DXT1, RGBA_DXT5 or YCoCg_DXT5 (converted back to
+ * RGB); alphaTexture: optional A_RGTC1 plane that supplies A (Hap Q Alpha), else NULL / 0.
+ * rgba must be 16-byte aligned with rowBytes a multiple of 16.  Host or device pointers. */
+unsigned int HapGpuDecompressRGBA(HapGpuContext *context,
+                                  const void *texture, unsigned long textureBytes, unsigned int textureFormat,
+                                  const void *alphaTexture, unsigned long alphaBytes,
+                                  unsigned int width, unsigned int height,
+                                  void *rgba, unsigned long rowBytes);
+
 /* Batched HapEncode: frame f is made of `count` textures
  * inputBuffers[f*count + i] of inputBuffersBytes[i] bytes each (every frame of
  * a batch has the same geometry).  Semantics, frame layout, chunk-count
@@ -136,7 +146,8 @@ enum HapGpuKernelClass {
     HapGpuKernel_FrameGather = 3,
     HapGpuKernel_DecodePlan = 4,
     HapGpuKernel_SnappyDecode = 5,
-    HapGpuKernel_ClassCount = 6
+    HapGpuKernel_BlockDecode = 6,
+    HapGpuKernel_ClassCount = 7
 };
 
 /* enable != 0: record a start/stop event pair around every kernel launch. */

@@ -101,6 +101,39 @@ def test_block_encode_bad_arguments(ctx, hap):
     assert ctx.compress_rgba(img, 8, 8, 32, L.FMT_DXT1, small)[0] == hap.HapResult.Buffer_Too_Small
 
 
+# ------------------------------------------------------------ block decode --
+@pytest.mark.parametrize("fmt", [L.FMT_DXT1, L.FMT_DXT5, L.FMT_YCOCG])
+def test_block_decode_bit_exact(ctx, fmt):
+    """DXT -> RGBA against the oracle's scalar decoders: encoder output and random blocks
+    (which reach DXT1's 3-colour mode and the 6-interpolant alpha mode the encoder never emits)."""
+    w, h = 256, 64
+    img = D.rgba(w, h, frame=4)
+    rng = np.random.default_rng(21)
+    bb = D.BLOCK_BYTES[fmt]
+    for blocks in (D.oracle_bc_encode(img, fmt), rng.integers(0, 256, (w // 4) * (h // 4) * bb, dtype=np.uint8).tobytes()):
+        want = D.oracle_bc_decode(blocks, fmt, w, h)
+        r, got = ctx.decompress_rgba(blocks, fmt, w, h)
+        assert r == 0
+        assert np.array_equal(np.frombuffer(got, dtype=np.uint8).reshape(h, w, 4), want)
+    # Hap Q Alpha: YCoCg colour + RGTC1 alpha plane, device resident, strided output
+    if fmt == L.FMT_YCOCG:
+        col = D.oracle_bc_encode(img, L.FMT_YCOCG)
+        alp = D.oracle_bc_encode(img, L.FMT_RGTC1)
+        want = D.oracle_bc_decode(col, L.FMT_YCOCG, w, h)
+        want[..., 3] = D.oracle_bc_decode(alp, L.FMT_RGTC1, w, h)
+        dcol = torch.from_numpy(np.frombuffer(col, dtype=np.uint8).copy()).cuda()
+        dalp = torch.from_numpy(np.frombuffer(alp, dtype=np.uint8).copy()).cuda()
+        stride = w * 4 + 64
+        dout = torch.zeros(h * stride, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        r, _ = ctx.decompress_rgba(dcol, L.FMT_YCOCG, w, h, rgba=dout, alpha=dalp, row_bytes=stride)
+        assert r == 0
+        got = dout.cpu().numpy().reshape(h, stride)[:, : w * 4].reshape(h, w, 4)
+        assert np.array_equal(got, want)
+        assert D.psnr(got[..., :3], img[..., :3]) > 30.0
+    assert ctx.decompress_rgba(bytes(8), L.FMT_RGTC1, 4, 4)[0] == 1      # not a colour format
+
+
 # ------------------------------------------------------------------ decode --
 @pytest.mark.parametrize("v", D.golden_vectors("frame"), ids=lambda v: v["name"])
 def test_decode_golden_frames(hap, v):
