@@ -469,6 +469,34 @@ def test_corrupt_fragment_table_falls_back(ctx, hap):
     assert hap.HapDecode(bytes(frame), 0, outputBufferBytes=len(tex)) == (0, tex, L.FMT_DXT5)
 
 
+@pytest.mark.parametrize("log2", [10, 11, 12, 14, 15, 16])
+def test_every_fragment_size_round_trips(hap, log2):
+    """All fragment sizes the API accepts, both granularities, each decoded by the matching ring size."""
+    import os
+    img = D.rgba(1024, 128, frame=log2)
+    for gran_env in ("0", "1"):
+        os.environ["HAP_AMD_BYTE_GRANULAR"] = gran_env
+        try:
+            c = hap.Context(0)
+        finally:
+            del os.environ["HAP_AMD_BYTE_GRANULAR"]
+        assert c.set_fragment_log2(log2) == 0
+        for fmt in (L.FMT_DXT1, L.FMT_YCOCG):
+            tex = D.oracle_bc_encode(img, fmt)
+            cap = hap.HapMaxEncodedLength([len(tex)], [fmt], [3])
+            out = np.zeros(cap, dtype=np.uint8)
+            r, used, res = c.encode_frames([[tex]], [fmt], [1], [3], [out], flags=hap.ENCODE_FRAGMENT_INDEX)
+            assert (r, res) == (0, [0])
+            frame = out[: used[0]].tobytes()
+            assert ORA.decode(frame, 0, len(tex)) == (0, tex, fmt)
+            dec = np.zeros(len(tex), dtype=np.uint8)
+            r, dused, dfmt, dres = c.decode_frames([frame], [len(frame)], 0, [dec])
+            assert (r, dres, dused, dfmt) == (0, [0], [len(tex)], [fmt])
+            assert dec.tobytes() == tex
+        c.close()
+    assert hap.Context(0).set_fragment_log2(9) == hap.HapResult.Bad_Arguments
+
+
 def test_byte_granular_streams_and_a_lying_table(hap):
     """Fragments are flagged 16-bit granular only when every element is; byte-granular streams take the
     byte kernel, and a table that promises more than the stream keeps falls back to the generic path."""
