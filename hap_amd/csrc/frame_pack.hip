@@ -78,7 +78,6 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
                                                          HapGpuCopyEntry *__restrict__ copies)
 {
     __shared__ unsigned long long scan_lds[4];
-    __shared__ unsigned long long carry_lds;
     HapGpuFrameEnc &frame = frames[blockIdx.x];
     const unsigned tid = threadIdx.x;
     const unsigned frag_bytes = 1u << frag_log2;
@@ -209,7 +208,6 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
         frame.bytes_used = frame.outer_header_len + sections_total;
         frame.status = 0;
     }
-    (void)carry_lds;
 }
 
 __global__ __launch_bounds__(64) void frame_gather_kernel(const HapGpuCopyEntry *__restrict__ copies, unsigned count)

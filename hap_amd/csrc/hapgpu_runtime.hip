@@ -31,7 +31,6 @@ int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsigned unit_cou
 
 namespace {
 constexpr int kSlots = 16;
-constexpr int kClasses = 7;
 
 struct timed_launch {
     int cls;

@@ -280,6 +280,17 @@ __device__ __forceinline__ int cwave_scan_max(int v)   // inclusive, values >= 0
     return v;
 }
 
+// run of consecutive 1 bits starting at bit `lane` of next:cur, capped at 32 (enough when a lane is
+// 2 bytes and copies are at most 64 bytes): one 32-bit funnel shift instead of 64-bit shifts
+__device__ __forceinline__ unsigned run_from32(unsigned long long cur, unsigned long long next, unsigned lane)
+{
+    const unsigned lo = lane < 32u ? (unsigned)cur : (unsigned)(cur >> 32);
+    const unsigned hi = lane < 32u ? (unsigned)(cur >> 32) : (unsigned)next;
+    const unsigned w = __builtin_amdgcn_alignbit(hi, lo, lane & 31u);
+    const unsigned inv = ~w;
+    return inv ? (unsigned)__builtin_ctz(inv) : 32u;
+}
+
 // equal bytes of data[a..] and data[b..], 16 per step, at most `limit`
 __device__ __forceinline__ unsigned match_extend16(const uint32_t *dw, unsigned a, unsigned b, unsigned limit)
 {
@@ -402,14 +413,20 @@ __global__ __launch_bounds__(256) void snappy_compress_wg_kernel(const HapGpuFra
 #endif
                     const unsigned cand = table[h];
                     my_hash = h;
+#ifdef HAP_NO_HASH
+                    if (false) {
+#else
                     if (cand < p && room >= 4u && lds_load32(dataw, cand) == cur) {
+#endif
                         best_len = (4u + match_extend16(dataw, cand + 4u, p + 4u, room - 4u)) & ~(GRAN - 1u);
                         best_off = p - cand;
                     }
                 }
 #pragma unroll
                 for (int d = kFixed - 1; d >= 0; d--) {          // nearer distances win ties
-                    const unsigned l = min(GRAN * run_from(eq[d][sub], sub == 0 ? eq[d][1] : 0ull, lane), room);
+                    const unsigned long long nx = sub == 0 ? eq[d][1] : 0ull;
+                    const unsigned l = min(GRAN == 2 ? 2u * run_from32(eq[d][sub], nx, lane)
+                                                     : run_from(eq[d][sub], nx, lane), room);
                     if (l >= best_len && l >= 4u) { best_len = l; best_off = (unsigned)(d + 1) * pitch; }
                 }
                 // greedy selection: the scalar unit hops from chosen copy to chosen copy
