@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--frag-log2", type=int, default=0, help="Snappy fragment size (log2 bytes); 0 = library default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    ap.add_argument("--foreign-frames", type=int, default=8,
+    ap.add_argument("--foreign-frames", type=int, default=24,
                     help="also time decoding of N frames made by the CPU reference encoder (no fragment table); 0 = skip")
     args = ap.parse_args()
 
@@ -324,6 +324,16 @@ def cpu_baseline(w, h, fmts, chunks, rgba, dec, tex_bytes, cap, budget_s):
         t_dec += t
     t_enc /= nwork
     t_dec /= nwork
+    # one hardware thread, one frame (the reference as a client would call it serially)
+    one_out = np.zeros(cap, dtype=np.uint8)
+    one_used = (C.c_ulong * 1)()
+    p1 = (C.c_void_p * count)(*[tex_host[0][i].ctypes.data for i in range(count)])
+    t_enc1 = enc(C.c_uint(count), p1, lens, cf, cc, ck, C.c_uint(1), one_out.ctypes.data_as(C.c_void_p), C.c_ulong(cap),
+                 one_used, C.c_uint(1), C.c_uint(1))
+    f1 = (C.c_void_p * 1)(frames[0].ctypes.data)
+    l1 = (C.c_ulong * 1)(len(frames[0]))
+    t_dec1 = sum(decp(f1, l1, C.c_uint(1), C.c_uint(idx), dout.ctypes.data_as(C.c_void_p), C.c_ulong(stride),
+                      C.c_uint(1), C.c_uint(1)) for idx in range(count))
     sample_n = sample
     sample = 1      # t_enc / t_dec are already per frame
     rgba_bytes = w * h * 4
@@ -335,7 +345,8 @@ def cpu_baseline(w, h, fmts, chunks, rgba, dec, tex_bytes, cap, budget_s):
                           nwork, sample_n, "unmodified reference hap.c + libsnappy 1.1.8" if kind == "reference" else "oracle/ C port", threads),
             "ms_per_frame": {"block_encode": round(t_bc * 1e3, 2), "hap_encode": round(t_enc / sample * 1e3, 2),
                              "hap_decode": round(t_dec / sample * 1e3, 2)},
-            "container_only_rgba_GBps": round(rgba_bytes / (t_enc / sample + t_dec / sample) / 1e9, 3)}
+            "container_only_rgba_GBps": round(rgba_bytes / (t_enc / sample + t_dec / sample) / 1e9, 3),
+            "single_thread_ms_per_frame": {"hap_encode": round(t_enc1 * 1e3, 2), "hap_decode": round(t_dec1 * 1e3, 2)}}
 
 
 if __name__ == "__main__":
