@@ -160,6 +160,46 @@ unsigned int HapDecode(const void *inputBuffer, unsigned long inputBufferBytes, 
     return rc;
 }
 
+/* The reference object also exports two helpers that hap.h does not declare (they are non-static in
+ * hap.c:732 and hap.c:932); kept for link compatibility with clients that reach for them. */
+int hap_get_section_at_index(const void *input_buffer, uint32_t input_buffer_bytes, unsigned int index,
+                             const void **section, uint32_t *section_length, unsigned int *section_type)
+{
+    hapf_reader r;
+    uint64_t off = 0;
+    unsigned rc;
+    hapf_reader_init_host(&r, input_buffer, input_buffer_bytes);
+    *section = NULL;
+    *section_length = 0;
+    *section_type = 0;
+    rc = hapf_locate(&r, input_buffer_bytes, index, &off, section_length, section_type);
+    if (rc == HapResult_No_Error)
+        *section = (const uint8_t *)input_buffer + off;
+    hapf_reader_free(&r);
+    return (int)rc;
+}
+
+unsigned int hap_decode_single_texture(const void *texture_section, uint32_t texture_section_length,
+                                       unsigned int texture_section_type, HapDecodeCallback callback, void *info,
+                                       void *outputBuffer, unsigned long outputBufferBytes,
+                                       unsigned long *outputBufferBytesUsed, unsigned int *outputBufferTextureFormat)
+{
+    /* re-wrap the bare section in an 8-byte top-level header and take the normal path (host memory only) */
+    uint8_t *frame;
+    unsigned rc;
+    if (!texture_section || !callback || !outputBuffer || !outputBufferTextureFormat)
+        return HapResult_Bad_Arguments;
+    frame = (uint8_t *)malloc((size_t)texture_section_length + 8u);
+    if (!frame)
+        return HapResult_Internal_Error;
+    hapf_write_section(frame, 8u, texture_section_length, texture_section_type);
+    memcpy(frame + 8, texture_section, texture_section_length);
+    rc = HapDecode(frame, (unsigned long)texture_section_length + 8ul, 0, callback, info, outputBuffer,
+                   outputBufferBytes, outputBufferBytesUsed, outputBufferTextureFormat);
+    free(frame);
+    return rc;
+}
+
 /* Inspectors read section headers only.  Host frames are parsed in place; for
  * device-resident frames the few header bytes are copied back. */
 typedef struct inspect_fetch {

@@ -289,6 +289,25 @@ def test_decode_malformed_frames_match_oracle(hap):
     assert hap.HapDecode(bytes(f), 0, outputBufferBytes=8192)[0] == hap.HapResult.Bad_Frame
 
 
+def test_undeclared_reference_exports(hap):
+    """hap.c exports hap_get_section_at_index / hap_decode_single_texture without declaring them."""
+    from hap_amd._lib import lib
+    a = D.stream_bytes(16 * 64 * 3, "runs")
+    b = D.stream_bytes(8 * 64 * 3, "mixed")
+    _, frame = ORA.encode([a, b], [L.FMT_YCOCG, L.FMT_RGTC1], [1, 0], [2, 1])
+    buf = (C.c_ubyte * len(frame)).from_buffer_copy(frame)
+    for idx, want, fmt in ((0, a, L.FMT_YCOCG), (1, b, L.FMT_RGTC1)):
+        sec, slen, stype = C.c_void_p(), C.c_uint32(), C.c_uint()
+        assert lib.hap_get_section_at_index(buf, C.c_uint32(len(frame)), idx, C.byref(sec), C.byref(slen), C.byref(stype)) == 0
+        out = (C.c_ubyte * len(want))()
+        used, ofmt = C.c_ulong(), C.c_uint()
+        lib.hap_decode_single_texture.restype = C.c_uint
+        r = lib.hap_decode_single_texture(sec, slen, stype, hap.api._serial_callback(), None, out, C.c_ulong(len(want)),
+                                          C.byref(used), C.byref(ofmt))
+        assert (r, used.value, ofmt.value) == (0, len(want), fmt) and bytes(out) == want
+    assert lib.hap_get_section_at_index(buf, C.c_uint32(len(frame)), 2, C.byref(sec), C.byref(slen), C.byref(stype)) == 1
+
+
 def test_decode_bad_arguments(hap):
     from hap_amd._lib import lib
     out = (C.c_ubyte * 64)()
