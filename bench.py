@@ -194,8 +194,8 @@ def main():
             cpu = {"error": repr(exc)}
 
     line = {
-        "metric": "RGBA GB/s, 8K Hap Q encode+decode (frames/s in fps)" if args.config == "C4"
-                  else "RGBA GB/s, %s encode+decode" % args.config,
+        "metric": "RGBA GB/s + frames/sec, 8K Hap Q encode+decode" if args.config == "C4"
+                  else "RGBA GB/s + frames/sec, %s encode+decode" % args.config,
         "value": round(value, 2), "unit": "GB/s", "fps": round(total_frames / elapsed, 1),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",

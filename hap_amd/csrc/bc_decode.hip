@@ -15,7 +15,14 @@ __device__ __forceinline__ int expand5(int q) { return (q << 3) | (q >> 2); }
 __device__ __forceinline__ int expand6(int q) { return (q << 2) | (q >> 4); }
 __device__ __forceinline__ int clamp255(int v) { return min(max(v, 0), 255); }
 
-// 16 alpha-style values of an 8-byte block (S3TC alpha / RGTC1)
+// byte `code` (0..7) of the 8-byte table hi:lo
+__device__ __forceinline__ unsigned pick8(unsigned hi, unsigned lo, unsigned code)
+{
+    return __builtin_amdgcn_perm(hi, lo, code) & 0xFFu;
+}
+
+// 16 alpha-style values of an 8-byte block (S3TC alpha / RGTC1): the 8-entry palette is packed into
+// two dwords and every pixel picks its byte with one v_perm_b32
 __device__ __forceinline__ void decode_alpha(uint2 blk, int (&out)[16])
 {
     const int a0 = (int)(blk.x & 255u), a1 = (int)((blk.x >> 8) & 255u);
@@ -33,28 +40,30 @@ __device__ __forceinline__ void decode_alpha(uint2 blk, int (&out)[16])
         v[6] = 0;
         v[7] = 255;
     }
-    const unsigned long long bits = (((unsigned long long)blk.y << 32) | blk.x) >> 16;
+    const unsigned lo = (unsigned)v[0] | ((unsigned)v[1] << 8) | ((unsigned)v[2] << 16) | ((unsigned)v[3] << 24);
+    const unsigned hi = (unsigned)v[4] | ((unsigned)v[5] << 8) | ((unsigned)v[6] << 16) | ((unsigned)v[7] << 24);
+    // 48 index bits = blk.x[16..31] | blk.y << 16 : pixels 0..7 in the low 24 bits, 8..15 above
+    const unsigned lo24 = (blk.x >> 16) | ((blk.y & 0xFFu) << 16);
+    const unsigned hi24 = blk.y >> 8;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const unsigned code = (unsigned)(bits >> (3 * i)) & 7u;
-        int r = v[0];
-#pragma unroll
-        for (int k = 1; k < 8; k++)
-            r = code == (unsigned)k ? v[k] : r;
-        out[i] = r;
+    for (int i = 0; i < 8; i++) {
+        out[i] = (int)pick8(hi, lo, (lo24 >> (3 * i)) & 7u);
+        out[8 + i] = (int)pick8(hi, lo, (hi24 >> (3 * i)) & 7u);
     }
 }
 
-__device__ __forceinline__ void decode_palette(uint2 blk, bool dxt1_modes, int (&pal)[4][3])
+// per-channel palettes, one byte per entry: pal[c] = entry0 | entry1<<8 | entry2<<16 | entry3<<24
+__device__ __forceinline__ void decode_palette(uint2 blk, bool dxt1_modes, unsigned (&pal)[3])
 {
     const unsigned c0 = blk.x & 0xFFFFu, c1 = blk.x >> 16;
-    pal[0][0] = expand5(c0 >> 11); pal[0][1] = expand6((c0 >> 5) & 63); pal[0][2] = expand5(c0 & 31);
-    pal[1][0] = expand5(c1 >> 11); pal[1][1] = expand6((c1 >> 5) & 63); pal[1][2] = expand5(c1 & 31);
+    const int e0[3] = {expand5(c0 >> 11), expand6((c0 >> 5) & 63), expand5(c0 & 31)};
+    const int e1[3] = {expand5(c1 >> 11), expand6((c1 >> 5) & 63), expand5(c1 & 31)};
     const bool four = !dxt1_modes || c0 > c1;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        pal[2][c] = four ? (2 * pal[0][c] + pal[1][c]) / 3 : (pal[0][c] + pal[1][c]) / 2;
-        pal[3][c] = four ? (pal[0][c] + 2 * pal[1][c]) / 3 : 0;
+        const int e2 = four ? (2 * e0[c] + e1[c]) / 3 : (e0[c] + e1[c]) / 2;
+        const int e3 = four ? (e0[c] + 2 * e1[c]) / 3 : 0;
+        pal[c] = (unsigned)e0[c] | ((unsigned)e1[c] << 8) | ((unsigned)e2 << 16) | ((unsigned)e3 << 24);
     }
 }
 
@@ -81,8 +90,24 @@ __global__ __launch_bounds__(256) void bc_decode_kernel(const uint8_t *__restric
         decode_alpha(make_uint2(v.x, v.y), a);          // DXT5: alpha; YCoCg: luma
         colour = make_uint2(v.z, v.w);
     }
-    int pal[4][3];
+    unsigned pal[3];
     decode_palette(colour, FMT == 0, pal);
+    if (FMT == 2) {
+        // undo the per-block chroma scaling once per palette entry (4x) instead of once per pixel:
+        // pal[0]/pal[1] become (Co/s)+128 and (Cg/s)+128 (division truncating toward zero)
+        unsigned co4 = 0, cg4 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int s = (int)(((pal[2] >> (8 * k)) & 255u) >> 3) + 1;
+            int co = (int)((pal[0] >> (8 * k)) & 255u) - 128, cg = (int)((pal[1] >> (8 * k)) & 255u) - 128;
+            co = co >= 0 ? co / s : -((-co) / s);
+            cg = cg >= 0 ? cg / s : -((-cg) / s);
+            co4 |= (unsigned)(co + 128) << (8 * k);
+            cg4 |= (unsigned)(cg + 128) << (8 * k);
+        }
+        pal[0] = co4;
+        pal[1] = cg4;
+    }
     int plane[16];
     if (HAS_ALPHA)
         decode_alpha(*reinterpret_cast<const uint2 *>(alpha_blocks + (size_t)id * 8u), plane);
@@ -94,26 +119,19 @@ __global__ __launch_bounds__(256) void bc_decode_kernel(const uint8_t *__restric
         for (int c = 0; c < 4; c++) {
             const int i = 4 * r + c;
             const unsigned k = (colour.y >> (2 * i)) & 3u;
-            int cr = pal[0][0], cg = pal[0][1], cb = pal[0][2];
-#pragma unroll
-            for (int q = 1; q < 4; q++) {
-                cr = k == (unsigned)q ? pal[q][0] : cr;
-                cg = k == (unsigned)q ? pal[q][1] : cg;
-                cb = k == (unsigned)q ? pal[q][2] : cb;
-            }
+            const int cr = (int)(__builtin_amdgcn_perm(0u, pal[0], k) & 0xFFu);
+            const int cg = (int)(__builtin_amdgcn_perm(0u, pal[1], k) & 0xFFu);
             int R, G, B, A;
             if (FMT == 2) {
-                const int s = (cb >> 3) + 1;
-                int co = cr - 128, cgg = cg - 128;
-                co = co >= 0 ? co / s : -((-co) / s);
-                cgg = cgg >= 0 ? cgg / s : -((-cgg) / s);
-                const int y = a[i];
+                const int co = cr - 128, cgg = cg - 128, y = a[i];
                 R = clamp255(y + co - cgg);
                 G = clamp255(y + cgg);
                 B = clamp255(y - co - cgg);
                 A = HAS_ALPHA ? plane[i] : 255;
             } else {
-                R = cr; G = cg; B = cb;
+                R = cr;
+                G = cg;
+                B = (int)(__builtin_amdgcn_perm(0u, pal[2], k) & 0xFFu);
                 A = HAS_ALPHA ? plane[i] : a[i];
             }
             px[c] = (unsigned)R | ((unsigned)G << 8) | ((unsigned)B << 16) | ((unsigned)A << 24);
