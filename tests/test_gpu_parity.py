@@ -245,6 +245,21 @@ def test_decode_far_back_references(hap):
     assert (r, fmt) == (0, L.FMT_DXT5) and out == want
 
 
+@pytest.mark.parametrize("chunks", [65, 300, 1000])
+def test_many_chunks(hap, chunks):
+    """Chunk counts beyond one wave / one workgroup of planner lanes, tiny chunks, mixed store-raw."""
+    tex = D.stream_bytes(16 * chunks * 6, "mixed", seed=chunks) if chunks < 1000 else D.stream_bytes(16 * chunks * 2, "runs", seed=7)
+    fmt = L.FMT_BC7
+    frame_ref = _encode_with(ORA, tex, fmt, L.COMP_SNAPPY, chunks)
+    assert hap.HapDecode(frame_ref, 0, outputBufferBytes=len(tex)) == (0, tex, fmt)
+    assert hap.HapGetFrameTextureChunkCount(frame_ref, 0) == (0, chunks)
+    r, ours = hap.HapEncode([tex], [fmt], [L.COMP_SNAPPY], [chunks])
+    assert r == 0
+    assert ORA.decode(ours, 0, len(tex)) == (0, tex, fmt)
+    assert hap.HapDecode(ours, 0, outputBufferBytes=len(tex)) == (0, tex, fmt)
+    assert ORA.chunk_count(ours, 0) in ((0, chunks), (0, 1))      # (0, 1): stored raw as a whole
+
+
 def test_decode_dual_texture(hap):
     a = D.stream_bytes(16 * 64 * 9, "runs")
     b = D.stream_bytes(8 * 64 * 9, "mixed")
