@@ -770,8 +770,6 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
             const unsigned elen = ((g0 >> 16) & 0x7Fu) / GRAN;
             const bool lit = (g0 >> 31) != 0;
             unsigned desc;                       // bit 31: resolved (LDS byte address), else output position
-            bool far = false;
-            unsigned far_pos = 0;
             if (lit) {
                 desc = 0x80000000u | (GRAN == 2 ? 0x40000000u : 0u) | (RING + ((g1 + GRAN * rel) & (kInBytes - 1)));
             } else {
@@ -783,14 +781,14 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
                 }
                 const unsigned q = g1 / GRAN + r;                // output position (in units) of the source
                 desc = q < opu + B ? (0x80000000u | ((GRAN * q) & (RING - 1))) : q;
-                // a stream's ring holds only the last RING bytes: older sources come back from memory
-                far = STREAM && q + RING < op + kOwnerBytes + 64u;
-                far_pos = q;
+                // a stream's ring holds only the last RING bytes: older sources come back from memory.
+                // The marker travels with the descriptor so that bytes copying from this byte inside
+                // the same step inherit it (STREAM implies GRAN == 1, bit 30 is free there).
+                if (STREAM && q + RING < op + kOwnerBytes + 64u)
+                    desc = 0xC0000000u | q;
             }
-            if (!active) {
+            if (!active)
                 desc = 0x80000000u;
-                far = false;
-            }
             // sources inside this 64-byte step: pointer jumping
             for (int round = 0; round < 7; round++) {
                 const bool pending = (desc >> 31) == 0;
@@ -802,19 +800,25 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
                     desc = g;
             }
             const unsigned a0 = desc & 0x3FFFFFFFu;
-            unsigned value = smem[a0];
+            const bool far = STREAM && (desc & 0x40000000u) != 0;
+            unsigned value = far ? 0u : (unsigned)smem[a0];
             if (GRAN == 2) {
                 // second byte: literals live in the 2 KiB staging ring (may wrap), copies are contiguous
                 const unsigned a1 = (desc & 0x40000000u) ? RING + ((a0 - RING + 1u) & (kInBytes - 1)) : a0 + 1u;
                 value |= (unsigned)smem[a1] << 8;
             }
             if (STREAM && __ballot(far) != 0) {
-                // far sources were flushed long ago by this wave; make those stores visible and
-                // bypass this CU's L1 for the read-back
+                // far sources were written to memory by THIS wave at least RING - 12 KiB of output ago:
+                // drain the wave's own stores, then read back past the CU's L1 (sc1), which may still
+                // hold the line as it was before those stores
+#ifdef HAP_FAR_FENCE
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
                 if (far)
-                    value = __hip_atomic_load(dst + far_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    value = __hip_atomic_load(dst + a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (active) {
                 if (GRAN == 2)
@@ -865,15 +869,24 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
     static const bool use_v1 = getenv("HAP_AMD_DECODE_V1") != nullptr;
     if (any_stream_or_copy_units) {
         static bool once = false;
+        static unsigned ring_log2 = 15;
         if (!once) {
             (void)hipFuncSetAttribute((const void *)snappy_decode_kernel<65536u, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes);
             (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, true, 1u>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes + kOwnerBytes + 64);
+            const char *e = getenv("HAP_AMD_STREAM_RING_LOG2");
+            if (e && atoi(e) >= 14 && atoi(e) <= 16)
+                ring_log2 = (unsigned)atoi(e);
             once = true;
         }
+        const unsigned tail = kInBytes + kOwnerBytes + 64;
         if (use_v1)
             hipLaunchKernelGGL((snappy_decode_kernel<65536u, false>), dim3(unit_count), dim3(64), 65536 + kInBytes, stream, units, unit_count, jobs);
+        else if (ring_log2 == 14)
+            hipLaunchKernelGGL((snappy_decode_fragment_kernel<16384u, true, 1u>), dim3(unit_count), dim3(64), 16384 + tail, stream, units, unit_count, jobs);
+        else if (ring_log2 == 15)
+            hipLaunchKernelGGL((snappy_decode_fragment_kernel<32768u, true, 1u>), dim3(unit_count), dim3(64), 32768 + tail, stream, units, unit_count, jobs);
         else
-            hipLaunchKernelGGL((snappy_decode_fragment_kernel<65536u, true, 1u>), dim3(unit_count), dim3(64), 65536 + kInBytes + kOwnerBytes + 64, stream, units, unit_count, jobs);
+            hipLaunchKernelGGL((snappy_decode_fragment_kernel<65536u, true, 1u>), dim3(unit_count), dim3(64), 65536 + tail, stream, units, unit_count, jobs);
     }
     const unsigned extra = kInBytes + (use_v1 ? 0u : kOwnerBytes + 64u);
     static bool once16 = false;

@@ -237,6 +237,24 @@ def test_decode_far_back_references(hap):
     stream += bytes([(63 << 2) | 3]) + (n).to_bytes(4, "little")               # copy-4 len 64 off n  -> head[0:64]
     stream += bytes([(39 << 2) | 3]) + (66000 + 64).to_bytes(4, "little")      # copy-4 len 40 off 66064
     want = head + head[:64] + head[n + 64 - 66064: n + 64 - 66064 + 40]
+    # a far copy (older than every ring size) followed, in the same production step, by copies of its
+    # output: the bytes taken from memory must propagate through the in-step dependency chase
+    stream += bytes([(9 << 2) | 2]) + (40000).to_bytes(2, "little")              # copy-2 len 10 off 40000
+    want += want[len(want) - 40000: len(want) - 40000 + 10]
+    stream += bytes([1 | ((11 - 4) << 2)]) + bytes([10])                          # copy-1 len 11 off 10 (overlapping)
+    for _ in range(11):
+        want += want[len(want) - 10: len(want) - 9]
+    stream += bytes([(5 << 2) | 2]) + (21).to_bytes(2, "little")                 # copy-2 len 6 off 21
+    want += want[len(want) - 21: len(want) - 15]
+    total = len(want)
+    hdr_len = 3 if n + 104 < (1 << 21) else 4
+    new_hdr = bytearray()
+    v = total
+    while v >= 0x80:
+        new_hdr.append((v & 0x7F) | 0x80)
+        v >>= 7
+    new_hdr.append(v)
+    stream = bytearray(new_hdr) + stream[hdr_len:]
     assert D.osnappy_uncompress(bytes(stream), total) == (0, want)
     tables = bytes([1, 0, 0, 2, 0x0B, 4, 0, 0, 3]) + len(stream).to_bytes(4, "little")
     body = len(tables).to_bytes(3, "little") + bytes([1]) + tables + bytes(stream)
