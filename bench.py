@@ -180,6 +180,12 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": measured_traffic(args.config, dom, nf),
                 "algorithmic_bytes_per_launch": int(algo[dom]), "avg_launch_ms": kernels[dom]["ms_avg"]}
 
+    host_path = None
+    if not args.no_cpu_baseline:
+        try:
+            host_path = host_pointer_path(ctx, rgba, frames, used, fmts, comps, chunks, tex_bytes, cap, w, h, flags)
+        except Exception as exc:
+            host_path = {"error": repr(exc)}
     foreign = None
     if args.foreign_frames and not args.no_cpu_baseline:
         try:
@@ -211,11 +217,35 @@ def main():
                              "algorithmic_GBps": round((sum(tex_bytes) + rgba_bytes) / (prof_bd[1] / prof_bd[0] * 1e-3) / 1e9, 1)}
                             if prof_bd[0] else None),
         "decode_of_reference_encoded_frames": foreign,
+        "host_pointer_path": host_path,
         "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
     }
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def host_pointer_path(ctx, rgba, frames, used, fmts, comps, chunks, tex_bytes, cap, w, h, flags, n=4):
+    """Same calls with pageable HOST buffers (what a plain hap.h client passes): PCIe-inclusive, never `value`."""
+    import numpy as np
+    n = min(n, len(rgba))
+    host_rgba = [rgba[i].cpu().numpy() for i in range(n)]
+    host_frames = [np.empty(cap, dtype=np.uint8) for _ in range(n)]
+    t0 = time.perf_counter()
+    r, hused, res = ctx.encode_frames_rgba(host_rgba, w, h, w * 4, fmts, comps, chunks, host_frames, flags=flags)
+    t_enc = time.perf_counter() - t0
+    if r != 0:
+        raise RuntimeError("host encode failed %r" % res)
+    outs = [np.empty(tex_bytes[0], dtype=np.uint8) for _ in range(n)]
+    t0 = time.perf_counter()
+    r, dused, _f, dres = ctx.decode_frames(host_frames, hused, 0, outs)
+    t_dec = time.perf_counter() - t0
+    if r != 0:
+        raise RuntimeError("host decode failed %r" % dres)
+    rgba_bytes = w * h * 4
+    return {"frames": n, "encode_rgba_GBps": round(n * rgba_bytes / t_enc / 1e9, 2), "decode_rgba_GBps": round(n * rgba_bytes / t_dec / 1e9, 2),
+            "encode_ms_per_frame": round(t_enc / n * 1e3, 2), "decode_ms_per_frame": round(t_dec / n * 1e3, 2),
+            "note": "pageable host memory over PCIe, includes staging copies"}
 
 
 def decode_foreign(ctx, dev, fmts, chunks, dec, tex_bytes, cap, n, rgba_bytes):
