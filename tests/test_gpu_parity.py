@@ -356,6 +356,62 @@ def test_decode_bad_arguments(hap):
     assert lib.HapDecode(buf, len(f), 0, null_cb, None, out, 64, None, C.byref(fmt)) == 1
 
 
+def test_chunk_offset_table(hap):
+    """Optional Chunk Offset Table (section 0x04, hap.c:697-700, 800-803): chunks stored out of order,
+    tables in a different order, plus an unknown section in the container."""
+    tex = D.stream_bytes(16 * 4 * 500, "runs", seed=77)
+    q = len(tex) // 4
+    comp = [D.osnappy_compress(tex[i * q:(i + 1) * q]) for i in range(4)]
+    order = [2, 0, 3, 1]                               # payload order
+    payload, offs = b"", [0] * 4
+    for i in order:
+        offs[i] = len(payload)
+        payload += comp[i]
+
+    def sec(t, body):
+        return len(body).to_bytes(3, "little") + bytes([t]) + body
+    tables = (sec(0x04, b"".join(o.to_bytes(4, "little") for o in offs)) + sec(0x77, b"ignored") +
+              sec(0x03, b"".join(len(c).to_bytes(4, "little") for c in comp)) + sec(0x02, bytes([0x0B] * 4)))
+    body = sec(0x01, tables) + payload
+    frame = sec(0xCE, body)
+    for name, api in CHECKERS:
+        assert api.decode(frame, 0, len(tex)) == (0, tex, L.FMT_DXT5), name
+    assert hap.HapDecode(frame, 0, outputBufferBytes=len(tex)) == (0, tex, L.FMT_DXT5)
+    assert hap.HapGetFrameTextureChunkCount(frame, 0) == (0, 4)
+    # an offset that points outside the section is refused (the reference would read out of bounds)
+    bad = bytearray(frame)
+    pos = bad.find(b"".join(o.to_bytes(4, "little") for o in offs))
+    bad[pos:pos + 4] = (len(payload) + 5).to_bytes(4, "little")
+    assert hap.HapDecode(bytes(bad), 0, outputBufferBytes=len(tex))[0] == hap.HapResult.Bad_Frame
+
+
+def test_edge_sizes_and_empty_tables(hap):
+    """Tiny and odd-sized textures, zero-length input, and a complex frame whose tables are empty
+    (chunk_count 0 -> success with 0 bytes)."""
+    for n in (1, 2, 7, 8, 9, 15, 16, 17, 31, 63, 65, 127, 4097):
+        tex = D.stream_bytes(n, "runs", seed=n)
+        for fmt in (L.FMT_DXT1, L.FMT_DXT5):
+            for comp in (L.COMP_NONE, L.COMP_SNAPPY):
+                for chunks in (1, 3):
+                    r, frame = hap.HapEncode([tex], [fmt], [comp], [chunks])
+                    ro, fo = ORA.encode([tex], [fmt], [comp], [chunks])
+                    assert r == ro == 0
+                    if comp == L.COMP_NONE:
+                        assert frame == fo
+                    # what the reference decodes from our frame is what it decodes from its own
+                    assert ORA.decode(frame, 0, n + 8) == ORA.decode(fo, 0, n + 8)
+                    assert hap.HapDecode(fo, 0, outputBufferBytes=n + 8) == ORA.decode(fo, 0, n + 8)
+                    assert hap.HapDecode(frame, 0, outputBufferBytes=n + 8) == ORA.decode(frame, 0, n + 8)
+    assert hap.HapEncode([b""], [L.FMT_DXT1], [1], [1], outputBufferBytes=256)[0] == ORA.encode([b""], [L.FMT_DXT1], [1], [1], out_bytes=256)[0]
+    # complex frame with zero-length tables: 8-byte headers carry a zero length
+    tables = bytes([0, 0, 0, 2, 0, 0, 0, 0]) + bytes([0, 0, 0, 3, 0, 0, 0, 0])
+    body = len(tables).to_bytes(3, "little") + bytes([1]) + tables
+    frame = len(body).to_bytes(3, "little") + bytes([0xCB]) + body
+    assert hap.HapDecode(frame, 0, outputBufferBytes=64) == ORA.decode(frame, 0, 64)
+    assert ORA.decode(frame, 0, 64)[0] == 0
+    assert hap.HapGetFrameTextureChunkCount(frame, 0) == ORA.chunk_count(frame, 0)
+
+
 def test_decode_partial_callback(hap):
     """A client that asks for only some chunks gets only those decoded (others left untouched)."""
     from hap_amd._lib import CALLBACK
