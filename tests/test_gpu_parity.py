@@ -561,6 +561,30 @@ def test_device_resident_batch_round_trip(ctx, hap):
             assert r == 0 and all(torch.equal(x, y) for x, y in zip(dec, dec2))
 
 
+def test_encode_is_deterministic_and_batch_independent(ctx, hap):
+    """G5 stand-in on one GPU: a frame's bytes do not depend on run, batch size or position in the batch
+    (round-synchronous hash inserts with LDS atomicMax make the compressor timing-independent), so
+    sharding frames over 1/2/4/8 GPUs cannot change them."""
+    from hap_amd import synth
+    w, h, fmts = 1024, 512, [L.FMT_YCOCG, L.FMT_RGTC1]
+    sizes = [(w // 4) * (h // 4) * 16, (w // 4) * (h // 4) * 8]
+    cap = hap.HapMaxEncodedLength(sizes, fmts, [6, 4])
+    rgba = [synth.rgba_frame(w, h, i, device="cuda") for i in range(6)]
+
+    def run(frames):
+        outs = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in frames]
+        torch.cuda.synchronize()
+        r, used, res = ctx.encode_frames_rgba(frames, w, h, w * 4, fmts, [1, 1], [6, 4], outs, flags=hap.ENCODE_FRAGMENT_INDEX)
+        assert r == 0 and res == [0] * len(frames)
+        return [o[:u].cpu().numpy().tobytes() for o, u in zip(outs, used)]
+    all6 = run(rgba)
+    assert run(rgba) == all6                                   # run to run
+    assert run(rgba[::-1]) == all6[::-1]                       # position in the batch
+    for i in (0, 3, 5):
+        assert run([rgba[i]]) == [all6[i]]                     # batch of one == shard of any size
+    assert run(rgba[1::2]) == all6[1::2]                       # the frames rank 1 of 2 would own
+
+
 def test_corrupt_fragment_table_falls_back(ctx, hap):
     tex = D.stream_bytes(16 * 4 * 3000, "runs")
     cap = hap.HapMaxEncodedLength([len(tex)], [L.FMT_DXT5], [4])
