@@ -316,7 +316,7 @@ __device__ __forceinline__ unsigned match_extend16(const uint32_t *dw, unsigned 
 }
 
 template <unsigned GRAN>     // bytes per lane: 1, or 2 (positions, offsets and lengths all even)
-__global__ __launch_bounds__(256) void snappy_compress_wg_kernel(const HapGpuFrameEnc *__restrict__ frames,
+__global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const HapGpuFrameEnc *__restrict__ frames,
                                                                 unsigned frag_log2, uint8_t *__restrict__ slots,
                                                                 unsigned slot_stride, uint32_t *__restrict__ frag_sizes)
 {
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void snappy_compress_wg_kernel(const HapGpuFra
     uint8_t *out = slots + (size_t)f * slot_stride;
 
     if (((uintptr_t)src & 15u) == 0) {
-        for (unsigned i = tid * 16u; i < n + 32u; i += 4096u) {
+        for (unsigned i = tid * 16u; i < n + 32u; i += 1024u * kWgWaves) {
             uint4 v = make_uint4(0, 0, 0, 0);
             if (i + 16u <= n) {
                 v = *reinterpret_cast<const uint4 *>(src + i);
@@ -358,10 +358,10 @@ __global__ __launch_bounds__(256) void snappy_compress_wg_kernel(const HapGpuFra
             *reinterpret_cast<uint4 *>(smem + i) = v;
         }
     } else {
-        for (unsigned i = tid; i < n + 32u; i += 256u)
+        for (unsigned i = tid; i < n + 32u; i += 64u * kWgWaves)
             smem[i] = i < n ? src[i] : (uint8_t)0;
     }
-    for (unsigned i = tid; i < kWgHashEntries; i += 256u)
+    for (unsigned i = tid; i < kWgHashEntries; i += 64u * kWgWaves)
         table[i] = 0u;
     __syncthreads();
 
@@ -555,9 +555,9 @@ extern "C" int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsig
         }
         const dim3 grid(max_frags_per_texture, 2, frame_count);
         if (granularity_mask & 1u)
-            hipLaunchKernelGGL(snappy_compress_wg_kernel<1u>, grid, dim3(256), lds2, stream, frames, frag_log2, (uint8_t *)slots, slot_stride, frag_sizes);
+            hipLaunchKernelGGL(snappy_compress_wg_kernel<1u>, grid, dim3(64 * kWgWaves), lds2, stream, frames, frag_log2, (uint8_t *)slots, slot_stride, frag_sizes);
         if (granularity_mask & 2u)
-            hipLaunchKernelGGL(snappy_compress_wg_kernel<2u>, grid, dim3(256), lds2, stream, frames, frag_log2, (uint8_t *)slots, slot_stride, frag_sizes);
+            hipLaunchKernelGGL(snappy_compress_wg_kernel<2u>, grid, dim3(64 * kWgWaves), lds2, stream, frames, frag_log2, (uint8_t *)slots, slot_stride, frag_sizes);
         return hipGetLastError() == hipSuccess ? 0 : 4;
     }
     const unsigned lds = compress_lds_bytes(frag_log2);
