@@ -642,9 +642,9 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
         // ---- 1. speculative parse: the element that would start at coordinate ip + lane ----
         const unsigned x = ip + lane;
         const unsigned wi = x >> 2, sh = x & 3u;
-        const unsigned w0 = inw[wi & 511u], w1 = inw[(wi + 1) & 511u], w2 = inw[(wi + 2) & 511u];
-        const unsigned lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
-        const unsigned hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+        const unsigned w0 = inw[wi & 511u], w1 = inw[(wi + 1) & 511u];
+        const unsigned lo = __builtin_amdgcn_alignbyte(w1, w0, sh);       // bytes x .. x+3
+        const unsigned hi = (w1 >> (8u * sh)) & 0xFFu;                     // byte x+4 (copy-4 / 4 length bytes)
         const unsigned tag = lo & 0xFFu, kind = tag & 3u;
         unsigned len, off = 0, hdr;
         bool special = false;                   // long literal: taken alone by the slow path
@@ -750,9 +750,11 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
         if (is_tok)
             owner[o_t / GRAN] = (uint8_t)(lane + 1u);
         // element attributes, fetched by the byte lanes with ds_bpermute
-        const int a0 = (int)(o_t | (len << 16) | (kind == 0 ? 0x80000000u : 0u));
-        const int a1 = (int)(kind == 0 ? x + hdr : op + o_t - off);    // literal: input coordinate; copy: source position
-        const int a2 = (int)off;
+        // a0: o_t (11 bits) | len (7) << 11 | literal flag << 18 ; a1: literal input coordinate or copy
+        // source position; a0 bits 19.. carry the low 13 bits of the offset, a1 is untouched -- the
+        // offset only matters for overlapping copies (off < len <= 64), so 13 bits are plenty
+        const int a0 = (int)(o_t | (len << 11) | (kind == 0 ? (1u << 18) : 0u) | (min(off, 8191u) << 19));
+        const int a1 = (int)(kind == 0 ? x + hdr : op + o_t - off);
         unsigned carry = 0;
         const unsigned opu = op / GRAN;
         for (unsigned B = 0; B < NU; B += 64u) {
@@ -765,10 +767,10 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
             const unsigned sl = (unsigned)(m - 1) & 63u;
             const unsigned g0 = (unsigned)lane_gather(a0, sl);
             const unsigned g1 = (unsigned)lane_gather(a1, sl);
-            const unsigned g2 = (unsigned)lane_gather(a2, sl);
-            const unsigned rel = b - (g0 & 0xFFFFu) / GRAN;
-            const unsigned elen = ((g0 >> 16) & 0x7Fu) / GRAN;
-            const bool lit = (g0 >> 31) != 0;
+            const unsigned g2 = g0 >> 19;                                  // offset, saturated at 8191
+            const unsigned rel = b - (g0 & 0x7FFu) / GRAN;
+            const unsigned elen = ((g0 >> 11) & 0x7Fu) / GRAN;
+            const bool lit = ((g0 >> 18) & 1u) != 0;
             unsigned desc;                       // bit 31: resolved (LDS byte address), else output position
             if (lit) {
                 desc = 0x80000000u | (GRAN == 2 ? 0x40000000u : 0u) | (RING + ((g1 + GRAN * rel) & (kInBytes - 1)));
