@@ -21,7 +21,6 @@ __device__ __forceinline__ int quant5(int v) { int t = v * 31 + 128; return (t +
 __device__ __forceinline__ int quant6(int v) { int t = v * 63 + 128; return (t + (t >> 8)) >> 8; }
 __device__ __forceinline__ int expand5(int q) { return (q << 3) | (q >> 2); }
 __device__ __forceinline__ int expand6(int q) { return (q << 2) | (q >> 4); }
-__device__ __forceinline__ int clamp255(int v) { return min(max(v, 0), 255); }
 
 // 8-byte alpha-style block: a0, a1, 16 x 3-bit codes (S3TC alpha / RGTC1 layout).
 __device__ __forceinline__ uint2 alpha_block(const int (&a)[16])

@@ -19,11 +19,11 @@
 
 enum {
     D_FRAMES = 0, D_SLOTS, D_FRAGSIZES, D_COPIES, D_TEX_STAGE, D_FRAME_STAGE, D_BC_TEX, D_RGBA_STAGE,
-    D_JOBS, D_CHUNKS, D_UNITS, D_IN_STAGE, D_OUT_STAGE
+    D_JOBS, D_CHUNKS, D_UNITS, D_IN_STAGE, D_OUT_STAGE, D_PTRS, D_PREFIX
 };
-enum { P_FRAMES = 0, P_JOBS, P_CHUNKS, P_PREFIX };
+enum { P_FRAMES = 0, P_JOBS, P_CHUNKS, P_PREFIX, P_PTRS };
 
-#define PREFIX_BYTES 16384u
+#define PREFIX_BYTES 65536u
 #define COPY_PIECE 65536u
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -507,6 +507,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     HapGpuChunkIn *hchunks, *dchunks;
     HapGpuDecodeUnit *dunits;
     unsigned *job_of_frame;
+    unsigned char *in_dev = NULL, *out_dev = NULL;     /* pointer classification, done once per buffer */
     int rc = 0;
 
     if (frame_count == 0)
@@ -524,7 +525,9 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     in_off = (size_t *)calloc(frame_count, sizeof(size_t));
     out_off = (size_t *)calloc(frame_count, sizeof(size_t));
     job_of_frame = (unsigned *)calloc(frame_count, sizeof(unsigned));
-    if (!plans || !readers || !fetchers || !in_off || !out_off || !job_of_frame) {
+    in_dev = (unsigned char *)calloc(frame_count, 1);
+    out_dev = (unsigned char *)calloc(frame_count, 1);
+    if (!plans || !readers || !fetchers || !in_off || !out_off || !job_of_frame || !in_dev || !out_dev) {
         rc = 1;
         goto fail_alloc;
     }
@@ -538,22 +541,35 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                 results[f] = HapResult_Bad_Arguments;
                 continue;
             }
-            if (is_dev(ctx, inputs[f]))
+            in_dev[f] = (unsigned char)is_dev(ctx, inputs[f]);
+            out_dev[f] = (unsigned char)is_dev(ctx, outputs[f]);
+            if (in_dev[f])
                 device_frames++;
         }
         if (device_frames) {
+            /* one gather kernel + one copy bring every device frame's header prefix to the host */
+            uint64_t *hptr = (uint64_t *)hapgpu_rt_pinned_scratch(rt, P_PTRS, sizeof(uint64_t) * 2u * frame_count);
+            uint64_t *dptr = (uint64_t *)hapgpu_rt_device_scratch(rt, D_PTRS, sizeof(uint64_t) * 2u * frame_count);
+            uint8_t *dprefix = (uint8_t *)hapgpu_rt_device_scratch(rt, D_PREFIX, (size_t)PREFIX_BYTES * frame_count);
             prefix = (uint8_t *)hapgpu_rt_pinned_scratch(rt, P_PREFIX, (size_t)PREFIX_BYTES * frame_count);
-            if (!prefix) {
+            if (!prefix || !hptr || !dptr || !dprefix) {
                 rc = 1;
                 goto fail_alloc;
             }
+            for (f = 0; f < frame_count; f++) {
+                const int dev_frame = results[f] == HapResult_No_Error && in_dev[f];
+                hptr[f] = dev_frame ? (uint64_t)(uintptr_t)inputs[f] : 0u;
+                hptr[frame_count + f] = input_bytes[f];
+            }
+            rc |= hapgpu_rt_h2d(rt, dptr, hptr, sizeof(uint64_t) * 2u * frame_count);
+            rc |= hapgpu_k_gather_prefixes(rt, dptr, dptr + frame_count, frame_count, PREFIX_BYTES, dprefix);
+            rc |= hapgpu_rt_d2h(rt, prefix, dprefix, (size_t)PREFIX_BYTES * frame_count);
         }
         for (f = 0; f < frame_count; f++) {
             if (results[f] != HapResult_No_Error)
                 continue;
-            if (is_dev(ctx, inputs[f])) {
+            if (in_dev[f]) {
                 size_t n = input_bytes[f] < PREFIX_BYTES ? input_bytes[f] : PREFIX_BYTES;
-                rc |= hapgpu_rt_d2h(rt, prefix + (size_t)PREFIX_BYTES * f, inputs[f], n);
                 hapf_reader_init_host(&readers[f], prefix + (size_t)PREFIX_BYTES * f, n);
                 fetchers[f].ctx = ctx;
                 fetchers[f].device_frame = (const uint8_t *)inputs[f];
@@ -639,7 +655,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
         total_units += units;
         p->frag_entries = p->frag_table_offset ? p->frag_entries : 0;
         p->unit_count = units;
-        if (!is_dev(ctx, outputs[f])) {
+        if (!out_dev[f]) {
             out_off[f] = out_stage_bytes + 1;
             out_stage_bytes += align_up(output_bytes[f], 256);
         }
@@ -812,6 +828,7 @@ finish:
         hapf_reader_free(&readers[f]);
     }
     free(plans); free(readers); free(fetchers); free(in_off); free(out_off); free(job_of_frame);
+    free(in_dev); free(out_dev);
     return first_error;
 
 fail_alloc:
@@ -822,5 +839,6 @@ fail_alloc:
         if (readers) hapf_reader_free(&readers[f]);
     }
     free(plans); free(readers); free(fetchers); free(in_off); free(out_off); free(job_of_frame);
+    free(in_dev); free(out_dev);
     return HapResult_Internal_Error;
 }

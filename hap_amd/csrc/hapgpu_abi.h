@@ -158,6 +158,9 @@ int hapgpu_k_frame_pack(hapgpu_rt *rt, HapGpuFrameEnc *frames, unsigned frame_co
                         unsigned frag_log2, const void *slots, unsigned slot_stride,
                         const uint32_t *frag_sizes, HapGpuCopyEntry *copies);
 int hapgpu_k_frame_gather(hapgpu_rt *rt, const HapGpuCopyEntry *copies, unsigned count);
+/* first `prefix` bytes of every device-resident frame (0 pointer = skip) -> out_dev + i * prefix */
+int hapgpu_k_gather_prefixes(hapgpu_rt *rt, const uint64_t *frames_dev, const uint64_t *lengths_dev,
+                             unsigned count, unsigned prefix, void *out_dev);
 /* clears `units` (all SKIP) then plans every job */
 int hapgpu_k_decode_plan(hapgpu_rt *rt, HapGpuDecodeJob *jobs, unsigned job_count,
                          HapGpuDecodeUnit *units, unsigned unit_count);

@@ -287,6 +287,40 @@ extern "C" int hapgpu_rt_timer_stop(hapgpu_rt *rt, double *ms)
     return 0;
 }
 
+// ---- header prefixes of device-resident frames ------------------------------------------------
+// The host parses section headers and tables (hap_frame.c); for frames that live in HBM their first
+// `prefix` bytes are gathered into one contiguous block so that a single copy brings them back.
+__global__ __launch_bounds__(256) void gather_prefix_kernel(const uint64_t *__restrict__ frames,
+                                                            const uint64_t *__restrict__ lengths, unsigned prefix,
+                                                            uint8_t *__restrict__ out)
+{
+    const uint8_t *src = (const uint8_t *)frames[blockIdx.x];
+    if (!src)
+        return;
+    const uint64_t n = lengths[blockIdx.x] < prefix ? lengths[blockIdx.x] : prefix;
+    uint8_t *dst = out + (size_t)blockIdx.x * prefix;
+    if ((((uintptr_t)src) & 15u) == 0) {
+        const unsigned wide = (unsigned)(n >> 4);
+        for (unsigned i = threadIdx.x; i < wide; i += 256u)
+            reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
+        for (unsigned i = (wide << 4) + threadIdx.x; i < n; i += 256u)
+            dst[i] = src[i];
+    } else {
+        for (unsigned i = threadIdx.x; i < n; i += 256u)
+            dst[i] = src[i];
+    }
+}
+
+extern "C" int hapgpu_k_gather_prefixes(hapgpu_rt *rt, const uint64_t *frames_dev, const uint64_t *lengths_dev,
+                                        unsigned count, unsigned prefix, void *out_dev)
+{
+    if (count == 0)
+        return 0;
+    hipLaunchKernelGGL(gather_prefix_kernel, dim3(count), dim3(256), 0, rt->stream, frames_dev, lengths_dev, prefix,
+                       (uint8_t *)out_dev);
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}
+
 // ---- launchers -----------------------------------------------------------------------------
 
 extern "C" int hapgpu_k_block_encode(hapgpu_rt *rt, const void *rgba, unsigned width, unsigned height,
