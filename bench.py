@@ -180,6 +180,8 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": measured_traffic(args.config, dom, nf),
                 "algorithmic_bytes_per_launch": int(algo[dom]), "avg_launch_ms": kernels[dom]["ms_avg"]}
 
+    if world > 1:
+        args.no_cpu_baseline = True       # the CPU / foreign / host-pointer legs are reported at N=1 only
     host_path = None
     if not args.no_cpu_baseline:
         try:
