@@ -114,7 +114,16 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
         }
         t->fpc = (t->chunk_bytes + frag_bytes - 1) / frag_bytes;
         /* 16-bit granular element streams need even chunk sizes (always true for block textures) */
-        t->gran_log2 = (t->compressor == HapCompressorSnappy && (t->chunk_bytes & 1u) == 0 && !ctx->byte_granular) ? 1u : 0u;
+        t->gran_log2 = 0u;
+        if (t->compressor == HapCompressorSnappy && !ctx->byte_granular) {
+            /* DXT1 blocks are two 4-byte fields (endpoints, indices): everything repeats on 4-byte
+               boundaries.  The alpha-style blocks of RGTC1 / DXT5 / YCoCg start their index bytes at
+               byte 2, so those streams are 2-byte granular. */
+            if (t->format == HapTextureFormat_RGB_DXT1 && (t->chunk_bytes & 3u) == 0)
+                t->gran_log2 = 2u;
+            else if ((t->chunk_bytes & 1u) == 0)
+                t->gran_log2 = 1u;
+        }
         if (t->compressor == HapCompressorSnappy)
             gran_mask |= 1u << t->gran_log2;
         if (t->compressor == HapCompressorSnappy) {

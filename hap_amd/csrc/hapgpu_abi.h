@@ -103,7 +103,7 @@ typedef struct HapGpuDecodeJob {
     uint32_t frag_log2;
     uint32_t frag_entries;   /* number of fragment-size entries */
     uint32_t unit_count;
-    uint32_t reserved;       /* granularity_log2 announced by the fragment table (0 bytes, 1 16-bit) */
+    uint32_t reserved;       /* granularity_log2 announced by the fragment table (0 bytes, 1 16-bit, 2 32-bit) */
     /* results */
     uint64_t bytes_used;
     uint32_t status;         /* HapResult or HAPGPU_STATUS_* */
@@ -115,6 +115,7 @@ typedef struct HapGpuDecodeJob {
 #define HAPGPU_UNIT_SNAPPY_FRAGMENT 2u /* bare elements producing exactly dst_len bytes */
 #define HAPGPU_UNIT_COPY 3u
 #define HAPGPU_UNIT_SNAPPY_FRAGMENT16 4u /* fragment whose elements are all 16-bit granular */
+#define HAPGPU_UNIT_SNAPPY_FRAGMENT32 5u /* ... all 32-bit granular */
 
 /* [device] one wavefront's worth of decode work */
 typedef struct HapGpuDecodeUnit {
@@ -165,7 +166,7 @@ int hapgpu_k_gather_prefixes(hapgpu_rt *rt, const uint64_t *frames_dev, const ui
 int hapgpu_k_decode_plan(hapgpu_rt *rt, HapGpuDecodeJob *jobs, unsigned job_count,
                          HapGpuDecodeUnit *units, unsigned unit_count);
 /* frag_log2: fragment size of the batch's FRAGMENT units (0: none present);
- * fragment_kinds: bit 0 byte-granular fragments present, bit 1 16-bit granular ones */
+ * fragment_kinds: bit g set = fragments of granularity_log2 g present */
 int hapgpu_k_snappy_decode(hapgpu_rt *rt, const HapGpuDecodeUnit *units, unsigned unit_count,
                            HapGpuDecodeJob *jobs, unsigned frag_log2, unsigned fragment_kinds,
                            int any_stream_or_copy_units);

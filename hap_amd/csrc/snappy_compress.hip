@@ -315,7 +315,7 @@ __device__ __forceinline__ unsigned match_extend16(const uint32_t *dw, unsigned 
     return min(l, limit);
 }
 
-template <unsigned GRAN>     // bytes per lane: 1, or 2 (positions, offsets and lengths all even)
+template <unsigned GRAN>     // bytes per lane: 1, 2 or 4 (positions, offsets and lengths all multiples of GRAN)
 __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const HapGpuFrameEnc *__restrict__ frames,
                                                                 unsigned frag_log2, uint8_t *__restrict__ slots,
                                                                 unsigned slot_stride, uint32_t *__restrict__ frag_sizes)
@@ -367,6 +367,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
 
     constexpr unsigned TB = 64u * GRAN;                 // bytes per tile
     const uint16_t *data16 = reinterpret_cast<const uint16_t *>(smem);
+    const uint32_t *data32 = reinterpret_cast<const uint32_t *>(smem);
     const unsigned tiles = (n + TB - 1u) / TB, supers = (tiles + 1u) / 2u;
     unsigned round_base = 0;
     // DXT1 / RGTC1 textures are arrays of 8-byte blocks, everything else 16-byte blocks (hap.c:287-294)
@@ -379,6 +380,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
         unsigned p_len[2] = {0, 0}, p_off[2] = {0, 0}, p_hash[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
         unsigned p_at[2] = {0, 0}, p_run[2] = {0, 0}, p_flags[2] = {0, 0}, p_byte[2] = {0, 0};
         (void)data16;
+        (void)data32;
         unsigned total = 0;
         if (have) {
             const unsigned super_end = min(n, (2u * k + 2u) * TB);
@@ -388,12 +390,12 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
             for (int sub = 0; sub < 2; sub++) {
                 const unsigned p = (2u * k + sub) * TB + GRAN * lane;
                 const bool in = p < n;
-                const unsigned here = GRAN == 2 ? (unsigned)data16[p >> 1] : (unsigned)data[p];
+                const unsigned here = GRAN == 4 ? data32[p >> 2] : GRAN == 2 ? (unsigned)data16[p >> 1] : (unsigned)data[p];
 #pragma unroll
                 for (int d = 0; d < kFixed; d++) {
                     const unsigned dist = (unsigned)(d + 1) * pitch;
                     const unsigned back = p >= dist ? p - dist : 0u;
-                    const unsigned there = GRAN == 2 ? (unsigned)data16[back >> 1] : (unsigned)data[back];
+                    const unsigned there = GRAN == 4 ? data32[back >> 2] : GRAN == 2 ? (unsigned)data16[back >> 1] : (unsigned)data[back];
                     eq[d][sub] = __ballot(in && p >= dist && here == there);
                 }
             }
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
 #pragma unroll
                 for (int d = kFixed - 1; d >= 0; d--) {          // nearer distances win ties
                     const unsigned long long nx = sub == 0 ? eq[d][1] : 0ull;
-                    const unsigned l = min(GRAN == 2 ? 2u * run_from32(eq[d][sub], nx, lane)
+                    const unsigned l = min(GRAN >= 2 ? GRAN * run_from32(eq[d][sub], nx, lane)
                                                      : run_from(eq[d][sub], nx, lane), room);
                     if (l >= best_len && l >= 4u) { best_len = l; best_off = (unsigned)(d + 1) * pitch; }
                 }
@@ -470,14 +472,14 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
                 else if (is_copy)
                     emit = copy1 ? 2u : 3u;
                 const unsigned long long e0 = __ballot(emit & 1u), e1 = __ballot(emit & 2u);
-                const unsigned long long e2 = GRAN == 2 ? __ballot(emit & 4u) : 0ull;
-                p_at[sub] = total + bits_below(e0) + 2u * bits_below(e1) + (GRAN == 2 ? 4u * bits_below(e2) : 0u);
+                const unsigned long long e2 = GRAN >= 2 ? __ballot(emit & 4u) : 0ull;
+                p_at[sub] = total + bits_below(e0) + 2u * bits_below(e1) + (GRAN >= 2 ? 4u * bits_below(e2) : 0u);
                 total += (unsigned)__popcll(e0) + 2u * (unsigned)__popcll(e1) + 4u * (unsigned)__popcll(e2);
                 p_len[sub] = best_len;
                 p_off[sub] = best_off;
                 p_hash[sub] = my_hash;
                 p_run[sub] = run;
-                p_byte[sub] = cur & (GRAN == 2 ? 0xFFFFu : 0xFFu);
+                p_byte[sub] = GRAN == 4 ? cur : (cur & (GRAN == 2 ? 0xFFFFu : 0xFFu));
                 p_flags[sub] = (is_lit ? 1u : 0u) | (is_start ? 2u : 0u) | (is_copy ? 4u : 0u) | (copy1 ? 8u : 0u);
             }
         }
@@ -509,8 +511,12 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
                         }
                     }
                     out[at] = (uint8_t)p_byte[sub];
-                    if (GRAN == 2)
+                    if (GRAN >= 2)
                         out[at + 1] = (uint8_t)(p_byte[sub] >> 8);
+                    if (GRAN == 4) {
+                        out[at + 2] = (uint8_t)(p_byte[sub] >> 16);
+                        out[at + 3] = (uint8_t)(p_byte[sub] >> 24);
+                    }
                 } else if (fl & 4u) {
                     if (fl & 8u) {
                         out[at] = (uint8_t)(1u | ((p_len[sub] - 4u) << 2) | ((p_off[sub] >> 8) << 5));
@@ -553,7 +559,8 @@ extern "C" int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsig
             static bool once2 = false;
             if (!once2) {
                 if (hipFuncSetAttribute((const void *)snappy_compress_wg_kernel<1u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess ||
-                    hipFuncSetAttribute((const void *)snappy_compress_wg_kernel<2u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+                    hipFuncSetAttribute((const void *)snappy_compress_wg_kernel<2u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess ||
+                    hipFuncSetAttribute((const void *)snappy_compress_wg_kernel<4u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
                     return 4;
                 once2 = true;
             }
@@ -563,6 +570,8 @@ extern "C" int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsig
             hipLaunchKernelGGL(snappy_compress_wg_kernel<1u>, grid, dim3(64 * kWgWaves), lds2, stream, frames, frag_log2, (uint8_t *)slots, slot_stride, frag_sizes);
         if (granularity_mask & 2u)
             hipLaunchKernelGGL(snappy_compress_wg_kernel<2u>, grid, dim3(64 * kWgWaves), lds2, stream, frames, frag_log2, (uint8_t *)slots, slot_stride, frag_sizes);
+        if (granularity_mask & 4u)
+            hipLaunchKernelGGL(snappy_compress_wg_kernel<4u>, grid, dim3(64 * kWgWaves), lds2, stream, frames, frag_log2, (uint8_t *)slots, slot_stride, frag_sizes);
         return hipGetLastError() == hipSuccess ? 0 : 4;
     }
     const unsigned lds = compress_lds_bytes(frag_log2);

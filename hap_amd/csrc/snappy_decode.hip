@@ -178,7 +178,8 @@ __global__ __launch_bounds__(64) void decode_plan_kernel(HapGpuDecodeJob *jobs, 
                             w.dst = (uint64_t)(dst + my_off + (unsigned long long)k * frag_bytes);
                             w.src_len = fs[k];
                             w.dst_len = min(frag_bytes, out_len - k * frag_bytes);
-                            w.kind = job->reserved ? HAPGPU_UNIT_SNAPPY_FRAGMENT16 : HAPGPU_UNIT_SNAPPY_FRAGMENT;
+                            w.kind = job->reserved == 2 ? HAPGPU_UNIT_SNAPPY_FRAGMENT32
+                                   : job->reserved == 1 ? HAPGPU_UNIT_SNAPPY_FRAGMENT16 : HAPGPU_UNIT_SNAPPY_FRAGMENT;
                             w.job = j;
                             u[k] = w;
                             at += fs[k];
@@ -303,7 +304,8 @@ __global__ __launch_bounds__(64) void snappy_decode_kernel(const HapGpuDecodeUni
             wave_copy((uint8_t *)u.dst, (const uint8_t *)u.src, u.src_len, lane);
         return;
     }
-    if ((u.kind == HAPGPU_UNIT_SNAPPY_FRAGMENT || u.kind == HAPGPU_UNIT_SNAPPY_FRAGMENT16) != FRAGMENT)
+    if ((u.kind == HAPGPU_UNIT_SNAPPY_FRAGMENT || u.kind == HAPGPU_UNIT_SNAPPY_FRAGMENT16 ||
+         u.kind == HAPGPU_UNIT_SNAPPY_FRAGMENT32) != FRAGMENT)
         return;
 
     const uint8_t *src = (const uint8_t *)u.src;
@@ -567,7 +569,8 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
         return;
     }
     if (STREAM ? u.kind != HAPGPU_UNIT_SNAPPY_STREAM
-               : u.kind != (GRAN == 2 ? HAPGPU_UNIT_SNAPPY_FRAGMENT16 : HAPGPU_UNIT_SNAPPY_FRAGMENT))
+               : u.kind != (GRAN == 4 ? HAPGPU_UNIT_SNAPPY_FRAGMENT32
+                                      : GRAN == 2 ? HAPGPU_UNIT_SNAPPY_FRAGMENT16 : HAPGPU_UNIT_SNAPPY_FRAGMENT))
         return;
 
     const uint8_t *src = (const uint8_t *)u.src;
@@ -773,7 +776,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
             const bool lit = ((g0 >> 18) & 1u) != 0;
             unsigned desc;                       // bit 31: resolved (LDS byte address), else output position
             if (lit) {
-                desc = 0x80000000u | (GRAN == 2 ? 0x40000000u : 0u) | (RING + ((g1 + GRAN * rel) & (kInBytes - 1)));
+                desc = 0x80000000u | (GRAN >= 2 ? 0x40000000u : 0u) | (RING + ((g1 + GRAN * rel) & (kInBytes - 1)));
             } else {
                 unsigned r = rel;
                 const unsigned offu = g2 / GRAN;
@@ -809,6 +812,15 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
                 const unsigned a1 = (desc & 0x40000000u) ? RING + ((a0 - RING + 1u) & (kInBytes - 1)) : a0 + 1u;
                 value |= (unsigned)smem[a1] << 8;
             }
+            if (GRAN == 4) {
+                // literals: 4 bytes at any byte position of the staging ring (two dwords + byte align);
+                // copies: one aligned dword of the output ring
+                const unsigned xs = a0 - RING;
+                const unsigned w0 = inw[(xs >> 2) & 511u], w1 = inw[((xs >> 2) + 1u) & 511u];
+                const unsigned lit4 = __builtin_amdgcn_alignbyte(w1, w0, xs & 3u);
+                const unsigned cpy4 = *reinterpret_cast<const uint32_t *>(smem + ((desc & 0x40000000u) ? 0u : a0));
+                value = (desc & 0x40000000u) ? lit4 : cpy4;
+            }
             if (STREAM && __ballot(far) != 0) {
                 // far sources were written to memory by THIS wave at least RING - 12 KiB of output ago:
                 // drain the wave's own stores, then read back past the CU's L1 (sc1), which may still
@@ -823,7 +835,9 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
                     value = __hip_atomic_load(dst + a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (active) {
-                if (GRAN == 2)
+                if (GRAN == 4)
+                    *reinterpret_cast<uint32_t *>(ring + ((op + 4u * b) & (RING - 1))) = value;
+                else if (GRAN == 2)
                     *reinterpret_cast<uint16_t *>(ring + ((op + 2u * b) & (RING - 1))) = (uint16_t)value;
                 else
                     ring[(op + b) & (RING - 1)] = (uint8_t)value;
@@ -896,6 +910,7 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
         (void)hipFuncSetAttribute((const void *)snappy_decode_kernel<65536u, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes);
         (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, false, 1u>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes + kOwnerBytes + 64);
         (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, false, 2u>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes + kOwnerBytes + 64);
+        (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, false, 4u>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes + kOwnerBytes + 64);
         once16 = true;
     }
 #define HAP_LAUNCH_FRAGMENT(RINGBYTES)                                                                                          \
@@ -909,6 +924,9 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
                                    RINGBYTES + extra, stream, units, unit_count, jobs);                                         \
             if (fragment_kinds & 2u)                                                                                            \
                 hipLaunchKernelGGL((snappy_decode_fragment_kernel<RINGBYTES, false, 2u>), dim3(unit_count), dim3(64),           \
+                                   RINGBYTES + extra, stream, units, unit_count, jobs);                                         \
+            if (fragment_kinds & 4u)                                                                                            \
+                hipLaunchKernelGGL((snappy_decode_fragment_kernel<RINGBYTES, false, 4u>), dim3(unit_count), dim3(64),           \
                                    RINGBYTES + extra, stream, units, unit_count, jobs);                                         \
         }                                                                                                                       \
     } while (0)

@@ -25,7 +25,8 @@
  * carries a private section (type 0x46) listing the compressed size of every
  * independently compressed Snappy fragment; decoders that do not know it skip
  * it (reference hap.c:701-703, HapVideoDRAFT.md:34), hap_amd's decoder uses it
- * to decode one chunk with many wavefronts.
+ * to decode one chunk with many wavefronts.  The table also records the
+ * granularity (1, 2 or 4 bytes) that every element of the streams honours.
  */
 #ifndef HAP_AMD_HAP_GPU_H
 #define HAP_AMD_HAP_GPU_H
