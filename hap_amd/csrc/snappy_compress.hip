@@ -432,7 +432,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
                     if (l >= best_len && l >= 4u) { best_len = l; best_off = (unsigned)(d + 1) * pitch; }
                 }
                 // greedy selection: the scalar unit hops from chosen copy to chosen copy
-#ifdef HAP_MIN_COPY2
+#ifdef HAP_MIN_COPY2      /* experiment: 3-byte copies only from this length up (-1.5 % decode time, +0.3 % bytes) */
                 const unsigned long long cand_mask = __ballot(in_range && best_len >= 4u &&
                                                               (best_len >= HAP_MIN_COPY2 || best_off < 2048u));
 #else
