@@ -412,6 +412,39 @@ def test_edge_sizes_and_empty_tables(hap):
     assert hap.HapGetFrameTextureChunkCount(frame, 0) == ORA.chunk_count(frame, 0)
 
 
+def test_concurrent_callers(hap):
+    """hap.h promises thread safety across frames (no global state in the reference); here calls on the
+    default context are serialised by a mutex and separate contexts run side by side."""
+    import threading
+    texs = [D.stream_bytes(16 * 8 * 700, kind, seed=i) for i, kind in enumerate(["runs", "mixed", "zero", "runs"])]
+    frames = [_encode_with(ORA, t, L.FMT_DXT5, L.COMP_SNAPPY, 8) for t in texs]
+    errors = []
+
+    def worker(i, own_context):
+        try:
+            c = hap.Context(0) if own_context else None
+            for _ in range(20):
+                if c is None:
+                    r, out, fmt = hap.HapDecode(frames[i], 0, outputBufferBytes=len(texs[i]))
+                    assert (r, out, fmt) == (0, texs[i], L.FMT_DXT5)
+                    r, f2 = hap.HapEncode([texs[i]], [L.FMT_DXT5], [1], [8])
+                    assert r == 0 and ORA.decode(f2, 0, len(texs[i]))[1] == texs[i]
+                else:
+                    dec = np.zeros(len(texs[i]), dtype=np.uint8)
+                    r, used, fm, res = c.decode_frames([frames[i]], [len(frames[i])], 0, [dec])
+                    assert r == 0 and dec.tobytes() == texs[i]
+            if c is not None:
+                c.close()
+        except Exception as exc:          # surfaced in the main thread
+            errors.append((i, own_context, repr(exc)))
+    threads = [threading.Thread(target=worker, args=(i, own)) for i in range(4) for own in (False, True)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_decode_partial_callback(hap):
     """A client that asks for only some chunks gets only those decoded (others left untouched)."""
     from hap_amd._lib import CALLBACK
