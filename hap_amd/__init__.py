@@ -3,10 +3,24 @@
 The product is the C-ABI shared library hap_amd/libhap_amd.so (headers in
 include/): HIP kernels for gfx950 behind the reference's hap.h API.  This
 Python package is a thin ctypes mirror of that API for tests and bench.py.
+
+The shared library is loaded on first use of an API name (so that
+`hap_amd.build` and `hap_amd.synth` can be imported before it exists); there is
+no Python or CPU implementation behind it -- a missing library raises ImportError.
 """
-from .api import (  # noqa: F401
-    HapCompressorNone, HapCompressorSnappy, HapResult, HapTextureFormat,
-    HapDecode, HapEncode, HapGetFrameTextureChunkCount, HapGetFrameTextureCount,
-    HapGetFrameTextureFormat, HapMaxEncodedLength, Context, ENCODE_FRAGMENT_INDEX,
-    DECODE_IGNORE_FRAGMENT_INDEX, KERNEL_CLASSES,
+_API_NAMES = (
+    "HapCompressorNone", "HapCompressorSnappy", "HapResult", "HapTextureFormat",
+    "HapDecode", "HapEncode", "HapGetFrameTextureChunkCount", "HapGetFrameTextureCount",
+    "HapGetFrameTextureFormat", "HapMaxEncodedLength", "Context", "ENCODE_FRAGMENT_INDEX",
+    "DECODE_IGNORE_FRAGMENT_INDEX", "KERNEL_CLASSES",
 )
+
+
+def __getattr__(name):
+    if name in _API_NAMES or name in ("api", "_lib"):
+        import importlib
+        module = importlib.import_module("." + ("_lib" if name == "_lib" else "api"), __name__)
+        if name in ("api", "_lib"):
+            return module
+        return getattr(module, name)
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))
