@@ -825,7 +825,8 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
             results[f] = HapResult_No_Error;
             hapb_decode(ctx, 1, &inputs[f], &input_bytes[f], index, &outputs[f], &output_bytes[f],
                         output_used ? &output_used[f] : NULL, output_formats ? &output_formats[f] : NULL,
-                        &results[f], flags | HAPGPU_DECODE_IGNORE_FRAGMENT_INDEX, NULL, NULL);
+                        &results[f], flags | HAPGPU_DECODE_IGNORE_FRAGMENT_INDEX,
+                        frame_count == 1 ? callback : NULL, callback_info);
         }
     }
 

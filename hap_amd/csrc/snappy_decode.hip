@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64) void decode_plan_kernel(HapGpuDecodeJob *jobs, 
     const unsigned frag_bytes = 1u << job->frag_log2;
     const unsigned per_chunk = (frag_sizes && n) ? job->frag_entries / n : 0u;
     unsigned long long run = 0;
-    bool bad_varint = false, bad_codec = false;
+    bool bad_varint = false, bad_codec = false, index_bad = false;
     for (unsigned base = 0; base < n; base += 64) {
         const unsigned i = base + lane;
         unsigned out_len = 0, hdr = 0, codec = 0;
@@ -188,6 +188,10 @@ __global__ __launch_bounds__(64) void decode_plan_kernel(HapGpuDecodeJob *jobs, 
                     }
                 }
                 if (!indexed) {
+                    // a table is present but does not describe this chunk: the host redoes the whole
+                    // texture without it (the launch may not even include the whole-stream kernel)
+                    if (per_chunk)
+                        index_bad = true;
                     HapGpuDecodeUnit w;
                     w.src = (uint64_t)(payload + c.src_off);
                     w.dst = (uint64_t)(dst + my_off);
@@ -201,6 +205,7 @@ __global__ __launch_bounds__(64) void decode_plan_kernel(HapGpuDecodeJob *jobs, 
         }
     }
     bad_codec = __ballot(bad_codec) != 0;
+    index_bad = __ballot(index_bad) != 0;
     if (lane == 0) {
         unsigned status = 0;
         if (bad_varint)
@@ -209,6 +214,8 @@ __global__ __launch_bounds__(64) void decode_plan_kernel(HapGpuDecodeJob *jobs, 
             status = kResTooSmall;
         else if (bad_codec)
             status = kResBadFrame;             // reference hap.c:637-640 via 867-875
+        else if (index_bad)
+            status = HAPGPU_STATUS_INDEX_MISMATCH;
         job->bytes_used = run;
         job->status = status;
     }

@@ -632,6 +632,20 @@ def test_corrupt_fragment_table_falls_back(ctx, hap):
     frame[pos + 4:pos + 8] = (e1 - 1).to_bytes(4, "little")   # but splits in the wrong place
     assert ORA.decode(bytes(frame), 0, len(tex)) == (0, tex, L.FMT_DXT5)
     assert hap.HapDecode(bytes(frame), 0, outputBufferBytes=len(tex)) == (0, tex, L.FMT_DXT5)
+    # entries that no longer add up to the chunk size (found by tools/fuzz_decode.py: the planner must
+    # hand the whole texture back to the generic path, not leave the chunk undecoded)
+    for delta in (1, 0x10000, -3):
+        bad = bytearray(out[: used[0]].tobytes())
+        bad[pos:pos + 4] = ((e0 + delta) & 0xFFFFFFFF).to_bytes(4, "little")
+        canary = np.full(len(tex), 0x5A, dtype=np.uint8)
+        r, u2, f2 = hap.HapDecode(bytes(bad), 0, outputBuffer=canary)
+        assert (r, u2, f2) == (0, len(tex), L.FMT_DXT5) and canary.tobytes() == tex
+    # a chunk size that disagrees with the table (and truncates the stream) is what the reference reports
+    sz = bytes(frame).find((e0 + 2).to_bytes(4, "little"), 0, 60)
+    if sz > 0:
+        bad = bytearray(out[: used[0]].tobytes())
+        bad[sz] = (bad[sz] - 7) & 0xFF
+        assert hap.HapDecode(bytes(bad), 0, outputBufferBytes=len(tex))[0] == ORA.decode(bytes(bad), 0, len(tex))[0]
 
 
 @pytest.mark.parametrize("log2", [10, 11, 12, 14, 15, 16])
