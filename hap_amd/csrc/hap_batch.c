@@ -107,6 +107,13 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
         if (t->compressor == HapCompressorSnappy) {
             t->chunk_count = hapf_limit_chunk_count(t->bytes, t->format, chunk_counts[i]);
             t->chunk_bytes = (unsigned)(t->bytes / t->chunk_count);
+        }
+        if (t->compressor == HapCompressorSnappy && t->chunk_bytes == 0) {
+            /* less than one block per chunk (not a real texture): the reference compresses
+               zero-length chunks, finds no gain and stores the section as-is (hap.c:478-495) */
+            t->compressor = HapCompressorNone;
+        }
+        if (t->compressor == HapCompressorSnappy) {
             any_snappy = 1;
         } else {
             t->chunk_count = 1;

@@ -402,6 +402,15 @@ def test_edge_sizes_and_empty_tables(hap):
                     assert ORA.decode(frame, 0, n + 8) == ORA.decode(fo, 0, n + 8)
                     assert hap.HapDecode(fo, 0, outputBufferBytes=n + 8) == ORA.decode(fo, 0, n + 8)
                     assert hap.HapDecode(frame, 0, outputBufferBytes=n + 8) == ORA.decode(frame, 0, n + 8)
+    # fewer bytes than chunks (chunk size 0): the reference finds no gain and stores the section as-is
+    for n in (1, 2, 3, 4, 5, 7, 12, 15):
+        tex = D.stream_bytes(n, "random", seed=100 + n)
+        for fmt in L.ALL_FORMATS:
+            for chunks in (2, 9, 29):
+                r, frame = hap.HapEncode([tex], [fmt], [L.COMP_SNAPPY], [chunks])
+                ro, fo = ORA.encode([tex], [fmt], [L.COMP_SNAPPY], [chunks])
+                assert r == ro == 0 and frame == fo
+                assert hap.HapDecode(frame, 0, outputBufferBytes=n + 8)[:2] == (0, tex)
     assert hap.HapEncode([b""], [L.FMT_DXT1], [1], [1], outputBufferBytes=256)[0] == ORA.encode([b""], [L.FMT_DXT1], [1], [1], out_bytes=256)[0]
     # complex frame with zero-length tables: 8-byte headers carry a zero length
     tables = bytes([0, 0, 0, 2, 0, 0, 0, 0]) + bytes([0, 0, 0, 3, 0, 0, 0, 0])
