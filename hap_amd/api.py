@@ -72,7 +72,7 @@ def HapEncode(inputBuffers, textureFormats, compressors, chunkCounts, outputBuff
     r = lib.HapEncode(n, ptrs, lens, (C.c_uint * n)(*textureFormats), (C.c_uint * n)(*compressors),
                       (C.c_uint * n)(*chunkCounts), oaddr, outputBufferBytes, C.byref(used))
     if own:
-        return r, (bytes(outputBuffer[: used.value]) if r == 0 else None)
+        return r, (C.string_at(outputBuffer, used.value) if r == 0 else None)
     return r, used.value
 
 
@@ -97,7 +97,7 @@ def HapDecode(inputBuffer, index=0, callback=None, outputBuffer=None, outputBuff
     cb = callback if callback is not None else _serial_callback()
     r = lib.HapDecode(iaddr, ilen, index, cb, None, oaddr, outputBufferBytes, C.byref(used), C.byref(fmt))
     if own:
-        return r, (bytes(outputBuffer[: used.value]) if r == 0 else None), fmt.value
+        return r, (C.string_at(outputBuffer, used.value) if r == 0 else None), fmt.value
     return r, used.value, fmt.value
 
 
@@ -117,6 +117,30 @@ def HapGetFrameTextureChunkCount(frame, index):
     a, n, _k = _addr_len(frame)
     out = C.c_int(-1)
     return lib.HapGetFrameTextureChunkCount(a, n, index, C.byref(out)), out.value
+
+
+def HapGpuGetFrameTextureChunkLayout(frame, index):
+    """Returns (result, [decoded offset of every chunk ..., decoded size of the texture])."""
+    a, n, _k = _addr_len(frame)
+    r, count = HapGetFrameTextureChunkCount(frame, index)
+    cap = max(1, count) + 1 if r == 0 else 2
+    offs = (C.c_ulong * cap)()
+    got = C.c_uint(0)
+    r = lib.HapGpuGetFrameTextureChunkLayout(a, n, index, cap, offs, C.byref(got))
+    return r, (list(offs[: got.value + 1]) if r == 0 else None)
+
+
+def HapGpuJoinChunkGroups(groupFrames, outputBufferBytes=None):
+    """Joins frames holding consecutive chunk groups (host buffers). Returns (result, frame bytes | None)."""
+    infos = [_addr_len(f) for f in groupFrames]
+    n = len(infos)
+    if outputBufferBytes is None:
+        outputBufferBytes = sum(i[1] for i in infos) + 64
+    out = (C.c_ubyte * max(1, outputBufferBytes))()
+    used = C.c_ulong(0)
+    r = lib.HapGpuJoinChunkGroups(n, (C.c_void_p * max(1, n))(*[i[0] for i in infos]),
+                                  (C.c_ulong * max(1, n))(*[i[1] for i in infos]), out, outputBufferBytes, C.byref(used))
+    return r, (C.string_at(out, used.value) if r == 0 else None)
 
 
 class Context:
@@ -157,7 +181,7 @@ class Context:
         used = C.c_ulong(0)
         r = lib.HapGpuCompressRGBA(self.handle, a, width, height, row_bytes, texture_format, oa, on, C.byref(used))
         if own:
-            return r, (bytes(output[: used.value]) if r == 0 else None)
+            return r, (C.string_at(output, used.value) if r == 0 else None)
         return r, used.value
 
     def decompress_rgba(self, texture, texture_format, width, height, rgba=None, alpha=None, row_bytes=None):
@@ -177,6 +201,17 @@ class Context:
         if own:
             return r, (C.string_at(oa, row_bytes * height) if r == 0 else None)
         return r, None
+
+    def decode_chunk_group(self, frame, index, first_chunk, chunk_count, output):
+        """Decodes chunks [first_chunk, first_chunk + chunk_count) into their place in `output`
+        (laid out as the whole texture). Returns (result, texture bytes, format)."""
+        ia, il, _k = _addr_len(frame)
+        oa, ol, _k2 = _addr_len(output)
+        used = C.c_ulong(0)
+        fmt = C.c_uint(0)
+        r = lib.HapGpuDecodeChunkGroup(self.handle, ia, il, index, first_chunk, chunk_count, oa, ol,
+                                       C.byref(used), C.byref(fmt))
+        return r, used.value, fmt.value
 
     @staticmethod
     def _ptr_array(bufs):

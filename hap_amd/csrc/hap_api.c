@@ -368,6 +368,97 @@ unsigned int HapGpuDecodeFrames(HapGpuContext *context, unsigned int frameCount,
     return r;
 }
 
+/* callback that "runs" one contiguous group of chunks (hap.h:113-130 lets a client run any subset) */
+typedef struct chunk_group {
+    unsigned first, count;
+} chunk_group;
+
+static void run_chunk_group(HapDecodeWorkFunction function, void *p, unsigned int count, void *info)
+{
+    const chunk_group *g = (const chunk_group *)info;
+    unsigned i;
+    for (i = g->first; i < count && i - g->first < g->count; i++)
+        function(p, i);
+}
+
+unsigned int HapGpuDecodeChunkGroup(HapGpuContext *context, const void *inputBuffer, unsigned long inputBufferBytes,
+                                    unsigned int index, unsigned int firstChunk, unsigned int chunkCount,
+                                    void *outputBuffer, unsigned long outputBufferBytes,
+                                    unsigned long *outputBufferBytesUsed, unsigned int *outputBufferTextureFormat)
+{
+    chunk_group g;
+    unsigned result = HapResult_Internal_Error, rc, fmt = 0;
+    unsigned long used = 0;
+    if (!context || !inputBuffer || index > 1 || !outputBuffer)
+        return HapResult_Bad_Arguments;
+    g.first = firstChunk;
+    g.count = chunkCount;
+    hapgpu_rt_lock(context->rt);
+    rc = hapb_decode(context, 1, &inputBuffer, &inputBufferBytes, index, &outputBuffer, &outputBufferBytes, &used,
+                     &fmt, &result, 0, run_chunk_group, &g);
+    hapgpu_rt_unlock(context->rt);
+    if (outputBufferTextureFormat)
+        *outputBufferTextureFormat = fmt;
+    if (rc == HapResult_No_Error && outputBufferBytesUsed)
+        *outputBufferBytesUsed = used;
+    return rc;
+}
+
+/* decoded position of every chunk: the running sum the reference builds in hap.c:794-838 */
+unsigned int HapGpuGetFrameTextureChunkLayout(const void *inputBuffer, unsigned long inputBufferBytes,
+                                              unsigned int index, unsigned int capacity,
+                                              unsigned long *decodedOffsets, unsigned int *chunkCount)
+{
+    hapf_reader r;
+    inspect_fetch f;
+    hapf_texture_plan plan;
+    unsigned result, n, i;
+    unsigned long cursor = 0;
+    if (!inputBuffer || index > 1 || !decodedOffsets || !chunkCount)
+        return HapResult_Bad_Arguments;
+    *chunkCount = 0;
+    open_reader(&r, &f, inputBuffer, inputBufferBytes);
+    hapf_plan_texture(&r, (uint32_t)inputBufferBytes, index, 1, &plan);
+    result = plan.result;
+    n = plan.mode == HAPGPU_JOB_COMPLEX ? (unsigned)plan.chunk_count : 1u;
+    if (result == HapResult_No_Error) {
+        *chunkCount = n;
+        if (capacity < n + 1u)
+            result = HapResult_Buffer_Too_Small;
+    }
+    for (i = 0; result == HapResult_No_Error && i < n; i++) {
+        uint64_t at = plan.mode == HAPGPU_JOB_COMPLEX ? plan.payload_offset + plan.chunks[i].src_off : plan.section_offset;
+        uint32_t len = plan.mode == HAPGPU_JOB_COMPLEX ? plan.chunks[i].src_len : plan.section_length;
+        unsigned codec = plan.mode == HAPGPU_JOB_COMPLEX ? (plan.chunks[i].codec & 0xFFu)
+                         : plan.mode == HAPGPU_JOB_RAW ? HAP_NIBBLE_NONE : HAP_NIBBLE_SNAPPY;
+        decodedOffsets[i] = cursor;
+        if (codec == HAP_NIBBLE_NONE) {
+            cursor += len;
+        } else if (codec == HAP_NIBBLE_SNAPPY) {
+            /* the stream's leading varint (snappy_uncompressed_length, hap.c:813) */
+            const unsigned take = len < 5u ? len : 5u;
+            const uint8_t *v = take ? hapf_need(&r, at, take) : NULL;
+            uint64_t value = 0;
+            unsigned k = 0, done = 0;
+            while (v && k < take && !done) {
+                value |= (uint64_t)(v[k] & 0x7Fu) << (7u * k);
+                done = !(v[k] & 0x80u);
+                k++;
+            }
+            if (!done || value > 0xFFFFFFFFull)
+                result = v || !take ? HapResult_Bad_Frame : HapResult_Internal_Error;
+            cursor += (unsigned long)value;
+        } else {
+            result = HapResult_Bad_Frame;             /* hap.c:637-640 */
+        }
+    }
+    if (result == HapResult_No_Error)
+        decodedOffsets[n] = cursor;
+    hapf_plan_free(&plan);
+    hapf_reader_free(&r);
+    return result;
+}
+
 unsigned int HapGpuSetProfiling(HapGpuContext *context, unsigned int enable)
 {
     if (!context)

@@ -768,21 +768,26 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                         if (!req[c])
                             all = 0;
                     if (!all) {
-                        /* chunks the client never asked for stay undecoded: blank their units */
-                        HapGpuDecodeUnit *blank = (HapGpuDecodeUnit *)calloc(1, sizeof(HapGpuDecodeUnit));
+                        /* chunks the client never asked for stay undecoded: blank their units
+                           (HAPGPU_UNIT_SKIP is 0; unit slots of consecutive chunks are contiguous) */
                         /* a staged (host) output must come back unchanged where nothing is decoded */
                         if (out_off[0])
                             rc |= hapgpu_rt_h2d(rt, out_stage + (out_off[0] - 1), outputs[0],
                                                 output_bytes[0] < hjobs[0].bytes_used ? output_bytes[0] : (size_t)hjobs[0].bytes_used);
-                        for (c = 0; blank && c < plans[0].chunk_count; c++) {
-                            unsigned k;
-                            if (req[c])
+                        for (c = 0; c < plans[0].chunk_count;) {
+                            unsigned first, units = 0;
+                            if (req[c]) {
+                                c++;
                                 continue;
-                            for (k = 0; k < plans[0].chunks[c].unit_count; k++)
-                                rc |= hapgpu_rt_h2d(rt, dunits + plans[0].chunks[c].unit_first + k, blank, sizeof(*blank));
+                            }
+                            first = plans[0].chunks[c].unit_first;
+                            while (c < plans[0].chunk_count && !req[c] &&
+                                   plans[0].chunks[c].unit_first == first + units) {
+                                units += plans[0].chunks[c].unit_count;
+                                c++;
+                            }
+                            rc |= hapgpu_rt_zero(rt, dunits + first, sizeof(HapGpuDecodeUnit) * (size_t)units);
                         }
-                        rc |= hapgpu_rt_sync(rt);
-                        free(blank);
                     }
                     free(req);
                 }

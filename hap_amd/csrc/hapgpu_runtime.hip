@@ -213,6 +213,14 @@ extern "C" int hapgpu_rt_d2d(hapgpu_rt *rt, void *dst, const void *src, size_t b
     return 0;
 }
 
+extern "C" int hapgpu_rt_zero(hapgpu_rt *rt, void *dst, size_t bytes)
+{
+    if (!bytes) return 0;
+    hipError_t e = hipMemsetAsync(dst, 0, bytes, rt->stream);
+    if (e != hipSuccess) { complain("hipMemsetAsync", e); return 4; }
+    return 0;
+}
+
 extern "C" int hapgpu_rt_sync(hapgpu_rt *rt)
 {
     hipError_t e = hipStreamSynchronize(rt->stream);

@@ -136,6 +136,45 @@ unsigned int HapGpuDecodeFrames(HapGpuContext *context, unsigned int frameCount,
                                 unsigned int *results,
                                 unsigned int flags);
 
+/* --- one frame split over several GPUs by chunk groups ------------------------ */
+
+/* HapDecode restricted to the chunks [firstChunk, firstChunk + chunkCount) of texture `index`:
+ * outputBuffer is laid out as the WHOLE texture and only the group's byte range is written; the
+ * rest is left untouched.  This is what a HapDecodeCallback that runs a subset of the work items
+ * obtains from HapDecode (reference hap.h:113-130, hap.c:852-862); like there, frames that are
+ * not chunked or have a single chunk are decoded completely.  *outputBufferBytesUsed is the
+ * size of the whole texture.  inputBuffer / outputBuffer: host or device. */
+unsigned int HapGpuDecodeChunkGroup(HapGpuContext *context,
+                                    const void *inputBuffer, unsigned long inputBufferBytes,
+                                    unsigned int index,
+                                    unsigned int firstChunk, unsigned int chunkCount,
+                                    void *outputBuffer, unsigned long outputBufferBytes,
+                                    unsigned long *outputBufferBytesUsed,
+                                    unsigned int *outputBufferTextureFormat);
+
+/* Where each chunk of texture `index` lands in the decoded texture: the running sum of decoded
+ * chunk sizes that the reference decoder builds (hap.c:794-838).  Writes chunkCount + 1 offsets
+ * (the last one is the decoded size of the texture); Buffer_Too_Small if capacity is less.
+ * Needs no GPU (inputBuffer: host or device). */
+unsigned int HapGpuGetFrameTextureChunkLayout(const void *inputBuffer, unsigned long inputBufferBytes,
+                                              unsigned int index, unsigned int capacity,
+                                              unsigned long *decodedOffsets, unsigned int *chunkCount);
+
+/* Joins frames that each hold one contiguous group of the chunks of the same texture(s) -- e.g.
+ * bands of block rows encoded on different GPUs -- into one ordinary Hap frame whose chunk list
+ * is the concatenation of the groups' lists, in the order given (frame layout: reference
+ * hap.c:430-442, 562-598).  All groups must have the same texture count and formats.  A group
+ * stored without chunks contributes a single chunk; if no chunk of a texture is compressed the
+ * texture is written as a plain uncompressed section, as the reference does when Snappy gains
+ * nothing (hap.c:478-495).  Fragment-size sections (type 0x46) are carried over when every
+ * group has a compatible one.  Host pointers only; needs no GPU.
+ * outputBufferBytes: the sum of the groups' sizes plus 64 always suffices. */
+unsigned int HapGpuJoinChunkGroups(unsigned int groupCount,
+                                   const void *const *groupFrames,
+                                   const unsigned long *groupFramesBytes,
+                                   void *outputBuffer, unsigned long outputBufferBytes,
+                                   unsigned long *outputBufferBytesUsed);
+
 /* --- measurement hooks (used by bench.py; see DESIGN.md "Measurement") --- */
 
 /* Kernel classes whose launches are bracketed with HIP events on the

@@ -85,6 +85,100 @@ def test_inspectors_on_golden_and_malformed_frames(hap):
                 assert hap.HapGetFrameTextureChunkCount(f, idx) == ora.chunk_count(f, idx)
 
 
+def _checkers():
+    ref = L.ref_api()
+    return [L.oracle_api()] + ([ref] if ref is not None else [])
+
+
+@pytest.mark.parametrize("fmt", [L.FMT_DXT1, L.FMT_DXT5, L.FMT_YCOCG, L.FMT_RGTC1, L.FMT_BC7])
+@pytest.mark.parametrize("groups", [1, 2, 5])
+def test_join_chunk_groups_is_a_frame_the_reference_decodes(hap, fmt, groups):
+    """HapGpuJoinChunkGroups (host-only): band frames made by the checker's encoder join into one
+    frame that the checker / reference decodes to the whole texture, with the chunk lists concatenated."""
+    ora = L.oracle_api()
+    block = 8 if fmt in (L.FMT_DXT1, L.FMT_RGTC1) else 16
+    band = block * 64 * 6
+    tex = D.stream_bytes(band * groups, "mixed", seed=groups)
+    frames = [ora.encode([tex[g * band:(g + 1) * band]], [fmt], [L.COMP_SNAPPY], [3])[1] for g in range(groups)]
+    r, joined = hap.HapGpuJoinChunkGroups(frames)
+    assert r == 0
+    for api in _checkers():
+        assert api.decode(joined, 0, len(tex) + 8) == (0, tex, fmt)
+        assert api.chunk_count(joined, 0) == (0, 3 * groups)
+        assert api.texture_count(joined) == (0, 1)
+    r, layout = hap.HapGpuGetFrameTextureChunkLayout(joined, 0)
+    assert (r, layout) == (0, [i * (band // 3) for i in range(3 * groups + 1)])
+    # a single group joins to a frame with the same content
+    if groups == 1:
+        assert ora.decode(joined, 0, len(tex)) == ora.decode(frames[0], 0, len(tex))
+
+
+def test_join_chunk_groups_mixed_storage_dual_texture_and_errors(hap):
+    ora = L.oracle_api()
+    # bands stored as-is (random), as one chunk, and chunked -> chunk list 1 + 1 + 4, unequal chunk sizes
+    a = D.stream_bytes(16 * 64 * 4, "random", seed=1)
+    b = D.stream_bytes(16 * 64 * 2, "runs", seed=2)
+    c = D.stream_bytes(16 * 64 * 8, "mixed", seed=3)
+    frames = [ora.encode([a], [L.FMT_DXT5], [1], [4])[1], ora.encode([b], [L.FMT_DXT5], [1], [1])[1],
+              ora.encode([c], [L.FMT_DXT5], [1], [4])[1]]
+    assert frames[0][3] >> 4 == 0xA and frames[1][3] >> 4 == 0xC
+    r, joined = hap.HapGpuJoinChunkGroups(frames)
+    assert r == 0
+    for api in _checkers():
+        assert api.decode(joined, 0, len(a + b + c)) == (0, a + b + c, L.FMT_DXT5)
+        assert api.chunk_count(joined, 0) == (0, 6)
+    assert hap.HapGpuGetFrameTextureChunkLayout(joined, 0) == \
+        (0, [0, len(a), len(a) + len(b)] + [len(a) + len(b) + (i + 1) * len(c) // 4 for i in range(4)])
+    # nothing compressed anywhere -> a plain uncompressed section (hap.c:478-495), byte-identical to the reference's frame
+    r, joined = hap.HapGpuJoinChunkGroups([frames[0], ora.encode([a[::-1]], [L.FMT_DXT5], [1], [2])[1]])
+    assert r == 0 and joined == ora.encode([a + a[::-1]], [L.FMT_DXT5], [0], [1])[1]
+    # two textures per frame (Hap Q Alpha): both joined, outer 0x0D section rebuilt
+    y = D.stream_bytes(16 * 256, "runs", seed=4)
+    al = D.stream_bytes(8 * 256, "mixed", seed=5)
+    duo = [ora.encode([y[g * 2048:(g + 1) * 2048], al[g * 1024:(g + 1) * 1024]], [L.FMT_YCOCG, L.FMT_RGTC1], [1, 1], [2, 2])[1]
+           for g in range(2)]
+    r, joined = hap.HapGpuJoinChunkGroups(duo)
+    assert r == 0 and joined[3] == 0x0D
+    for api in _checkers():
+        assert api.texture_count(joined) == (0, 2)
+        assert api.decode(joined, 0, len(y)) == (0, y, L.FMT_YCOCG)
+        assert api.decode(joined, 1, len(al)) == (0, al, L.FMT_RGTC1)
+    # errors: disagreeing formats / texture counts, malformed group, small output
+    other = ora.encode([b], [L.FMT_DXT1], [1], [1])[1]
+    assert hap.HapGpuJoinChunkGroups([frames[1], other])[0] == hap.HapResult.Bad_Frame
+    assert hap.HapGpuJoinChunkGroups([frames[1], duo[0]])[0] == hap.HapResult.Bad_Frame
+    assert hap.HapGpuJoinChunkGroups([frames[1], frames[2][:40]])[0] != 0
+    assert hap.HapGpuJoinChunkGroups([frames[1], frames[2]], outputBufferBytes=100)[0] == hap.HapResult.Buffer_Too_Small
+    assert hap.HapGpuJoinChunkGroups([])[0] == hap.HapResult.Bad_Arguments
+
+
+def test_chunk_layout_on_golden_and_malformed_frames(hap):
+    """The layout inspector equals the running sum of decoded chunk sizes (hap.c:794-838): checked against
+    what the checker decodes, chunk by chunk, on the golden frames; malformed input never crashes."""
+    ora = L.oracle_api()
+    rng = np.random.default_rng(2)
+    for v in D.golden_vectors("frame"):
+        if not v["frame"]:
+            continue
+        frame = bytes.fromhex(v["frame"])
+        for idx in (0, 1):
+            rc, n = ora.chunk_count(frame, idx)
+            r, layout = hap.HapGpuGetFrameTextureChunkLayout(frame, idx)
+            dec = ora.decode(frame, idx, 1 << 20)
+            if dec[0] == 0:
+                assert r == 0 and layout[0] == 0 and layout[-1] == len(dec[1])
+                assert len(layout) == max(1, n) + 1 and layout == sorted(layout)
+            elif rc != 0:
+                assert r != 0
+        for _ in range(60):
+            f = bytearray(frame)
+            f[int(rng.integers(0, len(f)))] = int(rng.integers(0, 256))
+            hap.HapGpuGetFrameTextureChunkLayout(bytes(f), 0)
+            hap.HapGpuJoinChunkGroups([bytes(f), frame])
+        for k in range(0, min(len(frame), 64)):
+            hap.HapGpuGetFrameTextureChunkLayout(frame[:k] or b"\0", 0)
+
+
 def test_no_gpu_means_loud_failure_not_fallback(hap):
     import torch
     if torch.cuda.is_available():

@@ -743,3 +743,80 @@ def test_full_size_configs_round_trip(ctx, hap, cfg):
         ro, oo, fo = ORA.decode(frame, 0, sizes[0])
         assert (ro, fo) == (0, fmts[0]) and oo == tex[0].cpu().numpy().tobytes()
         assert hap.HapGetFrameTextureChunkCount(frame, 0) == (0, chunks[0])
+
+
+# ------------------------------------------ one frame over several GPUs: chunk groups --
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("maker", ["checker", "ours+index"])
+def test_chunk_group_decode_fills_exactly_its_slice(ctx, hap, world, maker):
+    from hap_amd import shard
+    tex = D.stream_bytes(16 * 64 * 48, "mixed", seed=21)
+    if maker == "checker":
+        frame = ORA.encode([tex], [L.FMT_YCOCG], [1], [8])[1]
+    else:
+        out = np.zeros(hap.HapMaxEncodedLength([len(tex)], [L.FMT_YCOCG], [8]) + 4096, dtype=np.uint8)
+        r, used, _res = ctx.encode_frames([[tex]], [L.FMT_YCOCG], [1], [8], [out], flags=hap.ENCODE_FRAGMENT_INDEX)
+        assert r == 0
+        frame = out[: used[0]].tobytes()
+    r, layout = hap.HapGpuGetFrameTextureChunkLayout(frame, 0)
+    assert r == 0 and layout == [i * len(tex) // 8 for i in range(9)]
+    dframe = torch.frombuffer(bytearray(frame), dtype=torch.uint8).cuda()
+    whole = torch.full((len(tex),), 0xEE, dtype=torch.uint8, device="cuda")
+    for rank in range(world):
+        group = shard.chunk_group_for_rank(8, rank, world)
+        alone = torch.full((len(tex),), 0xEE, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        for dst in (alone, whole):
+            r, used, fmt = ctx.decode_chunk_group(dframe, 0, group.start, len(group), dst)
+            assert (r, used, fmt) == (0, len(tex), L.FMT_YCOCG)
+        a, b = layout[group.start], layout[group.start + len(group)]
+        got = alone.cpu().numpy().tobytes()
+        assert got[a:b] == tex[a:b] and got[:a] == b"\xEE" * a and got[b:] == b"\xEE" * (len(tex) - b)
+        # host frame + host output behave the same
+        host = np.full(len(tex), 0xEE, dtype=np.uint8)
+        assert ctx.decode_chunk_group(frame, 0, group.start, len(group), host)[0] == 0
+        assert host.tobytes() == got
+    assert whole.cpu().numpy().tobytes() == tex
+    # a group outside the chunk list decodes nothing; single-chunk frames decode completely (hap.c:852-858)
+    none = np.full(len(tex), 0xEE, dtype=np.uint8)
+    assert ctx.decode_chunk_group(frame, 0, 8, 4, none)[0] == 0 and none.tobytes() == b"\xEE" * len(tex)
+    one = ORA.encode([tex], [L.FMT_YCOCG], [1], [1])[1]
+    full = np.zeros(len(tex), dtype=np.uint8)
+    assert ctx.decode_chunk_group(one, 0, 5, 1, full)[0] == 0 and full.tobytes() == tex
+
+
+@pytest.mark.parametrize("formats", [[L.FMT_DXT1], [L.FMT_YCOCG, L.FMT_RGTC1]])
+@pytest.mark.parametrize("world", [2, 4])
+def test_row_bands_encoded_separately_join_into_the_whole_frame(ctx, hap, formats, world):
+    """C5-style encode: every 'GPU' block-compresses and packs its band of rows, HapGpuJoinChunkGroups makes one
+    frame; the checker decodes it to exactly the textures of the undivided picture."""
+    from hap_amd import shard
+    w, h, chunks = 256, 64 * world, 4 * world
+    img = D.rgba(w, h, frame=6)
+    band_rows = h // world
+    frames = []
+    for rank in range(world):
+        lo, hi, band_chunks = shard.band_for_rank(h // 4, chunks, rank, world)
+        assert (lo * 4, hi * 4, band_chunks) == (rank * band_rows, (rank + 1) * band_rows, 4)
+        band = np.ascontiguousarray(img[lo * 4: hi * 4])
+        cap = hap.HapMaxEncodedLength([w * band_rows // 16 * (8 if f in (L.FMT_DXT1, L.FMT_RGTC1) else 16) for f in formats],
+                                      formats, [band_chunks] * len(formats)) + 8192
+        out = np.zeros(cap, dtype=np.uint8)
+        r, used, res = ctx.encode_frames_rgba([band], w, band_rows, w * 4, formats, [1] * len(formats),
+                                              [band_chunks] * len(formats), [out], flags=hap.ENCODE_FRAGMENT_INDEX)
+        assert r == 0 and res == [0]
+        frames.append(out[: used[0]].tobytes())
+    r, joined = hap.HapGpuJoinChunkGroups(frames)
+    assert r == 0
+    assert hap.HapGetFrameTextureCount(joined) == (0, len(formats))
+    for idx, fmt in enumerate(formats):
+        want = D.oracle_bc_encode(img, fmt)
+        for name, api in CHECKERS:
+            assert api.decode(joined, idx, len(want)) == (0, want, fmt), name
+            assert api.chunk_count(joined, idx) == (0, chunks)
+        # our decoder: fragment tables were carried over (same answer with and without them)
+        for flags in (0, hap.DECODE_IGNORE_FRAGMENT_INDEX):
+            dec = np.zeros(len(want), dtype=np.uint8)
+            r, used, fmts, res = ctx.decode_frames([joined], [len(joined)], idx, [dec], flags=flags)
+            assert (r, used, fmts, res) == (0, [len(want)], [fmt], [0]) and dec.tobytes() == want
+    assert b"\x46" in joined[:4096]      # the private fragment-size section survived the join
