@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhap_amd.so")
+# HAP_AMD_LIBRARY: development override to load an experimental build of the same library
+LIB_PATH = os.environ.get("HAP_AMD_LIBRARY") or os.path.join(HERE, "libhap_amd.so")
 
 WORK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint)
 CALLBACK = C.CFUNCTYPE(None, WORK_FN, C.c_void_p, C.c_uint, C.c_void_p)

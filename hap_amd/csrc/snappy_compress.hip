@@ -21,6 +21,7 @@
 //      stores its own tag/data bytes.
 // HBM traffic: fragment read once, compressed bytes written once.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdlib.h>
 #include "hapgpu_abi.h"
@@ -44,6 +45,17 @@ __device__ __forceinline__ unsigned lds_load32(const uint32_t *words, unsigned b
 {
     const unsigned w = byte_off >> 2;
     return __builtin_amdgcn_alignbyte(words[w + 1], words[w], byte_off & 3u);
+}
+
+// wave-wide predicate mask; keep the argument a single compare so that it lowers to one v_cmp
+__device__ __forceinline__ unsigned long long ballot64(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global
+// store (s_waitcnt vmcnt(0)); the round barriers of the workgroup kernel exchange LDS data only, and waiting
+// for the element bytes to reach L2 twice per round was the largest single cost of the kernel.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // number of set bits of `mask` below this lane
@@ -254,9 +266,28 @@ __global__ __launch_bounds__(64) void snappy_compress_kernel(const HapGpuFrameEn
 //   * match extension compares 16 bytes per step (<= 4 steps), the covered-by-a-copy mask comes
 //     from a DPP max-scan instead of 64-bit scalar arithmetic in the selection loop.
 
-constexpr unsigned kWgWaves = 4;
+#ifdef HAP_PHASE_PROFILE
+// dev-only: shader-clock cycles per phase, summed over all waves (read with hapgpu_debug_phase_cycles)
+__device__ unsigned long long hap_phase_cycles[8];
+#define HAP_PHASE_MARK(slot)                                                        \
+    do {                                                                            \
+        const unsigned long long now_ = __builtin_readcyclecounter();               \
+        phase_acc_[slot] += now_ - phase_t_;                                        \
+        phase_t_ = now_;                                                            \
+    } while (0)
+#else
+#define HAP_PHASE_MARK(slot) do { } while (0)
+#endif
+
+#ifndef HAP_WG_WAVES
+#define HAP_WG_WAVES 4
+#endif
+constexpr unsigned kWgWaves = HAP_WG_WAVES;
 constexpr int kFixed = 4;      // candidates at 1..4 block pitches (8-byte or 16-byte blocks)
-constexpr unsigned kWgHashBits = 12;
+#ifndef HAP_WG_HASH_BITS
+#define HAP_WG_HASH_BITS 11
+#endif
+constexpr unsigned kWgHashBits = HAP_WG_HASH_BITS;
 constexpr unsigned kWgHashEntries = 1u << kWgHashBits;
 
 __device__ __forceinline__ int cdpp_row_shr(int v, int n)
@@ -315,6 +346,10 @@ __device__ __forceinline__ unsigned match_extend16(const uint32_t *dw, unsigned 
     return min(l, limit);
 }
 
+// two bytes at any byte address (global memory takes unaligned accesses)
+struct __attribute__((packed)) packed_u16 { uint16_t v; };
+__device__ __forceinline__ void store16(uint8_t *p, unsigned v) { reinterpret_cast<packed_u16 *>(p)->v = (uint16_t)v; }
+
 template <unsigned GRAN>     // bytes per lane: 1, 2 or 4 (positions, offsets and lengths all multiples of GRAN)
 __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const HapGpuFrameEnc *__restrict__ frames,
                                                                 unsigned frag_log2, uint8_t *__restrict__ slots,
@@ -327,7 +362,12 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
     uint32_t *table = reinterpret_cast<uint32_t *>(smem + frag_bytes + 32);      // kWgHashEntries
     uint32_t *roundsz = table + kWgHashEntries;                                  // kWgWaves
 
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));     // uniform: scalar register
+#ifdef HAP_PHASE_PROFILE
+    unsigned long long phase_t_ = __builtin_readcyclecounter();
+    unsigned long long phase_acc_[5] = {0, 0, 0, 0, 0};
+#endif
     const HapGpuFrameEnc &frame = frames[blockIdx.z];
     if (blockIdx.y >= frame.tex_count)
         return;
@@ -365,127 +405,191 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
         table[i] = 0u;
     __syncthreads();
 
+    HAP_PHASE_MARK(0);          // prologue: fragment -> LDS, table clear
+    using val_t = typename std::conditional<GRAN == 4, unsigned long long, unsigned>::type;
     constexpr unsigned TB = 64u * GRAN;                 // bytes per tile
+    constexpr unsigned GL = GRAN == 4 ? 2u : GRAN == 2 ? 1u : 0u;     // log2(GRAN)
     const uint16_t *data16 = reinterpret_cast<const uint16_t *>(smem);
     const uint32_t *data32 = reinterpret_cast<const uint32_t *>(smem);
     const unsigned tiles = (n + TB - 1u) / TB, supers = (tiles + 1u) / 2u;
     unsigned round_base = 0;
     // DXT1 / RGTC1 textures are arrays of 8-byte blocks, everything else 16-byte blocks (hap.c:287-294)
-    const unsigned pitch = (tex.format_nibble == 0xBu || tex.format_nibble == 0x1u) ? 8u : 16u;
+    const unsigned pitch_log2 = (tex.format_nibble == 0xBu || tex.format_nibble == 0x1u) ? 3u : 4u;
+    const bool upper = lane >= 32u;
+    const unsigned lane31 = lane & 31u;
+    (void)data16;
+    (void)data32;
 
+    // Everything that depends only on the tile (k, tile_base, range masks, element kind masks) lives on the
+    // scalar unit: `wave` is uniform, predicates reach the lanes through inverse ballots.
+#ifdef HAP_ABL_NO_LOOP
+    for (unsigned base = 0; base < 0u * supers; base += kWgWaves) {
+#else
     for (unsigned base = 0; base < supers; base += kWgWaves) {
+#endif
         const unsigned k = base + wave;
+#ifdef HAP_ABL_SKELETON
+        const bool have = false && k < supers;
+#else
         const bool have = k < supers;
+#endif
         // per-tile emission plan, kept in registers across the round barrier
-        unsigned p_len[2] = {0, 0}, p_off[2] = {0, 0}, p_hash[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
-        unsigned p_at[2] = {0, 0}, p_run[2] = {0, 0}, p_flags[2] = {0, 0}, p_byte[2] = {0, 0};
-        (void)data16;
-        (void)data32;
+        // (a lane's element is at most GRAN + 2 bytes: they travel as one value, low byte first)
+        unsigned p_hash[2] = {0, 0}, p_at[2] = {0, 0};
+        val_t p_val[2] = {0, 0};
+        unsigned long long m_e0[2] = {0, 0}, m_e1[2] = {0, 0}, m_e2[2] = {0, 0}, m_insert[2] = {0, 0};
         unsigned total = 0;
         if (have) {
             const unsigned super_end = min(n, (2u * k + 2u) * TB);
             // equality ballots for the fixed distances (block pitches of DXT data)
-            unsigned long long eq[kFixed][2];
+            unsigned long long eq[kFixed][2], in_mask[2];
 #pragma unroll
             for (int sub = 0; sub < 2; sub++) {
-                const unsigned p = (2u * k + sub) * TB + GRAN * lane;
-                const bool in = p < n;
+                const unsigned tile_base = (2u * k + sub) * TB;
+                const unsigned p = tile_base + GRAN * lane;
+                const unsigned cnt = tile_base < n ? min(64u, (n - tile_base) >> GL) : 0u;      // lanes with p < n
+                in_mask[sub] = cnt >= 64u ? ~0ull : ((1ull << cnt) - 1ull);
                 const unsigned here = GRAN == 4 ? data32[p >> 2] : GRAN == 2 ? (unsigned)data16[p >> 1] : (unsigned)data[p];
 #pragma unroll
                 for (int d = 0; d < kFixed; d++) {
-                    const unsigned dist = (unsigned)(d + 1) * pitch;
+                    const unsigned dist = (unsigned)(d + 1) << pitch_log2;
                     const unsigned back = p >= dist ? p - dist : 0u;
                     const unsigned there = GRAN == 4 ? data32[back >> 2] : GRAN == 2 ? (unsigned)data16[back >> 1] : (unsigned)data[back];
-                    eq[d][sub] = __ballot(in && p >= dist && here == there);
+                    unsigned long long reachable = ~0ull;                                        // lanes with p >= dist
+                    if (tile_base < dist) {
+                        const unsigned first = (dist - tile_base) >> GL;
+                        reachable = first >= 64u ? 0ull : ~0ull << first;
+                    }
+                    eq[d][sub] = ballot64(here == there) & in_mask[sub] & reachable;
                 }
             }
             unsigned skip = 0;
 #pragma unroll
             for (int sub = 0; sub < 2; sub++) {
-                const unsigned p = (2u * k + sub) * TB + GRAN * lane;
-                const bool in_range = p < n;
-                const unsigned room = in_range ? (min(64u, super_end - p) & ~(GRAN - 1u)) : 0u;
-                unsigned best_len = 0, best_off = 0, my_hash = 0xFFFFFFFFu;
+                const unsigned tile_base = (2u * k + sub) * TB;
+                const unsigned p = tile_base + GRAN * lane;
+                // bytes a copy starting here may span: up to the supertile end, 0 beyond the data
+                const unsigned room = min(64u, super_end > p ? super_end - p : 0u);
+                // best candidate as one key: (length << 3) | priority, nearer fixed distances win ties,
+                // the hash candidate (priority 0) only when strictly longer
+                unsigned best_key = 0, hash_off = 0;
                 const unsigned cur = lds_load32(dataw, p);
-                if (p + 4u <= n) {
 #ifdef HAP_MUL24_HASH
-                    const unsigned h = (__umul24(cur & 0xFFFFFFu, 0x9E3779u) + __umul24(cur >> 8, 0x85EBCBu)) >> (32u - kWgHashBits);
+                const unsigned h = (__umul24(cur & 0xFFFFFFu, 0x9E3779u) + __umul24(cur >> 8, 0x85EBCBu)) >> (32u - kWgHashBits);
 #else
-                    const unsigned h = (cur * 0x1e35a7bdu) >> (32u - kWgHashBits);
+                const unsigned h = (cur * 0x1e35a7bdu) >> (32u - kWgHashBits);
 #endif
+                const unsigned cnt4 = n >= tile_base + 4u ? min(64u, ((n - 4u - tile_base) >> GL) + 1u) : 0u;   // lanes with p + 4 <= n
+                const unsigned long long mask4 = cnt4 >= 64u ? ~0ull : ((1ull << cnt4) - 1ull);
+#ifndef HAP_NO_HASH
+                if (__builtin_amdgcn_inverse_ballot_w64(mask4)) {
                     const unsigned cand = table[h];
-                    my_hash = h;
-#ifdef HAP_NO_HASH
-                    if (false) {
+#ifdef HAP_SKIP_FIXED_HASH
+                    const unsigned gap = p - cand;      // a candidate at a block pitch is what the fixed distances find anyway
+                    const bool redundant = gap <= ((unsigned)kFixed << pitch_log2) && (gap & ((1u << pitch_log2) - 1u)) == 0u;
+                    if (cand < p && room >= 4u && !redundant && lds_load32(dataw, cand) == cur) {
 #else
                     if (cand < p && room >= 4u && lds_load32(dataw, cand) == cur) {
 #endif
-                        best_len = (4u + match_extend16(dataw, cand + 4u, p + 4u, room - 4u)) & ~(GRAN - 1u);
-                        best_off = p - cand;
+                        const unsigned l = (4u + match_extend16(dataw, cand + 4u, p + 4u, room - 4u)) & ~(GRAN - 1u);
+                        best_key = l << 3;
+                        hash_off = p - cand;
                     }
                 }
+#endif
+#ifdef HAP_ABL_NO_FIXED
+                for (int d = 0; d >= 0; d--) {
+#else
 #pragma unroll
-                for (int d = kFixed - 1; d >= 0; d--) {          // nearer distances win ties
-                    const unsigned long long nx = sub == 0 ? eq[d][1] : 0ull;
-                    const unsigned l = min(GRAN >= 2 ? GRAN * run_from32(eq[d][sub], nx, lane)
-                                                     : run_from(eq[d][sub], nx, lane), room);
-                    if (l >= best_len && l >= 4u) { best_len = l; best_off = (unsigned)(d + 1) * pitch; }
+                for (int d = kFixed - 1; d >= 0; d--) {
+#endif
+                    const unsigned long long c = eq[d][sub], nx = sub == 0 ? eq[d][1] : 0ull;
+                    unsigned l;
+                    if (GRAN >= 2) {
+                        // run of set bits starting at this lane, capped at 32 lanes (>= 64 bytes): one funnel shift
+                        const unsigned lo = upper ? (unsigned)(c >> 32) : (unsigned)c;
+                        const unsigned hi = upper ? (unsigned)nx : (unsigned)(c >> 32);
+                        const unsigned inv = ~__builtin_amdgcn_alignbit(hi, lo, lane31);
+                        l = min(inv ? (unsigned)__builtin_ctz(inv) : 32u, room >> GL);
+                    } else {
+                        l = min(run_from(c, nx, lane), room);
+                    }
+                    best_key = max(best_key, (l << (3u + GL)) | (unsigned)(kFixed - d));
                 }
+                const unsigned best_len = best_key >> 3, prio = best_key & 7u;
+                const unsigned best_off = prio ? ((unsigned)(kFixed + 1) - prio) << pitch_log2 : hash_off;
                 // greedy selection: the scalar unit hops from chosen copy to chosen copy
 #ifdef HAP_MIN_COPY2      /* experiment: 3-byte copies only from this length up (-1.5 % decode time, +0.3 % bytes) */
-                const unsigned long long cand_mask = __ballot(in_range && best_len >= 4u &&
-                                                              (best_len >= HAP_MIN_COPY2 || best_off < 2048u));
+                const unsigned long long cand_mask = ballot64(best_len >= 4u) &
+                                                     (ballot64(best_len >= HAP_MIN_COPY2) | ballot64(best_off < 2048u));
 #else
-                const unsigned long long cand_mask = __ballot(in_range && best_len >= 4u);
+                const unsigned long long cand_mask = ballot64(best_len >= 4u);
 #endif
                 unsigned long long sel = 0;
-                unsigned cursor = min(skip, 64u);
-                unsigned carry = skip > 64u ? skip - 64u : 0u;
+                unsigned cursor = skip;                                  // first position not yet covered
+                const unsigned next_free = lane + (best_len >> GL);     // ... after taking this lane's copy
+#ifdef HAP_ABL_NO_SELECT
+                sel = cand_mask & 0x1111111111111111ull;
+                while (false) {
+#else
                 while (cursor < 64u) {
+#endif
                     const unsigned long long rest = cand_mask >> cursor;
                     if (!rest)
                         break;
                     const unsigned s = cursor + (unsigned)__builtin_ctzll(rest);
                     sel |= 1ull << s;
-                    cursor = s + (unsigned)__builtin_amdgcn_readlane((int)best_len, (int)s) / GRAN;
-                    if (cursor > 64u)
-                        carry = cursor - 64u;
+                    cursor = (unsigned)__builtin_amdgcn_readlane((int)next_free, (int)s);
                 }
-                const bool is_copy = (sel >> lane) & 1ull;
-                // covered[l] <=> some chosen copy (or the carry-in) spans position l
-                const int reach = cwave_scan_max(is_copy ? (int)(lane + best_len / GRAN) : 0);
-                const bool covered = (unsigned)reach > lane || lane < skip;
+                const unsigned carry = cursor > 64u ? cursor - 64u : 0u;
+                // covered <=> some chosen copy (or the carry-in) spans the position
+                const int reach = cwave_scan_max(__builtin_amdgcn_inverse_ballot_w64(sel) ? (int)next_free : 0);
+                const unsigned long long skipmask = skip >= 64u ? ~0ull : ((1ull << skip) - 1ull);
+                const unsigned long long lit = ~(ballot64((unsigned)reach > lane) | skipmask) & in_mask[sub];
                 skip = carry;
-                const unsigned long long lit = __ballot(in_range && !covered);
                 const unsigned long long starts = lit & ~(lit << 1);
-                const bool is_lit = (lit >> lane) & 1ull;
-                const bool is_start = (starts >> lane) & 1ull;
                 unsigned run = 0;                          // literal run length in BYTES
-                if (is_start) {
+                if (__builtin_amdgcn_inverse_ballot_w64(starts)) {
                     const unsigned long long a = ~(lit >> lane);
                     run = GRAN * (a ? (unsigned)__builtin_ctzll(a) : 64u);
                 }
-                const bool copy1 = best_len < 12u && best_off < 2048u;
-                unsigned emit = 0;
-                if (is_lit)
-                    emit = GRAN + (is_start ? (run > 60u ? 2u : 1u) : 0u);
-                else if (is_copy)
-                    emit = copy1 ? 2u : 3u;
-                const unsigned long long e0 = __ballot(emit & 1u), e1 = __ballot(emit & 2u);
-                const unsigned long long e2 = GRAN >= 2 ? __ballot(emit & 4u) : 0ull;
+                const unsigned long long longrun = ballot64(run > 60u);                 // subset of starts
+                const unsigned long long copy1 = ballot64(best_len < 12u) & ballot64(best_off < 2048u);
+                const unsigned long long copy2 = sel & ~copy1;
+                // bytes a lane emits: literal GRAN (+1 at a run start, +2 when the run is long), copy 2 or 3;
+                // as bit planes of that count, composed on the scalar unit
+                unsigned long long e0, e1, e2;
+                if (GRAN == 1) {
+                    e0 = (lit & ~starts) | longrun | copy2; e1 = starts | sel; e2 = 0ull;
+                } else if (GRAN == 2) {
+                    e0 = (starts & ~longrun) | copy2; e1 = (lit & ~longrun) | sel; e2 = longrun;
+                } else {
+                    e0 = (starts & ~longrun) | copy2; e1 = longrun | sel; e2 = lit;
+                }
                 p_at[sub] = total + bits_below(e0) + 2u * bits_below(e1) + (GRAN >= 2 ? 4u * bits_below(e2) : 0u);
                 total += (unsigned)__popcll(e0) + 2u * (unsigned)__popcll(e1) + 4u * (unsigned)__popcll(e2);
-                p_len[sub] = best_len;
-                p_off[sub] = best_off;
-                p_hash[sub] = my_hash;
-                p_run[sub] = run;
-                p_byte[sub] = GRAN == 4 ? cur : (cur & (GRAN == 2 ? 0xFFFFu : 0xFFu));
-                p_flags[sub] = (is_lit ? 1u : 0u) | (is_start ? 2u : 0u) | (is_copy ? 4u : 0u) | (copy1 ? 8u : 0u);
+                // the element bytes of this lane (whatever lies beyond its byte count is never stored)
+                val_t v = (val_t)cur;                                                   // literal inside a run
+                if (__builtin_amdgcn_inverse_ballot_w64(starts))
+                    v = run > 60u ? (val_t)(0xF0u | ((run - 1u) << 8)) | ((val_t)cur << 16)
+                                  : (val_t)((run - 1u) << 2) | ((val_t)cur << 8);
+                if (__builtin_amdgcn_inverse_ballot_w64(sel))
+                    v = (val_t)(__builtin_amdgcn_inverse_ballot_w64(copy1)
+                                    ? (1u | ((best_len - 4u) << 2) | ((best_off >> 8) << 5) | ((best_off & 0xFFu) << 8))
+                                    : (2u | ((best_len - 1u) << 2) | (best_off << 8)));
+                p_val[sub] = v;
+                p_hash[sub] = h;
+                m_e0[sub] = e0;
+                m_e1[sub] = e1;
+                m_e2[sub] = e2;
+                m_insert[sub] = (lit | sel) & mask4;       // only element starts are remembered (see the single-wave kernel)
             }
         }
         if (lane == 0)
             roundsz[wave] = total;
-        __syncthreads();
+        HAP_PHASE_MARK(1);      // analysis
+        lds_barrier();
+        HAP_PHASE_MARK(2);      // wait for the slowest wave of the round
         unsigned my_base = round_base, all = 0;
 #pragma unroll
         for (unsigned w = 0; w < kWgWaves; w++) {
@@ -499,46 +603,67 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
 #pragma unroll
             for (int sub = 0; sub < 2; sub++) {
                 const unsigned p = (2u * k + sub) * TB + GRAN * lane;
-                unsigned at = my_base + p_at[sub];
-                const unsigned fl = p_flags[sub];
-                if (fl & 1u) {
-                    if (fl & 2u) {
-                        if (p_run[sub] > 60u) {
-                            out[at++] = (uint8_t)(60u << 2);
-                            out[at++] = (uint8_t)(p_run[sub] - 1u);
-                        } else {
-                            out[at++] = (uint8_t)((p_run[sub] - 1u) << 2);
-                        }
-                    }
-                    out[at] = (uint8_t)p_byte[sub];
-                    if (GRAN >= 2)
-                        out[at + 1] = (uint8_t)(p_byte[sub] >> 8);
-                    if (GRAN == 4) {
-                        out[at + 2] = (uint8_t)(p_byte[sub] >> 16);
-                        out[at + 3] = (uint8_t)(p_byte[sub] >> 24);
-                    }
-                } else if (fl & 4u) {
-                    if (fl & 8u) {
-                        out[at] = (uint8_t)(1u | ((p_len[sub] - 4u) << 2) | ((p_off[sub] >> 8) << 5));
-                        out[at + 1] = (uint8_t)p_off[sub];
-                    } else {
-                        out[at] = (uint8_t)(2u | ((p_len[sub] - 1u) << 2));
-                        out[at + 1] = (uint8_t)p_off[sub];
-                        out[at + 2] = (uint8_t)(p_off[sub] >> 8);
-                    }
+                // byte count of the lane's element = e0 + 2 e1 + 4 e2: whole 16-bit pieces first, then the odd byte
+                uint8_t *dst = out + my_base + p_at[sub];
+                const val_t v = p_val[sub];
+#ifdef HAP_ABL_NO_STORE
+                if (v == (val_t)0x12345679u && p_at[sub] == 0x7FFFFFFu)
+#endif
+                {
+                const unsigned long long e0 = m_e0[sub], e1 = m_e1[sub], e2 = m_e2[sub];
+                if (__builtin_amdgcn_inverse_ballot_w64(e1 | e2))
+                    store16(dst, (unsigned)v);
+                if (GRAN >= 2 && __builtin_amdgcn_inverse_ballot_w64(e2))
+                    store16(dst + 2, (unsigned)(v >> 16));
+                if (GRAN == 4 && __builtin_amdgcn_inverse_ballot_w64(e2 & e1))
+                    store16(dst + 4, (unsigned)((unsigned long long)v >> 32));
+                if (GRAN == 1 && __builtin_amdgcn_inverse_ballot_w64(e0 & ~e1))
+                    dst[0] = (uint8_t)v;
+                if (__builtin_amdgcn_inverse_ballot_w64(e0 & e1 & ~e2))
+                    dst[2] = (uint8_t)(v >> 16);
+                if (GRAN == 4 && __builtin_amdgcn_inverse_ballot_w64(e0 & e2 & ~e1))
+                    dst[4] = (uint8_t)((unsigned long long)v >> 32);
                 }
-                // only element starts are remembered (see the single-wave kernel)
-                if ((fl & 5u) && p_hash[sub] != 0xFFFFFFFFu)
+#ifndef HAP_ABL_NO_INSERT
+                if (__builtin_amdgcn_inverse_ballot_w64(m_insert[sub]))
                     atomicMax(&table[p_hash[sub]], p);
+#endif
             }
         }
-        __syncthreads();
+        HAP_PHASE_MARK(3);      // emission + table inserts
+        lds_barrier();
+        HAP_PHASE_MARK(4);      // second barrier
     }
     if (tid == 0)
         frag_sizes[f] = round_base;
+#ifdef HAP_PHASE_PROFILE
+    if (lane == 0) {
+        for (int i = 0; i < 5; i++)
+            atomicAdd(&hap_phase_cycles[i], phase_acc_[i]);
+        atomicAdd(&hap_phase_cycles[5], 1ull);
+    }
+#endif
 }
 
 } // namespace
+
+extern "C" int hapgpu_debug_phase_cycles(unsigned long long *out, int reset)
+{
+#ifdef HAP_PHASE_PROFILE
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess)
+        return 1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(hap_phase_cycles), sizeof(zero)) != hipSuccess)
+        return 1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(hap_phase_cycles), zero, sizeof(zero)) != hipSuccess)
+        return 1;
+    return 0;
+#else
+    (void)out;
+    (void)reset;
+    return 2;   /* not compiled in (build with -DHAP_PHASE_PROFILE) */
+#endif
+}
 
 // LDS bytes needed per workgroup for a fragment size
 static unsigned compress_lds_bytes(unsigned frag_log2) { return (1u << frag_log2) + 16u + kHashEntries * 2u; }
