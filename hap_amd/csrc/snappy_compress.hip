@@ -283,6 +283,10 @@ __device__ unsigned long long hap_phase_cycles[8];
 #define HAP_WG_WAVES 4
 #endif
 constexpr unsigned kWgWaves = HAP_WG_WAVES;
+#ifndef HAP_WG_SUBS
+#define HAP_WG_SUBS 2
+#endif
+constexpr unsigned kSubs = HAP_WG_SUBS;   // tiles per wave per round (one "supertile"; copies never cross it)
 constexpr int kFixed = 4;      // candidates at 1..4 block pitches (8-byte or 16-byte blocks)
 #ifndef HAP_WG_HASH_BITS
 #define HAP_WG_HASH_BITS 11
@@ -320,6 +324,62 @@ __device__ __forceinline__ unsigned run_from32(unsigned long long cur, unsigned 
     const unsigned w = __builtin_amdgcn_alignbit(hi, lo, lane & 31u);
     const unsigned inv = ~w;
     return inv ? (unsigned)__builtin_ctz(inv) : 32u;
+}
+
+// does any lane of any tile still extend its hash match?  (scalar answer)
+__device__ __forceinline__ bool any_more(const bool (&more)[kSubs])
+{
+    unsigned long long m = 0;
+#pragma unroll
+    for (unsigned i = 0; i < kSubs; i++)
+        m |= __builtin_amdgcn_ballot_w64(more[i]);
+    return m != 0;
+}
+
+// Greedy left-to-right choice of non-overlapping copies on the scalar unit: from `cursor`, take the first
+// candidate lane s at or after it (bit s of `cand`), mark it in `sel`, continue at next_free[s] (the lane after
+// that copy's last position), until lane 64 is passed or no candidate is left.  Hand-written because the
+// compiler's structured form of this loop costs twice the scalar instructions, and this loop is where the
+// kernel's scalar time goes:
+//     while (cursor < 64) { rest = cand >> cursor; if (!rest) break;
+//                           s = cursor + ctz(rest); sel |= 1 << s; cursor = readlane(next_free, s); }
+__device__ __forceinline__ void greedy_select(unsigned long long cand, unsigned next_free, unsigned &cursor,
+                                              unsigned long long &sel)
+{
+    unsigned long long rest;
+    unsigned step;
+    asm volatile("s_cmp_lt_u32 %[cur], 64\n\t"
+                 "s_cbranch_scc0 2f\n"
+                 "1:\n\t"
+                 "s_lshr_b64 %[rest], %[cand], %[cur]\n\t"      // SCC = (rest != 0)
+                 "s_cbranch_scc0 2f\n\t"
+                 "s_ff1_i32_b64 %[step], %[rest]\n\t"
+                 "s_add_u32 %[cur], %[cur], %[step]\n\t"
+                 "s_bitset1_b64 %[sel], %[cur]\n\t"
+                 "v_readlane_b32 %[cur], %[next], %[cur]\n\t"
+                 "s_cmp_lt_u32 %[cur], 64\n\t"
+                 "s_cbranch_scc1 1b\n"
+                 "2:"
+                 : [cur] "+s"(cursor), [sel] "+s"(sel), [rest] "=&s"(rest), [step] "=&s"(step)
+                 : [cand] "s"(cand), [next] "v"(next_free)
+                 : "scc");
+}
+
+// number of equal leading bytes (0..16) of the 16 bytes at LDS byte offsets a and b
+__device__ __forceinline__ unsigned match16(const uint32_t *dw, unsigned a, unsigned b)
+{
+    const unsigned wa = a >> 2, sa = a & 3u, wb = b >> 2, sb = b & 3u;
+    const unsigned a0 = dw[wa], a1 = dw[wa + 1], a2 = dw[wa + 2], a3 = dw[wa + 3], a4 = dw[wa + 4];
+    const unsigned b0 = dw[wb], b1 = dw[wb + 1], b2 = dw[wb + 2], b3 = dw[wb + 3], b4 = dw[wb + 4];
+    const unsigned d0 = __builtin_amdgcn_alignbyte(a1, a0, sa) ^ __builtin_amdgcn_alignbyte(b1, b0, sb);
+    const unsigned d1 = __builtin_amdgcn_alignbyte(a2, a1, sa) ^ __builtin_amdgcn_alignbyte(b2, b1, sb);
+    const unsigned d2 = __builtin_amdgcn_alignbyte(a3, a2, sa) ^ __builtin_amdgcn_alignbyte(b3, b2, sb);
+    const unsigned d3 = __builtin_amdgcn_alignbyte(a4, a3, sa) ^ __builtin_amdgcn_alignbyte(b4, b3, sb);
+    return d0 ? ((unsigned)__builtin_ctz(d0) >> 3)
+         : d1 ? 4u + ((unsigned)__builtin_ctz(d1) >> 3)
+         : d2 ? 8u + ((unsigned)__builtin_ctz(d2) >> 3)
+         : d3 ? 12u + ((unsigned)__builtin_ctz(d3) >> 3)
+              : 16u;
 }
 
 // equal bytes of data[a..] and data[b..], 16 per step, at most `limit`
@@ -368,14 +428,14 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
     unsigned long long phase_t_ = __builtin_readcyclecounter();
     unsigned long long phase_acc_[5] = {0, 0, 0, 0, 0};
 #endif
-    const HapGpuFrameEnc &frame = frames[blockIdx.z];
-    if (blockIdx.y >= frame.tex_count)
-        return;
-    const HapGpuTexEnc &tex = frame.tex[blockIdx.y];
-    if (tex.compressor != 1u || (1u << tex.reserved) != GRAN)
-        return;
+    // one trip to memory for the whole descriptor (field-by-field reads with the early exits between them
+    // cost a scalar-load round trip each)
+    const HapGpuTexEnc tex = frames[blockIdx.z].tex[blockIdx.y < 2u ? blockIdx.y : 0u];
+    const unsigned tex_count = frames[blockIdx.z].tex_count;
     const unsigned x = blockIdx.x;
-    if (x >= tex.chunk_count * tex.frags_per_chunk)
+    // (one combined test, no short-circuit: every field is requested before the first wait)
+    if ((blockIdx.y >= tex_count) | (tex.compressor != 1u) | ((1u << tex.reserved) != GRAN) |
+        (x >= tex.chunk_count * tex.frags_per_chunk) | (tex.src == 0) | (tex.chunk_bytes == 0))
         return;
     const unsigned chunk = x / tex.frags_per_chunk, j = x - chunk * tex.frags_per_chunk;
     const unsigned begin = j << frag_log2;
@@ -385,17 +445,30 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
     uint8_t *out = slots + (size_t)f * slot_stride;
 
     if (((uintptr_t)src & 15u) == 0) {
-        for (unsigned i = tid * 16u; i < n + 32u; i += 1024u * kWgWaves) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (i + 16u <= n) {
-                v = *reinterpret_cast<const uint4 *>(src + i);
-            } else if (i < n) {
-                unsigned w[4] = {0, 0, 0, 0};
-                for (unsigned k = 0; i + k < n; k++)
-                    w[k >> 2] |= (unsigned)src[i + k] << (8 * (k & 3));
-                v = make_uint4(w[0], w[1], w[2], w[3]);
+        // all loads of a batch are in flight before the first one is waited for
+        constexpr unsigned kBatch = 4;
+        constexpr unsigned kStride = 1024u * kWgWaves;
+        for (unsigned i0 = tid * 16u; i0 < n + 32u; i0 += kBatch * kStride) {
+            uint4 v[kBatch];
+#pragma unroll
+            for (unsigned u = 0; u < kBatch; u++) {
+                const unsigned i = i0 + u * kStride;
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (i + 16u <= n)
+                    v[u] = *reinterpret_cast<const uint4 *>(src + i);
             }
-            *reinterpret_cast<uint4 *>(smem + i) = v;
+#pragma unroll
+            for (unsigned u = 0; u < kBatch; u++) {
+                const unsigned i = i0 + u * kStride;
+                if (i < n && i + 16u > n) {                 // ragged end (never for whole blocks)
+                    unsigned w[4] = {0, 0, 0, 0};
+                    for (unsigned k = 0; i + k < n; k++)
+                        w[k >> 2] |= (unsigned)src[i + k] << (8 * (k & 3));
+                    v[u] = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                if (i < n + 32u)
+                    *reinterpret_cast<uint4 *>(smem + i) = v[u];
+            }
         }
     } else {
         for (unsigned i = tid; i < n + 32u; i += 64u * kWgWaves)
@@ -411,7 +484,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
     constexpr unsigned GL = GRAN == 4 ? 2u : GRAN == 2 ? 1u : 0u;     // log2(GRAN)
     const uint16_t *data16 = reinterpret_cast<const uint16_t *>(smem);
     const uint32_t *data32 = reinterpret_cast<const uint32_t *>(smem);
-    const unsigned tiles = (n + TB - 1u) / TB, supers = (tiles + 1u) / 2u;
+    const unsigned tiles = (n + TB - 1u) / TB, supers = (tiles + kSubs - 1u) / kSubs;
     unsigned round_base = 0;
     // DXT1 / RGTC1 textures are arrays of 8-byte blocks, everything else 16-byte blocks (hap.c:287-294)
     const unsigned pitch_log2 = (tex.format_nibble == 0xBu || tex.format_nibble == 0x1u) ? 3u : 4u;
@@ -435,17 +508,17 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
 #endif
         // per-tile emission plan, kept in registers across the round barrier
         // (a lane's element is at most GRAN + 2 bytes: they travel as one value, low byte first)
-        unsigned p_hash[2] = {0, 0}, p_at[2] = {0, 0};
-        val_t p_val[2] = {0, 0};
-        unsigned long long m_e0[2] = {0, 0}, m_e1[2] = {0, 0}, m_e2[2] = {0, 0}, m_insert[2] = {0, 0};
+        unsigned p_hash[kSubs] = {}, p_at[kSubs] = {};
+        val_t p_val[kSubs] = {};
+        unsigned long long m_e0[kSubs] = {}, m_e1[kSubs] = {}, m_e2[kSubs] = {}, m_insert[kSubs] = {};
         unsigned total = 0;
         if (have) {
-            const unsigned super_end = min(n, (2u * k + 2u) * TB);
+            const unsigned super_end = min(n, (kSubs * k + kSubs) * TB);
             // equality ballots for the fixed distances (block pitches of DXT data)
-            unsigned long long eq[kFixed][2], in_mask[2];
+            unsigned long long eq[kFixed][kSubs], in_mask[kSubs];
 #pragma unroll
-            for (int sub = 0; sub < 2; sub++) {
-                const unsigned tile_base = (2u * k + sub) * TB;
+            for (int sub = 0; sub < (int)kSubs; sub++) {
+                const unsigned tile_base = (kSubs * k + sub) * TB;
                 const unsigned p = tile_base + GRAN * lane;
                 const unsigned cnt = tile_base < n ? min(64u, (n - tile_base) >> GL) : 0u;      // lanes with p < n
                 in_mask[sub] = cnt >= 64u ? ~0ull : ((1ull << cnt) - 1ull);
@@ -463,47 +536,71 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
                     eq[d][sub] = ballot64(here == there) & in_mask[sub] & reachable;
                 }
             }
-            unsigned skip = 0;
+            // ---- candidates, both tiles side by side so that their LDS round trips overlap ----
+            unsigned room2[kSubs], cur2[kSubs], h2[kSubs], hlen[kSubs], hoff[kSubs], cand2[kSubs];
+            unsigned long long mask4[kSubs];
+            bool more[kSubs];
 #pragma unroll
-            for (int sub = 0; sub < 2; sub++) {
-                const unsigned tile_base = (2u * k + sub) * TB;
+            for (int sub = 0; sub < (int)kSubs; sub++) {
+                const unsigned tile_base = (kSubs * k + sub) * TB;
                 const unsigned p = tile_base + GRAN * lane;
                 // bytes a copy starting here may span: up to the supertile end, 0 beyond the data
-                const unsigned room = min(64u, super_end > p ? super_end - p : 0u);
-                // best candidate as one key: (length << 3) | priority, nearer fixed distances win ties,
-                // the hash candidate (priority 0) only when strictly longer
-                unsigned best_key = 0, hash_off = 0;
-                const unsigned cur = lds_load32(dataw, p);
+                room2[sub] = min(64u, super_end > p ? super_end - p : 0u);
+                cur2[sub] = lds_load32(dataw, p);
 #ifdef HAP_MUL24_HASH
-                const unsigned h = (__umul24(cur & 0xFFFFFFu, 0x9E3779u) + __umul24(cur >> 8, 0x85EBCBu)) >> (32u - kWgHashBits);
+                h2[sub] = (__umul24(cur2[sub] & 0xFFFFFFu, 0x9E3779u) + __umul24(cur2[sub] >> 8, 0x85EBCBu)) >> (32u - kWgHashBits);
 #else
-                const unsigned h = (cur * 0x1e35a7bdu) >> (32u - kWgHashBits);
+                h2[sub] = (cur2[sub] * 0x1e35a7bdu) >> (32u - kWgHashBits);
 #endif
                 const unsigned cnt4 = n >= tile_base + 4u ? min(64u, ((n - 4u - tile_base) >> GL) + 1u) : 0u;   // lanes with p + 4 <= n
-                const unsigned long long mask4 = cnt4 >= 64u ? ~0ull : ((1ull << cnt4) - 1ull);
+                mask4[sub] = cnt4 >= 64u ? ~0ull : ((1ull << cnt4) - 1ull);
+            }
+#pragma unroll
+            for (int sub = 0; sub < (int)kSubs; sub++) {
+                const unsigned p = (kSubs * k + sub) * TB + GRAN * lane;
+                hlen[sub] = 0;
+                hoff[sub] = 0;
+                more[sub] = false;
+                cand2[sub] = 0;
 #ifndef HAP_NO_HASH
-                if (__builtin_amdgcn_inverse_ballot_w64(mask4)) {
-                    const unsigned cand = table[h];
-#ifdef HAP_SKIP_FIXED_HASH
-                    const unsigned gap = p - cand;      // a candidate at a block pitch is what the fixed distances find anyway
-                    const bool redundant = gap <= ((unsigned)kFixed << pitch_log2) && (gap & ((1u << pitch_log2) - 1u)) == 0u;
-                    if (cand < p && room >= 4u && !redundant && lds_load32(dataw, cand) == cur) {
-#else
-                    if (cand < p && room >= 4u && lds_load32(dataw, cand) == cur) {
-#endif
-                        const unsigned l = (4u + match_extend16(dataw, cand + 4u, p + 4u, room - 4u)) & ~(GRAN - 1u);
-                        best_key = l << 3;
-                        hash_off = p - cand;
-                    }
+                // hash candidate: the first 16 bytes are compared at once, without branching
+                const unsigned c = table[h2[sub]];
+                const bool valid = __builtin_amdgcn_inverse_ballot_w64(mask4[sub]) && c < p && room2[sub] >= 4u;
+                cand2[sub] = valid ? c : 0u;
+                const unsigned m = match16(dataw, cand2[sub], p);
+                if (valid && m >= 4u) {
+                    hlen[sub] = min(m, room2[sub]);
+                    hoff[sub] = p - c;
+                    more[sub] = m == 16u && room2[sub] > 16u;
                 }
 #endif
+            }
+            // longer hash matches (uncommon): both tiles advance together, 16 bytes per step
+            while (any_more(more)) {
+#pragma unroll
+                for (int sub = 0; sub < (int)kSubs; sub++) {
+                    if (more[sub]) {
+                        const unsigned p = (kSubs * k + sub) * TB + GRAN * lane;
+                        const unsigned m = match16(dataw, cand2[sub] + hlen[sub], p + hlen[sub]);
+                        hlen[sub] = min(hlen[sub] + m, room2[sub]);
+                        more[sub] = m == 16u && hlen[sub] < room2[sub];
+                    }
+                }
+            }
+            unsigned best_len2[kSubs], best_off2[kSubs];
+#pragma unroll
+            for (int sub = 0; sub < (int)kSubs; sub++) {
+                const unsigned room = room2[sub];
+                // best candidate as one key: (length << 3) | priority, nearer fixed distances win ties,
+                // the hash candidate (priority 0) only when strictly longer
+                unsigned best_key = (hlen[sub] & ~(GRAN - 1u)) << 3;
 #ifdef HAP_ABL_NO_FIXED
                 for (int d = 0; d >= 0; d--) {
 #else
 #pragma unroll
                 for (int d = kFixed - 1; d >= 0; d--) {
 #endif
-                    const unsigned long long c = eq[d][sub], nx = sub == 0 ? eq[d][1] : 0ull;
+                    const unsigned long long c = eq[d][sub], nx = sub + 1 < (int)kSubs ? eq[d][sub + 1 < (int)kSubs ? sub + 1 : sub] : 0ull;
                     unsigned l;
                     if (GRAN >= 2) {
                         // run of set bits starting at this lane, capped at 32 lanes (>= 64 bytes): one funnel shift
@@ -516,8 +613,15 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
                     }
                     best_key = max(best_key, (l << (3u + GL)) | (unsigned)(kFixed - d));
                 }
-                const unsigned best_len = best_key >> 3, prio = best_key & 7u;
-                const unsigned best_off = prio ? ((unsigned)(kFixed + 1) - prio) << pitch_log2 : hash_off;
+                const unsigned prio = best_key & 7u;
+                best_len2[sub] = best_key >> 3;
+                best_off2[sub] = prio ? ((unsigned)(kFixed + 1) - prio) << pitch_log2 : hoff[sub];
+            }
+            unsigned skip = 0;
+#pragma unroll
+            for (int sub = 0; sub < (int)kSubs; sub++) {
+                const unsigned best_len = best_len2[sub], best_off = best_off2[sub];
+                const unsigned cur = cur2[sub], h = h2[sub];
                 // greedy selection: the scalar unit hops from chosen copy to chosen copy
 #ifdef HAP_MIN_COPY2      /* experiment: 3-byte copies only from this length up (-1.5 % decode time, +0.3 % bytes) */
                 const unsigned long long cand_mask = ballot64(best_len >= 4u) &
@@ -526,21 +630,9 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
                 const unsigned long long cand_mask = ballot64(best_len >= 4u);
 #endif
                 unsigned long long sel = 0;
-                unsigned cursor = skip;                                  // first position not yet covered
+                unsigned cursor = (unsigned)__builtin_amdgcn_readfirstlane((int)skip);   // first position not yet covered
                 const unsigned next_free = lane + (best_len >> GL);     // ... after taking this lane's copy
-#ifdef HAP_ABL_NO_SELECT
-                sel = cand_mask & 0x1111111111111111ull;
-                while (false) {
-#else
-                while (cursor < 64u) {
-#endif
-                    const unsigned long long rest = cand_mask >> cursor;
-                    if (!rest)
-                        break;
-                    const unsigned s = cursor + (unsigned)__builtin_ctzll(rest);
-                    sel |= 1ull << s;
-                    cursor = (unsigned)__builtin_amdgcn_readlane((int)next_free, (int)s);
-                }
+                greedy_select(cand_mask, next_free, cursor, sel);
                 const unsigned carry = cursor > 64u ? cursor - 64u : 0u;
                 // covered <=> some chosen copy (or the carry-in) spans the position
                 const int reach = cwave_scan_max(__builtin_amdgcn_inverse_ballot_w64(sel) ? (int)next_free : 0);
@@ -582,7 +674,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
                 m_e0[sub] = e0;
                 m_e1[sub] = e1;
                 m_e2[sub] = e2;
-                m_insert[sub] = (lit | sel) & mask4;       // only element starts are remembered (see the single-wave kernel)
+                m_insert[sub] = (lit | sel) & mask4[sub];       // only element starts are remembered (see the single-wave kernel)
             }
         }
         if (lane == 0)
@@ -601,8 +693,8 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
         round_base += all;
         if (have) {
 #pragma unroll
-            for (int sub = 0; sub < 2; sub++) {
-                const unsigned p = (2u * k + sub) * TB + GRAN * lane;
+            for (int sub = 0; sub < (int)kSubs; sub++) {
+                const unsigned p = (kSubs * k + sub) * TB + GRAN * lane;
                 // byte count of the lane's element = e0 + 2 e1 + 4 e2: whole 16-bit pieces first, then the odd byte
                 uint8_t *dst = out + my_base + p_at[sub];
                 const val_t v = p_val[sub];

@@ -9,6 +9,9 @@ from hap_amd import synth
 nf = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 30
 w, h, fmts, chunks = 7680, 4320, [0x01], [24]
 ctx = hap_amd.Context(0)
+for a in sys.argv:
+    if a.startswith("--frag="):
+        ctx.set_fragment_log2(int(a[7:]))
 rgba = [synth.rgba_frame(w, h, i, device="cuda") for i in range(nf)]
 tb = w * h
 cap = hap_amd.HapMaxEncodedLength([tb], fmts, chunks)
