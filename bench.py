@@ -133,6 +133,21 @@ def main():
         ctx.decode_frames(frames, used, idx, dec[idx])
     dec_ms = ctx.timer_stop()
 
+    # the size-for-speed option (HAPGPU_ENCODE_COARSE_MATCHES), reported beside the default; never `value`
+    coarse = None
+    if world == 1 and hasattr(hap_amd, "ENCODE_COARSE_MATCHES"):
+        cflags = flags | hap_amd.ENCODE_COARSE_MATCHES
+        ctx.encode_frames_rgba(rgba, w, h, w * 4, fmts, comps, chunks, frames, flags=cflags)
+        ctx.timer_start()
+        r, cused, _ = ctx.encode_frames_rgba(rgba, w, h, w * 4, fmts, comps, chunks, frames, flags=cflags)
+        for idx in range(len(fmts)):
+            ctx.decode_frames(frames, cused, idx, dec[idx])
+        c_ms = ctx.timer_stop()
+        coarse = {"rgba_GBps": round(nf * rgba_bytes / (c_ms * 1e-3) / 1e9, 2), "ms": round(c_ms, 3),
+                  "snappy_ratio": round(sum(cused) / nf / sum(tex_bytes), 4),
+                  "note": "encode+decode with 32-bit granular element streams for every format"}
+        r, used, _ = ctx.encode_frames_rgba(rgba, w, h, w * 4, fmts, comps, chunks, frames, flags=flags)
+
     # DXT -> RGBA, untimed extra: what a player without texture units needs after HapDecode
     rgba_out = torch.empty(w * h * 4, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
@@ -218,6 +233,7 @@ def main():
         "texture_to_rgba": ({"us_per_frame": round(prof_bd[1] / prof_bd[0] * 1e3, 2),
                              "algorithmic_GBps": round((sum(tex_bytes) + rgba_bytes) / (prof_bd[1] / prof_bd[0] * 1e-3) / 1e9, 1)}
                             if prof_bd[0] else None),
+        "coarse_matches_option": coarse,
         "decode_of_reference_encoded_frames": foreign,
         "host_pointer_path": host_path,
         "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,

@@ -11,7 +11,7 @@ no Python or CPU implementation behind it -- a missing library raises ImportErro
 _API_NAMES = (
     "HapCompressorNone", "HapCompressorSnappy", "HapResult", "HapTextureFormat",
     "HapDecode", "HapEncode", "HapGetFrameTextureChunkCount", "HapGetFrameTextureCount",
-    "HapGetFrameTextureFormat", "HapMaxEncodedLength", "Context", "ENCODE_FRAGMENT_INDEX",
+    "HapGetFrameTextureFormat", "HapMaxEncodedLength", "Context", "ENCODE_FRAGMENT_INDEX", "ENCODE_COARSE_MATCHES",
     "DECODE_IGNORE_FRAGMENT_INDEX", "KERNEL_CLASSES", "HapGpuGetFrameTextureChunkLayout", "HapGpuJoinChunkGroups",
 )
 

@@ -26,6 +26,7 @@ class HapResult:
 
 
 ENCODE_FRAGMENT_INDEX = 0x1
+ENCODE_COARSE_MATCHES = 0x2
 DECODE_IGNORE_FRAGMENT_INDEX = 0x1
 KERNEL_CLASSES = ["block_encode", "snappy_compress", "frame_pack", "frame_gather", "decode_plan", "snappy_decode",
                   "block_decode"]

@@ -106,8 +106,9 @@ unsigned long HapMaxEncodedLength(unsigned int count, unsigned long *lengths,
 
 static unsigned env_encode_flags(void)
 {
-    const char *e = getenv("HAP_AMD_FRAGMENT_INDEX");
-    return (e && atoi(e) != 0) ? HAPGPU_ENCODE_FRAGMENT_INDEX : 0u;
+    const char *e = getenv("HAP_AMD_FRAGMENT_INDEX"), *c = getenv("HAP_AMD_COARSE_MATCHES");
+    return ((e && atoi(e) != 0) ? HAPGPU_ENCODE_FRAGMENT_INDEX : 0u) |
+           ((c && atoi(c) != 0) ? HAPGPU_ENCODE_COARSE_MATCHES : 0u);
 }
 
 /* reference hap.c:506-604 */

@@ -126,7 +126,7 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
             /* DXT1 blocks are two 4-byte fields (endpoints, indices): everything repeats on 4-byte
                boundaries.  The alpha-style blocks of RGTC1 / DXT5 / YCoCg start their index bytes at
                byte 2, so those streams are 2-byte granular. */
-            if (t->format == HapTextureFormat_RGB_DXT1 && (t->chunk_bytes & 3u) == 0)
+            if ((t->format == HapTextureFormat_RGB_DXT1 || (flags & HAPGPU_ENCODE_COARSE_MATCHES)) && (t->chunk_bytes & 3u) == 0)
                 t->gran_log2 = 2u;
             else if ((t->chunk_bytes & 1u) == 0)
                 t->gran_log2 = 1u;

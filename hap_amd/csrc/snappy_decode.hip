@@ -546,6 +546,8 @@ __device__ __forceinline__ int wave_scan_max(int v)
     return v;
 }
 
+__device__ __forceinline__ unsigned long long ballot64(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
 __device__ __forceinline__ int lane_gather(int v, unsigned src_lane)
 {
     return __builtin_amdgcn_ds_bpermute((int)(src_lane << 2), v);
@@ -738,13 +740,12 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
         }
 
         // ---- 3. output positions ----
-        bool is_tok = (T >> lane) & 1ull;
+        bool is_tok = __builtin_amdgcn_inverse_ballot_w64(T);
         int incl = wave_scan_add(is_tok ? (int)len : 0);
         unsigned o_t = (unsigned)incl - (is_tok ? len : 0u);
         // keep at most kOwnerBytes of output per pass (prefix-closed because o_t is monotone)
-        const unsigned long long keep = __ballot(is_tok && o_t + len <= kOwnerBytes);
-        T = keep;
-        is_tok = (T >> lane) & 1ull;
+        T &= ballot64(o_t + len <= kOwnerBytes);
+        is_tok = __builtin_amdgcn_inverse_ballot_w64(T);
         const unsigned last = 63u - (unsigned)__builtin_clzll(T);
         const unsigned N = (unsigned)__builtin_amdgcn_readlane(incl, (int)last);
         const unsigned adv = last + (unsigned)__builtin_amdgcn_readlane((int)tokbytes, (int)last);
@@ -803,8 +804,8 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
                 desc = 0x80000000u;
             // sources inside this 64-byte step: pointer jumping
             for (int round = 0; round < 7; round++) {
-                const bool pending = (desc >> 31) == 0;
-                if (__ballot(pending) == 0)
+                const bool pending = (int)desc >= 0;
+                if (ballot64((int)desc >= 0) == 0)
                     break;
                 const unsigned from = (desc - (opu + B)) & 63u;
                 const unsigned g = (unsigned)lane_gather((int)desc, from);

@@ -41,6 +41,9 @@ typedef struct HapGpuContext HapGpuContext;
 
 /* Encode flags */
 #define HAPGPU_ENCODE_FRAGMENT_INDEX 0x1u   /* emit the private fragment-size section (type 0x46) */
+#define HAPGPU_ENCODE_COARSE_MATCHES 0x2u   /* Snappy elements on 32-bit boundaries for every texture format, not just
+                                               DXT1 (whose blocks are two 32-bit fields): about 1.7x the compress and
+                                               1.15x the decompress rate for about 5 % more bytes on YCoCg-DXT5 */
 
 /* Decode flags */
 #define HAPGPU_DECODE_IGNORE_FRAGMENT_INDEX 0x1u /* decode as a decoder unaware of section 0x46 would */

@@ -820,3 +820,28 @@ def test_row_bands_encoded_separately_join_into_the_whole_frame(ctx, hap, format
             r, used, fmts, res = ctx.decode_frames([joined], [len(joined)], idx, [dec], flags=flags)
             assert (r, used, fmts, res) == (0, [len(want)], [fmt], [0]) and dec.tobytes() == want
     assert b"\x46" in joined[:4096]      # the private fragment-size section survived the join
+
+
+@pytest.mark.parametrize("fmt", [L.FMT_DXT5, L.FMT_YCOCG, L.FMT_RGTC1, L.FMT_BC7])
+def test_coarse_matches_flag_round_trips(ctx, hap, fmt):
+    """HAPGPU_ENCODE_COARSE_MATCHES: 32-bit granular element streams for every format -- still ordinary Snappy that
+    the checker / reference decode, a few percent larger, and our decoder takes its 32-bit path for them."""
+    block = 8 if fmt == L.FMT_RGTC1 else 16
+    tex = D.stream_bytes(block * 64 * 300, "mixed", seed=31)
+    sizes = {}
+    for flags in (hap.ENCODE_FRAGMENT_INDEX, hap.ENCODE_FRAGMENT_INDEX | hap.ENCODE_COARSE_MATCHES, hap.ENCODE_COARSE_MATCHES):
+        out = np.zeros(hap.HapMaxEncodedLength([len(tex)], [fmt], [6]) + 65536, dtype=np.uint8)
+        r, used, res = ctx.encode_frames([[tex]], [fmt], [1], [6], [out], flags=flags)
+        assert r == 0 and res == [0]
+        frame = out[: used[0]].tobytes()
+        sizes[flags] = len(frame)
+        for name, api in CHECKERS:
+            assert api.decode(frame, 0, len(tex)) == (0, tex, fmt), name
+        for dflags in (0, hap.DECODE_IGNORE_FRAGMENT_INDEX):
+            dec = np.zeros(len(tex), dtype=np.uint8)
+            r, du, df, dr = ctx.decode_frames([frame], [len(frame)], 0, [dec], flags=dflags)
+            assert (r, du, df, dr) == (0, [len(tex)], [fmt], [0]) and dec.tobytes() == tex
+        if flags & hap.ENCODE_FRAGMENT_INDEX:
+            at = frame.find(bytes([0x46, 1, 13]))        # section type, version, log2(8 KiB)
+            assert at > 0 and frame[at + 3] == (2 if flags & hap.ENCODE_COARSE_MATCHES else 1)
+    assert sizes[hap.ENCODE_FRAGMENT_INDEX | hap.ENCODE_COARSE_MATCHES] < 1.25 * sizes[hap.ENCODE_FRAGMENT_INDEX]
