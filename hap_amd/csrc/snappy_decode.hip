@@ -631,12 +631,12 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
     }
 
     while (!failed && ip < in_end) {
-        // ---- staging window: keep >= 256 bytes ahead of ip ----
+        // ---- staging window: keep >= 384 bytes ahead of ip (a window's last element may be a 256-byte literal) ----
         if (!pend_valid && next_g < granules && ip + 3 * (kInGranule / 2) >= in_hi) {
             pend = load_granule(next_g);
             pend_valid = true;
         }
-        if (ip + 256u > in_hi && in_hi < granules * kInGranule) {
+        if (ip + 384u > in_hi && in_hi < granules * kInGranule) {
             const unsigned g = ip / kInGranule;
             if (g + 1 == next_g) {
                 store_granule(next_g, pend_valid ? pend : load_granule(next_g));
@@ -659,11 +659,14 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
         const unsigned hi = (w1 >> (8u * sh)) & 0xFFu;                     // byte x+4 (copy-4 / 4 length bytes)
         const unsigned tag = lo & 0xFFu, kind = tag & 3u;
         unsigned len, off = 0, hdr;
-        bool special = false;                   // long literal: taken alone by the slow path
+        bool special = false;                   // literal with a 2..4 byte length: taken alone by the slow path
         if (kind == 0) {
             len = (tag >> 2) + 1u;
             hdr = 1;
-            if (len > 60u) {
+            if (len == 61u) {                   // one length byte: up to 256 bytes, handled like any element
+                len = ((lo >> 8) & 0xFFu) + 1u;
+                hdr = 2;
+            } else if (len > 61u) {
                 special = true;
                 hdr = 1u + (len - 60u);
             }
@@ -761,10 +764,10 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
         if (is_tok)
             owner[o_t / GRAN] = (uint8_t)(lane + 1u);
         // element attributes, fetched by the byte lanes with ds_bpermute
-        // a0: o_t (11 bits) | len (7) << 11 | literal flag << 18 ; a1: literal input coordinate or copy
-        // source position; a0 bits 19.. carry the low 13 bits of the offset, a1 is untouched -- the
-        // offset only matters for overlapping copies (off < len <= 64), so 13 bits are plenty
-        const int a0 = (int)(o_t | (len << 11) | (kind == 0 ? (1u << 18) : 0u) | (min(off, 8191u) << 19));
+        // a0: o_t (11 bits) | len (9) << 11 | literal flag << 20 | offset saturated at 127 << 21 -- the offset
+        // only matters for overlapping copies (off < len <= 64); a1: literal input coordinate or copy source
+        // position
+        const int a0 = (int)(o_t | (len << 11) | (kind == 0 ? (1u << 20) : 0u) | (min(off, 127u) << 21));
         const int a1 = (int)(kind == 0 ? x + hdr : op + o_t - off);
         unsigned carry = 0;
         const unsigned opu = op / GRAN;
@@ -778,10 +781,10 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
             const unsigned sl = (unsigned)(m - 1) & 63u;
             const unsigned g0 = (unsigned)lane_gather(a0, sl);
             const unsigned g1 = (unsigned)lane_gather(a1, sl);
-            const unsigned g2 = g0 >> 19;                                  // offset, saturated at 8191
+            const unsigned g2 = g0 >> 21;                                  // offset, saturated at 127
             const unsigned rel = b - (g0 & 0x7FFu) / GRAN;
-            const unsigned elen = ((g0 >> 11) & 0x7Fu) / GRAN;
-            const bool lit = ((g0 >> 18) & 1u) != 0;
+            const unsigned elen = ((g0 >> 11) & 0x1FFu) / GRAN;
+            const bool lit = ((g0 >> 20) & 1u) != 0;
             unsigned desc;                       // bit 31: resolved (LDS byte address), else output position
             if (lit) {
                 desc = 0x80000000u | (GRAN >= 2 ? 0x40000000u : 0u) | (RING + ((g1 + GRAN * rel) & (kInBytes - 1)));
