@@ -17,10 +17,40 @@ namespace {
 
 constexpr int kFmtDXT1 = 0, kFmtDXT5 = 1, kFmtYCoCg = 2, kFmtRGTC1 = 3;
 
-__device__ __forceinline__ int quant5(int v) { int t = v * 31 + 128; return (t + (t >> 8)) >> 8; }
-__device__ __forceinline__ int quant6(int v) { int t = v * 63 + 128; return (t + (t >> 8)) >> 8; }
+// clamp(t, lo, hi) with lo <= hi: one v_med3_i32
+__device__ __forceinline__ int imed3(int t, int lo, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(t), "v"(lo), "v"(hi));
+    return r;
+}
+
+// Inline-asm helpers below must never consume the result of a v_dot4 directly: gfx950 needs wait states between
+// a dot product and a different VALU reader, and the compiler does not see through the asm to insert them.
+// a * b + c on the 24-bit multiplier (full rate; the 32-bit one is quarter rate); |a|, |b| < 2^23
+__device__ __forceinline__ int mad24(int a, int b, int c)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+template <int K>      // K: inline constant (-16..64)
+__device__ __forceinline__ int mad24k(int a, int c)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "i"(K), "v"(c));
+    return r;
+}
+
+// exact floor(x / 7) for 0 <= x < 13107 and floor(x / 3) for 0 <= x < 32768 with one full-rate 24-bit multiply
+__device__ __forceinline__ int div7(int x) { return (int)(__umul24((unsigned)x, 9363u) >> 16); }
+__device__ __forceinline__ int div3(int x) { return (int)(__umul24((unsigned)x, 21846u) >> 16); }
+
+__device__ __forceinline__ int quant5(int v) { int t = mad24k<31>(v, 128); return (t + (t >> 8)) >> 8; }
+__device__ __forceinline__ int quant6(int v) { int t = mad24k<63>(v, 128); return (t + (t >> 8)) >> 8; }
 __device__ __forceinline__ int expand5(int q) { return (q << 3) | (q >> 2); }
 __device__ __forceinline__ int expand6(int q) { return (q << 2) | (q >> 4); }
+
 
 // 8-byte alpha-style block: a0, a1, 16 x 3-bit codes (S3TC alpha / RGTC1 layout).
 __device__ __forceinline__ uint2 alpha_block(const int (&a)[16])
@@ -39,24 +69,29 @@ __device__ __forceinline__ uint2 alpha_block(const int (&a)[16])
         int prev = a0;
 #pragma unroll
         for (int j = 1; j < 8; j++) {
-            const int q = ((7 - j) * a0 + j * a1) / 7;
+            const int q = div7((7 - j) * a0 + j * a1);
             t[j - 1] = prev + q;      // q_{j-1} + q_j
             prev = q;
         }
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const int v2 = 2 * a[i];
-            unsigned r = 0;
-#pragma unroll
-            for (int j = 0; j < 7; j++)
-                r += (v2 < t[j]) ? 1u : 0u;
-            // ramp position -> S3TC code: 0->0, 7->1, r->r+1 (nibble table)
-            const unsigned code = (0x17654320u >> (4u * r)) & 7u;
+            // r = number of thresholds above v2: med3(t, v2, v2 + 1) is v2 + (v2 < t ? 1 : 0) for integers
+            const int m0 = imed3(t[0], v2, v2 + 1), m1 = imed3(t[1], v2, v2 + 1);
+            const int m2 = imed3(t[2], v2, v2 + 1), m3 = imed3(t[3], v2, v2 + 1);
+            const int m4 = imed3(t[4], v2, v2 + 1), m5 = imed3(t[5], v2, v2 + 1);
+            const int m6 = imed3(t[6], v2, v2 + 1);
+            const unsigned r = (unsigned)((m0 + m1 + m2) + (m3 + m4 + m5) + mad24k<-14>(a[i], m6));
+            // ramp position -> S3TC code: 0->0, 7->1, r->r+1 (byte table 00 02 03 04 | 05 06 07 01, one v_perm)
+            const unsigned code = __builtin_amdgcn_perm(0x01070605u, 0x04030200u, r);
+            // three bits in from the top: after 8 pixels the codes occupy bits 31:8, pixel 0 lowest
             if (i < 8)
-                lo24 |= code << (3 * i);
+                lo24 = __builtin_amdgcn_alignbit(code, lo24, 3);
             else
-                hi24 |= code << (3 * (i - 8));
+                hi24 = __builtin_amdgcn_alignbit(code, hi24, 3);
         }
+        lo24 >>= 8;
+        hi24 >>= 8;
     }
     const unsigned long long bits = (unsigned long long)lo24 | ((unsigned long long)hi24 << 24);
     const unsigned long long v = (unsigned long long)(unsigned)a0 | ((unsigned long long)(unsigned)a1 << 8) | (bits << 16);
@@ -67,21 +102,26 @@ __device__ __forceinline__ uint2 alpha_block(const int (&a)[16])
 // bytes (c0 | c1<<8 | c2<<16), top byte zero.  Lowest index wins ties.
 __device__ __forceinline__ unsigned nearest4(const unsigned (&px)[16], const unsigned (&pal)[4])
 {
-    // |p - c_k|^2 orders like |c_k|^2 - 2 p.c_k; scale by 4 and put k in the low bits so that one
-    // signed min picks the smallest distance with the smallest index on ties
+    // |p - c_k|^2 orders like |c_k|^2 - 2 p.c_k; scale by 4 and put k in the low bits so that one signed min
+    // picks the smallest distance with the smallest index on ties: s_k = 4|c_k|^2 + k - 8 p.c_k.
+    // With the complemented pixel p' = 255 - p (per byte), p.c_k = 255 sum(c_k) - p'.c_k, so
+    // s_k = (4|c_k|^2 + k - 2040 sum(c_k)) + (p'.c_k << 3): one dot product and one shift-add per entry.
     int base[4];
 #pragma unroll
     for (int k = 0; k < 4; k++)
-        base[k] = 4 * (int)__builtin_amdgcn_udot4(pal[k], pal[k], 0u, false) + k;
+        base[k] = 4 * (int)__builtin_amdgcn_udot4(pal[k], pal[k], 0u, false) + k -
+                  2040 * (int)__builtin_amdgcn_udot4(pal[k], 0x00010101u, 0u, false);
     unsigned idx = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        const int s0 = base[0] - 8 * (int)__builtin_amdgcn_udot4(px[i], pal[0], 0u, false);
-        const int s1 = base[1] - 8 * (int)__builtin_amdgcn_udot4(px[i], pal[1], 0u, false);
-        const int s2 = base[2] - 8 * (int)__builtin_amdgcn_udot4(px[i], pal[2], 0u, false);
-        const int s3 = base[3] - 8 * (int)__builtin_amdgcn_udot4(px[i], pal[3], 0u, false);
+        const unsigned q = px[i] ^ 0x00FFFFFFu;
+        const int s0 = (int)(__builtin_amdgcn_udot4(q, pal[0], 0u, false) << 3) + base[0];
+        const int s1 = (int)(__builtin_amdgcn_udot4(q, pal[1], 0u, false) << 3) + base[1];
+        const int s2 = (int)(__builtin_amdgcn_udot4(q, pal[2], 0u, false) << 3) + base[2];
+        const int s3 = (int)(__builtin_amdgcn_udot4(q, pal[3], 0u, false) << 3) + base[3];
         const int best = min(min(s0, s1), min(s2, s3));
-        idx |= ((unsigned)best & 3u) << (2 * i);
+        // shift the two index bits in from the top: after 16 pixels pixel 0 sits in bits 1:0
+        idx = __builtin_amdgcn_alignbit((unsigned)best, idx, 2);
     }
     return idx;
 }
@@ -94,8 +134,8 @@ __device__ __forceinline__ void palette_from_565(unsigned c0, unsigned c1, bool 
     const int r1 = expand5(c1 >> 11), g1 = expand6((c1 >> 5) & 63), b1 = blue ? expand5(c1 & 31) : 0;
     pal[0] = pack3(r0, g0, b0);
     pal[1] = pack3(r1, g1, b1);
-    pal[2] = pack3((2 * r0 + r1) / 3, (2 * g0 + g1) / 3, (2 * b0 + b1) / 3);
-    pal[3] = pack3((r0 + 2 * r1) / 3, (g0 + 2 * g1) / 3, (b0 + 2 * b1) / 3);
+    pal[2] = pack3(div3(2 * r0 + r1), div3(2 * g0 + g1), div3(2 * b0 + b1));
+    pal[3] = pack3(div3(r0 + 2 * r1), div3(g0 + 2 * g1), div3(b0 + 2 * b1));
 }
 
 // DXT1-style colour block from 16 packed RGB pixels (alpha byte already cleared).
@@ -118,8 +158,8 @@ __device__ __forceinline__ uint2 colour_block(const unsigned (&px)[16])
         const int dr = 2 * (int)(px[i] & 255u) - mr;
         const int dg = 2 * (int)((px[i] >> 8) & 255u) - mg;
         const int db = 2 * (int)((px[i] >> 16) & 255u) - mb;
-        cov_rg += dr * dg;
-        cov_bg += db * dg;
+        cov_rg = mad24(dr, dg, cov_rg);
+        cov_bg = mad24(db, dg, cov_bg);
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -156,7 +196,7 @@ __device__ __forceinline__ uint2 ycocg_colour_block(const int (&co)[16], const i
     const int mo = lo_o + hi_o, mg = lo_g + hi_g;
 #pragma unroll
     for (int i = 0; i < 16; i++)
-        cov += (2 * co[i] - mo) * (2 * cg[i] - mg);
+        cov = mad24(2 * co[i] - mo, 2 * cg[i] - mg, cov);
     lo_o = (lo_o - 128) * s + 128; hi_o = (hi_o - 128) * s + 128;
     lo_g = (lo_g - 128) * s + 128; hi_g = (hi_g - 128) * s + 128;
     int ins = (hi_o - lo_o) >> 4; lo_o += ins; hi_o -= ins;
@@ -178,15 +218,17 @@ __device__ __forceinline__ uint2 ycocg_colour_block(const int (&co)[16], const i
 }
 
 template <int FMT, bool WIDE>
-__global__ __launch_bounds__(256) void bc_encode_kernel(const uint8_t *__restrict__ rgba, size_t row_bytes,
-                                                        unsigned blocks_x, unsigned blocks_total,
-                                                        uint8_t *__restrict__ out)
+__global__ __launch_bounds__(64) void bc_encode_kernel(const uint8_t *__restrict__ rgba, size_t row_bytes,
+                                                       unsigned blocks_x, unsigned blocks_total,
+                                                       uint8_t *__restrict__ out)
 {
-    const unsigned id = blockIdx.x * 256u + threadIdx.x;
-    if (id >= blocks_total)
+    // one wavefront per 64 blocks of one block row: the row's address is scalar, no division per lane
+    const unsigned by = blockIdx.y, bx = blockIdx.x * 64u + threadIdx.x;
+    if (bx >= blocks_x)
         return;
-    const unsigned by = id / blocks_x, bx = id - by * blocks_x;
-    const uint8_t *src = rgba + (size_t)(4u * by) * row_bytes + 16u * (size_t)bx;
+    (void)blocks_total;
+    const size_t id = (size_t)by * blocks_x + bx;
+    const uint8_t *src = rgba + (size_t)(4u * by) * row_bytes + 16u * bx;
     unsigned p[16];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -203,13 +245,13 @@ __global__ __launch_bounds__(256) void bc_encode_kernel(const uint8_t *__restric
 #pragma unroll
         for (int i = 0; i < 16; i++)
             a[i] = (int)(p[i] >> 24);
-        *reinterpret_cast<uint2 *>(out + (size_t)id * 8u) = alpha_block(a);
+        *reinterpret_cast<uint2 *>(out + id * 8u) = alpha_block(a);
     } else if (FMT == kFmtDXT1) {
         unsigned px[16];
 #pragma unroll
         for (int i = 0; i < 16; i++)
             px[i] = p[i] & 0x00FFFFFFu;
-        *reinterpret_cast<uint2 *>(out + (size_t)id * 8u) = colour_block(px);
+        *reinterpret_cast<uint2 *>(out + id * 8u) = colour_block(px);
     } else if (FMT == kFmtDXT5) {
         int a[16];
         unsigned px[16];
@@ -219,7 +261,7 @@ __global__ __launch_bounds__(256) void bc_encode_kernel(const uint8_t *__restric
             px[i] = p[i] & 0x00FFFFFFu;
         }
         const uint2 ab = alpha_block(a), cb = colour_block(px);
-        *reinterpret_cast<uint4 *>(out + (size_t)id * 16u) = make_uint4(ab.x, ab.y, cb.x, cb.y);
+        *reinterpret_cast<uint4 *>(out + id * 16u) = make_uint4(ab.x, ab.y, cb.x, cb.y);
     } else {
         int y[16], co[16], cg[16];
 #pragma unroll
@@ -232,7 +274,7 @@ __global__ __launch_bounds__(256) void bc_encode_kernel(const uint8_t *__restric
             cg[i] = (int)min(__builtin_amdgcn_udot4(q ^ 0x00FF00FFu, 0x00010201u, 4u, false) >> 2, 255u);
         }
         const uint2 ab = alpha_block(y), cb = ycocg_colour_block(co, cg);
-        *reinterpret_cast<uint4 *>(out + (size_t)id * 16u) = make_uint4(ab.x, ab.y, cb.x, cb.y);
+        *reinterpret_cast<uint4 *>(out + id * 16u) = make_uint4(ab.x, ab.y, cb.x, cb.y);
     }
 }
 
@@ -240,7 +282,7 @@ template <int FMT>
 void launch(const void *rgba, size_t row_bytes, unsigned bx, unsigned by, void *out, bool wide, hipStream_t stream)
 {
     const unsigned total = bx * by;
-    const dim3 grid((total + 255u) / 256u), block(256);
+    const dim3 grid((bx + 63u) / 64u, by), block(64);
     if (wide)
         hipLaunchKernelGGL((bc_encode_kernel<FMT, true>), grid, block, 0, stream, (const uint8_t *)rgba, row_bytes, bx, total, (uint8_t *)out);
     else

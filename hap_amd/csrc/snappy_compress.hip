@@ -611,11 +611,19 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
                     } else {
                         l = min(run_from(c, nx, lane), room);
                     }
+#ifndef HAP_PREFER_NEAR   /* equal-length candidates: the farther one keeps dependency chains in the decoder short */
+                    best_key = max(best_key, (l << (3u + GL)) | (unsigned)(d + 1));
+#else
                     best_key = max(best_key, (l << (3u + GL)) | (unsigned)(kFixed - d));
+#endif
                 }
                 const unsigned prio = best_key & 7u;
                 best_len2[sub] = best_key >> 3;
+#ifndef HAP_PREFER_NEAR   /* equal-length candidates: the farther one keeps dependency chains in the decoder short */
+                best_off2[sub] = prio ? prio << pitch_log2 : hoff[sub];
+#else
                 best_off2[sub] = prio ? ((unsigned)(kFixed + 1) - prio) << pitch_log2 : hoff[sub];
+#endif
             }
             unsigned skip = 0;
 #pragma unroll
