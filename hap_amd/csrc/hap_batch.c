@@ -268,7 +268,8 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
         }
         rc |= (unsigned)hapgpu_rt_h2d(rt, dframes, hframes, sizeof(HapGpuFrameEnc) * live);
         if (any_snappy)
-            rc |= (unsigned)hapgpu_k_snappy_compress(rt, dframes, live, max_frags_per_tex, frag_log2, dslots, slot_stride, dfragsizes, gran_mask);
+            rc |= (unsigned)hapgpu_k_snappy_compress(rt, dframes, live, max_frags_per_tex, frag_log2, dslots, slot_stride, dfragsizes,
+                                                     gran_mask | (count << 8));   /* bits 8..: textures per frame */
         rc |= (unsigned)hapgpu_k_frame_pack(rt, dframes, live, frag_log2, dslots, slot_stride, dfragsizes, dcopies);
         rc |= (unsigned)hapgpu_k_frame_gather(rt, dcopies, frags_per_frame * live);
         rc |= (unsigned)hapgpu_rt_d2h(rt, hframes, dframes, sizeof(HapGpuFrameEnc) * live);

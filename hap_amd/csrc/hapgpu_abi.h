@@ -155,7 +155,7 @@ int hapgpu_k_block_decode(hapgpu_rt *rt, const void *blocks, const void *alpha, 
 int hapgpu_k_snappy_compress(hapgpu_rt *rt, const HapGpuFrameEnc *frames, unsigned frame_count,
                              unsigned max_frags_per_texture, unsigned frag_log2,
                              void *slots, unsigned slot_stride, uint32_t *frag_sizes,
-                             unsigned granularity_mask /* bit g set: some texture has granularity_log2 == g */);
+                             unsigned granularity_mask /* bit g (0..2) set: some texture has granularity_log2 == g; bits 8..: textures per frame */);
 int hapgpu_k_frame_pack(hapgpu_rt *rt, HapGpuFrameEnc *frames, unsigned frame_count,
                         unsigned frag_log2, const void *slots, unsigned slot_stride,
                         const uint32_t *frag_sizes, HapGpuCopyEntry *copies);

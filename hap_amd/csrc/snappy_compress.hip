@@ -410,12 +410,19 @@ __device__ __forceinline__ unsigned match_extend16(const uint32_t *dw, unsigned 
 struct __attribute__((packed)) packed_u16 { uint16_t v; };
 __device__ __forceinline__ void store16(uint8_t *p, unsigned v) { reinterpret_cast<packed_u16 *>(p)->v = (uint16_t)v; }
 
-template <unsigned GRAN>     // bytes per lane: 1, 2 or 4 (positions, offsets and lengths all multiples of GRAN)
+// GRAN: bytes per lane: 1, 2 or 4 (positions, offsets and lengths all multiples of GRAN).
+// FL: log2 of the fragment size when known at compile time (the default, 13), 0 = run-time value: with a fixed
+//     size the LDS is a static array and every address offset a compile-time constant.
+template <unsigned GRAN, unsigned FL>
 __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const HapGpuFrameEnc *__restrict__ frames,
-                                                                unsigned frag_log2, uint8_t *__restrict__ slots,
+                                                                unsigned frag_log2_arg, uint8_t *__restrict__ slots,
                                                                 unsigned slot_stride, uint32_t *__restrict__ frag_sizes)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr unsigned kStaticBytes = FL ? (1u << FL) + 32u + kWgHashEntries * 4u + kWgWaves * 4u : 16u;
+    extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
+    __shared__ __attribute__((aligned(16))) uint8_t static_lds[kStaticBytes];
+    uint8_t *const smem = FL ? static_lds : dynamic_lds;
+    const unsigned frag_log2 = FL ? FL : frag_log2_arg;
     const unsigned frag_bytes = 1u << frag_log2;
     uint32_t *dataw = reinterpret_cast<uint32_t *>(smem);                        // frag_bytes + 32
     const uint8_t *data = smem;
@@ -783,20 +790,31 @@ extern "C" int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsig
         if (lds2 > 65536u) {
             static bool once2 = false;
             if (!once2) {
-                if (hipFuncSetAttribute((const void *)snappy_compress_wg_kernel<1u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess ||
-                    hipFuncSetAttribute((const void *)snappy_compress_wg_kernel<2u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess ||
-                    hipFuncSetAttribute((const void *)snappy_compress_wg_kernel<4u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+                if (hipFuncSetAttribute((const void *)snappy_compress_wg_kernel<1u, 0u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess ||
+                    hipFuncSetAttribute((const void *)snappy_compress_wg_kernel<2u, 0u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess ||
+                    hipFuncSetAttribute((const void *)snappy_compress_wg_kernel<4u, 0u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
                     return 4;
                 once2 = true;
             }
         }
-        const dim3 grid(max_frags_per_texture, 2, frame_count);
+        const unsigned textures = (granularity_mask >> 8) == 1u ? 1u : 2u;      // bits 8..: textures per frame (0 = unknown)
+        const dim3 grid(max_frags_per_texture, textures, frame_count), block(64 * kWgWaves);
+#define HAP_LAUNCH_COMPRESS(G)                                                                                                  \
+        do {                                                                                                                    \
+            if (frag_log2 == 13u)                                                                                               \
+                hipLaunchKernelGGL((snappy_compress_wg_kernel<G, 13u>), grid, block, 0, stream, frames, frag_log2,              \
+                                   (uint8_t *)slots, slot_stride, frag_sizes);                                                  \
+            else                                                                                                                \
+                hipLaunchKernelGGL((snappy_compress_wg_kernel<G, 0u>), grid, block, lds2, stream, frames, frag_log2,            \
+                                   (uint8_t *)slots, slot_stride, frag_sizes);                                                  \
+        } while (0)
         if (granularity_mask & 1u)
-            hipLaunchKernelGGL(snappy_compress_wg_kernel<1u>, grid, dim3(64 * kWgWaves), lds2, stream, frames, frag_log2, (uint8_t *)slots, slot_stride, frag_sizes);
+            HAP_LAUNCH_COMPRESS(1u);
         if (granularity_mask & 2u)
-            hipLaunchKernelGGL(snappy_compress_wg_kernel<2u>, grid, dim3(64 * kWgWaves), lds2, stream, frames, frag_log2, (uint8_t *)slots, slot_stride, frag_sizes);
+            HAP_LAUNCH_COMPRESS(2u);
         if (granularity_mask & 4u)
-            hipLaunchKernelGGL(snappy_compress_wg_kernel<4u>, grid, dim3(64 * kWgWaves), lds2, stream, frames, frag_log2, (uint8_t *)slots, slot_stride, frag_sizes);
+            HAP_LAUNCH_COMPRESS(4u);
+#undef HAP_LAUNCH_COMPRESS
         return hipGetLastError() == hipSuccess ? 0 : 4;
     }
     const unsigned lds = compress_lds_bytes(frag_log2);

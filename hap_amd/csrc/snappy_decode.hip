@@ -512,6 +512,7 @@ __global__ __launch_bounds__(64) void snappy_decode_kernel(const HapGpuDecodeUni
 // length mismatch fails the unit.  Used for FRAGMENT units (output never wraps the ring).
 
 constexpr unsigned kOwnerBytes = 1024;      // output bytes handled per window pass
+constexpr unsigned kFragmentTail = 2048u /* kInBytes */ + kOwnerBytes + 64u;   // LDS of the v2 kernel beyond its ring
 
 __device__ __forceinline__ int dpp_row_shr(int identity, int v, int n)
 {
@@ -559,7 +560,12 @@ template <unsigned RING, bool STREAM, unsigned GRAN>
 __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpuDecodeUnit *__restrict__ units,
                                                                     unsigned unit_count, HapGpuDecodeJob *jobs)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // Statically sized LDS when it fits the 64 KiB static limit: the compiler then knows every LDS address
+    // offset at compile time (with a dynamic array each address computation carries an extra add of the base).
+    constexpr bool kStaticLds = RING + kFragmentTail <= 65536u;
+    extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
+    __shared__ __attribute__((aligned(16))) uint8_t static_lds[kStaticLds ? RING + kFragmentTail : 16u];
+    uint8_t *const smem = kStaticLds ? static_lds : dynamic_lds;
     uint8_t *ring = smem;                                          // [0, RING): output
     uint32_t *inw = reinterpret_cast<uint32_t *>(smem + RING);     // [RING, RING+2048): staged input
     uint8_t *owner = smem + RING + kInBytes;                       // [.., +1024+64): owner map
@@ -887,6 +893,9 @@ extern "C" int hapgpu_launch_decode_plan(HapGpuDecodeJob *jobs, unsigned job_cou
 }
 
 // frag_log2: fragment size of FRAGMENT units in this batch (0 = none present).
+// dynamic LDS to request for the v2 kernel: none when its ring + tail fit the static array
+static constexpr unsigned fragment_dynamic_lds(unsigned ring) { return ring + kFragmentTail <= 65536u ? 0u : ring + kFragmentTail; }
+
 extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsigned unit_count, HapGpuDecodeJob *jobs,
                                            unsigned frag_log2, unsigned fragment_kinds, int any_stream_or_copy_units,
                                            hipStream_t stream)
@@ -905,15 +914,14 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
                 ring_log2 = (unsigned)atoi(e);
             once = true;
         }
-        const unsigned tail = kInBytes + kOwnerBytes + 64;
         if (use_v1)
             hipLaunchKernelGGL((snappy_decode_kernel<65536u, false>), dim3(unit_count), dim3(64), 65536 + kInBytes, stream, units, unit_count, jobs);
         else if (ring_log2 == 14)
-            hipLaunchKernelGGL((snappy_decode_fragment_kernel<16384u, true, 1u>), dim3(unit_count), dim3(64), 16384 + tail, stream, units, unit_count, jobs);
+            hipLaunchKernelGGL((snappy_decode_fragment_kernel<16384u, true, 1u>), dim3(unit_count), dim3(64), fragment_dynamic_lds(16384u), stream, units, unit_count, jobs);
         else if (ring_log2 == 15)
-            hipLaunchKernelGGL((snappy_decode_fragment_kernel<32768u, true, 1u>), dim3(unit_count), dim3(64), 32768 + tail, stream, units, unit_count, jobs);
+            hipLaunchKernelGGL((snappy_decode_fragment_kernel<32768u, true, 1u>), dim3(unit_count), dim3(64), fragment_dynamic_lds(32768u), stream, units, unit_count, jobs);
         else
-            hipLaunchKernelGGL((snappy_decode_fragment_kernel<65536u, true, 1u>), dim3(unit_count), dim3(64), 65536 + tail, stream, units, unit_count, jobs);
+            hipLaunchKernelGGL((snappy_decode_fragment_kernel<65536u, true, 1u>), dim3(unit_count), dim3(64), fragment_dynamic_lds(65536u), stream, units, unit_count, jobs);
     }
     const unsigned extra = kInBytes + (use_v1 ? 0u : kOwnerBytes + 64u);
     static bool once16 = false;
@@ -932,13 +940,13 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
         } else {                                                                                                                \
             if (fragment_kinds & 1u)                                                                                            \
                 hipLaunchKernelGGL((snappy_decode_fragment_kernel<RINGBYTES, false, 1u>), dim3(unit_count), dim3(64),           \
-                                   RINGBYTES + extra, stream, units, unit_count, jobs);                                         \
+                                   fragment_dynamic_lds(RINGBYTES), stream, units, unit_count, jobs);                       \
             if (fragment_kinds & 2u)                                                                                            \
                 hipLaunchKernelGGL((snappy_decode_fragment_kernel<RINGBYTES, false, 2u>), dim3(unit_count), dim3(64),           \
-                                   RINGBYTES + extra, stream, units, unit_count, jobs);                                         \
+                                   fragment_dynamic_lds(RINGBYTES), stream, units, unit_count, jobs);                       \
             if (fragment_kinds & 4u)                                                                                            \
                 hipLaunchKernelGGL((snappy_decode_fragment_kernel<RINGBYTES, false, 4u>), dim3(unit_count), dim3(64),           \
-                                   RINGBYTES + extra, stream, units, unit_count, jobs);                                         \
+                                   fragment_dynamic_lds(RINGBYTES), stream, units, unit_count, jobs);                       \
         }                                                                                                                       \
     } while (0)
     switch (frag_log2) {
