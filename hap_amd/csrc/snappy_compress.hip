@@ -608,6 +608,10 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
                 for (int d = kFixed - 1; d >= 0; d--) {
 #endif
                     const unsigned long long c = eq[d][sub], nx = sub + 1 < (int)kSubs ? eq[d][sub + 1 < (int)kSubs ? sub + 1 : sub] : 0ull;
+#ifndef HAP_KEEP_EMPTY_DISTANCE
+                    if (c == 0ull)                    // (uniform) nothing of this tile repeats at this distance
+                        continue;
+#endif
                     unsigned l;
                     if (GRAN >= 2) {
                         // run of set bits starting at this lane, capped at 32 lanes (>= 64 bytes): one funnel shift
