@@ -49,6 +49,15 @@ def _load():
         "HapGpuDecodeChunkGroup": (u, [vp, vp, ul, u, u, u, vp, ul, P(ul), P(u)]),
         "HapGpuGetFrameTextureChunkLayout": (u, [vp, ul, u, u, P(ul), P(u)]),
         "HapGpuJoinChunkGroups": (u, [u, P(vp), P(ul), vp, ul, P(ul)]),
+        "HapSequenceWriterOpen": (u, [C.c_char_p, u, u, u, u, P(vp)]),
+        "HapSequenceWriterAppend": (u, [vp, vp, ul]),
+        "HapSequenceWriterClose": (u, [vp]),
+        "HapSequenceReaderOpen": (u, [C.c_char_p, P(vp)]),
+        "HapSequenceReaderClose": (None, [vp]),
+        "HapSequenceReaderInfo": (u, [vp, P(u), P(u), P(u), P(u), P(u)]),
+        "HapSequenceReaderFrameBytes": (ul, [vp, u]),
+        "HapSequenceReaderRead": (u, [vp, u, u, vp, ul, P(ul)]),
+        "HapGpuDecodeSequence": (u, [vp, vp, u, u, u, u, P(vp), P(ul), P(ul), P(u), P(u)]),
         "HapGpuSetProfiling": (u, [vp, u]),
         "HapGpuCollectProfile": (u, [vp, P(ul), P(C.c_double)]),
         "HapGpuTimerStart": (u, [vp]),

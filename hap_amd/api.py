@@ -4,6 +4,7 @@ meaning and result codes as /root/reference/source/hap.h:40-152).
 Buffers may be bytes / bytearray / numpy arrays (host) or objects exposing
 `data_ptr()` + `numel()`/`nbytes` (torch CUDA tensors -> used in place)."""
 import ctypes as C
+import os
 
 from ._lib import CALLBACK, WORK_FN, lib
 
@@ -144,6 +145,73 @@ def HapGpuJoinChunkGroups(groupFrames, outputBufferBytes=None):
     return r, (C.string_at(out, used.value) if r == 0 else None)
 
 
+class SequenceWriter:
+    """include/hap_sequence.h: append complete Hap frames to a sequence file."""
+
+    def __init__(self, path, width=0, height=0, rate=(60, 1)):
+        h = C.c_void_p()
+        r = lib.HapSequenceWriterOpen(os.fsencode(path), width, height, rate[0], rate[1], C.byref(h))
+        if r != 0:
+            raise OSError("HapSequenceWriterOpen(%r) failed with HapResult %d" % (path, r))
+        self.handle = h
+
+    def append(self, frame):
+        a, n, _k = _addr_len(frame)
+        return lib.HapSequenceWriterAppend(self.handle, a, n)
+
+    def close(self):
+        r = 0
+        if self.handle:
+            r = lib.HapSequenceWriterClose(self.handle)
+            self.handle = None
+        return r
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class SequenceReader:
+    """include/hap_sequence.h: random access to the frames of a sequence file."""
+
+    def __init__(self, path):
+        h = C.c_void_p()
+        r = lib.HapSequenceReaderOpen(os.fsencode(path), C.byref(h))
+        if r != 0:
+            raise OSError("HapSequenceReaderOpen(%r) failed with HapResult %d" % (path, r))
+        self.handle = h
+        v = [C.c_uint(0) for _ in range(5)]
+        lib.HapSequenceReaderInfo(h, *[C.byref(x) for x in v])
+        self.width, self.height, self.rate, self.frame_count = v[0].value, v[1].value, (v[2].value, v[3].value), v[4].value
+
+    def frame_bytes(self, i):
+        return lib.HapSequenceReaderFrameBytes(self.handle, i)
+
+    def read(self, first, count=1):
+        """Returns (result, [frame bytes, ...])."""
+        total = sum(self.frame_bytes(first + i) for i in range(count)) if first + count <= self.frame_count else 0
+        buf = (C.c_ubyte * max(1, total))()
+        offs = (C.c_ulong * (count + 1))()
+        r = lib.HapSequenceReaderRead(self.handle, first, count, buf, total, offs)
+        if r != 0:
+            return r, None
+        raw = C.string_at(buf, total)
+        return 0, [raw[offs[i]:offs[i + 1]] for i in range(count)]
+
+    def close(self):
+        if self.handle:
+            lib.HapSequenceReaderClose(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 class Context:
     """HapGpuContext: device + stream + scratch (include/hap_gpu.h)."""
 
@@ -258,6 +326,16 @@ class Context:
         fmts = (C.c_uint * nf)()
         results = (C.c_uint * nf)()
         r = lib.HapGpuDecodeFrames(self.handle, nf, ptrs, lens, index, optrs, olens, used, fmts, results, flags)
+        return r, list(used), list(fmts), list(results)
+
+    def decode_sequence(self, reader, first, count, index, outputs, batch=0):
+        """Disk -> pinned double buffer -> GPU (HapGpuDecodeSequence). Returns (result, used[], formats[], results[])."""
+        optrs, oinfos = self._ptr_array(outputs)
+        olens = (C.c_ulong * count)(*[i[1] for i in oinfos])
+        used = (C.c_ulong * count)()
+        fmts = (C.c_uint * count)()
+        results = (C.c_uint * count)()
+        r = lib.HapGpuDecodeSequence(self.handle, reader.handle, first, count, index, batch, optrs, olens, used, fmts, results)
         return r, list(used), list(fmts), list(results)
 
     def set_profiling(self, on):

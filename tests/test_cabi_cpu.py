@@ -30,8 +30,8 @@ def hap():
 
 def test_every_declared_symbol_is_exported(hap):
     lib = C.CDLL(os.path.join(ROOT, "hap_amd", "libhap_amd.so"))
-    names = _declared_functions("hap.h") + _declared_functions("hap_gpu.h")
-    assert len(names) >= 19
+    names = _declared_functions("hap.h") + _declared_functions("hap_gpu.h") + _declared_functions("hap_sequence.h")
+    assert len(names) >= 31
     for n in names:
         assert hasattr(lib, n), n
     for n in ("HapMaxEncodedLength", "HapEncode", "HapDecode", "HapGetFrameTextureCount",
@@ -83,6 +83,54 @@ def test_inspectors_on_golden_and_malformed_frames(hap):
             for idx in (0, 1, 2):
                 assert hap.HapGetFrameTextureFormat(f, idx) == ora.texture_format(f, idx)
                 assert hap.HapGetFrameTextureChunkCount(f, idx) == ora.chunk_count(f, idx)
+
+
+def test_sequence_file_round_trip_and_malformed_files(hap, tmp_path):
+    """include/hap_sequence.h (no GPU): frames come back byte for byte, the index is validated on open."""
+    ora = L.oracle_api()
+    frames = [ora.encode([D.stream_bytes(16 * 64 * (5 + i), "mixed", seed=i)], [L.FMT_DXT5], [1], [1 + i % 3])[1] for i in range(9)]
+    path = str(tmp_path / "clip.hapseq")
+    with hap.SequenceWriter(path, 256, 64, (30000, 1001)) as w:
+        for f in frames:
+            assert w.append(f) == 0
+        assert w.append(b"") == hap.HapResult.Bad_Arguments
+    r = hap.SequenceReader(path)
+    assert (r.width, r.height, r.rate, r.frame_count) == (256, 64, (30000, 1001), 9)
+    assert [r.frame_bytes(i) for i in range(10)] == [len(f) for f in frames] + [0]
+    assert r.read(0, 9) == (0, frames) and r.read(4, 3) == (0, frames[4:7]) and r.read(8, 1) == (0, frames[8:])
+    assert r.read(8, 2)[0] == hap.HapResult.Bad_Arguments and r.read(9, 1)[0] == hap.HapResult.Bad_Arguments
+    r.close()
+    raw = open(path, "rb").read()
+    assert len(raw) == 64 + sum(map(len, frames)) + 8 * 10 and raw[:8] == b"HAPSEQ1\0"
+    # every frame stored exactly as written: the reference inspectors read them straight from the file image
+    at = 64
+    for f in frames:
+        assert raw[at:at + len(f)] == f
+        at += len(f)
+
+    def opens(data):
+        bad = str(tmp_path / "bad.hapseq")
+        open(bad, "wb").write(data)
+        try:
+            hap.SequenceReader(bad).close()
+            return True
+        except OSError:
+            return False
+    assert opens(raw)
+    assert not opens(raw[:40]) and not opens(b"NOTASEQ\0" + raw[8:]) and not opens(raw[:-8])       # short / magic / index cut
+    patched = bytearray(raw)
+    patched[32:40] = (len(raw) + 1).to_bytes(8, "little")                                               # index beyond the file
+    assert not opens(bytes(patched))
+    patched = bytearray(raw)
+    idx = int.from_bytes(raw[32:40], "little")
+    patched[idx + 8:idx + 16] = (10).to_bytes(8, "little")                                              # offsets out of order
+    assert not opens(bytes(patched))
+    with pytest.raises(OSError):
+        hap.SequenceReader(str(tmp_path / "missing.hapseq"))
+    with hap.SequenceWriter(str(tmp_path / "empty.hapseq")) as w:
+        pass
+    e = hap.SequenceReader(str(tmp_path / "empty.hapseq"))
+    assert e.frame_count == 0 and e.read(0, 1)[0] == hap.HapResult.Bad_Arguments
 
 
 def _checkers():

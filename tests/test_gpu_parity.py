@@ -845,3 +845,52 @@ def test_coarse_matches_flag_round_trips(ctx, hap, fmt):
             at = frame.find(bytes([0x46, 1, 13]))        # section type, version, log2(8 KiB)
             assert at > 0 and frame[at + 3] == (2 if flags & hap.ENCODE_COARSE_MATCHES else 1)
     assert sizes[hap.ENCODE_FRAGMENT_INDEX | hap.ENCODE_COARSE_MATCHES] < 1.25 * sizes[hap.ENCODE_FRAGMENT_INDEX]
+
+
+# ------------------------------------------------ frame sequences from storage --
+@pytest.mark.parametrize("batch", [0, 1, 3, 16])
+def test_decode_sequence_from_file_matches_frame_by_frame(ctx, hap, tmp_path, batch):
+    """hap_sequence.h: frames written to a sequence file come back through the double-buffered
+    disk -> pinned memory -> GPU pipeline exactly as HapDecode returns them one at a time."""
+    w, h, n = 256, 128, 11
+    texs, frames = [], []
+    path = str(tmp_path / "clip.hapseq")
+    with hap.SequenceWriter(path, w, h) as writer:
+        for i in range(n):
+            img = D.rgba(w, h, frame=i)
+            tex = D.oracle_bc_encode(img, L.FMT_YCOCG)
+            # every other frame from the CPU checker (no fragment table), the rest from the GPU encoder
+            if i % 2:
+                frame = ORA.encode([tex], [L.FMT_YCOCG], [1], [4])[1]
+            else:
+                out = np.zeros(hap.HapMaxEncodedLength([len(tex)], [L.FMT_YCOCG], [4]) + 4096, dtype=np.uint8)
+                r, used, _res = ctx.encode_frames_rgba([img], w, h, w * 4, [L.FMT_YCOCG], [1], [4], [out], flags=hap.ENCODE_FRAGMENT_INDEX)
+                assert r == 0
+                frame = out[: used[0]].tobytes()
+            assert writer.append(frame) == 0
+            texs.append(tex)
+            frames.append(frame)
+    reader = hap.SequenceReader(path)
+    assert reader.frame_count == n and reader.read(0, n) == (0, frames)
+    # device outputs
+    outs = [torch.zeros(len(texs[0]), dtype=torch.uint8, device="cuda") for _ in range(n)]
+    torch.cuda.synchronize()
+    r, used, fmts, res = ctx.decode_sequence(reader, 0, n, 0, outs, batch=batch)
+    assert (r, used, fmts, res) == (0, [len(texs[0])] * n, [L.FMT_YCOCG] * n, [0] * n)
+    for o, t in zip(outs, texs):
+        assert o.cpu().numpy().tobytes() == t
+    # host outputs, a sub-range
+    houts = [np.zeros(len(texs[0]), dtype=np.uint8) for _ in range(4)]
+    r, used, fmts, res = ctx.decode_sequence(reader, 5, 4, 0, houts, batch=batch)
+    assert r == 0 and res == [0] * 4 and [o.tobytes() for o in houts] == texs[5:9]
+    # errors: range outside the file, a frame that is damaged on disk
+    assert ctx.decode_sequence(reader, n, 1, 0, houts[:1])[0] == hap.HapResult.Bad_Arguments
+    reader.close()
+    raw = bytearray(open(path, "rb").read())
+    at = 64 + sum(len(f) for f in frames[:2])
+    raw[at + 3] = 0x77                                   # frame 2: unknown section type
+    open(path, "wb").write(bytes(raw))
+    reader = hap.SequenceReader(path)
+    r, used, fmts, res = ctx.decode_sequence(reader, 0, 5, 0, outs[:5], batch=batch)
+    assert r == hap.HapResult.Bad_Frame and res == [0, 0, hap.HapResult.Bad_Frame, 0, 0]
+    reader.close()
