@@ -86,6 +86,10 @@ def main():
     frames = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(nf)]
     dec = [[torch.empty(tb, dtype=torch.uint8, device=dev) for _ in range(nf)] for tb in tex_bytes]
     comps = [1] * len(fmts)
+    # the buffers stay where they are for the whole run: resolve their addresses once, as a C client would
+    rgba = hap_amd.BufferList(rgba)
+    frames = hap_amd.BufferList(frames)
+    dec = [hap_amd.BufferList(d) for d in dec]
     torch.cuda.synchronize()
 
     used_box = [None]

@@ -212,6 +212,22 @@ class SequenceReader:
         self.close()
 
 
+class BufferList:
+    """A list of buffers whose addresses and sizes are looked up once: pass it wherever the batched calls take
+    a list of buffers that stay in place from call to call (a C client simply keeps its pointer array)."""
+
+    def __init__(self, buffers):
+        self.buffers = list(buffers)
+        self.infos = [_addr_len(b) for b in self.buffers]
+        self.pointers = (C.c_void_p * len(self.buffers))(*[i[0] for i in self.infos])
+
+    def __len__(self):
+        return len(self.buffers)
+
+    def __getitem__(self, i):
+        return self.buffers[i]
+
+
 class Context:
     """HapGpuContext: device + stream + scratch (include/hap_gpu.h)."""
 
@@ -284,6 +300,8 @@ class Context:
 
     @staticmethod
     def _ptr_array(bufs):
+        if isinstance(bufs, BufferList):          # addresses resolved once, reused call after call
+            return bufs.pointers, bufs.infos
         infos = [_addr_len(b) for b in bufs]
         return (C.c_void_p * len(bufs))(*[i[0] for i in infos]), infos
 
