@@ -511,8 +511,15 @@ __global__ __launch_bounds__(64) void snappy_decode_kernel(const HapGpuDecodeUni
 // Same results and failure semantics as the serial kernel: any malformed element, bad offset or
 // length mismatch fails the unit.  Used for FRAGMENT units (output never wraps the ring).
 
-constexpr unsigned kOwnerBytes = 1024;      // output bytes handled per window pass
-constexpr unsigned kFragmentTail = 2048u /* kInBytes */ + kOwnerBytes + 64u;   // LDS of the v2 kernel beyond its ring
+#ifndef HAP_V2_IN_BYTES
+#define HAP_V2_IN_BYTES 1024
+#endif
+#ifndef HAP_V2_OWNER_BYTES
+#define HAP_V2_OWNER_BYTES 512
+#endif
+constexpr unsigned kV2InBytes = HAP_V2_IN_BYTES, kV2InGranule = kV2InBytes / 2u;   // staged input: two granules
+constexpr unsigned kOwnerBytes = HAP_V2_OWNER_BYTES;      // output bytes handled per window pass
+constexpr unsigned kFragmentTail = kV2InBytes + kOwnerBytes + 64u;   // LDS of the v2 kernel beyond its ring
 
 __device__ __forceinline__ int dpp_row_shr(int identity, int v, int n)
 {
@@ -568,7 +575,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
     uint8_t *const smem = kStaticLds ? static_lds : dynamic_lds;
     uint8_t *ring = smem;                                          // [0, RING): output
     uint32_t *inw = reinterpret_cast<uint32_t *>(smem + RING);     // [RING, RING+2048): staged input
-    uint8_t *owner = smem + RING + kInBytes;                       // [.., +1024+64): owner map
+    uint8_t *owner = smem + RING + kV2InBytes;                       // [.., +1024+64): owner map
     const unsigned lane = threadIdx.x;
     if (blockIdx.x >= unit_count)
         return;
@@ -596,9 +603,11 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
     const unsigned out_len = u.dst_len;
 
     auto load_granule = [&](unsigned g) -> uint4 {
-        const unsigned x = g * kInGranule + lane * 16u;
+        const unsigned x = g * kV2InGranule + lane * 16u;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (x >= shift && x + 16u <= in_end) {
+        if (lane * 16u >= kV2InGranule) {
+            // (granules smaller than 64 x 16 bytes: the upper lanes have nothing to fetch)
+        } else if (x >= shift && x + 16u <= in_end) {
             v = *reinterpret_cast<const uint4 *>(src_al + x);
         } else if (x + 16u > shift && x < in_end) {
             unsigned w[4] = {0, 0, 0, 0};
@@ -612,14 +621,15 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
         return v;
     };
     auto store_granule = [&](unsigned g, uint4 v) {
-        *reinterpret_cast<uint4 *>(smem + RING + ((g & 1u) * kInGranule) + lane * 16u) = v;
+        if (lane * 16u < kV2InGranule)
+            *reinterpret_cast<uint4 *>(smem + RING + ((g & 1u) * kV2InGranule) + lane * 16u) = v;
     };
 
     unsigned ip = shift;
-    const unsigned granules = (in_end + kInGranule - 1) / kInGranule;
+    const unsigned granules = (in_end + kV2InGranule - 1) / kV2InGranule;
     store_granule(0, load_granule(0));
     store_granule(1, load_granule(1));
-    unsigned next_g = 2, in_hi = 2 * kInGranule;
+    unsigned next_g = 2, in_hi = 2 * kV2InGranule;
     uint4 pend = make_uint4(0, 0, 0, 0);
     bool pend_valid = false;
     __syncthreads();
@@ -630,7 +640,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
         // skip the length prefix (validated by the plan kernel)
         unsigned b;
         do {
-            b = smem[RING + (ip & (kInBytes - 1))];
+            b = smem[RING + (ip & (kV2InBytes - 1))];
             ip++;
         } while ((b & 0x80u) && ip < in_end);
         ip = uniform(ip);
@@ -638,12 +648,12 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
 
     while (!failed && ip < in_end) {
         // ---- staging window: keep >= 384 bytes ahead of ip (a window's last element may be a 256-byte literal) ----
-        if (!pend_valid && next_g < granules && ip + 3 * (kInGranule / 2) >= in_hi) {
+        if (!pend_valid && next_g < granules && ip + 3 * (kV2InGranule / 2) >= in_hi) {
             pend = load_granule(next_g);
             pend_valid = true;
         }
-        if (ip + 384u > in_hi && in_hi < granules * kInGranule) {
-            const unsigned g = ip / kInGranule;
+        if (ip + 384u > in_hi && in_hi < granules * kV2InGranule) {
+            const unsigned g = ip / kV2InGranule;
             if (g + 1 == next_g) {
                 store_granule(next_g, pend_valid ? pend : load_granule(next_g));
                 next_g += 1;
@@ -653,14 +663,14 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
                 next_g = g + 2;
             }
             pend_valid = false;
-            in_hi = next_g * kInGranule;
+            in_hi = next_g * kV2InGranule;
             __syncthreads();
         }
 
         // ---- 1. speculative parse: the element that would start at coordinate ip + lane ----
         const unsigned x = ip + lane;
         const unsigned wi = x >> 2, sh = x & 3u;
-        const unsigned w0 = inw[wi & 511u], w1 = inw[(wi + 1) & 511u];
+        const unsigned w0 = inw[wi & (kV2InBytes / 4u - 1u)], w1 = inw[(wi + 1) & (kV2InBytes / 4u - 1u)];
         const unsigned lo = __builtin_amdgcn_alignbyte(w1, w0, sh);       // bytes x .. x+3
         const unsigned hi = (w1 >> (8u * sh)) & 0xFFu;                     // byte x+4 (copy-4 / 4 length bytes)
         const unsigned tag = lo & 0xFFu, kind = tag & 3u;
@@ -735,7 +745,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
                 const bool staged = ip + done + n <= in_hi;
                 if (lane < n) {
                     const unsigned y = ip + done + lane;
-                    ring[(op + lane) & (RING - 1)] = staged ? smem[RING + (y & (kInBytes - 1))] : src_al[y];
+                    ring[(op + lane) & (RING - 1)] = staged ? smem[RING + (y & (kV2InBytes - 1))] : src_al[y];
                 }
                 op += n;
                 if (STREAM && op - flushed >= 2 * kSegment) {
@@ -793,7 +803,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
             const bool lit = ((g0 >> 20) & 1u) != 0;
             unsigned desc;                       // bit 31: resolved (LDS byte address), else output position
             if (lit) {
-                desc = 0x80000000u | (GRAN >= 2 ? 0x40000000u : 0u) | (RING + ((g1 + GRAN * rel) & (kInBytes - 1)));
+                desc = 0x80000000u | (GRAN >= 2 ? 0x40000000u : 0u) | (RING + ((g1 + GRAN * rel) & (kV2InBytes - 1)));
             } else {
                 unsigned r = rel;
                 const unsigned offu = g2 / GRAN;
@@ -826,14 +836,14 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
             unsigned value = far ? 0u : (unsigned)smem[a0];
             if (GRAN == 2) {
                 // second byte: literals live in the 2 KiB staging ring (may wrap), copies are contiguous
-                const unsigned a1 = (desc & 0x40000000u) ? RING + ((a0 - RING + 1u) & (kInBytes - 1)) : a0 + 1u;
+                const unsigned a1 = (desc & 0x40000000u) ? RING + ((a0 - RING + 1u) & (kV2InBytes - 1)) : a0 + 1u;
                 value |= (unsigned)smem[a1] << 8;
             }
             if (GRAN == 4) {
                 // literals: 4 bytes at any byte position of the staging ring (two dwords + byte align);
                 // copies: one aligned dword of the output ring
                 const unsigned xs = a0 - RING;
-                const unsigned w0 = inw[(xs >> 2) & 511u], w1 = inw[((xs >> 2) + 1u) & 511u];
+                const unsigned w0 = inw[(xs >> 2) & (kV2InBytes / 4u - 1u)], w1 = inw[((xs >> 2) + 1u) & (kV2InBytes / 4u - 1u)];
                 const unsigned lit4 = __builtin_amdgcn_alignbyte(w1, w0, xs & 3u);
                 const unsigned cpy4 = *reinterpret_cast<const uint32_t *>(smem + ((desc & 0x40000000u) ? 0u : a0));
                 value = (desc & 0x40000000u) ? lit4 : cpy4;
@@ -908,7 +918,7 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
         static unsigned ring_log2 = 15;
         if (!once) {
             (void)hipFuncSetAttribute((const void *)snappy_decode_kernel<65536u, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes);
-            (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, true, 1u>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes + kOwnerBytes + 64);
+            (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, true, 1u>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kFragmentTail);
             const char *e = getenv("HAP_AMD_STREAM_RING_LOG2");
             if (e && atoi(e) >= 14 && atoi(e) <= 16)
                 ring_log2 = (unsigned)atoi(e);
@@ -927,9 +937,9 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
     static bool once16 = false;
     if (!once16 && frag_log2 == 16) {
         (void)hipFuncSetAttribute((const void *)snappy_decode_kernel<65536u, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes);
-        (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, false, 1u>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes + kOwnerBytes + 64);
-        (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, false, 2u>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes + kOwnerBytes + 64);
-        (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, false, 4u>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes + kOwnerBytes + 64);
+        (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, false, 1u>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kFragmentTail);
+        (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, false, 2u>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kFragmentTail);
+        (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, false, 4u>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kFragmentTail);
         once16 = true;
     }
 #define HAP_LAUNCH_FRAGMENT(RINGBYTES)                                                                                          \
