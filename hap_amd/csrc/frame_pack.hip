@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
                         itab[4] = (uint8_t)HAP_FRAGMENT_TABLE_VERSION;
                         itab[5] = (uint8_t)frag_log2;
                         itab[6] = (uint8_t)tex.reserved;          // granularity_log2 of the element streams
-                        itab[7] = 0;
+                        itab[7] = (uint8_t)(tex.reserved >> 8);   // match window in 256-byte units, 0 = whole fragment
                     }
                 }
                 // pass 2: positions, tables, moves

@@ -263,7 +263,15 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
                 te->frags_per_chunk = g[i].fpc;
                 te->frag_first = k * frags_per_frame + (i ? g[0].chunk_count * g[0].fpc : 0u);
                 te->emit_index = (flags & HAPGPU_ENCODE_FRAGMENT_INDEX) ? 1u : 0u;
-                te->reserved = g[i].gran_log2;
+                /* 8 KiB fragments keep hash matches within 3 KiB so that the decoder can halve its ring -- except for
+                   small textures, whose block rows are short enough for the row above to lie inside the fragment
+                   (rows of up to ~5 KiB: below 1080p for 16-byte blocks, below 4K for 8-byte blocks) */
+                {
+                    const int small_blocks = g[i].format == HapTextureFormat_RGB_DXT1 || g[i].format == HapTextureFormat_A_RGTC1;
+                    const int windowed = frag_log2 == 13u && !ctx->compress_v1 &&
+                                         g[i].bytes >= (small_blocks ? ((size_t)2u << 20) : ((size_t)1u << 20));
+                    te->reserved = g[i].gran_log2 | (windowed ? (HAP_FRAGMENT_WINDOW_256 << 8) : 0u);
+                }
             }
         }
         rc |= (unsigned)hapgpu_rt_h2d(rt, dframes, hframes, sizeof(HapGpuFrameEnc) * live);
@@ -732,8 +740,13 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                     job->frag_sizes = (uint64_t)(uintptr_t)(frame_dev + p->frag_table_offset);
                     job->frag_log2 = p->frag_log2;
                     job->frag_entries = p->frag_entries;
-                    job->reserved = p->frag_gran_log2;
-                    frag_kinds |= 1u << p->frag_gran_log2;
+                    job->reserved = p->frag_gran_log2 | (p->frag_window256 << 8);
+                    /* bits 0..2: plain fragment kernels needed, bits 4..6: windowed ones (8 KiB fragments whose
+                       table promises offsets of at most 3 KiB) */
+                    if (p->frag_log2 == 13u && p->frag_window256 != 0 && p->frag_window256 <= HAP_FRAGMENT_WINDOW_256)
+                        frag_kinds |= 16u << p->frag_gran_log2;
+                    else
+                        frag_kinds |= 1u << p->frag_gran_log2;
                 }
                 if (p->chunk_count > 0)
                     memcpy(hchunks + chunk_cursor, p->chunks, sizeof(HapGpuChunkIn) * (size_t)p->chunk_count);

@@ -13,6 +13,7 @@ struct HapGpuContext {
     hapgpu_rt *rt;
     unsigned frag_log2;
     unsigned byte_granular;   /* HAP_AMD_BYTE_GRANULAR=1: never emit 16-bit granular element streams */
+    unsigned compress_v1;     /* HAP_AMD_COMPRESS_V1: the first-generation compressor (no match window) */
 };
 
 /* inputs_are_device != 0: every input pointer is known to be device memory (skips classification) */

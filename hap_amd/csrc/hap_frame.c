@@ -257,6 +257,7 @@ static void plan_complex(hapf_reader *r, hapf_texture_plan *plan, int want_chunk
         body[frags] == HAP_FRAGMENT_TABLE_VERSION && body[frags + 1] >= 10 && body[frags + 1] <= 16) {
         plan->frag_log2 = body[frags + 1];
         plan->frag_gran_log2 = body[frags + 2] <= 2 ? body[frags + 2] : 0u;
+        plan->frag_window256 = body[frags + 3];
         plan->frag_entries = (frag_bytes - 4u) / 4u;
         plan->frag_table_offset = plan->section_offset + box.header_len + (uint64_t)frags + 4u;
     }

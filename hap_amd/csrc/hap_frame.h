@@ -48,6 +48,7 @@ typedef struct hapf_texture_plan {
     uint32_t frag_entries;
     uint32_t frag_log2;
     uint32_t frag_gran_log2;/* 1: the table promises 16-bit granular element streams */
+    uint32_t frag_window256;/* copy offsets never exceed this many 256-byte units (0: no promise) */
     unsigned unit_count;    /* filled by the batch layer: GPU work units reserved for this texture */
 } hapf_texture_plan;
 

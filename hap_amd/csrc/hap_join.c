@@ -23,7 +23,7 @@ typedef struct joined_texture {
     unsigned chunk_count;
     int all_raw;
     int keep_index;           /* every group brought a compatible fragment table */
-    unsigned frag_log2, frag_gran_log2, frags_per_chunk;
+    unsigned frag_log2, frag_gran_log2, frag_window256, frags_per_chunk;
     uint64_t payload;         /* stored bytes of all chunks */
     uint64_t body;            /* section length, header excluded */
     unsigned header_len;
@@ -117,11 +117,16 @@ unsigned int HapGpuJoinChunkGroups(unsigned int groupCount, const void *const *g
                     j->frags_per_chunk = per_chunk;
                     j->frag_log2 = p->frag_log2;
                     j->frag_gran_log2 = p->frag_gran_log2;
+                    j->frag_window256 = p->frag_window256;
                 } else if (per_chunk != j->frags_per_chunk || p->frag_log2 != j->frag_log2) {
                     j->keep_index = 0;
                 }
                 if (p->frag_gran_log2 < j->frag_gran_log2)
                     j->frag_gran_log2 = p->frag_gran_log2;   /* the weakest promise holds for all */
+                if (p->frag_window256 == 0 || j->frag_window256 == 0)
+                    j->frag_window256 = 0;                   /* someone makes no promise: none for the whole */
+                else if (p->frag_window256 > j->frag_window256)
+                    j->frag_window256 = p->frag_window256;
             }
         }
         if (j->frags_per_chunk == 0)
@@ -178,7 +183,7 @@ unsigned int HapGpuJoinChunkGroups(unsigned int groupCount, const void *const *g
                 isec[4] = (uint8_t)HAP_FRAGMENT_TABLE_VERSION;
                 isec[5] = (uint8_t)j->frag_log2;
                 isec[6] = (uint8_t)j->frag_gran_log2;
-                isec[7] = 0;
+                isec[7] = (uint8_t)j->frag_window256;
                 ftab = isec + 8u;
             }
             payload = sec + j->header_len + 4u + ilen;

@@ -46,7 +46,8 @@ typedef struct HapGpuTexEnc {
     uint32_t frags_per_chunk;
     uint32_t frag_first;     /* global index of this texture's first fragment */
     uint32_t emit_index;     /* write the fragment-size section */
-    uint32_t reserved;       /* granularity_log2 of the element stream: 0 = bytes, 1 = every position, offset
+    uint32_t reserved;       /* bits 8..15: match window in 256-byte units (0 = whole fragment); bits 0..7:
+                                granularity_log2 of the element stream: 0 = bytes, 1 = every position, offset
                                 and length even (lets the decoder move 16 bits per lane) */
 } HapGpuTexEnc;
 
@@ -103,7 +104,8 @@ typedef struct HapGpuDecodeJob {
     uint32_t frag_log2;
     uint32_t frag_entries;   /* number of fragment-size entries */
     uint32_t unit_count;
-    uint32_t reserved;       /* granularity_log2 announced by the fragment table (0 bytes, 1 16-bit, 2 32-bit) */
+    uint32_t reserved;       /* bits 0..7: granularity_log2 announced by the fragment table (0 bytes, 1 16-bit,
+                                2 32-bit); bits 8..15: its match window in 256-byte units (0 = none announced) */
     /* results */
     uint64_t bytes_used;
     uint32_t status;         /* HapResult or HAPGPU_STATUS_* */
@@ -116,6 +118,9 @@ typedef struct HapGpuDecodeJob {
 #define HAPGPU_UNIT_COPY 3u
 #define HAPGPU_UNIT_SNAPPY_FRAGMENT16 4u /* fragment whose elements are all 16-bit granular */
 #define HAPGPU_UNIT_SNAPPY_FRAGMENT32 5u /* ... all 32-bit granular */
+#define HAPGPU_UNIT_WINDOWED 0x10u       /* flag on the three fragment kinds: every copy offset is <= 3 KiB, so an 8 KiB
+                                            fragment decodes through a 4 KiB LDS ring (twice the waves per CU) */
+#define HAP_FRAGMENT_WINDOW_256 12u      /* that window in 256-byte units, as written to the fragment table */
 
 /* [device] one wavefront's worth of decode work */
 typedef struct HapGpuDecodeUnit {

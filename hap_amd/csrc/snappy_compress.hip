@@ -441,7 +441,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
     const unsigned tex_count = frames[blockIdx.z].tex_count;
     const unsigned x = blockIdx.x;
     // (one combined test, no short-circuit: every field is requested before the first wait)
-    if ((blockIdx.y >= tex_count) | (tex.compressor != 1u) | ((1u << tex.reserved) != GRAN) |
+    if ((blockIdx.y >= tex_count) | (tex.compressor != 1u) | ((1u << (tex.reserved & 0xFFu)) != GRAN) |
         (x >= tex.chunk_count * tex.frags_per_chunk) | (tex.src == 0) | (tex.chunk_bytes == 0))
         return;
     const unsigned chunk = x / tex.frags_per_chunk, j = x - chunk * tex.frags_per_chunk;
@@ -449,6 +449,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
     const unsigned n = min(frag_bytes, tex.chunk_bytes - begin);
     const uint8_t *src = (const uint8_t *)tex.src + (size_t)chunk * tex.chunk_bytes + begin;
     const unsigned f = tex.frag_first + x;
+    const unsigned window = (tex.reserved >> 8) ? (tex.reserved >> 8) * 256u : 0xFFFFFFFFu;
     uint8_t *out = slots + (size_t)f * slot_stride;
 
     if (((uintptr_t)src & 15u) == 0) {
@@ -572,7 +573,10 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
 #ifndef HAP_NO_HASH
                 // hash candidate: the first 16 bytes are compared at once, without branching
                 const unsigned c = table[h2[sub]];
-                const bool valid = __builtin_amdgcn_inverse_ballot_w64(mask4[sub]) && c < p && room2[sub] >= 4u;
+                // (a match window, when the texture asks for one, keeps hash candidates close: the decoder then
+                // needs only half a fragment of LDS)
+                const bool valid = __builtin_amdgcn_inverse_ballot_w64(mask4[sub]) && c < p && room2[sub] >= 4u &&
+                                   p - c <= window;
                 cand2[sub] = valid ? c : 0u;
                 const unsigned m = match16(dataw, cand2[sub], p);
                 if (valid && m >= 4u) {

@@ -178,8 +178,11 @@ __global__ __launch_bounds__(64) void decode_plan_kernel(HapGpuDecodeJob *jobs, 
                             w.dst = (uint64_t)(dst + my_off + (unsigned long long)k * frag_bytes);
                             w.src_len = fs[k];
                             w.dst_len = min(frag_bytes, out_len - k * frag_bytes);
-                            w.kind = job->reserved == 2 ? HAPGPU_UNIT_SNAPPY_FRAGMENT32
-                                   : job->reserved == 1 ? HAPGPU_UNIT_SNAPPY_FRAGMENT16 : HAPGPU_UNIT_SNAPPY_FRAGMENT;
+                            const unsigned gran = job->reserved & 0xFFu, window256 = (job->reserved >> 8) & 0xFFu;
+                            w.kind = gran == 2 ? HAPGPU_UNIT_SNAPPY_FRAGMENT32
+                                   : gran == 1 ? HAPGPU_UNIT_SNAPPY_FRAGMENT16 : HAPGPU_UNIT_SNAPPY_FRAGMENT;
+                            if (job->frag_log2 == 13u && window256 != 0 && window256 <= HAP_FRAGMENT_WINDOW_256)
+                                w.kind |= HAPGPU_UNIT_WINDOWED;
                             w.job = j;
                             u[k] = w;
                             at += fs[k];
@@ -311,8 +314,9 @@ __global__ __launch_bounds__(64) void snappy_decode_kernel(const HapGpuDecodeUni
             wave_copy((uint8_t *)u.dst, (const uint8_t *)u.src, u.src_len, lane);
         return;
     }
-    if ((u.kind == HAPGPU_UNIT_SNAPPY_FRAGMENT || u.kind == HAPGPU_UNIT_SNAPPY_FRAGMENT16 ||
-         u.kind == HAPGPU_UNIT_SNAPPY_FRAGMENT32) != FRAGMENT)
+    const unsigned plain_kind = u.kind & ~HAPGPU_UNIT_WINDOWED;       // (this kernel always holds whole fragments)
+    if ((plain_kind == HAPGPU_UNIT_SNAPPY_FRAGMENT || plain_kind == HAPGPU_UNIT_SNAPPY_FRAGMENT16 ||
+         plain_kind == HAPGPU_UNIT_SNAPPY_FRAGMENT32) != FRAGMENT)
         return;
 
     const uint8_t *src = (const uint8_t *)u.src;
@@ -563,7 +567,9 @@ __device__ __forceinline__ int lane_gather(int v, unsigned src_lane)
 
 // GRAN = 2: every element of the unit has even length and (copies) even offset, so one lane moves
 // 16 bits (FRAGMENT16 units, produced by hap_amd's 16-bit granular compressor).
-template <unsigned RING, bool STREAM, unsigned GRAN>
+// SLIDE: the unit is a fragment larger than the ring whose copies all stay within RING - 1 KiB (promised by the
+// fragment table, checked here): finished output leaves the ring in 1 KiB segments while decoding goes on.
+template <unsigned RING, bool STREAM, unsigned GRAN, bool SLIDE = false>
 __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpuDecodeUnit *__restrict__ units,
                                                                     unsigned unit_count, HapGpuDecodeJob *jobs)
 {
@@ -591,9 +597,13 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
         return;
     }
     if (STREAM ? u.kind != HAPGPU_UNIT_SNAPPY_STREAM
-               : u.kind != (GRAN == 4 ? HAPGPU_UNIT_SNAPPY_FRAGMENT32
-                                      : GRAN == 2 ? HAPGPU_UNIT_SNAPPY_FRAGMENT16 : HAPGPU_UNIT_SNAPPY_FRAGMENT))
+               : u.kind != ((GRAN == 4 ? HAPGPU_UNIT_SNAPPY_FRAGMENT32
+                                       : GRAN == 2 ? HAPGPU_UNIT_SNAPPY_FRAGMENT16 : HAPGPU_UNIT_SNAPPY_FRAGMENT) |
+                            (SLIDE ? HAPGPU_UNIT_WINDOWED : 0u)))
         return;
+    constexpr bool kFlushEarly = STREAM || SLIDE;
+    constexpr unsigned kFlushSegment = SLIDE ? 1024u : kSegment;
+    constexpr unsigned kFlushAt = SLIDE ? 1024u : 2u * kSegment;
 
     const uint8_t *src = (const uint8_t *)u.src;
     uint8_t *dst = (uint8_t *)u.dst;
@@ -634,7 +644,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
     bool pend_valid = false;
     __syncthreads();
 
-    bool failed = !STREAM && out_len > RING;
+    bool failed = !kFlushEarly && out_len > RING;
     unsigned op = 0, flushed = 0;
     if (STREAM) {
         // skip the length prefix (validated by the plan kernel)
@@ -748,8 +758,8 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
                     ring[(op + lane) & (RING - 1)] = staged ? smem[RING + (y & (kV2InBytes - 1))] : src_al[y];
                 }
                 op += n;
-                if (STREAM && op - flushed >= 2 * kSegment) {
-                    const unsigned upto = op & ~(kSegment - 1);
+                if (kFlushEarly && op - flushed >= kFlushAt) {
+                    const unsigned upto = op & ~(kFlushSegment - 1);
                     flush_ring<RING>(ring, dst, flushed, upto, lane);
                     flushed = upto;
                 }
@@ -769,8 +779,8 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
         const unsigned N = (unsigned)__builtin_amdgcn_readlane(incl, (int)last);
         const unsigned adv = last + (unsigned)__builtin_amdgcn_readlane((int)tokbytes, (int)last);
         // validity of every element of the pass
-        const bool bad = is_tok && ((kind != 0 && (off == 0 || off > op + o_t)) || len > out_len - op - o_t ||
-                                    o_t > out_len - op || ((len | off) & (GRAN - 1u)));
+        const bool bad = is_tok && ((kind != 0 && (off == 0 || off > op + o_t || (SLIDE && off > RING - 1024u))) ||
+                                    len > out_len - op - o_t || o_t > out_len - op || ((len | off) & (GRAN - 1u)));
         if (__ballot(bad) != 0) { failed = true; break; }
 
         // ---- 4. owner map + per-byte production ----
@@ -872,8 +882,8 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
         }
         op += N;
         ip += adv;
-        if (STREAM && op - flushed >= 2 * kSegment) {
-            const unsigned upto = op & ~(kSegment - 1);
+        if (kFlushEarly && op - flushed >= kFlushAt) {
+            const unsigned upto = op & ~(kFlushSegment - 1);
             flush_ring<RING>(ring, dst, flushed, upto, lane);
             flushed = upto;
         }
@@ -959,6 +969,15 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
                                    fragment_dynamic_lds(RINGBYTES), stream, units, unit_count, jobs);                       \
         }                                                                                                                       \
     } while (0)
+    // 8 KiB fragments whose table promises a 3 KiB match window: 4 KiB ring, twice the waves per CU
+    if (!use_v1 && frag_log2 == 13u) {
+        if (fragment_kinds & 16u)
+            hipLaunchKernelGGL((snappy_decode_fragment_kernel<4096u, false, 1u, true>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs);
+        if (fragment_kinds & 32u)
+            hipLaunchKernelGGL((snappy_decode_fragment_kernel<4096u, false, 2u, true>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs);
+        if (fragment_kinds & 64u)
+            hipLaunchKernelGGL((snappy_decode_fragment_kernel<4096u, false, 4u, true>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs);
+    }
     switch (frag_log2) {
     case 0: break;
     case 10: case 11: case 12: case 13: HAP_LAUNCH_FRAGMENT(8192u); break;

@@ -702,7 +702,7 @@ def test_byte_granular_streams_and_a_lying_table(hap):
     assert (r, res) == (0, [0])
     frame = bytearray(out[: used[0]].tobytes())
     pos = frame.find(bytes([0x46, 1, 13, 0, 0]), 0, 200)
-    assert pos > 0                                           # granularity byte 0 = bytes
+    assert pos > 0                                           # granularity byte 0 = bytes (small texture: no match window)
     assert ORA.decode(bytes(frame), 0, len(tex)) == (0, tex, L.FMT_YCOCG)
     assert hap.HapDecode(bytes(frame), 0, outputBufferBytes=len(tex)) == (0, tex, L.FMT_YCOCG)
     frame[pos + 3] = 1                                       # claim 16-bit granularity (false: odd lengths exist)
@@ -894,3 +894,50 @@ def test_decode_sequence_from_file_matches_frame_by_frame(ctx, hap, tmp_path, ba
     r, used, fmts, res = ctx.decode_sequence(reader, 0, 5, 0, outs[:5], batch=batch)
     assert r == hap.HapResult.Bad_Frame and res == [0, 0, hap.HapResult.Bad_Frame, 0, 0]
     reader.close()
+
+
+def test_match_window_promise_is_checked_and_optional(ctx, hap):
+    """8 KiB fragments announce a 3 KiB match window (table byte 7) so that the decoder can run them through a
+    4 KiB ring.  Frames without the promise (older files, joined frames of mixed origin) take the full-size ring;
+    a frame whose promise is a lie (a hand-made far copy) is detected and decoded the generic way."""
+    tex = D.stream_bytes(16 * 64 * 1024, "mixed", seed=41)          # 1 MiB: large enough for the window to be used
+    out = np.zeros(hap.HapMaxEncodedLength([len(tex)], [L.FMT_YCOCG], [2]) + 4096, dtype=np.uint8)
+    r, used, res = ctx.encode_frames([[tex]], [L.FMT_YCOCG], [1], [2], [out], flags=hap.ENCODE_FRAGMENT_INDEX)
+    assert r == 0
+    frame = bytearray(out[: used[0]].tobytes())
+    at = frame.find(bytes([0x46, 1, 13, 1, 12]))
+    assert at > 0
+    assert hap.HapDecode(bytes(frame), 0, outputBufferBytes=len(tex)) == (0, tex, L.FMT_YCOCG)
+    for name, api in CHECKERS:
+        assert api.decode(bytes(frame), 0, len(tex)) == (0, tex, L.FMT_YCOCG), name
+    # no promise: same bytes, whole-fragment ring
+    plain = bytearray(frame)
+    plain[at + 4] = 0
+    assert hap.HapDecode(bytes(plain), 0, outputBufferBytes=len(tex)) == (0, tex, L.FMT_YCOCG)
+    # a tighter promise than the streams keep (1 x 256 bytes is certainly violated by hash matches or is harmless):
+    tight = bytearray(frame)
+    tight[at + 4] = 1
+    assert hap.HapDecode(bytes(tight), 0, outputBufferBytes=len(tex)) == (0, tex, L.FMT_YCOCG)
+    # small textures keep the whole fragment as their window (their block rows are short enough to matter)
+    small = tex[: 16 * 64 * 96]
+    r, used, res = ctx.encode_frames([[small]], [L.FMT_YCOCG], [1], [2], [out], flags=hap.ENCODE_FRAGMENT_INDEX)
+    assert r == 0 and out[: used[0]].tobytes().find(bytes([0x46, 1, 13, 1, 0])) > 0
+    assert hap.HapDecode(out[: used[0]].tobytes(), 0, outputBufferBytes=len(small)) == (0, small, L.FMT_YCOCG)
+    # a hand-made fragment whose copy reaches 6 KiB back, filed under a table that promises 3 KiB
+    lit = bytes(range(256)) * 24                                     # 6144 literal bytes
+    def literal(b):
+        return bytes([61 << 2]) + (len(b) - 1).to_bytes(2, "little") + b
+    stream = literal(lit) + literal(bytes(2048 - 64)) + bytes([2 | (63 << 2)]) + (6144 + 2048 - 64).to_bytes(2, "little")
+    want = lit + bytes(2048 - 64) + lit[:64]
+    assert len(want) == 8192
+    chunk = bytes([0x80, 0x40]) + stream                            # varint 8192
+    tables = bytes([1, 0, 0, 2, 0x0B]) + bytes([4, 0, 0, 3]) + len(chunk).to_bytes(4, "little") + \
+        bytes([8, 0, 0, 0x46, 1, 13, 0, 12]) + len(stream).to_bytes(4, "little")
+    body = len(tables).to_bytes(3, "little") + bytes([1]) + tables + chunk
+    lying = len(body).to_bytes(3, "little") + bytes([0xCE]) + body
+    for name, api in CHECKERS:
+        assert api.decode(lying, 0, 8192) == (0, want, L.FMT_DXT5), name
+    assert hap.HapDecode(lying, 0, outputBufferBytes=8192) == (0, want, L.FMT_DXT5)
+    honest = bytearray(lying)
+    honest[honest.find(bytes([0x46, 1, 13, 0, 12])) + 4] = 0
+    assert hap.HapDecode(bytes(honest), 0, outputBufferBytes=8192) == (0, want, L.FMT_DXT5)

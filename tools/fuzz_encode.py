@@ -18,6 +18,8 @@ fails = 0
 t0 = time.time()
 for it in range(N):
     n = int(rng.integers(1, 300000)) if it % 3 else int(rng.integers(1, 3000))
+    if it % 10 == 7:                       # large textures: 8 KiB fragments with the 3 KiB match window
+        n = 16 * int(rng.integers(65536, 140000))
     kind = ["zero", "random", "mixed", "runs"][int(rng.integers(0, 4))]
     tex = bytearray(D.stream_bytes(n, kind, seed=it))
     if rng.integers(0, 2):                 # sprinkle noise / structure breaks
