@@ -183,8 +183,8 @@ def main():
         "decode_plan": None,
         "snappy_decode": nf * (frame_bytes * (tex_bytes[0] / bsum) + tex_bytes[0]) if len(fmts) == 1 else None,
     }
-    bc_bytes = sum(blocks * (64 + BLOCK_BYTES[f]) for f in fmts) / len(fmts)
-    algo["block_encode"] = bc_bytes
+    # block encode: one launch per texture format over the whole batch
+    algo["block_encode"] = nf * sum(blocks * (64 + BLOCK_BYTES[f]) for f in fmts) / len(fmts)
     if len(fmts) > 1:
         algo["snappy_decode"] = nf * (frame_bytes + bsum) / len(fmts)
     kernels = {}

@@ -218,15 +218,13 @@ __device__ __forceinline__ uint2 ycocg_colour_block(const int (&co)[16], const i
 }
 
 template <int FMT, bool WIDE>
-__global__ __launch_bounds__(64) void bc_encode_kernel(const uint8_t *__restrict__ rgba, size_t row_bytes,
-                                                       unsigned blocks_x, unsigned blocks_total,
-                                                       uint8_t *__restrict__ out)
+__device__ __forceinline__ void encode_block(const uint8_t *__restrict__ rgba, size_t row_bytes, unsigned blocks_x,
+                                             uint8_t *__restrict__ out)
 {
     // one wavefront per 64 blocks of one block row: the row's address is scalar, no division per lane
     const unsigned by = blockIdx.y, bx = blockIdx.x * 64u + threadIdx.x;
     if (bx >= blocks_x)
         return;
-    (void)blocks_total;
     const size_t id = (size_t)by * blocks_x + bx;
     const uint8_t *src = rgba + (size_t)(4u * by) * row_bytes + 16u * bx;
     unsigned p[16];
@@ -278,6 +276,39 @@ __global__ __launch_bounds__(64) void bc_encode_kernel(const uint8_t *__restrict
     }
 }
 
+template <int FMT, bool WIDE>
+__global__ __launch_bounds__(64) void bc_encode_kernel(const uint8_t *__restrict__ rgba, size_t row_bytes,
+                                                       unsigned blocks_x, unsigned blocks_total,
+                                                       uint8_t *__restrict__ out)
+{
+    (void)blocks_total;
+    encode_block<FMT, WIDE>(rgba, row_bytes, blocks_x, out);
+}
+
+// a batch of equally sized pictures in one launch: picture blockIdx.z, addresses from device arrays
+template <int FMT, bool WIDE>
+__global__ __launch_bounds__(64) void bc_encode_batch_kernel(const uint64_t *__restrict__ sources,
+                                                             const uint64_t *__restrict__ outputs, size_t row_bytes,
+                                                             unsigned blocks_x)
+{
+    const uint8_t *rgba = (const uint8_t *)sources[blockIdx.z];
+    uint8_t *out = (uint8_t *)outputs[blockIdx.z];
+    if (!rgba || !out)
+        return;
+    encode_block<FMT, WIDE>(rgba, row_bytes, blocks_x, out);
+}
+
+template <int FMT>
+void launch_batch(const uint64_t *sources, const uint64_t *outputs, unsigned pictures, size_t row_bytes, unsigned bx,
+                  unsigned by, bool wide, hipStream_t stream)
+{
+    const dim3 grid((bx + 63u) / 64u, by, pictures), block(64);
+    if (wide)
+        hipLaunchKernelGGL((bc_encode_batch_kernel<FMT, true>), grid, block, 0, stream, sources, outputs, row_bytes, bx);
+    else
+        hipLaunchKernelGGL((bc_encode_batch_kernel<FMT, false>), grid, block, 0, stream, sources, outputs, row_bytes, bx);
+}
+
 template <int FMT>
 void launch(const void *rgba, size_t row_bytes, unsigned bx, unsigned by, void *out, bool wide, hipStream_t stream)
 {
@@ -308,6 +339,26 @@ extern "C" int hapgpu_launch_block_encode(const void *rgba, unsigned width, unsi
     case 0x83F3: if ((uintptr_t)out & 15u) return 1; launch<kFmtDXT5>(rgba, row_bytes, bx, by, out, wide, stream); break;
     case 0x01: if ((uintptr_t)out & 15u) return 1; launch<kFmtYCoCg>(rgba, row_bytes, bx, by, out, wide, stream); break;
     case 0x8DBB: if ((uintptr_t)out & 7u) return 1; launch<kFmtRGTC1>(rgba, row_bytes, bx, by, out, wide, stream); break;
+    default: return 1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}
+
+// Batch variant: `pictures` RGBA images of the same geometry whose addresses (and output addresses) are in device
+// arrays; wide != 0 promises 16-byte aligned sources and row pitch.  Outputs must be 8/16-byte aligned.
+extern "C" int hapgpu_launch_block_encode_batch(const uint64_t *sources, const uint64_t *outputs, unsigned pictures,
+                                                unsigned width, unsigned height, size_t row_bytes, unsigned format,
+                                                int wide, hipStream_t stream)
+{
+    if (!sources || !outputs || pictures == 0 || width == 0 || height == 0 || (width & 3u) || (height & 3u) ||
+        row_bytes < (size_t)width * 4u || (row_bytes & 3u) || pictures > 65535u || height / 4u > 65535u)
+        return 1;
+    const unsigned bx = width / 4u, by = height / 4u;
+    switch (format) {
+    case 0x83F0: launch_batch<kFmtDXT1>(sources, outputs, pictures, row_bytes, bx, by, wide != 0, stream); break;
+    case 0x83F3: launch_batch<kFmtDXT5>(sources, outputs, pictures, row_bytes, bx, by, wide != 0, stream); break;
+    case 0x01: launch_batch<kFmtYCoCg>(sources, outputs, pictures, row_bytes, bx, by, wide != 0, stream); break;
+    case 0x8DBB: launch_batch<kFmtRGTC1>(sources, outputs, pictures, row_bytes, bx, by, wide != 0, stream); break;
     default: return 1;
     }
     return hipGetLastError() == hipSuccess ? 0 : 4;

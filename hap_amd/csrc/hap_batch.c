@@ -19,9 +19,9 @@
 
 enum {
     D_FRAMES = 0, D_SLOTS, D_FRAGSIZES, D_COPIES, D_TEX_STAGE, D_FRAME_STAGE, D_BC_TEX, D_RGBA_STAGE,
-    D_JOBS, D_CHUNKS, D_UNITS, D_IN_STAGE, D_OUT_STAGE, D_PTRS, D_PREFIX
+    D_JOBS, D_CHUNKS, D_UNITS, D_IN_STAGE, D_OUT_STAGE, D_PTRS, D_PREFIX, D_BC_PTRS
 };
-enum { P_FRAMES = 0, P_JOBS, P_CHUNKS, P_PREFIX, P_PTRS };
+enum { P_FRAMES = 0, P_JOBS, P_CHUNKS, P_PREFIX, P_PTRS, P_BC_PTRS };   /* (8, 9: hap_sequence.c) */
 
 #define PREFIX_BYTES 65536u
 #define COPY_PIECE 65536u
@@ -424,6 +424,8 @@ unsigned hapb_encode_rgba(HapGpuContext *ctx, unsigned frame_count, const void *
     unsigned i, f, rc;
     uint8_t *textures, *rgba_stage = NULL;
     const void **tex_ptrs;
+    uint64_t *hsrc, *dsrc;
+    int wide = 1;
     if (frame_count == 0)
         return HapResult_No_Error;
     if (!results || !rgba_frames || count == 0 || count > 2 || !formats || width == 0 || height == 0 ||
@@ -448,12 +450,16 @@ unsigned hapb_encode_rgba(HapGpuContext *ctx, unsigned frame_count, const void *
     rgba_bytes = (size_t)row_bytes * (height - 1u) + (size_t)width * 4u;
     textures = (uint8_t *)hapgpu_rt_device_scratch(rt, D_BC_TEX, per_frame * frame_count);
     tex_ptrs = (const void **)malloc(sizeof(void *) * (size_t)frame_count * count);
-    if (!textures || !tex_ptrs) {
+    /* address table of the batched block-encode launches: [sources][outputs of texture 0][of texture 1] */
+    hsrc = (uint64_t *)hapgpu_rt_pinned_scratch(rt, P_BC_PTRS, sizeof(uint64_t) * 3u * frame_count);
+    dsrc = (uint64_t *)hapgpu_rt_device_scratch(rt, D_BC_PTRS, sizeof(uint64_t) * 3u * frame_count);
+    if (!textures || !tex_ptrs || !hsrc || !dsrc) {
         free(tex_ptrs);
         for (f = 0; f < frame_count; f++)
             results[f] = HapResult_Internal_Error;
         return HapResult_Internal_Error;
     }
+    memset(hsrc, 0, sizeof(uint64_t) * 3u * frame_count);       /* address 0: the kernel skips the picture */
     for (f = 0; f < frame_count; f++) {
         const void *src = rgba_frames[f];
         for (i = 0; i < count; i++)
@@ -471,12 +477,25 @@ unsigned hapb_encode_rgba(HapGpuContext *ctx, unsigned frame_count, const void *
                 break;
             src = rgba_stage + align_up(rgba_bytes, 256) * f;
         }
+        hsrc[f] = (uint64_t)(uintptr_t)src;
+        if (((uintptr_t)src | row_bytes) & 15u)
+            wide = 0;
         for (i = 0; i < count; i++) {
             uint8_t *t = textures + per_frame * f + tex_off[i];
-            int k = hapgpu_k_block_encode(rt, src, width, height, row_bytes, formats[i], t);
-            if (k == 0)
-                tex_ptrs[(size_t)f * count + i] = t;
+            hsrc[(size_t)(1u + i) * frame_count + f] = (uint64_t)(uintptr_t)t;
+            tex_ptrs[(size_t)f * count + i] = t;
         }
+    }
+    /* one launch per texture format over the whole batch (addresses travel as a small device table) */
+    if (hapgpu_rt_h2d(rt, dsrc, hsrc, sizeof(uint64_t) * (size_t)(1u + count) * frame_count) == 0) {
+        for (i = 0; i < count; i++)
+            if (hapgpu_k_block_encode_batch(rt, dsrc, dsrc + (size_t)(1u + i) * frame_count, frame_count, width, height,
+                                            row_bytes, formats[i], wide) != 0)
+                for (f = 0; f < frame_count; f++)
+                    tex_ptrs[(size_t)f * count + i] = NULL;
+    } else {
+        for (f = 0; f < (unsigned)frame_count * count; f++)
+            tex_ptrs[f] = NULL;
     }
     rc = hapb_encode(ctx, frame_count, count, tex_ptrs, tex_bytes, formats, compressors, chunk_counts, outputs,
                      output_bytes, output_used, results, flags, 1);

@@ -155,6 +155,9 @@ void hapgpu_rt_unlock(hapgpu_rt *rt);
 /* kernels: all asynchronous on the runtime's stream; 0 = launched */
 int hapgpu_k_block_encode(hapgpu_rt *rt, const void *rgba, unsigned width, unsigned height,
                           size_t row_bytes, unsigned hap_texture_format, void *out);
+/* pictures of one geometry in one launch; sources / outputs: DEVICE arrays of device addresses (0 = skip) */
+int hapgpu_k_block_encode_batch(hapgpu_rt *rt, const uint64_t *sources, const uint64_t *outputs, unsigned pictures,
+                                unsigned width, unsigned height, size_t row_bytes, unsigned hap_texture_format, int wide);
 int hapgpu_k_block_decode(hapgpu_rt *rt, const void *blocks, const void *alpha, unsigned width, unsigned height,
                           unsigned hap_texture_format, void *rgba, size_t row_bytes);
 int hapgpu_k_snappy_compress(hapgpu_rt *rt, const HapGpuFrameEnc *frames, unsigned frame_count,

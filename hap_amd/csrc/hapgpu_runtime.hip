@@ -14,6 +14,9 @@
 extern "C" {
 int hapgpu_launch_block_encode(const void *rgba, unsigned width, unsigned height, size_t row_bytes,
                                unsigned format, void *out, hipStream_t stream);
+int hapgpu_launch_block_encode_batch(const uint64_t *sources, const uint64_t *outputs, unsigned pictures,
+                                     unsigned width, unsigned height, size_t row_bytes, unsigned format,
+                                     int wide, hipStream_t stream);
 int hapgpu_launch_block_decode(const void *blocks, const void *alpha, unsigned width, unsigned height,
                                unsigned format, void *rgba, size_t row_bytes, hipStream_t stream);
 int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsigned frame_count, unsigned max_frags_per_texture,
@@ -336,6 +339,15 @@ extern "C" int hapgpu_k_block_encode(hapgpu_rt *rt, const void *rgba, unsigned w
 {
     scoped_timing st(rt, 0);
     return hapgpu_launch_block_encode(rgba, width, height, row_bytes, hap_texture_format, out, rt->stream);
+}
+
+extern "C" int hapgpu_k_block_encode_batch(hapgpu_rt *rt, const uint64_t *sources, const uint64_t *outputs,
+                                           unsigned pictures, unsigned width, unsigned height, size_t row_bytes,
+                                           unsigned hap_texture_format, int wide)
+{
+    scoped_timing st(rt, 0);
+    return hapgpu_launch_block_encode_batch(sources, outputs, pictures, width, height, row_bytes, hap_texture_format,
+                                            wide, rt->stream);
 }
 
 extern "C" int hapgpu_k_block_decode(hapgpu_rt *rt, const void *blocks, const void *alpha, unsigned width,
