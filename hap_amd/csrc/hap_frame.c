@@ -204,8 +204,7 @@ unsigned hapf_locate(hapf_reader *r, uint32_t frame_bytes, unsigned index,
 static void plan_complex(hapf_reader *r, hapf_texture_plan *plan, int want_chunks)
 {
     hapf_section box, s;
-    const uint8_t *body;
-    uint64_t left, at = 0;
+    uint64_t left, at = 0, base;
     int64_t codecs = -1, sizes = -1, offsets = -1, frags = -1;
     uint32_t frag_bytes = 0;
     int rc = read_section_at(r, plan->section_offset, plan->section_length, &box);
@@ -218,15 +217,14 @@ static void plan_complex(hapf_reader *r, hapf_texture_plan *plan, int want_chunk
     }
     plan->payload_offset = plan->section_offset + box.header_len + box.length;
     plan->payload_length = plan->section_length - (box.header_len + box.length);
-    body = box.length ? hapf_need(r, plan->section_offset + box.header_len, box.length) : (const uint8_t *)"";
-    if (!body) {
-        plan->result = HapResult_Bad_Frame;
-        return;
-    }
+    /* The tables are read piece by piece (section headers, then the few tables of interest): the body of
+       the fragment-size section can be tens of kilobytes that the host never looks at, and frames in
+       device memory only have a short prefix copied back. */
+    base = plan->section_offset + box.header_len;
     left = box.length;
     while (left > 0) {
         unsigned n = 0;
-        rc = hapf_read_section(body + at, (uint32_t)left, &s);
+        rc = read_section_at(r, base + at, (uint32_t)left, &s);
         if (rc != HapResult_No_Error) {
             plan->result = (unsigned)rc;
             return;
@@ -253,28 +251,51 @@ static void plan_complex(hapf_reader *r, hapf_texture_plan *plan, int want_chunk
         plan->result = HapResult_Bad_Frame;
         return;
     }
-    if (frags >= 0 && frag_bytes >= 4u && (frag_bytes & 3u) == 0 &&
-        body[frags] == HAP_FRAGMENT_TABLE_VERSION && body[frags + 1] >= 10 && body[frags + 1] <= 16) {
-        plan->frag_log2 = body[frags + 1];
-        plan->frag_gran_log2 = body[frags + 2] <= 2 ? body[frags + 2] : 0u;
-        plan->frag_window256 = body[frags + 3];
-        plan->frag_entries = (frag_bytes - 4u) / 4u;
-        plan->frag_table_offset = plan->section_offset + box.header_len + (uint64_t)frags + 4u;
+    if (frags >= 0 && frag_bytes >= 4u && (frag_bytes & 3u) == 0) {
+        const uint8_t *fh = hapf_need(r, base + (uint64_t)frags, 4u);
+        if (!fh) {
+            plan->result = HapResult_Bad_Frame;
+            return;
+        }
+        if (fh[0] == HAP_FRAGMENT_TABLE_VERSION && fh[1] >= 10 && fh[1] <= 16) {
+            plan->frag_log2 = fh[1];
+            plan->frag_gran_log2 = fh[2] <= 2 ? fh[2] : 0u;
+            plan->frag_window256 = fh[3];
+            plan->frag_entries = (frag_bytes - 4u) / 4u;
+            plan->frag_table_offset = base + (uint64_t)frags + 4u;
+        }
     }
     if (want_chunks && plan->chunk_count > 0) {
+        const size_t n = (size_t)plan->chunk_count;
+        const uint8_t *t;
         uint64_t run = 0;
         int i;
-        plan->chunks = (HapGpuChunkIn *)calloc((size_t)plan->chunk_count, sizeof(HapGpuChunkIn));
+        plan->chunks = (HapGpuChunkIn *)calloc(n, sizeof(HapGpuChunkIn));
         if (!plan->chunks) {
             plan->result = HapResult_Internal_Error;
             return;
         }
+        /* (each table is consumed before the next one is asked for: a fetched range stays valid only until
+           the next request) */
+        t = hapf_need(r, base + (uint64_t)codecs, n);
+        for (i = 0; t && i < plan->chunk_count; i++)
+            plan->chunks[i].codec = t[i];
+        if (t)
+            t = hapf_need(r, base + (uint64_t)sizes, 4u * n);
+        for (i = 0; t && i < plan->chunk_count; i++)
+            plan->chunks[i].src_len = le32(t + 4 * (size_t)i);
+        if (t && offsets >= 0) {
+            t = hapf_need(r, base + (uint64_t)offsets, 4u * n);
+            for (i = 0; t && i < plan->chunk_count; i++)
+                plan->chunks[i].src_off = le32(t + 4 * (size_t)i);
+        }
+        if (!t) {
+            plan->result = HapResult_Bad_Frame;
+            return;
+        }
         for (i = 0; i < plan->chunk_count; i++) {
             HapGpuChunkIn *c = &plan->chunks[i];
-            uint64_t begin;
-            c->codec = body[codecs + i];
-            c->src_len = le32(body + sizes + 4 * (int64_t)i);
-            begin = offsets >= 0 ? le32(body + offsets + 4 * (int64_t)i) : run;
+            const uint64_t begin = offsets >= 0 ? c->src_off : run;
             run += c->src_len;
             /* hardening (the reference has no such check, hap.c:798-809) */
             if (begin + c->src_len > plan->payload_length) {
