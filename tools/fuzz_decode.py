@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import _data as D, _libs as L, hap_amd
 ORA = L.oracle_api()
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
-N = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+N = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 2000
 ctx = hap_amd.Context(0)
 img = D.rgba(256, 64, 1)
 bases = []
@@ -19,6 +19,17 @@ for fmt, chunks in ((L.FMT_YCOCG, 4), (L.FMT_DXT1, 1), (L.FMT_DXT5, 3)):
     out = np.zeros(cap, dtype=np.uint8)
     r, used, _ = ctx.encode_frames([[tex]], [fmt], [1], [chunks], [out], flags=1)
     bases.append((out[:used[0]].tobytes(), len(tex)))
+# large textures: 8 KiB fragments with the 3 KiB match window (sliding 4 KiB ring in the decoder), 16- and 32-bit streams
+if "--large" in sys.argv:
+    big = D.rgba(1024, 1024, 2)
+    for fmt, chunks in ((L.FMT_YCOCG, 6), (L.FMT_DXT5, 1)):
+        tex = D.oracle_bc_encode(big, fmt)
+        out = np.zeros(hap_amd.HapMaxEncodedLength([len(tex)], [fmt], [chunks]), dtype=np.uint8)
+        r, used, _ = ctx.encode_frames([[tex]], [fmt], [1], [chunks], [out], flags=1)
+        assert r == 0 and bytes([0x46, 1, 13, 1, 12]) in out[:512].tobytes()
+        bases = [(out[:used[0]].tobytes(), len(tex))] + bases
+        r, used, _ = ctx.encode_frames([[tex]], [fmt], [1], [chunks], [out], flags=3)
+        bases = [(out[:used[0]].tobytes(), len(tex))] + bases
 a = D.oracle_bc_encode(img, L.FMT_YCOCG); b = D.oracle_bc_encode(img, L.FMT_RGTC1)
 bases.append((ORA.encode([a, b], [L.FMT_YCOCG, L.FMT_RGTC1], [1, 1], [2, 2])[1], len(a)))
 def oracle_in_child(frame, idx, cap):
