@@ -1,14 +1,18 @@
-// snappy_compress.hip -- per-fragment Snappy compressor for gfx950.
+// snappy_compress.hip -- per-fragment Snappy compressors for gfx950.
 //
 // Replaces the snappy_compress call-out of the reference's chunk loop (hap.c:448-476, call at
 // hap.c:453).  libsnappy itself compresses independent 64 KiB fragments with a per-fragment
-// hash table; here a fragment is 2^frag_log2 bytes (default 16 KiB) so that
-// fragment + hash table fit in LDS several times per CU, and one wavefront compresses one
-// fragment.  Output is ordinary Snappy elements (literal / copy-1 / copy-2); a chunk's stream is
-// varint(chunk bytes) followed by its fragments' element runs, concatenated by the pack/gather
-// kernels (frame_pack.hip).  The produced bytes differ from libsnappy's (Snappy encoding is not
-// unique); parity is defined as: the reference decoder reproduces the input exactly.
+// hash table; here a fragment is 2^frag_log2 bytes (default 8 KiB) so that
+// fragment + hash table fit in LDS many times per CU.  Output is ordinary Snappy elements
+// (literal / copy-1 / copy-2); a chunk's stream is varint(chunk bytes) followed by its fragments'
+// element runs, concatenated by the pack/gather kernels (frame_pack.hip).  The produced bytes
+// differ from libsnappy's (Snappy encoding is not unique); parity is defined as: the reference
+// decoder reproduces the input exactly.
 //
+// Two kernels:
+//   snappy_compress_wg_kernel  (default)  four wavefronts per fragment, 1/2/4 bytes per lane, see below;
+//   snappy_compress_kernel     (HAP_AMD_COMPRESS_V1=1, kept for A/B runs)  one wavefront per fragment,
+//                              one byte per lane:
 // Per 64-byte tile, lane l owns input position p = tile*64 + l:
 //   1. match finding, all lanes at once: (a) hash of the 4 bytes at p -> most recent earlier
 //      position with that hash (LDS u16 table, updated after the lookup), verified and extended
@@ -263,21 +267,14 @@ __global__ __launch_bounds__(64) void snappy_compress_kernel(const HapGpuFrameEn
 //   * copies never cross a supertile boundary, so supertiles are independent; their sizes are
 //     exchanged through LDS at the round barrier and every wave writes its bytes straight to
 //     their final position (no staging, no compaction pass).
-//   * match extension compares 16 bytes per step (<= 4 steps), the covered-by-a-copy mask comes
-//     from a DPP max-scan instead of 64-bit scalar arithmetic in the selection loop.
+//   * lanes hold 1, 2 or 4 bytes (GRAN): with 16/32-bit granular positions, offsets and lengths a wave covers
+//     128 / 256 bytes per tile, and the decoder moves as much per lane (the fragment table records it);
+//   * candidates: the hash probe of both tiles is verified side by side, 16 bytes per compare and without a
+//     branch (the two LDS round trips overlap), plus four block-pitch distances through ballots;
+//   * what depends only on the tile (range masks, kinds of elements, byte counts) is scalar work; lanes get
+//     the masks back through inverse ballots; the greedy selection is a hand-written scalar loop;
+//   * every lane's element leaves as one value with 16-bit stores; the round barriers order LDS traffic only.
 
-#ifdef HAP_PHASE_PROFILE
-// dev-only: shader-clock cycles per phase, summed over all waves (read with hapgpu_debug_phase_cycles)
-__device__ unsigned long long hap_phase_cycles[8];
-#define HAP_PHASE_MARK(slot)                                                        \
-    do {                                                                            \
-        const unsigned long long now_ = __builtin_readcyclecounter();               \
-        phase_acc_[slot] += now_ - phase_t_;                                        \
-        phase_t_ = now_;                                                            \
-    } while (0)
-#else
-#define HAP_PHASE_MARK(slot) do { } while (0)
-#endif
 
 #ifndef HAP_WG_WAVES
 #define HAP_WG_WAVES 4
@@ -313,17 +310,6 @@ __device__ __forceinline__ int cwave_scan_max(int v)   // inclusive, values >= 0
     v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false));
     v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false));
     return v;
-}
-
-// run of consecutive 1 bits starting at bit `lane` of next:cur, capped at 32 (enough when a lane is
-// 2 bytes and copies are at most 64 bytes): one 32-bit funnel shift instead of 64-bit shifts
-__device__ __forceinline__ unsigned run_from32(unsigned long long cur, unsigned long long next, unsigned lane)
-{
-    const unsigned lo = lane < 32u ? (unsigned)cur : (unsigned)(cur >> 32);
-    const unsigned hi = lane < 32u ? (unsigned)(cur >> 32) : (unsigned)next;
-    const unsigned w = __builtin_amdgcn_alignbit(hi, lo, lane & 31u);
-    const unsigned inv = ~w;
-    return inv ? (unsigned)__builtin_ctz(inv) : 32u;
 }
 
 // does any lane of any tile still extend its hash match?  (scalar answer)
@@ -382,30 +368,6 @@ __device__ __forceinline__ unsigned match16(const uint32_t *dw, unsigned a, unsi
               : 16u;
 }
 
-// equal bytes of data[a..] and data[b..], 16 per step, at most `limit`
-__device__ __forceinline__ unsigned match_extend16(const uint32_t *dw, unsigned a, unsigned b, unsigned limit)
-{
-    unsigned l = 0;
-    while (l < limit) {
-        const unsigned wa = (a + l) >> 2, sa = (a + l) & 3u, wb = (b + l) >> 2, sb = (b + l) & 3u;
-        const unsigned a0 = dw[wa], a1 = dw[wa + 1], a2 = dw[wa + 2], a3 = dw[wa + 3], a4 = dw[wa + 4];
-        const unsigned b0 = dw[wb], b1 = dw[wb + 1], b2 = dw[wb + 2], b3 = dw[wb + 3], b4 = dw[wb + 4];
-        const unsigned d0 = __builtin_amdgcn_alignbyte(a1, a0, sa) ^ __builtin_amdgcn_alignbyte(b1, b0, sb);
-        const unsigned d1 = __builtin_amdgcn_alignbyte(a2, a1, sa) ^ __builtin_amdgcn_alignbyte(b2, b1, sb);
-        const unsigned d2 = __builtin_amdgcn_alignbyte(a3, a2, sa) ^ __builtin_amdgcn_alignbyte(b3, b2, sb);
-        const unsigned d3 = __builtin_amdgcn_alignbyte(a4, a3, sa) ^ __builtin_amdgcn_alignbyte(b4, b3, sb);
-        if (d0 | d1 | d2 | d3) {
-            l += d0 ? ((unsigned)__builtin_ctz(d0) >> 3)
-               : d1 ? 4u + ((unsigned)__builtin_ctz(d1) >> 3)
-               : d2 ? 8u + ((unsigned)__builtin_ctz(d2) >> 3)
-                    : 12u + ((unsigned)__builtin_ctz(d3) >> 3);
-            break;
-        }
-        l += 16u;
-    }
-    return min(l, limit);
-}
-
 // two bytes at any byte address (global memory takes unaligned accesses)
 struct __attribute__((packed)) packed_u16 { uint16_t v; };
 __device__ __forceinline__ void store16(uint8_t *p, unsigned v) { reinterpret_cast<packed_u16 *>(p)->v = (uint16_t)v; }
@@ -431,10 +393,6 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
 
     const unsigned tid = threadIdx.x, lane = tid & 63u;
     const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));     // uniform: scalar register
-#ifdef HAP_PHASE_PROFILE
-    unsigned long long phase_t_ = __builtin_readcyclecounter();
-    unsigned long long phase_acc_[5] = {0, 0, 0, 0, 0};
-#endif
     // one trip to memory for the whole descriptor (field-by-field reads with the early exits between them
     // cost a scalar-load round trip each)
     const HapGpuTexEnc tex = frames[blockIdx.z].tex[blockIdx.y < 2u ? blockIdx.y : 0u];
@@ -485,8 +443,6 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
     for (unsigned i = tid; i < kWgHashEntries; i += 64u * kWgWaves)
         table[i] = 0u;
     __syncthreads();
-
-    HAP_PHASE_MARK(0);          // prologue: fragment -> LDS, table clear
     using val_t = typename std::conditional<GRAN == 4, unsigned long long, unsigned>::type;
     constexpr unsigned TB = 64u * GRAN;                 // bytes per tile
     constexpr unsigned GL = GRAN == 4 ? 2u : GRAN == 2 ? 1u : 0u;     // log2(GRAN)
@@ -503,17 +459,9 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
 
     // Everything that depends only on the tile (k, tile_base, range masks, element kind masks) lives on the
     // scalar unit: `wave` is uniform, predicates reach the lanes through inverse ballots.
-#ifdef HAP_ABL_NO_LOOP
-    for (unsigned base = 0; base < 0u * supers; base += kWgWaves) {
-#else
     for (unsigned base = 0; base < supers; base += kWgWaves) {
-#endif
         const unsigned k = base + wave;
-#ifdef HAP_ABL_SKELETON
-        const bool have = false && k < supers;
-#else
         const bool have = k < supers;
-#endif
         // per-tile emission plan, kept in registers across the round barrier
         // (a lane's element is at most GRAN + 2 bytes: they travel as one value, low byte first)
         unsigned p_hash[kSubs] = {}, p_at[kSubs] = {};
@@ -555,11 +503,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
                 // bytes a copy starting here may span: up to the supertile end, 0 beyond the data
                 room2[sub] = min(64u, super_end > p ? super_end - p : 0u);
                 cur2[sub] = lds_load32(dataw, p);
-#ifdef HAP_MUL24_HASH
-                h2[sub] = (__umul24(cur2[sub] & 0xFFFFFFu, 0x9E3779u) + __umul24(cur2[sub] >> 8, 0x85EBCBu)) >> (32u - kWgHashBits);
-#else
                 h2[sub] = (cur2[sub] * 0x1e35a7bdu) >> (32u - kWgHashBits);
-#endif
                 const unsigned cnt4 = n >= tile_base + 4u ? min(64u, ((n - 4u - tile_base) >> GL) + 1u) : 0u;   // lanes with p + 4 <= n
                 mask4[sub] = cnt4 >= 64u ? ~0ull : ((1ull << cnt4) - 1ull);
             }
@@ -570,7 +514,6 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
                 hoff[sub] = 0;
                 more[sub] = false;
                 cand2[sub] = 0;
-#ifndef HAP_NO_HASH
                 // hash candidate: the first 16 bytes are compared at once, without branching
                 const unsigned c = table[h2[sub]];
                 // (a match window, when the texture asks for one, keeps hash candidates close: the decoder then
@@ -584,7 +527,6 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
                     hoff[sub] = p - c;
                     more[sub] = m == 16u && room2[sub] > 16u;
                 }
-#endif
             }
             // longer hash matches (uncommon): both tiles advance together, 16 bytes per step
             while (any_more(more)) {
@@ -605,17 +547,11 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
                 // best candidate as one key: (length << 3) | priority, nearer fixed distances win ties,
                 // the hash candidate (priority 0) only when strictly longer
                 unsigned best_key = (hlen[sub] & ~(GRAN - 1u)) << 3;
-#ifdef HAP_ABL_NO_FIXED
-                for (int d = 0; d >= 0; d--) {
-#else
 #pragma unroll
                 for (int d = kFixed - 1; d >= 0; d--) {
-#endif
                     const unsigned long long c = eq[d][sub], nx = sub + 1 < (int)kSubs ? eq[d][sub + 1 < (int)kSubs ? sub + 1 : sub] : 0ull;
-#ifndef HAP_KEEP_EMPTY_DISTANCE
                     if (c == 0ull)                    // (uniform) nothing of this tile repeats at this distance
                         continue;
-#endif
                     unsigned l;
                     if (GRAN >= 2) {
                         // run of set bits starting at this lane, capped at 32 lanes (>= 64 bytes): one funnel shift
@@ -626,19 +562,11 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
                     } else {
                         l = min(run_from(c, nx, lane), room);
                     }
-#ifndef HAP_PREFER_NEAR   /* equal-length candidates: the farther one keeps dependency chains in the decoder short */
                     best_key = max(best_key, (l << (3u + GL)) | (unsigned)(d + 1));
-#else
-                    best_key = max(best_key, (l << (3u + GL)) | (unsigned)(kFixed - d));
-#endif
                 }
                 const unsigned prio = best_key & 7u;
                 best_len2[sub] = best_key >> 3;
-#ifndef HAP_PREFER_NEAR   /* equal-length candidates: the farther one keeps dependency chains in the decoder short */
                 best_off2[sub] = prio ? prio << pitch_log2 : hoff[sub];
-#else
-                best_off2[sub] = prio ? ((unsigned)(kFixed + 1) - prio) << pitch_log2 : hoff[sub];
-#endif
             }
             unsigned skip = 0;
 #pragma unroll
@@ -646,12 +574,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
                 const unsigned best_len = best_len2[sub], best_off = best_off2[sub];
                 const unsigned cur = cur2[sub], h = h2[sub];
                 // greedy selection: the scalar unit hops from chosen copy to chosen copy
-#ifdef HAP_MIN_COPY2      /* experiment: 3-byte copies only from this length up (-1.5 % decode time, +0.3 % bytes) */
-                const unsigned long long cand_mask = ballot64(best_len >= 4u) &
-                                                     (ballot64(best_len >= HAP_MIN_COPY2) | ballot64(best_off < 2048u));
-#else
                 const unsigned long long cand_mask = ballot64(best_len >= 4u);
-#endif
                 unsigned long long sel = 0;
                 unsigned cursor = (unsigned)__builtin_amdgcn_readfirstlane((int)skip);   // first position not yet covered
                 const unsigned next_free = lane + (best_len >> GL);     // ... after taking this lane's copy
@@ -702,9 +625,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
         }
         if (lane == 0)
             roundsz[wave] = total;
-        HAP_PHASE_MARK(1);      // analysis
         lds_barrier();
-        HAP_PHASE_MARK(2);      // wait for the slowest wave of the round
         unsigned my_base = round_base, all = 0;
 #pragma unroll
         for (unsigned w = 0; w < kWgWaves; w++) {
@@ -721,9 +642,6 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
                 // byte count of the lane's element = e0 + 2 e1 + 4 e2: whole 16-bit pieces first, then the odd byte
                 uint8_t *dst = out + my_base + p_at[sub];
                 const val_t v = p_val[sub];
-#ifdef HAP_ABL_NO_STORE
-                if (v == (val_t)0x12345679u && p_at[sub] == 0x7FFFFFFu)
-#endif
                 {
                 const unsigned long long e0 = m_e0[sub], e1 = m_e1[sub], e2 = m_e2[sub];
                 if (__builtin_amdgcn_inverse_ballot_w64(e1 | e2))
@@ -739,46 +657,17 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
                 if (GRAN == 4 && __builtin_amdgcn_inverse_ballot_w64(e0 & e2 & ~e1))
                     dst[4] = (uint8_t)((unsigned long long)v >> 32);
                 }
-#ifndef HAP_ABL_NO_INSERT
                 if (__builtin_amdgcn_inverse_ballot_w64(m_insert[sub]))
                     atomicMax(&table[p_hash[sub]], p);
-#endif
             }
         }
-        HAP_PHASE_MARK(3);      // emission + table inserts
         lds_barrier();
-        HAP_PHASE_MARK(4);      // second barrier
     }
     if (tid == 0)
         frag_sizes[f] = round_base;
-#ifdef HAP_PHASE_PROFILE
-    if (lane == 0) {
-        for (int i = 0; i < 5; i++)
-            atomicAdd(&hap_phase_cycles[i], phase_acc_[i]);
-        atomicAdd(&hap_phase_cycles[5], 1ull);
-    }
-#endif
 }
 
 } // namespace
-
-extern "C" int hapgpu_debug_phase_cycles(unsigned long long *out, int reset)
-{
-#ifdef HAP_PHASE_PROFILE
-    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipDeviceSynchronize() != hipSuccess)
-        return 1;
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(hap_phase_cycles), sizeof(zero)) != hipSuccess)
-        return 1;
-    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(hap_phase_cycles), zero, sizeof(zero)) != hipSuccess)
-        return 1;
-    return 0;
-#else
-    (void)out;
-    (void)reset;
-    return 2;   /* not compiled in (build with -DHAP_PHASE_PROFILE) */
-#endif
-}
 
 // LDS bytes needed per workgroup for a fragment size
 static unsigned compress_lds_bytes(unsigned frag_log2) { return (1u << frag_log2) + 16u + kHashEntries * 2u; }
