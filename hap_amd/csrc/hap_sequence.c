@@ -330,11 +330,13 @@ unsigned int HapGpuDecodeSequence(HapGpuContext *ctx, HapSequenceReader *r, unsi
         free(ptrs); free(lens);
         return HapResult_Internal_Error;
     }
+    /* the context stays locked for the whole call: the two read-ahead buffers are its scratch and must not be
+       resized by another thread's call while the helper thread fills them */
     hapgpu_rt_lock(ctx->rt);
     pinned[0] = hapgpu_rt_pinned_scratch(ctx->rt, P_SEQ0, biggest);
     pinned[1] = batches > 1 ? hapgpu_rt_pinned_scratch(ctx->rt, P_SEQ1, biggest) : pinned[0];
-    hapgpu_rt_unlock(ctx->rt);
     if (!pinned[0] || !pinned[1]) {
+        hapgpu_rt_unlock(ctx->rt);
         free(ptrs); free(lens);
         return HapResult_Internal_Error;
     }
@@ -371,17 +373,16 @@ unsigned int HapGpuDecodeSequence(HapGpuContext *ctx, HapSequenceReader *r, unsi
             else
                 read_main(&job);
         }
-        hapgpu_rt_lock(ctx->rt);
         rc = hapb_decode(ctx, n, ptrs, lens, index, outputs + done, output_bytes + done,
                          output_used ? output_used + done : NULL, output_formats ? output_formats + done : NULL,
                          results + done, 0, NULL, NULL);
-        hapgpu_rt_unlock(ctx->rt);
         if (rc != HapResult_No_Error && first_error == HapResult_No_Error)
             first_error = rc;
         done += n;
     }
     if (thread_live)
         pthread_join(thread, NULL);
+    hapgpu_rt_unlock(ctx->rt);
     free(ptrs);
     free(lens);
     return first_error;
