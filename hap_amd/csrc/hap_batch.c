@@ -33,7 +33,7 @@ static int is_dev(HapGpuContext *c, const void *p) { return hapgpu_rt_is_device_
 /* ================================================================== encode */
 
 typedef struct tex_geom {
-    unsigned format, compressor, chunk_count, chunk_bytes, header_len, fpc, nibble, gran_log2;
+    unsigned format, compressor, chunk_count, chunk_bytes, header_len, fpc, nibble, gran_log2, field_period;
     unsigned long bytes;
     size_t bound;        /* hap_max_encoded_length for the requested compressor (hap.c:386) */
 } tex_geom;
@@ -131,8 +131,20 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
             else if ((t->chunk_bytes & 1u) == 0)
                 t->gran_log2 = 1u;
         }
+        /* alpha-style blocks (2 endpoint + 6 index bytes [+ 4 + 4 of the colour half]) go to the field-per-lane
+           compressor when everything lines up: default fragment size, whole blocks per chunk, 16-bit streams */
+        t->field_period = 0u;
+        if (t->compressor == HapCompressorSnappy && t->gran_log2 == 1u && frag_log2 == 13u && !ctx->compress_v1 &&
+            !getenv("HAP_AMD_POSITION_LANES")) {
+            if ((t->format == HapTextureFormat_RGBA_DXT5 || t->format == HapTextureFormat_YCoCg_DXT5) &&
+                (t->chunk_bytes & 15u) == 0)
+                t->field_period = 4u;
+            /* (RGTC1 alone stays with the position-per-lane kernel: alpha planes are full of matches that start
+               inside the 6 index bytes -- measured 0.25 against 0.45 of the texture size -- which whole-field
+               equality cannot see) */
+        }
         if (t->compressor == HapCompressorSnappy)
-            gran_mask |= 1u << t->gran_log2;
+            gran_mask |= t->field_period == 4u ? 32u : t->field_period == 2u ? 16u : 1u << t->gran_log2;
         if (t->compressor == HapCompressorSnappy) {
             /* header choice uses the layout that will actually be written (hap.c:425-428) */
             size_t ilen = hapf_instructions_length(t->chunk_count);
@@ -270,7 +282,7 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
                     const int small_blocks = g[i].format == HapTextureFormat_RGB_DXT1 || g[i].format == HapTextureFormat_A_RGTC1;
                     const int windowed = frag_log2 == 13u && !ctx->compress_v1 &&
                                          g[i].bytes >= (small_blocks ? ((size_t)2u << 20) : ((size_t)1u << 20));
-                    te->reserved = g[i].gran_log2 | (windowed ? (HAP_FRAGMENT_WINDOW_256 << 8) : 0u);
+                    te->reserved = g[i].gran_log2 | (windowed ? (HAP_FRAGMENT_WINDOW_256 << 8) : 0u) | (g[i].field_period << 16);
                 }
             }
         }

@@ -400,6 +400,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
     const unsigned x = blockIdx.x;
     // (one combined test, no short-circuit: every field is requested before the first wait)
     if ((blockIdx.y >= tex_count) | (tex.compressor != 1u) | ((1u << (tex.reserved & 0xFFu)) != GRAN) |
+        (((tex.reserved >> 16) & 0xFu) != 0u) |        // field-per-lane textures belong to the kernel below
         (x >= tex.chunk_count * tex.frags_per_chunk) | (tex.src == 0) | (tex.chunk_bytes == 0))
         return;
     const unsigned chunk = x / tex.frags_per_chunk, j = x - chunk * tex.frags_per_chunk;
@@ -667,6 +668,303 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
         frag_sizes[f] = round_base;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// field-per-lane compressor for block textures
+// ------------------------------------------------------------------------------------------
+//
+// DXT5 / YCoCg-DXT5 blocks are four fields -- 2 endpoint bytes and 6 index bytes of the alpha-style half, 4
+// endpoint bytes and 4 index bytes of the colour half -- and RGTC1 blocks the first two.  Matches in such data
+// start and end at field boundaries (a CPU model of this kernel on the 8K test stream: same compressed size as the
+// position-per-lane kernel), so here a lane owns one FIELD instead of one 16-bit position: a tile of 64 lanes is
+// 256 bytes (16 or 32 blocks), equality at a distance is one 8-byte LDS read and a masked compare, and a
+// fragment takes 4 rounds instead of 8.  Candidates: the same field 1..4 blocks back (runs through ballots, as
+// above) and the most recent field with the same hash (type + value); neighbouring lanes whose hash candidates
+// lie at the same distance join into one copy.  Everything else -- synchronous rounds, table inserts between
+// rounds (every field is inserted), greedy selection on the scalar unit, direct final-position stores, 16-bit
+// granular elements, match window -- is as in the kernel above.
+__device__ __forceinline__ int cwave_scan_add(int v)   // inclusive
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+
+#ifndef HAP_FIELD_SUBS
+#define HAP_FIELD_SUBS 1
+#endif
+constexpr unsigned kFieldSubs = HAP_FIELD_SUBS;   // tiles (256 bytes each) per wave per round
+
+template <unsigned PERIOD>      // fields per block: 4 = [2, 6, 4, 4] bytes (16-byte blocks), 2 = [2, 6] (8-byte blocks)
+__device__ __forceinline__ unsigned field_offset(unsigned j)      // byte position of field j, fields counted from a block boundary
+{
+    if (PERIOD == 4)
+        return (j >> 2) * 16u + __builtin_amdgcn_ubfe(0x0C080200u, (j & 3u) * 8u, 8u);
+    return (j >> 1) * 8u + 2u * (j & 1u);
+}
+
+template <unsigned PERIOD>
+__global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(const HapGpuFrameEnc *__restrict__ frames,
+                                                                   uint8_t *__restrict__ slots, unsigned slot_stride,
+                                                                   uint32_t *__restrict__ frag_sizes)
+{
+    constexpr unsigned FL = 13u, kFragBytes = 1u << FL;
+    constexpr unsigned kBlock = PERIOD == 4 ? 16u : 8u;
+    constexpr unsigned TB = 64u / PERIOD * kBlock;                // 256 bytes per tile
+    __shared__ __attribute__((aligned(16))) uint8_t smem[kFragBytes + 32u + kWgHashEntries * 4u + kWgWaves * 4u];
+    uint32_t *table = reinterpret_cast<uint32_t *>(smem + kFragBytes + 32);
+    uint32_t *roundsz = table + kWgHashEntries;
+
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const HapGpuTexEnc tex = frames[blockIdx.z].tex[blockIdx.y < 2u ? blockIdx.y : 0u];
+    const unsigned tex_count = frames[blockIdx.z].tex_count;
+    const unsigned x = blockIdx.x;
+    if ((blockIdx.y >= tex_count) | (tex.compressor != 1u) | (((tex.reserved >> 16) & 0xFu) != PERIOD) |
+        (x >= tex.chunk_count * tex.frags_per_chunk) | (tex.src == 0) | (tex.chunk_bytes == 0))
+        return;
+    const unsigned chunk = x / tex.frags_per_chunk, j = x - chunk * tex.frags_per_chunk;
+    const unsigned begin = j << FL;
+    const unsigned n = min(kFragBytes, tex.chunk_bytes - begin);          // a whole number of blocks (host-checked)
+    const uint8_t *src = (const uint8_t *)tex.src + (size_t)chunk * tex.chunk_bytes + begin;
+    const unsigned f = tex.frag_first + x;
+    uint8_t *out = slots + (size_t)f * slot_stride;
+    const unsigned window = ((tex.reserved >> 8) & 0xFFu) ? ((tex.reserved >> 8) & 0xFFu) * 256u : 0xFFFFFFFFu;
+
+    if (((uintptr_t)src & 15u) == 0) {
+        uint4 v[3];
+#pragma unroll
+        for (unsigned u = 0; u < 3; u++) {
+            const unsigned i = tid * 16u + u * 4096u;
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (i + 16u <= n)
+                v[u] = *reinterpret_cast<const uint4 *>(src + i);
+        }
+#pragma unroll
+        for (unsigned u = 0; u < 3; u++) {
+            const unsigned i = tid * 16u + u * 4096u;
+            if (i < n && i + 16u > n) {                 // (n is a multiple of 8: an 8-byte tail is possible)
+                unsigned w[4] = {0, 0, 0, 0};
+                for (unsigned k = 0; i + k < n; k++)
+                    w[k >> 2] |= (unsigned)src[i + k] << (8 * (k & 3));
+                v[u] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            if (i < kFragBytes + 32u)
+                *reinterpret_cast<uint4 *>(smem + i) = v[u];
+        }
+    } else {
+        for (unsigned i = tid; i < n + 32u; i += 64u * kWgWaves)
+            smem[i] = i < n ? src[i] : (uint8_t)0;
+    }
+    for (unsigned i = tid; i < kWgHashEntries; i += 64u * kWgWaves)
+        table[i] = 0u;
+    __syncthreads();
+
+    // per-lane constants: field type, position of the 8-byte half block that holds the field, compare masks
+    const unsigned t = lane & (PERIOD - 1u);
+    const unsigned half = (lane / PERIOD) * kBlock + ((PERIOD == 4 && (t & 2u)) ? 8u : 0u);
+    const unsigned m1 = PERIOD == 4 ? (t == 0 ? 0x0000FFFFu : t == 1 ? 0xFFFF0000u : t == 2 ? 0xFFFFFFFFu : 0u)
+                                    : (t == 0 ? 0x0000FFFFu : 0xFFFF0000u);
+    const unsigned m2 = PERIOD == 4 ? ((t & 1u) ? 0xFFFFFFFFu : 0u) : (t == 1 ? 0xFFFFFFFFu : 0u);
+    const unsigned size = PERIOD == 4 ? (t == 0 ? 2u : t == 1 ? 6u : 4u) : (t == 0 ? 2u : 6u);
+    const bool upper = lane >= 32u;
+    const unsigned lane31 = lane & 31u;
+    const unsigned my_off = field_offset<PERIOD>(lane);
+
+    const unsigned tiles = (n + TB - 1u) / TB, supers = (tiles + kFieldSubs - 1u) / kFieldSubs;
+    unsigned round_base = 0;
+    for (unsigned base = 0; base < supers; base += kWgWaves) {
+        const unsigned k = base + wave;
+        const bool have = k < supers;
+        unsigned p_at[kFieldSubs] = {}, p_lo[kFieldSubs] = {}, p_hi[kFieldSubs] = {}, p_cnt[kFieldSubs] = {}, p_hash[kFieldSubs] = {};
+        unsigned long long m_in[kFieldSubs] = {};
+        unsigned total = 0;
+        if (have) {
+            const unsigned super_base = kFieldSubs * k * TB;
+            const unsigned lanes_in_super = min(64u * kFieldSubs, (n - super_base) / kBlock * PERIOD);
+            unsigned long long eq[kFixed][kFieldSubs], in_mask[kFieldSubs];
+            unsigned ux[kFieldSubs], vx[kFieldSubs];
+#pragma unroll
+            for (int sub = 0; sub < (int)kFieldSubs; sub++) {
+                const unsigned tile_base = super_base + sub * TB;
+                const unsigned cnt = lanes_in_super > 64u * sub ? min(64u, lanes_in_super - 64u * sub) : 0u;
+                in_mask[sub] = cnt >= 64u ? ~0ull : ((1ull << cnt) - 1ull);
+                const uint2 xv = *reinterpret_cast<const uint2 *>(smem + tile_base + half);
+                ux[sub] = xv.x;
+                vx[sub] = xv.y;
+#pragma unroll
+                for (int d = 0; d < kFixed; d++) {
+                    const unsigned dist = (unsigned)(d + 1) * kBlock;
+                    const unsigned at = tile_base + half;
+                    const uint2 yv = *reinterpret_cast<const uint2 *>(smem + (at >= dist ? at - dist : 0u));
+                    unsigned long long reachable = ~0ull;
+                    if (tile_base == 0u)
+                        reachable = ~0ull << ((unsigned)(d + 1) * PERIOD);
+                    eq[d][sub] = ballot64((((xv.x ^ yv.x) & m1) | ((xv.y ^ yv.y) & m2)) == 0u) & in_mask[sub] & reachable;
+                }
+            }
+            // hash candidates: most recent field of the same type and value (inserted in earlier rounds)
+            unsigned hd[kFieldSubs], hh[kFieldSubs];
+#pragma unroll
+            for (int sub = 0; sub < (int)kFieldSubs; sub++) {
+                const unsigned tile_base = super_base + sub * TB;
+                const unsigned fi = tile_base / kBlock * PERIOD + lane;          // field index inside the fragment
+                const unsigned a = ux[sub] & m1, b = vx[sub] & m2;
+                const unsigned z = a ^ __builtin_amdgcn_alignbit(b, b, 19) ^ (t << 29);
+                hh[sub] = (z * 0x9E3779B1u) >> (32u - kWgHashBits);
+                const unsigned c = table[hh[sub]];
+                const unsigned gap = fi - c;                                     // in fields
+                const unsigned dist = gap / PERIOD * kBlock;
+                const bool valid = __builtin_amdgcn_inverse_ballot_w64(in_mask[sub]) && c < fi &&
+                                   (gap & (PERIOD - 1u)) == 0u && dist <= window;
+                const unsigned at = tile_base + half;
+                const uint2 yv = *reinterpret_cast<const uint2 *>(smem + (valid ? at - dist : 0u));
+                hd[sub] = (valid && ((((ux[sub] ^ yv.x) & m1) | ((vx[sub] ^ yv.y) & m2)) == 0u)) ? dist : 0u;
+            }
+            unsigned best_k2[kFieldSubs], best_off2[kFieldSubs];
+#pragma unroll
+            for (int sub = 0; sub < (int)kFieldSubs; sub++) {
+                const unsigned room_lanes = lanes_in_super > 64u * sub + lane ? min(16u, lanes_in_super - 64u * sub - lane) : 0u;
+                // lanes to the right whose hash candidate lies at the same distance join this one
+                const unsigned next_hd = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hd[sub], 0x130, 0xF, 0xF, false);
+                const unsigned long long same = ballot64(next_hd == hd[sub]) & ballot64(hd[sub] != 0u);
+                unsigned best_key;
+                {
+                    const unsigned lo = upper ? (unsigned)(same >> 32) : (unsigned)same;
+                    const unsigned hi = upper ? 0u : (unsigned)(same >> 32);
+                    const unsigned inv = ~__builtin_amdgcn_alignbit(hi, lo, lane31);
+                    const unsigned more = inv ? (unsigned)__builtin_ctz(inv) : 32u;
+                    best_key = hd[sub] ? (min(1u + more, room_lanes) << 3) : 0u;
+                }
+#pragma unroll
+                for (int d = kFixed - 1; d >= 0; d--) {
+                    const unsigned long long c = eq[d][sub], nx = sub + 1 < (int)kFieldSubs ? eq[d][sub + 1 < (int)kFieldSubs ? sub + 1 : sub] : 0ull;
+                    if (c == 0ull)
+                        continue;
+                    const unsigned lo = upper ? (unsigned)(c >> 32) : (unsigned)c;
+                    const unsigned hi = upper ? (unsigned)nx : (unsigned)(c >> 32);
+                    const unsigned inv = ~__builtin_amdgcn_alignbit(hi, lo, lane31);
+                    const unsigned l = min(inv ? (unsigned)__builtin_ctz(inv) : 32u, room_lanes);
+                    best_key = max(best_key, (l << 3) | (unsigned)(d + 1));            // farther wins ties
+                }
+                const unsigned prio = best_key & 7u;
+                best_k2[sub] = best_key >> 3;
+                best_off2[sub] = prio ? prio * kBlock : hd[sub];
+            }
+            unsigned skip = 0;
+#pragma unroll
+            for (int sub = 0; sub < (int)kFieldSubs; sub++) {
+                const unsigned kk = best_k2[sub], best_off = best_off2[sub];
+                const unsigned best_len = field_offset<PERIOD>(lane + kk) - my_off;        // bytes of kk fields from here
+                const unsigned long long cand_mask = ballot64(best_len >= 4u);
+                unsigned long long sel = 0;
+                unsigned cursor = (unsigned)__builtin_amdgcn_readfirstlane((int)skip);
+                const unsigned next_free = lane + kk;
+                greedy_select(cand_mask, next_free, cursor, sel);
+                const unsigned carry = cursor > 64u ? cursor - 64u : 0u;
+                const int reach = cwave_scan_max(__builtin_amdgcn_inverse_ballot_w64(sel) ? (int)next_free : 0);
+                const unsigned long long skipmask = skip >= 64u ? ~0ull : ((1ull << skip) - 1ull);
+                const unsigned long long lit = ~(ballot64((unsigned)reach > lane) | skipmask) & in_mask[sub];
+                skip = carry;
+                const unsigned long long starts = lit & ~(lit << 1);
+                unsigned run = 0;                          // literal run length in BYTES
+                if (__builtin_amdgcn_inverse_ballot_w64(starts)) {
+                    const unsigned long long a = ~(lit >> lane);
+                    const unsigned r = a ? (unsigned)__builtin_ctzll(a) : 64u;
+                    run = field_offset<PERIOD>(lane + r) - my_off;
+                }
+                // this lane's element: literal = [run header] + the field's bytes, copy = 2 or 3 bytes
+                unsigned cnt = 0, vlo = 0, vhi = 0;
+                if (__builtin_amdgcn_inverse_ballot_w64(lit)) {
+                    // field bytes, low byte first
+                    unsigned flo, fhi = 0;
+                    if (PERIOD == 4 && t >= 2u) {
+                        flo = t == 2u ? ux[sub] : vx[sub];
+                    } else if (t == 0u) {
+                        flo = ux[sub] & 0xFFFFu;
+                    } else {
+                        flo = (ux[sub] >> 16) | (vx[sub] << 16);
+                        fhi = vx[sub] >> 16;
+                    }
+                    cnt = size;
+                    vlo = flo;
+                    vhi = fhi;
+                    if (run != 0u) {
+                        if (run > 60u) {
+                            vhi = (fhi << 16) | (flo >> 16);
+                            vlo = (flo << 16) | ((run - 1u) << 8) | 0xF0u;
+                            cnt += 2u;
+                        } else {
+                            vhi = (fhi << 8) | (flo >> 24);
+                            vlo = (flo << 8) | ((run - 1u) << 2);
+                            cnt += 1u;
+                        }
+                    }
+                } else if (__builtin_amdgcn_inverse_ballot_w64(sel)) {
+                    if (best_len < 12u && best_off < 2048u) {
+                        vlo = 1u | ((best_len - 4u) << 2) | ((best_off >> 8) << 5) | ((best_off & 0xFFu) << 8);
+                        cnt = 2u;
+                    } else {
+                        vlo = 2u | ((best_len - 1u) << 2) | (best_off << 8);
+                        cnt = 3u;
+                    }
+                }
+                const int incl = cwave_scan_add((int)cnt);
+                p_at[sub] = total + (unsigned)incl - cnt;
+                total += (unsigned)__builtin_amdgcn_readlane(incl, 63);
+                p_lo[sub] = vlo;
+                p_hi[sub] = vhi;
+                p_cnt[sub] = cnt;
+                p_hash[sub] = hh[sub];
+                m_in[sub] = in_mask[sub];
+            }
+        }
+        if (lane == 0)
+            roundsz[wave] = total;
+        lds_barrier();
+        unsigned my_base = round_base, all = 0;
+#pragma unroll
+        for (unsigned w = 0; w < kWgWaves; w++) {
+            const unsigned sz = roundsz[w];
+            if (w < wave)
+                my_base += sz;
+            all += sz;
+        }
+        round_base += all;
+        if (have) {
+#pragma unroll
+            for (int sub = 0; sub < (int)kFieldSubs; sub++) {
+                uint8_t *dst = out + my_base + p_at[sub];
+                const unsigned cnt = p_cnt[sub], vlo = p_lo[sub], vhi = p_hi[sub];
+                if (cnt >= 2u)
+                    store16(dst, vlo);
+                if (cnt >= 4u)
+                    store16(dst + 2, vlo >> 16);
+                if (cnt >= 6u)
+                    store16(dst + 4, vhi);
+                if (cnt == 8u)
+                    store16(dst + 6, vhi >> 16);
+                if (cnt == 3u)
+                    dst[2] = (uint8_t)(vlo >> 16);
+                if (cnt == 5u)
+                    dst[4] = (uint8_t)vhi;
+                if (cnt == 7u)
+                    dst[6] = (uint8_t)(vhi >> 16);
+                // every field is remembered (candidates are looked up by field, not by element)
+                if (__builtin_amdgcn_inverse_ballot_w64(m_in[sub]))
+                    atomicMax(&table[p_hash[sub]], (kFieldSubs * k + sub) * TB / kBlock * PERIOD + lane);
+            }
+        }
+        lds_barrier();
+    }
+    if (tid == 0)
+        frag_sizes[f] = round_base;
+}
+
 } // namespace
 
 // LDS bytes needed per workgroup for a fragment size
@@ -705,6 +1003,12 @@ extern "C" int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsig
                 hipLaunchKernelGGL((snappy_compress_wg_kernel<G, 0u>), grid, block, lds2, stream, frames, frag_log2,            \
                                    (uint8_t *)slots, slot_stride, frag_sizes);                                                  \
         } while (0)
+        if (frag_log2 == 13u && (granularity_mask & 16u))
+            hipLaunchKernelGGL((snappy_compress_field_kernel<2u>), grid, block, 0, stream, frames, (uint8_t *)slots,
+                               slot_stride, frag_sizes);
+        if (frag_log2 == 13u && (granularity_mask & 32u))
+            hipLaunchKernelGGL((snappy_compress_field_kernel<4u>), grid, block, 0, stream, frames, (uint8_t *)slots,
+                               slot_stride, frag_sizes);
         if (granularity_mask & 1u)
             HAP_LAUNCH_COMPRESS(1u);
         if (granularity_mask & 2u)
