@@ -36,6 +36,7 @@ unsigned int HapGpuCreate(int device, HapGpuContext **context)
         const char *e = getenv("HAP_AMD_BYTE_GRANULAR");
         c->byte_granular = ((e && atoi(e) != 0) || getenv("HAP_AMD_COMPRESS_V1")) ? 1u : 0u;
         c->compress_v1 = getenv("HAP_AMD_COMPRESS_V1") ? 1u : 0u;
+        c->position_lanes = getenv("HAP_AMD_POSITION_LANES") ? 1u : 0u;
     }
     *context = c;
     return HapResult_No_Error;

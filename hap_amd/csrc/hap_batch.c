@@ -135,7 +135,7 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
            compressor when everything lines up: default fragment size, whole blocks per chunk, 16-bit streams */
         t->field_period = 0u;
         if (t->compressor == HapCompressorSnappy && t->gran_log2 == 1u && frag_log2 == 13u && !ctx->compress_v1 &&
-            !getenv("HAP_AMD_POSITION_LANES")) {
+            !ctx->position_lanes) {
             if ((t->format == HapTextureFormat_RGBA_DXT5 || t->format == HapTextureFormat_YCoCg_DXT5) &&
                 (t->chunk_bytes & 15u) == 0)
                 t->field_period = 4u;

@@ -14,6 +14,7 @@ struct HapGpuContext {
     unsigned frag_log2;
     unsigned byte_granular;   /* HAP_AMD_BYTE_GRANULAR=1: never emit 16-bit granular element streams */
     unsigned compress_v1;     /* HAP_AMD_COMPRESS_V1: the first-generation compressor (no match window) */
+    unsigned position_lanes;  /* HAP_AMD_POSITION_LANES: never use the field-per-lane compressor */
 };
 
 /* inputs_are_device != 0: every input pointer is known to be device memory (skips classification) */
