@@ -134,17 +134,18 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
         /* alpha-style blocks (2 endpoint + 6 index bytes [+ 4 + 4 of the colour half]) go to the field-per-lane
            compressor when everything lines up: default fragment size, whole blocks per chunk, 16-bit streams */
         t->field_period = 0u;
-        if (t->compressor == HapCompressorSnappy && t->gran_log2 == 1u && frag_log2 == 13u && !ctx->compress_v1 &&
-            !ctx->position_lanes) {
-            if ((t->format == HapTextureFormat_RGBA_DXT5 || t->format == HapTextureFormat_YCoCg_DXT5) &&
+        if (t->compressor == HapCompressorSnappy && frag_log2 == 13u && !ctx->compress_v1 && !ctx->position_lanes) {
+            if (t->gran_log2 == 1u && (t->format == HapTextureFormat_RGBA_DXT5 || t->format == HapTextureFormat_YCoCg_DXT5) &&
                 (t->chunk_bytes & 15u) == 0)
                 t->field_period = 4u;
+            else if (t->gran_log2 == 2u && t->format == HapTextureFormat_RGB_DXT1 && (t->chunk_bytes & 7u) == 0)
+                t->field_period = 10u;      /* 2 fields per block, the [4, 4] layout (code 2 | 8) */
             /* (RGTC1 alone stays with the position-per-lane kernel: alpha planes are full of matches that start
                inside the 6 index bytes -- measured 0.25 against 0.45 of the texture size -- which whole-field
                equality cannot see) */
         }
         if (t->compressor == HapCompressorSnappy)
-            gran_mask |= t->field_period == 4u ? 32u : t->field_period == 2u ? 16u : 1u << t->gran_log2;
+            gran_mask |= t->field_period == 4u ? 32u : t->field_period == 10u ? 64u : t->field_period == 2u ? 16u : 1u << t->gran_log2;
         if (t->compressor == HapCompressorSnappy) {
             /* header choice uses the layout that will actually be written (hap.c:425-428) */
             size_t ilen = hapf_instructions_length(t->chunk_count);

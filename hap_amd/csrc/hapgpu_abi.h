@@ -47,7 +47,7 @@ typedef struct HapGpuTexEnc {
     uint32_t frag_first;     /* global index of this texture's first fragment */
     uint32_t emit_index;     /* write the fragment-size section */
     uint32_t reserved;       /* bits 16..19: fields per block for the field-per-lane compressor (0: position per lane,
-                                2: RGTC1, 4: DXT5 / YCoCg-DXT5); bits 8..15: match window in 256-byte units (0 = whole fragment); bits 0..7:
+                                2: RGTC1 layout, 4: DXT5 / YCoCg-DXT5, 10: DXT1); bits 8..15: match window in 256-byte units (0 = whole fragment); bits 0..7:
                                 granularity_log2 of the element stream: 0 = bytes, 1 = every position, offset
                                 and length even (lets the decoder move 16 bits per lane) */
 } HapGpuTexEnc;
@@ -164,7 +164,7 @@ int hapgpu_k_block_decode(hapgpu_rt *rt, const void *blocks, const void *alpha, 
 int hapgpu_k_snappy_compress(hapgpu_rt *rt, const HapGpuFrameEnc *frames, unsigned frame_count,
                              unsigned max_frags_per_texture, unsigned frag_log2,
                              void *slots, unsigned slot_stride, uint32_t *frag_sizes,
-                             unsigned granularity_mask /* bit g (0..2) set: some position-per-lane texture has granularity_log2 == g; bit 4 / 5: some texture uses the field-per-lane kernel with 2 / 4 fields per block; bits 8..: textures per frame */);
+                             unsigned granularity_mask /* bit g (0..2) set: some position-per-lane texture has granularity_log2 == g; bit 4 / 5 / 6: some texture uses the field-per-lane kernel ([2,6] / [2,6,4,4] / [4,4] fields per block); bits 8..: textures per frame */);
 int hapgpu_k_frame_pack(hapgpu_rt *rt, HapGpuFrameEnc *frames, unsigned frame_count,
                         unsigned frag_log2, const void *slots, unsigned slot_stride,
                         const uint32_t *frag_sizes, HapGpuCopyEntry *copies);

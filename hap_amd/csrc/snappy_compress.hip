@@ -699,15 +699,17 @@ __device__ __forceinline__ int cwave_scan_add(int v)   // inclusive
 #endif
 constexpr unsigned kFieldSubs = HAP_FIELD_SUBS;   // tiles (256 bytes each) per wave per round
 
-template <unsigned PERIOD>      // fields per block: 4 = [2, 6, 4, 4] bytes (16-byte blocks), 2 = [2, 6] (8-byte blocks)
+// Field layouts: PERIOD 4 = [2, 6, 4, 4] bytes (DXT5 / YCoCg-DXT5, 16-byte blocks); PERIOD 2 = [2, 6] (RGTC1 layout,
+// not used: see hap_batch.c) or, with COLOUR, [4, 4] (DXT1: endpoints, indices).
+template <unsigned PERIOD, bool COLOUR>
 __device__ __forceinline__ unsigned field_offset(unsigned j)      // byte position of field j, fields counted from a block boundary
 {
     if (PERIOD == 4)
         return (j >> 2) * 16u + __builtin_amdgcn_ubfe(0x0C080200u, (j & 3u) * 8u, 8u);
-    return (j >> 1) * 8u + 2u * (j & 1u);
+    return (j >> 1) * 8u + (COLOUR ? 4u : 2u) * (j & 1u);
 }
 
-template <unsigned PERIOD>
+template <unsigned PERIOD, bool COLOUR = false>
 __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(const HapGpuFrameEnc *__restrict__ frames,
                                                                    uint8_t *__restrict__ slots, unsigned slot_stride,
                                                                    uint32_t *__restrict__ frag_sizes)
@@ -724,7 +726,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
     const HapGpuTexEnc tex = frames[blockIdx.z].tex[blockIdx.y < 2u ? blockIdx.y : 0u];
     const unsigned tex_count = frames[blockIdx.z].tex_count;
     const unsigned x = blockIdx.x;
-    if ((blockIdx.y >= tex_count) | (tex.compressor != 1u) | (((tex.reserved >> 16) & 0xFu) != PERIOD) |
+    if ((blockIdx.y >= tex_count) | (tex.compressor != 1u) | (((tex.reserved >> 16) & 0xFu) != (PERIOD | (COLOUR ? 8u : 0u))) |
         (x >= tex.chunk_count * tex.frags_per_chunk) | (tex.src == 0) | (tex.chunk_bytes == 0))
         return;
     const unsigned chunk = x / tex.frags_per_chunk, j = x - chunk * tex.frags_per_chunk;
@@ -768,12 +770,12 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
     const unsigned t = lane & (PERIOD - 1u);
     const unsigned half = (lane / PERIOD) * kBlock + ((PERIOD == 4 && (t & 2u)) ? 8u : 0u);
     const unsigned m1 = PERIOD == 4 ? (t == 0 ? 0x0000FFFFu : t == 1 ? 0xFFFF0000u : t == 2 ? 0xFFFFFFFFu : 0u)
-                                    : (t == 0 ? 0x0000FFFFu : 0xFFFF0000u);
+                      : COLOUR ? (t == 0 ? 0xFFFFFFFFu : 0u) : (t == 0 ? 0x0000FFFFu : 0xFFFF0000u);
     const unsigned m2 = PERIOD == 4 ? ((t & 1u) ? 0xFFFFFFFFu : 0u) : (t == 1 ? 0xFFFFFFFFu : 0u);
-    const unsigned size = PERIOD == 4 ? (t == 0 ? 2u : t == 1 ? 6u : 4u) : (t == 0 ? 2u : 6u);
+    const unsigned size = PERIOD == 4 ? (t == 0 ? 2u : t == 1 ? 6u : 4u) : COLOUR ? 4u : (t == 0 ? 2u : 6u);
     const bool upper = lane >= 32u;
     const unsigned lane31 = lane & 31u;
-    const unsigned my_off = field_offset<PERIOD>(lane);
+    const unsigned my_off = field_offset<PERIOD, COLOUR>(lane);
 
     const unsigned tiles = (n + TB - 1u) / TB, supers = (tiles + kFieldSubs - 1u) / kFieldSubs;
     unsigned round_base = 0;
@@ -859,7 +861,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
 #pragma unroll
             for (int sub = 0; sub < (int)kFieldSubs; sub++) {
                 const unsigned kk = best_k2[sub], best_off = best_off2[sub];
-                const unsigned best_len = field_offset<PERIOD>(lane + kk) - my_off;        // bytes of kk fields from here
+                const unsigned best_len = field_offset<PERIOD, COLOUR>(lane + kk) - my_off;        // bytes of kk fields from here
                 const unsigned long long cand_mask = ballot64(best_len >= 4u);
                 unsigned long long sel = 0;
                 unsigned cursor = (unsigned)__builtin_amdgcn_readfirstlane((int)skip);
@@ -875,7 +877,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
                 if (__builtin_amdgcn_inverse_ballot_w64(starts)) {
                     const unsigned long long a = ~(lit >> lane);
                     const unsigned r = a ? (unsigned)__builtin_ctzll(a) : 64u;
-                    run = field_offset<PERIOD>(lane + r) - my_off;
+                    run = field_offset<PERIOD, COLOUR>(lane + r) - my_off;
                 }
                 // this lane's element: literal = [run header] + the field's bytes, copy = 2 or 3 bytes
                 unsigned cnt = 0, vlo = 0, vhi = 0;
@@ -884,6 +886,8 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
                     unsigned flo, fhi = 0;
                     if (PERIOD == 4 && t >= 2u) {
                         flo = t == 2u ? ux[sub] : vx[sub];
+                    } else if (COLOUR) {
+                        flo = t == 0u ? ux[sub] : vx[sub];
                     } else if (t == 0u) {
                         flo = ux[sub] & 0xFFFFu;
                     } else {
@@ -1005,6 +1009,9 @@ extern "C" int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsig
         } while (0)
         if (frag_log2 == 13u && (granularity_mask & 16u))
             hipLaunchKernelGGL((snappy_compress_field_kernel<2u>), grid, block, 0, stream, frames, (uint8_t *)slots,
+                               slot_stride, frag_sizes);
+        if (frag_log2 == 13u && (granularity_mask & 64u))
+            hipLaunchKernelGGL((snappy_compress_field_kernel<2u, true>), grid, block, 0, stream, frames, (uint8_t *)slots,
                                slot_stride, frag_sizes);
         if (frag_log2 == 13u && (granularity_mask & 32u))
             hipLaunchKernelGGL((snappy_compress_field_kernel<4u>), grid, block, 0, stream, frames, (uint8_t *)slots,
