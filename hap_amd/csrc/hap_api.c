@@ -69,6 +69,42 @@ HapGpuContext *HapGpuDefaultContext(void)
     return g_default;
 }
 
+/* hap.h has no context argument, and the reference is re-entrant (no globals in hap.c): a client may call
+ * HapDecode from several threads at once, or again from inside its HapDecodeCallback (hap.h:113-130) while the
+ * outer call is still waiting for it.  A context serves one call at a time, so the hap.h entry points take
+ * whichever default context is free and add one (same device, own stream and scratch) when all are busy. */
+#define HAP_DEFAULT_POOL 8
+static HapGpuContext *g_pool[HAP_DEFAULT_POOL];
+static unsigned g_pool_count;
+static pthread_mutex_t g_pool_lock = PTHREAD_MUTEX_INITIALIZER;
+
+/* returns a default context with its lock HELD, or NULL when there is no GPU */
+static HapGpuContext *acquire_default_context(void)
+{
+    HapGpuContext *first = HapGpuDefaultContext(), *c = NULL;
+    unsigned i;
+    if (!first)
+        return NULL;
+    pthread_mutex_lock(&g_pool_lock);
+    if (g_pool_count == 0)
+        g_pool[g_pool_count++] = first;
+    for (i = 0; i < g_pool_count && !c; i++)
+        if (hapgpu_rt_trylock(g_pool[i]->rt) == 0)
+            c = g_pool[i];
+    if (!c && g_pool_count < HAP_DEFAULT_POOL &&
+        HapGpuCreate(hapgpu_rt_device(first->rt), &c) == HapResult_No_Error) {
+        c->frag_log2 = first->frag_log2;
+        g_pool[g_pool_count++] = c;
+        hapgpu_rt_lock(c->rt);
+    }
+    pthread_mutex_unlock(&g_pool_lock);
+    if (!c) {
+        c = first;                 /* pool exhausted: wait for the first one */
+        hapgpu_rt_lock(c->rt);
+    }
+    return c;
+}
+
 unsigned int HapGpuSetFragmentLog2(HapGpuContext *context, unsigned int log2_bytes)
 {
     if (!context || log2_bytes < 10 || log2_bytes > 16)
@@ -126,10 +162,9 @@ unsigned int HapEncode(unsigned int count, const void **inputBuffers, unsigned l
     if (count == 0 || count > 2 || !inputBuffers || !inputBuffersBytes || !textureFormats || !compressors ||
         !chunkCounts || !outputBuffer || outputBufferBytes == 0 || !outputBufferBytesUsed)
         return HapResult_Bad_Arguments;
-    ctx = HapGpuDefaultContext();
+    ctx = acquire_default_context();
     if (!ctx)
         return HapResult_Internal_Error;
-    hapgpu_rt_lock(ctx->rt);
     rc = hapb_encode(ctx, 1, count, (const void *const *)inputBuffers, inputBuffersBytes, textureFormats,
                      compressors, chunkCounts, &out, &outputBufferBytes, &used, &result, env_encode_flags(), 0);
     hapgpu_rt_unlock(ctx->rt);
@@ -149,10 +184,9 @@ unsigned int HapDecode(const void *inputBuffer, unsigned long inputBufferBytes, 
     unsigned long used = 0;
     if (!inputBuffer || index > 1 || !callback || !outputBuffer || !outputBufferTextureFormat)
         return HapResult_Bad_Arguments;
-    ctx = HapGpuDefaultContext();
+    ctx = acquire_default_context();
     if (!ctx)
         return HapResult_Internal_Error;
-    hapgpu_rt_lock(ctx->rt);
     rc = hapb_decode(ctx, 1, &inputBuffer, &inputBufferBytes, index, &outputBuffer, &outputBufferBytes, &used,
                      &fmt, &result, 0, callback, info);
     hapgpu_rt_unlock(ctx->rt);

@@ -151,8 +151,13 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
             size_t ilen = hapf_instructions_length(t->chunk_count);
             if (flags & HAPGPU_ENCODE_FRAGMENT_INDEX)
                 ilen += 8u + 4u * (size_t)t->chunk_count * t->fpc;
-            if (ilen + 4u > 0xFFFFFFu)
-                return HapResult_Bad_Arguments;   /* instruction container must fit a 24-bit length */
+            if (ilen + 4u > 0xFFFFFFu) {          /* instruction container must fit a 24-bit length */
+                for (f = 0; f < frame_count; f++) {
+                    results[f] = HapResult_Bad_Arguments;
+                    output_used[f] = 0;
+                }
+                return HapResult_Bad_Arguments;
+            }
             if (t->bytes + ilen + 4u > 0xFFFFFFu)
                 t->header_len = 8u;
         }
@@ -214,7 +219,9 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
             }
             if (!is_dev(ctx, outputs[f])) {
                 stage_off_out[f] = out_total + 1;
-                out_total += align_up(frame_raw_bound, 256);
+                /* (+8 per texture: a section written in the chunked form may exceed header + bytes by up to
+                   header_len - 1 bytes, see the comparison in frame_pack_kernel / hap.c:478) */
+                out_total += align_up(frame_raw_bound + 8u * count, 256);
             }
         }
         stage_in_bytes = in_total;
@@ -565,6 +572,8 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     HapGpuDecodeUnit *dunits;
     unsigned *job_of_frame;
     unsigned char *in_dev = NULL, *out_dev = NULL;     /* pointer classification, done once per buffer */
+    unsigned char *client_marks = NULL;                /* what the client's callback asked for (single-frame path) */
+    unsigned client_marks_count = 0;
     int rc = 0;
 
     if (frame_count == 0)
@@ -662,7 +671,8 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
             p->frag_table_offset = 0;
         if (p->mode == HAPGPU_JOB_COMPLEX) {
             unsigned per_chunk = 0;
-            if (p->frag_table_offset && p->chunk_count > 0 && p->frag_entries % (unsigned)p->chunk_count == 0)
+            if (p->frag_table_offset && p->chunk_count > 0 && p->frag_entries >= (unsigned)p->chunk_count &&
+                p->frag_entries % (unsigned)p->chunk_count == 0)
                 per_chunk = p->frag_entries / (unsigned)p->chunk_count;
             else
                 p->frag_table_offset = 0;
@@ -809,7 +819,16 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                 } else {
                     marks.count = (unsigned)plans[0].chunk_count;
                     marks.requested = req;
-                    callback(mark_chunk, &marks, marks.count, callback_info);
+                    if (ctx->preset_marks && ctx->preset_count == marks.count)
+                        memcpy(req, ctx->preset_marks, marks.count);      /* retry: the client was asked already */
+                    else
+                        callback(mark_chunk, &marks, marks.count, callback_info);
+                    free(client_marks);
+                    client_marks = (unsigned char *)malloc(marks.count);
+                    if (client_marks) {
+                        memcpy(client_marks, req, marks.count);
+                        client_marks_count = marks.count;
+                    }
                     for (c = 0; c < plans[0].chunk_count; c++)
                         if (!req[c])
                             all = 0;
@@ -881,10 +900,16 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
             if (results[f] != HAPGPU_STATUS_INDEX_MISMATCH)
                 continue;
             results[f] = HapResult_No_Error;
+            if (frame_count == 1 && client_marks) {
+                ctx->preset_marks = client_marks;
+                ctx->preset_count = client_marks_count;
+            }
             hapb_decode(ctx, 1, &inputs[f], &input_bytes[f], index, &outputs[f], &output_bytes[f],
                         output_used ? &output_used[f] : NULL, output_formats ? &output_formats[f] : NULL,
                         &results[f], flags | HAPGPU_DECODE_IGNORE_FRAGMENT_INDEX,
                         frame_count == 1 ? callback : NULL, callback_info);
+            ctx->preset_marks = NULL;
+            ctx->preset_count = 0;
         }
     }
 
@@ -896,7 +921,7 @@ finish:
         hapf_reader_free(&readers[f]);
     }
     free(plans); free(readers); free(fetchers); free(in_off); free(out_off); free(job_of_frame);
-    free(in_dev); free(out_dev);
+    free(in_dev); free(out_dev); free(client_marks);
     return first_error;
 
 fail_alloc:
@@ -907,6 +932,6 @@ fail_alloc:
         if (readers) hapf_reader_free(&readers[f]);
     }
     free(plans); free(readers); free(fetchers); free(in_off); free(out_off); free(job_of_frame);
-    free(in_dev); free(out_dev);
+    free(in_dev); free(out_dev); free(client_marks);
     return HapResult_Internal_Error;
 }

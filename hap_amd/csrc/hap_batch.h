@@ -15,6 +15,10 @@ struct HapGpuContext {
     unsigned byte_granular;   /* HAP_AMD_BYTE_GRANULAR=1: never emit 16-bit granular element streams */
     unsigned compress_v1;     /* HAP_AMD_COMPRESS_V1: the first-generation compressor (no match window) */
     unsigned position_lanes;  /* HAP_AMD_POSITION_LANES: never use the field-per-lane compressor */
+    /* chunk marks collected from the client's HapDecodeCallback, handed to the retry of a frame whose fragment
+       table turned out wrong: the callback is invoked exactly once per HapDecode, as in the reference */
+    const unsigned char *preset_marks;
+    unsigned preset_count;
 };
 
 /* inputs_are_device != 0: every input pointer is known to be device memory (skips classification) */

@@ -66,7 +66,9 @@ int hapf_read_section(const uint8_t *p, uint32_t available, hapf_section *out)
         out->header_len = 8u;
     }
     out->type = p[3];
-    if ((uint32_t)(out->header_len + out->length) > available)
+    /* hardening: compared in 64 bits.  The reference adds in 32 bits (hap.c:160-181), so a length of
+       0xFFFFFFF8 and more wraps and is accepted there; such a section cannot exist in `available` bytes. */
+    if ((uint64_t)out->header_len + out->length > available)
         return HapResult_Bad_Frame;
     return HapResult_No_Error;
 }
@@ -189,6 +191,8 @@ unsigned hapf_locate(hapf_reader *r, uint32_t frame_bytes, unsigned index,
         *section_offset = top.header_len + cursor + s.header_len;
         *section_length = s.length;
         *section_type = s.type;
+        if (*section_offset + s.length > frame_bytes)
+            return HapResult_Bad_Frame;
         return HapResult_No_Error;
     }
     if (index != 0)
@@ -196,6 +200,8 @@ unsigned hapf_locate(hapf_reader *r, uint32_t frame_bytes, unsigned index,
     *section_offset = top.header_len;
     *section_length = top.length;
     *section_type = top.type;
+    if (*section_offset + top.length > frame_bytes)
+        return HapResult_Bad_Frame;
     return HapResult_No_Error;
 }
 
@@ -236,6 +242,10 @@ static void plan_complex(hapf_reader *r, hapf_texture_plan *plan, int want_chunk
         case HAP_SECTION_OFFSETS: offsets = (int64_t)at; n = s.length / 4u; break;
         case HAP_SECTION_FRAGMENTS: frags = (int64_t)at; frag_bytes = s.length; break;
         default: break;               /* unknown sections are skipped */
+        }
+        if (n > 0x7FFFFFFFu) {
+            plan->result = HapResult_Bad_Frame;
+            return;
         }
         if (n != 0) {
             if (plan->chunk_count != 0 && (int)n != plan->chunk_count) {
@@ -350,6 +360,8 @@ unsigned hapf_texture_count(hapf_reader *r, unsigned long frame_bytes, unsigned 
             rc = read_section_at(r, cursor, (uint32_t)(frame_bytes - cursor), &s);
             if (rc != HapResult_No_Error)
                 return (unsigned)rc;
+            if ((uint64_t)cursor + s.header_len + s.length > 0xFFFFFFFFu)
+                return HapResult_Bad_Frame;
             cursor += s.header_len + s.length;
             *count += 1;
         }

@@ -109,7 +109,8 @@ unsigned int HapGpuJoinChunkGroups(unsigned int groupCount, const void *const *g
                     j->all_raw = 0;
             }
             j->chunk_count += (unsigned)p->chunk_count;
-            if (!p->frag_table_offset || p->chunk_count <= 0 || p->frag_entries % (unsigned)p->chunk_count) {
+            if (!p->frag_table_offset || p->chunk_count <= 0 || p->frag_entries == 0 ||
+                p->frag_entries % (unsigned)p->chunk_count) {
                 j->keep_index = 0;
             } else {
                 const unsigned per_chunk = p->frag_entries / (unsigned)p->chunk_count;

@@ -152,6 +152,9 @@ int hapgpu_rt_zero(hapgpu_rt *rt, void *dst, size_t bytes);
 int hapgpu_rt_sync(hapgpu_rt *rt);
 void hapgpu_rt_lock(hapgpu_rt *rt);
 void hapgpu_rt_unlock(hapgpu_rt *rt);
+/* 0: the lock was free and is now held by the caller */
+int hapgpu_rt_trylock(hapgpu_rt *rt);
+int hapgpu_rt_device(hapgpu_rt *rt);
 
 /* kernels: all asynchronous on the runtime's stream; 0 = launched */
 int hapgpu_k_block_encode(hapgpu_rt *rt, const void *rgba, unsigned width, unsigned height,

@@ -133,6 +133,16 @@ extern "C" void hapgpu_rt_lock(hapgpu_rt *rt)
 
 extern "C" void hapgpu_rt_unlock(hapgpu_rt *rt) { pthread_mutex_unlock(&rt->lock); }
 
+extern "C" int hapgpu_rt_trylock(hapgpu_rt *rt)
+{
+    if (pthread_mutex_trylock(&rt->lock) != 0)
+        return 1;
+    (void)hipSetDevice(rt->device);
+    return 0;
+}
+
+extern "C" int hapgpu_rt_device(hapgpu_rt *rt) { return rt->device; }
+
 extern "C" int hapgpu_rt_is_device_ptr(hapgpu_rt *rt, const void *p)
 {
     (void)rt;

@@ -85,6 +85,27 @@ def test_inspectors_on_golden_and_malformed_frames(hap):
                 assert hap.HapGetFrameTextureChunkCount(f, idx) == ora.chunk_count(f, idx)
 
 
+@pytest.mark.timeout(30)
+def test_section_lengths_that_wrap_32_bits_are_rejected(hap):
+    """Hardening beyond the reference (hap.c:160-181 adds header + length in 32 bits): a section length of
+    0xFFFFFFF8 and more used to wrap the bound check -- the texture counter then never advanced (a hang) and the
+    planner accepted a 4 GiB section over a 16-byte frame."""
+    huge = (0xFFFFFFF8).to_bytes(4, "little")
+    # top: multi-image section, 16 bytes of payload; inside: an 8-byte header announcing 0xFFFFFFF8 bytes
+    f1 = (16).to_bytes(3, "little") + b"\x0d" + b"\0\0\0\xcf" + huge + bytes(8)
+    assert len(f1) == 20
+    assert hap.HapGetFrameTextureCount(f1)[0] == hap.HapResult.Bad_Frame
+    assert hap.HapGetFrameTextureFormat(f1, 0)[0] == hap.HapResult.Bad_Frame
+    assert hap.HapGetFrameTextureChunkCount(f1, 0)[0] == hap.HapResult.Bad_Frame
+    assert hap.HapGpuJoinChunkGroups([f1, f1])[0] == hap.HapResult.Bad_Frame
+    # a 16-byte frame whose only section claims 0xFFFFFFF9 bytes (raw and Snappy flavours)
+    for type_byte in (0xAB, 0xBB, 0xCB):
+        f2 = b"\0\0\0" + bytes([type_byte]) + (0xFFFFFFF9).to_bytes(4, "little") + bytes(8)
+        assert hap.HapGetFrameTextureCount(f2)[0] == hap.HapResult.Bad_Frame
+        assert hap.HapGetFrameTextureChunkCount(f2, 0)[0] == hap.HapResult.Bad_Frame
+        assert hap.HapGpuGetFrameTextureChunkLayout(f2, 0)[0] == hap.HapResult.Bad_Frame
+
+
 def test_sequence_file_round_trip_and_malformed_files(hap, tmp_path):
     """include/hap_sequence.h (no GPU): frames come back byte for byte, the index is validated on open."""
     ora = L.oracle_api()

@@ -25,6 +25,10 @@ def test_container_code_is_clean_under_asan_and_ubsan(tmp_path):
     body = bytes(f[hdr + 4: hdr + 4 + ilen]) + table
     inner = len(body).to_bytes(3, "little") + bytes([1]) + body + bytes(f[hdr + 4 + ilen:])
     frames.append(len(inner).to_bytes(3, "little") + bytes([f[3]]) + inner)
+    # section lengths that wrap the reference's 32-bit bound check (hap.c:160-181): once a hang / a 4 GiB plan
+    huge = (0xFFFFFFF8).to_bytes(4, "little")
+    frames.append((16).to_bytes(3, "little") + b"\x0d" + b"\0\0\0\xcf" + huge + bytes(8))
+    frames.append(b"\0\0\0\xcb" + (0xFFFFFFF9).to_bytes(4, "little") + bytes(8))
     paths = []
     for i, fr in enumerate(frames):
         p = tmp_path / ("frame%d.bin" % i)
