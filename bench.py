@@ -8,9 +8,13 @@ One "step" = one pass of the hot path over one 60-frame batch:
     frame_gather] -> Hap Q frame (HBM) -> [decode_plan, snappy_decode] -> texture (HBM)
 value = frames * W*H*4 bytes / seconds for encode+decode together (decimal GB/s).
 
-Multi-GPU: one process per GPU (torchrun), frames are independent so every rank runs the
-same pipeline on its own 60 frames (weak scaling), no data-path collective; the only
-torch.distributed traffic is the barrier and the MAX-reduce of the elapsed time.
+Multi-GPU: one process per GPU (`python bench.py --gpus N` starts the N ranks itself when no
+launcher did), frames are independent: the 60-frame stream is split f -> GPU f mod N (SURVEY 8e,
+"strong" scaling, 8/8/8/8/7/7/7/7 at N = 8) with no data-path collective; the only
+torch.distributed traffic of the headline is the barrier and the MAX-reduce of the elapsed time.
+At N > 1 the line also carries the weak-scaling figure (a whole stream per GPU) and the C5
+chunk-group split of one 16K frame without and with the RCCL gather.  At N = 1 it carries a "c5"
+object: the north-star's 16K Hap Q Alpha target config timed the same way.
 
 Extra objects on the JSON line: "roofline" for the dominant kernel (HIP events recorded on the
 library's own stream around every launch of the timed region) and "cpu_baseline" (the
@@ -40,69 +44,182 @@ CONFIGS = {
 BLOCK_BYTES = {0x83F0: 8, 0x8DBB: 8, 0x83F3: 16, 0x01: 16}
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="C4", choices=sorted(CONFIGS))
-    ap.add_argument("--frames", type=int, default=0, help="frames per batch (default: the config's)")
+    ap.add_argument("--frames", type=int, default=0, help="frames of the stream (default: the config's)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong: the stream is split over the ranks, frame f -> rank f mod N (SURVEY 8e); "
+                         "weak: every rank gets a whole stream of its own")
     ap.add_argument("--no-fragment-index", action="store_true")
     ap.add_argument("--frag-log2", type=int, default=0, help="Snappy fragment size (log2 bytes); 0 = library default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--foreign-frames", type=int, default=24,
                     help="also time decoding of N frames made by the CPU reference encoder (no fragment table); 0 = skip")
-    args = ap.parse_args()
+    ap.add_argument("--c5-frames", type=int, default=2,
+                    help="also time N frames of C5 (16K Hap Q Alpha, the north-star's target config) at N=1; 0 = skip")
+    ap.add_argument("--selftest-cpu", action="store_true",
+                    help="launch / rank / reduction logic only, gloo on CPU, a sleep in place of the codec (tests)")
+    return ap.parse_args()
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of ourselves, one per GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def frames_of_rank(total, rank, world, scaling):
+    """Frame numbers (seeds of the synthetic stream) this rank works on."""
+    if scaling == "weak":
+        return list(range(rank * total, (rank + 1) * total))
+    return list(range(rank, total, world))          # hap_amd.shard.frames_for_rank: 60 over 8 -> 8/8/8/8/7/7/7/7
+
+
+class Stream:
+    """One rank's share of a synthetic stream with every buffer resident in HBM, and the timed step over it."""
+
+    def __init__(self, hap_amd, ctx, dev, config, frame_ids, flags):
+        from hap_amd import synth
+        self.hap, self.ctx = hap_amd, ctx
+        self.w, self.h, self.fmts, self.chunks, _n = CONFIGS[config]
+        self.nf = len(frame_ids)
+        self.flags = flags
+        w, h = self.w, self.h
+        self.tex_bytes = [(w // 4) * (h // 4) * BLOCK_BYTES[f] for f in self.fmts]
+        self.cap = hap_amd.HapMaxEncodedLength(self.tex_bytes, self.fmts, self.chunks)
+        self.rgba_bytes = w * h * 4
+        self.comps = [1] * len(self.fmts)
+        # the buffers stay where they are for the whole run: resolve their addresses once, as a C client would
+        self.rgba = hap_amd.BufferList([synth.rgba_frame(w, h, i, device=dev) for i in frame_ids])
+        self.frames = hap_amd.BufferList([torch.empty(self.cap, dtype=torch.uint8, device=dev) for _ in frame_ids])
+        self.dec = [hap_amd.BufferList([torch.empty(tb, dtype=torch.uint8, device=dev) for _ in frame_ids])
+                    for tb in self.tex_bytes]
+        self.used = None
+        torch.cuda.synchronize()
+
+    def encode(self, flags=None):
+        r, used, results = self.ctx.encode_frames_rgba(self.rgba, self.w, self.h, self.w * 4, self.fmts, self.comps,
+                                                       self.chunks, self.frames, flags=self.flags if flags is None else flags)
+        if r != 0:
+            raise RuntimeError("encode failed: %r %r" % (r, results[:4]))
+        return used
+
+    def decode(self, used):
+        for idx in range(len(self.fmts)):
+            r, dused, _dfmts, dres = self.ctx.decode_frames(self.frames, used, idx, self.dec[idx])
+            if r != 0 or dused[0] != self.tex_bytes[idx]:
+                raise RuntimeError("decode failed: %r %r" % (r, dres[:4]))
+
+    def step(self):
+        if self.nf == 0:
+            return
+        self.used = self.encode()
+        self.decode(self.used)
+
+    def timed(self, steps, warmup, fence):
+        """K steps between fences; returns (seconds, per-class HIP-event profile of the timed region)."""
+        for _ in range(warmup):
+            self.step()
+        self.ctx.set_profiling(True)
+        self.ctx.collect_profile()            # drop anything recorded so far
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        prof = self.ctx.collect_profile()
+        self.ctx.set_profiling(False)
+        return elapsed, prof
+
+    def split_rates(self):
+        """separate encode / decode wall times of one untimed extra pass (events on the library's stream)"""
+        self.ctx.timer_start()
+        used = self.encode()
+        enc_ms = self.ctx.timer_stop()
+        self.ctx.timer_start()
+        self.decode(used)
+        dec_ms = self.ctx.timer_stop()
+        return enc_ms, dec_ms
+
+    def kernel_table(self, prof, steps, config):
+        """Per kernel class: launches, time, algorithmic GB/s.  Algorithmic bytes per step follow SURVEY 8d:
+        block encode 64 + sum(b) per block (the RGBA is counted once however many launches read it), Snappy compress
+        b(1 + c), decode b(1 + c), gather 2 c b."""
+        nf = self.nf
+        blocks = (self.w // 4) * (self.h // 4)
+        bsum = sum(self.tex_bytes)
+        frame_bytes = sum(self.used) / max(nf, 1)
+        per_step = {"block_encode": nf * blocks * (64 + sum(BLOCK_BYTES[f] for f in self.fmts)),
+                    "snappy_compress": nf * (bsum + frame_bytes),
+                    "frame_gather": nf * 2 * frame_bytes,
+                    "snappy_decode": nf * (frame_bytes + bsum)}
+        kernels = {}
+        for name, (launches, ms) in prof.items():
+            if not launches:
+                continue
+            k = {"launches": int(launches), "ms_total": round(ms, 4), "ms_avg": round(ms / launches, 5)}
+            if name in per_step:
+                k["algorithmic_bytes_per_launch"] = int(per_step[name] * steps / launches)
+                k["algorithmic_GBps"] = round(per_step[name] * steps / (ms * 1e-3) / 1e9, 1)
+            kernels[name] = k
+        return kernels, frame_bytes / bsum
+
+    def roofline(self, kernels, config, kernel=None):
+        cands = [k for k in kernels if "algorithmic_GBps" in kernels[k]]
+        dom = kernel or max(cands, key=lambda k: kernels[k]["ms_total"])
+        achieved = kernels[dom]["algorithmic_GBps"]
+        traffic, source = measured_traffic(config, dom, self.nf)
+        return {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": source,
+                "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_launch"],
+                "avg_launch_ms": kernels[dom]["ms_avg"]}
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(respawn_under_torchrun(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1 or "RANK" in os.environ:     # launched by torch.distributed.run
+    dist = None
+    if "RANK" in os.environ:                                      # launched by torch.distributed.run
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    else:
-        dist = None
-        torch.cuda.set_device(local_rank)
+        if not args.selftest_cpu:
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group("gloo" if args.selftest_cpu else "nccl", rank=rank, world_size=world)
+        world = dist.get_world_size()
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but %d rank(s) were started" % (args.gpus, world))
+    if args.selftest_cpu:
+        return selftest_cpu(args, dist, rank, world)
+    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     import hap_amd
-    from hap_amd import synth
 
-    w, h, fmts, chunks, nf_default = CONFIGS[args.config]
-    nf = args.frames or nf_default
+    nf_total = args.frames or CONFIGS[args.config][4]
     ctx = hap_amd.Context(local_rank)
     if args.frag_log2:
         ctx.set_fragment_log2(args.frag_log2)
     flags = 0 if args.no_fragment_index else hap_amd.ENCODE_FRAGMENT_INDEX
-    tex_bytes = [(w // 4) * (h // 4) * BLOCK_BYTES[f] for f in fmts]
-    cap = hap_amd.HapMaxEncodedLength(tex_bytes, fmts, chunks)
-    rgba_bytes = w * h * 4
-
-    rgba = [synth.rgba_frame(w, h, rank * nf + i, device=dev) for i in range(nf)]
-    frames = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(nf)]
-    dec = [[torch.empty(tb, dtype=torch.uint8, device=dev) for _ in range(nf)] for tb in tex_bytes]
-    comps = [1] * len(fmts)
-    # the buffers stay where they are for the whole run: resolve their addresses once, as a C client would
-    rgba = hap_amd.BufferList(rgba)
-    frames = hap_amd.BufferList(frames)
-    dec = [hap_amd.BufferList(d) for d in dec]
-    torch.cuda.synchronize()
-
-    used_box = [None]
-
-    def step():
-        r, used, results = ctx.encode_frames_rgba(rgba, w, h, w * 4, fmts, comps, chunks, frames, flags=flags)
-        if r != 0:
-            raise RuntimeError("encode failed: %r %r" % (r, results[:4]))
-        used_box[0] = used
-        for idx in range(len(fmts)):
-            r, dused, dfmts, dres = ctx.decode_frames(frames, used, idx, dec[idx])
-            if r != 0 or dused[0] != tex_bytes[idx]:
-                raise RuntimeError("decode failed: %r %r" % (r, dres[:4]))
 
     def fence():
         torch.cuda.synchronize()
@@ -111,140 +228,292 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    ctx.set_profiling(True)
-    ctx.collect_profile()            # drop anything recorded so far
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    prof = ctx.collect_profile()
-    ctx.set_profiling(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    def max_over_ranks(seconds):
+        if dist is None:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
 
-    # separate encode / decode wall rates (untimed extra pass, events on the library's stream)
-    ctx.timer_start()
-    r, used, _ = ctx.encode_frames_rgba(rgba, w, h, w * 4, fmts, comps, chunks, frames, flags=flags)
-    enc_ms = ctx.timer_stop()
-    ctx.timer_start()
-    for idx in range(len(fmts)):
-        ctx.decode_frames(frames, used, idx, dec[idx])
-    dec_ms = ctx.timer_stop()
+    stream = Stream(hap_amd, ctx, dev, args.config, frames_of_rank(nf_total, rank, world, args.scaling), flags)
+    elapsed, prof = stream.timed(args.steps, args.warmup, fence)
+    elapsed = max_over_ranks(elapsed)
+    total_frames = (nf_total if args.scaling == "strong" else nf_total * world) * args.steps
+    rgba_bytes = stream.rgba_bytes
+    value = total_frames * rgba_bytes / elapsed / 1e9
 
-    # the size-for-speed option (HAPGPU_ENCODE_COARSE_MATCHES), reported beside the default; never `value`
-    coarse = None
-    if world == 1 and hasattr(hap_amd, "ENCODE_COARSE_MATCHES"):
-        cflags = flags | hap_amd.ENCODE_COARSE_MATCHES
-        ctx.encode_frames_rgba(rgba, w, h, w * 4, fmts, comps, chunks, frames, flags=cflags)
-        ctx.timer_start()
-        r, cused, _ = ctx.encode_frames_rgba(rgba, w, h, w * 4, fmts, comps, chunks, frames, flags=cflags)
-        for idx in range(len(fmts)):
-            ctx.decode_frames(frames, cused, idx, dec[idx])
-        c_ms = ctx.timer_stop()
-        coarse = {"rgba_GBps": round(nf * rgba_bytes / (c_ms * 1e-3) / 1e9, 2), "ms": round(c_ms, 3),
-                  "snappy_ratio": round(sum(cused) / nf / sum(tex_bytes), 4),
-                  "note": "encode+decode with 32-bit granular element streams for every format"}
-        r, used, _ = ctx.encode_frames_rgba(rgba, w, h, w * 4, fmts, comps, chunks, frames, flags=flags)
-
-    # DXT -> RGBA, untimed extra: what a player without texture units needs after HapDecode
-    rgba_out = torch.empty(w * h * 4, dtype=torch.uint8, device=dev)
-    torch.cuda.synchronize()
-    ctx.set_profiling(True)
-    ctx.collect_profile()
-    for i in range(min(nf, 16)):
-        ctx.decompress_rgba(dec[0][i], fmts[0], w, h, rgba=rgba_out, alpha=(dec[1][i] if len(fmts) > 1 else None))
-    prof_bd = ctx.collect_profile().get("block_decode", (0, 0.0))
-    ctx.set_profiling(False)
+    other = None
+    if world > 1:
+        # the other scaling mode beside the headline (same kernels, same step; a second timed region)
+        mode = "weak" if args.scaling == "strong" else "strong"
+        del stream.rgba, stream.frames, stream.dec
+        torch.cuda.empty_cache()
+        s2 = Stream(hap_amd, ctx, dev, args.config, frames_of_rank(nf_total, rank, world, mode), flags)
+        e2, _p2 = s2.timed(args.steps, 1, fence)
+        e2 = max_over_ranks(e2)
+        f2 = (nf_total if mode == "strong" else nf_total * world) * args.steps
+        other = {"scaling": mode, "value": round(f2 * rgba_bytes / e2 / 1e9, 2), "unit": "GB/s", "fps": round(f2 / e2, 1),
+                 "ms_per_step": round(e2 / args.steps * 1e3, 3), "frames_per_step": f2 // args.steps}
+        del s2
+        torch.cuda.empty_cache()
+        groups = c5_chunk_groups(hap_amd, ctx, dist, dev, rank, world, fence)
+    else:
+        groups = None
 
     if rank != 0:
         if dist is not None:
+            dist.barrier()
             dist.destroy_process_group()
         return
-
-    total_frames = nf * world * args.steps
-    value = total_frames * rgba_bytes / elapsed / 1e9
-    frame_bytes = sum(used) / nf
-    ratio = frame_bytes / sum(tex_bytes)
-
-    # ---- roofline of the dominant kernel: algorithmic bytes per launch / mean launch time ----
-    blocks = (w // 4) * (h // 4)
-    bsum = sum(tex_bytes)
-    algo = {
-        "block_encode": None,      # filled per launch below (one launch per frame per texture)
-        "snappy_compress": nf * (bsum + frame_bytes),
-        "frame_pack": None,
-        "frame_gather": nf * 2 * frame_bytes,
-        "decode_plan": None,
-        "snappy_decode": nf * (frame_bytes * (tex_bytes[0] / bsum) + tex_bytes[0]) if len(fmts) == 1 else None,
-    }
-    # block encode: one launch per texture format over the whole batch
-    algo["block_encode"] = nf * sum(blocks * (64 + BLOCK_BYTES[f]) for f in fmts) / len(fmts)
-    if len(fmts) > 1:
-        algo["snappy_decode"] = nf * (frame_bytes + bsum) / len(fmts)
-    kernels = {}
-    for name, (launches, ms) in prof.items():
-        if launches:
-            kernels[name] = {"launches": int(launches), "ms_total": round(ms, 4), "ms_avg": round(ms / launches, 5)}
-            if algo.get(name):
-                kernels[name]["algorithmic_GBps"] = round(algo[name] / (ms / launches * 1e-3) / 1e9, 1)
-    dom = max((k for k in kernels if algo.get(k)), key=lambda k: kernels[k]["ms_total"])
-    achieved = kernels[dom]["algorithmic_GBps"]
-    roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": measured_traffic(args.config, dom, nf),
-                "algorithmic_bytes_per_launch": int(algo[dom]), "avg_launch_ms": kernels[dom]["ms_avg"]}
-
-    if world > 1:
-        args.no_cpu_baseline = True       # the CPU / foreign / host-pointer legs are reported at N=1 only
-    host_path = None
-    if not args.no_cpu_baseline:
-        try:
-            host_path = host_pointer_path(ctx, rgba, frames, used, fmts, comps, chunks, tex_bytes, cap, w, h, flags)
-        except Exception as exc:
-            host_path = {"error": repr(exc)}
-    foreign = None
-    if args.foreign_frames and not args.no_cpu_baseline:
-        try:
-            foreign = decode_foreign(ctx, dev, fmts, chunks, dec, tex_bytes, cap, min(args.foreign_frames, nf), rgba_bytes)
-        except Exception as exc:
-            foreign = {"error": repr(exc)}
-    cpu = None
-    if not args.no_cpu_baseline:
-        try:
-            cpu = cpu_baseline(w, h, fmts, chunks, rgba, dec, tex_bytes, cap, args.cpu_seconds)
-        except Exception as exc:       # the baseline is reported, never required
-            cpu = {"error": repr(exc)}
 
     line = {
         "metric": "RGBA GB/s + frames/sec, 8K Hap Q encode+decode" if args.config == "C4"
                   else "RGBA GB/s + frames/sec, %s encode+decode" % args.config,
         "value": round(value, 2), "unit": "GB/s", "fps": round(total_frames / elapsed, 1),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "%s: %dx%d %s, %s chunks, Snappy, %d-frame batch per GPU, device-resident" % (
-            args.config, w, h, "+".join("%#x" % f for f in fmts), "+".join(map(str, chunks)), nf),
-            "frames_per_step_per_gpu": nf, "fragment_index": not args.no_fragment_index,
-            "snappy_ratio": round(ratio, 4), "parallelism": "frame-shard x%d" % world},
-        "encode_only": {"rgba_GBps": round(nf * rgba_bytes / (enc_ms * 1e-3) / 1e9, 2), "ms": round(enc_ms, 3)},
-        "decode_only": {"rgba_GBps": round(nf * rgba_bytes / (dec_ms * 1e-3) / 1e9, 2), "ms": round(dec_ms, 3),
-                        "texture_GBps": round(nf * bsum / (dec_ms * 1e-3) / 1e9, 2)},
-        "texture_to_rgba": ({"us_per_frame": round(prof_bd[1] / prof_bd[0] * 1e3, 2),
-                             "algorithmic_GBps": round((sum(tex_bytes) + rgba_bytes) / (prof_bd[1] / prof_bd[0] * 1e-3) / 1e9, 1)}
-                            if prof_bd[0] else None),
-        "coarse_matches_option": coarse,
-        "decode_of_reference_encoded_frames": foreign,
-        "host_pointer_path": host_path,
-        "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
     }
+    w, h, fmts, chunks = stream.w, stream.h, stream.fmts, stream.chunks
+    if world == 1:
+        kernels, ratio = stream.kernel_table(prof, args.steps, args.config)
+        enc_ms, dec_ms = stream.split_rates()
+        nf, bsum = stream.nf, sum(stream.tex_bytes)
+        line["config"] = {"workload": "%s: %dx%d %s, %s chunks, Snappy, %d-frame stream, device-resident" % (
+            args.config, w, h, "+".join("%#x" % f for f in fmts), "+".join(map(str, chunks)), nf_total),
+            "frames_per_step": nf_total, "fragment_index": not args.no_fragment_index,
+            "snappy_ratio": round(ratio, 4), "parallelism": "single GPU"}
+        line["encode_only"] = {"rgba_GBps": round(nf * rgba_bytes / (enc_ms * 1e-3) / 1e9, 2), "ms": round(enc_ms, 3)}
+        line["decode_only"] = {"rgba_GBps": round(nf * rgba_bytes / (dec_ms * 1e-3) / 1e9, 2), "ms": round(dec_ms, 3),
+                               "texture_GBps": round(nf * bsum / (dec_ms * 1e-3) / 1e9, 2)}
+        line["texture_to_rgba"] = texture_to_rgba(stream, dev)
+        line["coarse_matches_option"] = coarse_option(stream, hap_amd)
+        stream.used = stream.encode()
+        extras = {}
+        if not args.no_cpu_baseline:
+            for name, fn in (("host_pointer_path", lambda: host_pointer_path(ctx, stream.rgba, stream.frames, stream.used, fmts,
+                                                                                stream.comps, chunks, stream.tex_bytes, stream.cap, w, h, flags)),
+                             ("decode_of_reference_encoded_frames",
+                              lambda: decode_foreign(ctx, dev, fmts, chunks, stream.dec, stream.tex_bytes, stream.cap,
+                                                     min(args.foreign_frames, nf), rgba_bytes) if args.foreign_frames else None),
+                             ("cpu_baseline", lambda: cpu_baseline(w, h, fmts, chunks, stream.rgba, stream.dec, stream.tex_bytes,
+                                                                    stream.cap, args.cpu_seconds))):
+                try:
+                    extras[name] = fn()
+                except Exception as exc:       # these legs are reported, never required
+                    extras[name] = {"error": repr(exc)}
+        line["decode_of_reference_encoded_frames"] = extras.get("decode_of_reference_encoded_frames")
+        line["host_pointer_path"] = extras.get("host_pointer_path")
+        line["roofline"] = stream.roofline(kernels, args.config)
+        line["kernels"] = kernels
+        line["cpu_baseline"] = extras.get("cpu_baseline")
+        if args.c5_frames and args.config != "C5":
+            del stream
+            torch.cuda.empty_cache()
+            try:
+                line["c5"] = c5_target(hap_amd, ctx, dev, args.c5_frames, flags, fence)
+            except Exception as exc:
+                line["c5"] = {"error": repr(exc)}
+    else:
+        per_rank = [len(frames_of_rank(nf_total, r, world, args.scaling)) for r in range(world)]
+        line["config"] = {"workload": "%s: %dx%d %s, %s chunks, Snappy, %d-frame stream, device-resident" % (
+            args.config, w, h, "+".join("%#x" % f for f in fmts), "+".join(map(str, chunks)), nf_total),
+            "frames_per_step": total_frames // args.steps, "frames_per_rank": per_rank,
+            "fragment_index": not args.no_fragment_index,
+            "parallelism": "frame f -> GPU f mod %d, no data-path collective" % world if args.scaling == "strong"
+                           else "a whole stream per GPU, no data-path collective"}
+        line["other_scaling_mode"] = other
+        line["c5_chunk_groups"] = groups
+        kernels, _ratio = stream.kernel_table(prof, args.steps, args.config)
+        line["roofline"] = stream.roofline(kernels, args.config)
+        line["roofline"]["note"] = "rank 0's launches (%d frames per step)" % stream.nf
+        line["cpu_baseline"] = None
     print(json.dumps(line))
+    sys.stdout.flush()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def selftest_cpu(args, dist, rank, world):
+    """The launch path without a GPU: same spawning, rank split, barrier and MAX-reduce, gloo instead of RCCL and a
+    sleep of 1 ms per frame instead of the codec.  Used by tests/test_sharding_gloo.py; never a measurement."""
+    nf_total = args.frames or CONFIGS[args.config][4]
+    mine = frames_of_rank(nf_total, rank, world, args.scaling)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(1e-3 * len(mine))
+    fence()
+    elapsed = time.perf_counter() - t0
+    counts = [len(mine)]
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        box = [None] * world
+        dist.all_gather_object(box, len(mine))
+        counts = box
+    if rank == 0:
+        total = (nf_total if args.scaling == "strong" else nf_total * world) * args.steps
+        print(json.dumps({"selftest": True, "n_gpus": world, "scaling": args.scaling, "frames_per_rank": counts,
+                          "frames_per_step": total // args.steps, "ms_per_step": round(elapsed / args.steps * 1e3, 3)}))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def texture_to_rgba(stream, dev):
+    """DXT -> RGBA, untimed extra: what a player without texture units needs after HapDecode"""
+    ctx, w, h, fmts = stream.ctx, stream.w, stream.h, stream.fmts
+    rgba_out = torch.empty(w * h * 4, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx.set_profiling(True)
+    ctx.collect_profile()
+    for i in range(min(stream.nf, 16)):
+        ctx.decompress_rgba(stream.dec[0][i], fmts[0], w, h, rgba=rgba_out, alpha=(stream.dec[1][i] if len(fmts) > 1 else None))
+    n, ms = ctx.collect_profile().get("block_decode", (0, 0.0))
+    ctx.set_profiling(False)
+    if not n:
+        return None
+    return {"us_per_frame": round(ms / n * 1e3, 2),
+            "algorithmic_GBps": round((sum(stream.tex_bytes) + stream.rgba_bytes) / (ms / n * 1e-3) / 1e9, 1)}
+
+
+def coarse_option(stream, hap_amd):
+    """the size-for-speed option (HAPGPU_ENCODE_COARSE_MATCHES), reported beside the default; never `value`"""
+    if not hasattr(hap_amd, "ENCODE_COARSE_MATCHES"):
+        return None
+    cflags = stream.flags | hap_amd.ENCODE_COARSE_MATCHES
+    stream.encode(cflags)
+    stream.ctx.timer_start()
+    cused = stream.encode(cflags)
+    stream.decode(cused)
+    c_ms = stream.ctx.timer_stop()
+    return {"rgba_GBps": round(stream.nf * stream.rgba_bytes / (c_ms * 1e-3) / 1e9, 2), "ms": round(c_ms, 3),
+            "snappy_ratio": round(sum(cused) / stream.nf / sum(stream.tex_bytes), 4),
+            "note": "encode+decode with 32-bit granular element streams for every format"}
+
+
+def c5_target(hap_amd, ctx, dev, frames, flags, fence, steps=3):
+    """The north-star's target config beside the headline: 16384x16384 Hap Q Alpha (YCoCg-DXT5 + RGTC1, 64 + 64 chunks,
+    two-texture frame), `frames` frames per step on this GPU.  Same step, same timing rules."""
+    s = Stream(hap_amd, ctx, dev, "C5", list(range(frames)), flags)
+    elapsed, prof = s.timed(steps, 1, fence)
+    kernels, ratio = s.kernel_table(prof, steps, "C5")
+    enc_ms, dec_ms = s.split_rates()
+    total = frames * steps
+    return {"workload": "C5: 16384x16384 0x1+0x8dbb, 64+64 chunks, Snappy, %d frames per step, device-resident" % frames,
+            "value": round(total * s.rgba_bytes / elapsed / 1e9, 2), "unit": "GB/s", "fps": round(total / elapsed, 2),
+            "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 3), "snappy_ratio": round(ratio, 4),
+            "encode_only": {"rgba_GBps": round(frames * s.rgba_bytes / (enc_ms * 1e-3) / 1e9, 2), "ms": round(enc_ms, 3)},
+            "decode_only": {"rgba_GBps": round(frames * s.rgba_bytes / (dec_ms * 1e-3) / 1e9, 2), "ms": round(dec_ms, 3),
+                            "texture_GBps": round(frames * sum(s.tex_bytes) / (dec_ms * 1e-3) / 1e9, 2)},
+            "roofline": s.roofline(kernels, "C5", kernel="snappy_decode"),
+            "kernels": kernels}
+
+
+def c5_chunk_groups(hap_amd, ctx, dist, dev, rank, world, fence, reps=3):
+    """One 16K Hap Q Alpha frame split over the ranks by chunk groups: rank r encodes its band of block
+    rows as a frame of chunks/W chunks; band frames are gathered on rank 0 (RCCL send/recv over xGMI) and joined
+    (HapGpuJoinChunkGroups); then every rank decodes its chunk group of the joined frame in place and the slices are
+    gathered on rank 0.  Reported without and with the gathers.  All ranks call this; rank 0 gets the dict."""
+    from hap_amd import shard, synth
+    w = h = 16384
+    nchunks = 64
+    fmts = [0x01, 0x8DBB]
+    try:
+        lo, hi, band_chunks = shard.band_for_rank(h // 4, nchunks, rank, world)
+    except ValueError as exc:
+        return {"skipped": str(exc)}
+    rows = (hi - lo) * 4
+    band = synth.rgba_frame(w, rows, 1000 + rank, device=dev)
+    tex_bytes = [(w // 4) * (rows // 4) * b for b in (16, 8)]
+    cap = hap_amd.HapMaxEncodedLength(tex_bytes, fmts, [band_chunks] * 2)
+    out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    def encode_band():
+        r, used, res = ctx.encode_frames_rgba([band], w, rows, w * 4, fmts, [1, 1], [band_chunks] * 2, [out],
+                                              flags=hap_amd.ENCODE_FRAGMENT_INDEX)
+        if r != 0:
+            raise RuntimeError("band encode failed %r %r" % (r, res))
+        return out[: used[0]]
+
+    t = {}
+    encode_band()
+    fence(); t0 = time.perf_counter()
+    for _ in range(reps):
+        piece = encode_band()
+    fence(); t["encode_bands_ms"] = (time.perf_counter() - t0) / reps * 1e3
+    shard.gather_variable(piece, root=0)                                   # warm the send/recv path
+    fence(); t0 = time.perf_counter()
+    parts = shard.gather_variable(piece, root=0)
+    fence(); t["gather_band_frames_ms"] = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    frame = None
+    if parts is not None:
+        r, frame = hap_amd.HapGpuJoinChunkGroups([p.cpu().numpy() for p in parts])
+        if r != 0:
+            raise RuntimeError("join failed %r" % r)
+    t["join_on_host_ms"] = (time.perf_counter() - t0) * 1e3
+    n = torch.tensor([len(frame) if frame is not None else 0], dtype=torch.int64, device=dev)
+    dist.broadcast(n, src=0)
+    dframe = torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
+    if rank == 0:
+        dframe.copy_(torch.frombuffer(bytearray(frame), dtype=torch.uint8))
+    dist.broadcast(dframe, src=0)
+    frame = dframe.cpu().numpy()
+    ok = True
+    for idx in (0, 1):
+        r, layout = hap_amd.HapGpuGetFrameTextureChunkLayout(frame, idx)
+        if r != 0:
+            raise RuntimeError("layout failed %r" % r)
+        whole = torch.zeros(layout[-1], dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        group = shard.chunk_group_for_rank(len(layout) - 1, rank, world)
+
+        def decode_group():
+            r, _used, fmt = ctx.decode_chunk_group(dframe, idx, group.start, len(group), whole)
+            if r != 0 or fmt != fmts[idx]:
+                raise RuntimeError("group decode failed %r" % r)
+        decode_group()
+        fence(); t0 = time.perf_counter()
+        for _ in range(reps):
+            decode_group()
+        fence(); t["decode_groups_tex%d_ms" % idx] = (time.perf_counter() - t0) / reps * 1e3
+        bounds = [layout[(len(layout) - 1) * r // world] for r in range(world + 1)]
+        shard.exchange_slices(whole, bounds, root=0)
+        fence(); t0 = time.perf_counter()
+        shard.exchange_slices(whole, bounds, root=0)
+        fence(); t["gather_slices_tex%d_ms" % idx] = (time.perf_counter() - t0) * 1e3
+        want = torch.empty(tex_bytes[idx], dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        r, _u = ctx.compress_rgba(band, w, rows, w * 4, fmts[idx], want)
+        a, b = layout[group.start], layout[group.start + len(group)]
+        ok = ok and r == 0 and bool(torch.equal(whole[a:b], want))
+    flag = torch.tensor([1 if ok else 0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    for k in list(t):
+        v = torch.tensor([t[k]], dtype=torch.float64, device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        t[k] = float(v.item())
+    rgba_gb = w * h * 4 / 1e9
+    enc = t["encode_bands_ms"]
+    dec = t["decode_groups_tex0_ms"] + t["decode_groups_tex1_ms"]
+    enc_g = enc + t["gather_band_frames_ms"] + t["join_on_host_ms"]
+    dec_g = dec + t["gather_slices_tex0_ms"] + t["gather_slices_tex1_ms"]
+    return {"workload": "one 16384x16384 Hap Q Alpha frame, 64+64 chunks, split by chunk groups over %d GPUs" % world,
+            "bit_exact": bool(flag.item()), "frame_bytes": int(n.item()),
+            "without_gather": {"encode_rgba_GBps": round(rgba_gb / (enc / 1e3), 1), "decode_rgba_GBps": round(rgba_gb / (dec / 1e3), 1)},
+            "with_rccl_gather_to_rank0": {"encode_rgba_GBps": round(rgba_gb / (enc_g / 1e3), 1),
+                                          "decode_rgba_GBps": round(rgba_gb / (dec_g / 1e3), 1)},
+            "ms": {k: round(v, 3) for k, v in t.items()}}
 
 
 def host_pointer_path(ctx, rgba, frames, used, fmts, comps, chunks, tex_bytes, cap, w, h, flags, n=4):
@@ -323,18 +592,22 @@ def decode_foreign(ctx, dev, fmts, chunks, dec, tex_bytes, cap, n, rgba_bytes):
 
 
 def measured_traffic(config, kernel, frames):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC pass (FETCH_SIZE and
-    WRITE_SIZE collected in separate runs by tools/prof_traffic.sh; FETCH doubled as the MI355X
-    guide prescribes for wide streaming reads).  None when no measurement exists for this config."""
-    path = os.path.join(ROOT, "profiles", "traffic_%s.json" % config.lower())
+    """HBM bytes per launch of `kernel` from this round's rocprofv3 PMC passes over THIS command
+    (tools/prof_traffic.sh <config>: FETCH_SIZE and WRITE_SIZE in separate runs; FETCH doubled as the MI355X guide
+    prescribes for wide streaming reads; the raw per-dispatch CSV summaries are committed beside the json under
+    profiles/).  Counters cannot be read from inside the timed process, so the bench line carries the profile's
+    figure scaled to the frames per launch of this run, and names its source.  (None, None) when the round has no
+    profile for the config."""
+    name = "r02_traffic_%s.json" % config.lower()
+    path = os.path.join(ROOT, "profiles", name)
     try:
         with open(path) as f:
             t = json.load(f)
         k = t["kernels"][kernel]
     except (OSError, KeyError, ValueError):
-        return None
-    scale = 1.0 if k["per"] == "frame" else frames / float(t["frames_per_launch"])
-    return int((2.0 * k["fetch"] + k["write"]) * 1024 * scale)
+        return None, None
+    scale = frames / float(t["frames_per_launch"])
+    return int((2.0 * k["fetch_kib"] + k["write_kib"]) * 1024 * scale), "profiles/" + name
 
 
 def cpu_baseline(w, h, fmts, chunks, rgba, dec, tex_bytes, cap, budget_s):

@@ -99,3 +99,39 @@ def ref_snappy_uncompress(stream, cap):
     ln = C.c_size_t(cap)
     r = s.snappy_uncompress(bytes(stream), C.c_size_t(len(stream)), out, C.byref(ln))
     return r, (bytes(out[: ln.value]) if r == 0 else None)
+
+
+# ---- third-party pin of the block layouts: Pillow's DDS reader (S3TC / RGTC, HapVideoDRAFT.md:22-27) ----
+def dds_file(blocks, w, h, fourcc):
+    """A minimal legacy DDS file around `blocks` (FourCC pixel format: b"DXT1", b"DXT5", b"ATI1")."""
+    import struct
+    flags = 0x1 | 0x2 | 0x4 | 0x1000 | 0x80000            # caps, height, width, pixel format, linear size
+    head = struct.pack("<4sIIIIIII44x", b"DDS ", 124, flags, h, w, len(blocks), 0, 1)
+    pixel_format = struct.pack("<II4sIIIII", 32, 0x4, fourcc, 0, 0, 0, 0, 0)
+    caps = struct.pack("<IIIII", 0x1000, 0, 0, 0, 0)
+    return head + pixel_format + caps + bytes(blocks)
+
+
+PILLOW_FOURCC = {L.FMT_DXT1: b"DXT1", L.FMT_DXT5: b"DXT5", L.FMT_YCOCG: b"DXT5", L.FMT_RGTC1: b"ATI1"}
+
+
+def pillow_bc_decode(blocks, fmt, w, h):
+    """Decodes block data with Pillow (no code of ours involved).  DXT1/DXT5 -> RGBA, RGTC1 -> one plane;
+    scaled YCoCg-DXT5 is read as the DXT5 texture it is (R = Co, G = Cg, B = scale code, A = Y)."""
+    import io
+    from PIL import Image
+    im = Image.open(io.BytesIO(dds_file(blocks, w, h, PILLOW_FOURCC[fmt])))
+    im.load()
+    return np.asarray(im).copy()
+
+
+def shader_ycocg_to_rgb(tex):
+    """The float reconstruction a Hap Q player's fragment shader does on the sampled DXT5 texel
+    (van Waveren & Castano, cited by HapVideoDRAFT.md:24): tex = uint8 [h, w, 4] = (Co, Cg, scale, Y)."""
+    t = tex.astype(np.float64) / 255.0
+    scale = 1.0 / (t[..., 2] * (255.0 / 8.0) + 1.0)
+    co = (t[..., 0] - 128.0 / 255.0) * scale
+    cg = (t[..., 1] - 128.0 / 255.0) * scale
+    y = t[..., 3]
+    rgb = np.stack([y + co - cg, y + cg, y - co - cg], axis=-1)
+    return np.clip(np.rint(rgb * 255.0), 0, 255).astype(np.uint8)

@@ -118,6 +118,38 @@ class HapApi:
         self.callback_calls = calls[0]
         return r, (bytes(out[: used.value]) if r == 0 else None), fmt.value
 
+    # numpy variants for full-size frames (no Python-level byte shuffling)
+    def encode_np(self, textures, formats, compressors, chunks):
+        """textures: list of C-contiguous uint8 arrays. Returns (result, uint8 array or None)."""
+        import numpy as np
+        n = len(textures)
+        ptrs = (C.c_void_p * n)(*[t.ctypes.data for t in textures])
+        lens = (C.c_ulong * n)(*[t.size for t in textures])
+        cap = self.max_encoded_length([t.size for t in textures], formats, chunks)
+        out = np.empty(cap, dtype=np.uint8)
+        used = C.c_ulong(0)
+        r = self._enc(C.c_uint(n), ptrs, lens, (C.c_uint * n)(*formats), (C.c_uint * n)(*compressors),
+                      (C.c_uint * n)(*chunks), out.ctypes.data_as(C.c_void_p), C.c_ulong(cap), C.byref(used))
+        return r, (out[: used.value] if r == 0 else None)
+
+    def decode_np(self, frame, index, out_bytes):
+        """frame: uint8 array. Returns (result, uint8 array or None, format); serial callback."""
+        import numpy as np
+        out = np.empty(max(1, out_bytes), dtype=np.uint8)
+        used = C.c_ulong(0)
+        fmt = C.c_uint(0)
+        calls = [0]
+
+        def cb(fn, p, count, info):
+            calls[0] += 1
+            for i in range(count):
+                fn(p, i)
+        cbo = CALLBACK(cb)
+        r = self._dec(frame.ctypes.data_as(C.c_void_p), C.c_ulong(frame.size), C.c_uint(index), cbo, None,
+                      out.ctypes.data_as(C.c_void_p), C.c_ulong(out_bytes), C.byref(used), C.byref(fmt))
+        self.callback_calls = calls[0]
+        return r, (out[: used.value] if r == 0 else None), fmt.value
+
     def texture_count(self, frame):
         buf = (C.c_ubyte * max(1, len(frame))).from_buffer_copy(bytes(frame) or b"\0")
         n = C.c_uint(0)

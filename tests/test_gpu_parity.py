@@ -134,6 +134,39 @@ def test_block_decode_bit_exact(ctx, fmt):
     assert ctx.decompress_rgba(bytes(8), L.FMT_RGTC1, 4, 4)[0] == 1      # not a colour format
 
 
+@pytest.mark.parametrize("fmt", [L.FMT_DXT1, L.FMT_DXT5, L.FMT_YCOCG, L.FMT_RGTC1])
+def test_gpu_blocks_against_pillow(ctx, fmt):
+    """Third-party pin: what bc_encode.hip writes is decoded by Pillow's DDS reader -- no code of
+    ours between the GPU's bytes and the picture -- and what bc_decode.hip reconstructs equals Pillow's decode."""
+    pytest.importorskip("PIL")
+    w, h = 512, 256
+    img = D.rgba(w, h, frame=2)
+    r, blocks = ctx.compress_rgba(img, w, h, w * 4, fmt)
+    assert r == 0
+    theirs = D.pillow_bc_decode(blocks, fmt, w, h)
+    if fmt == L.FMT_RGTC1:
+        assert D.psnr(theirs, img[..., 3]) > 40.0
+        return
+    if fmt == L.FMT_YCOCG:
+        rgb = D.shader_ycocg_to_rgb(theirs)
+        assert D.psnr(rgb, img[..., :3]) > 33.0
+        r, got = ctx.decompress_rgba(blocks, fmt, w, h)
+        got = np.frombuffer(got, dtype=np.uint8).reshape(h, w, 4)
+        assert r == 0 and np.abs(got[..., :3].astype(int) - rgb.astype(int)).max() <= 2
+        return
+    assert D.psnr(theirs[..., :3], img[..., :3]) > 30.0
+    rng = np.random.default_rng(31)
+    random_blocks = rng.integers(0, 256, (w // 4) * (h // 4) * D.BLOCK_BYTES[fmt], dtype=np.uint8).tobytes()
+    for data in (blocks, random_blocks):
+        r, got = ctx.decompress_rgba(data, fmt, w, h)
+        got = np.frombuffer(got, dtype=np.uint8).reshape(h, w, 4)
+        want = D.pillow_bc_decode(data, fmt, w, h)
+        # (DXT1's transparent texels: Hap1 is opaque RGB, alpha stays 255 on our side)
+        assert r == 0 and np.array_equal(got[..., :3], want[..., :3])
+        if fmt == L.FMT_DXT5:
+            assert np.array_equal(got[..., 3], want[..., 3])
+
+
 # ------------------------------------------------------------------ decode --
 @pytest.mark.parametrize("v", D.golden_vectors("frame"), ids=lambda v: v["name"])
 def test_decode_golden_frames(hap, v):
@@ -713,36 +746,90 @@ def test_byte_granular_streams_and_a_lying_table(hap):
     assert r == 0 and ORA.decode(f16, 0, len(tex)) == (0, tex, L.FMT_YCOCG)
 
 
-@pytest.mark.parametrize("cfg", ["C2", "C3", "C4"])
+FULL_SIZE = {"C2": (3840, 2160, [L.FMT_DXT1], [1], 1),
+             "C3": (3840, 2160, [L.FMT_DXT5], [8], 1),
+             "C4": (7680, 4320, [L.FMT_YCOCG], [24], 3),
+             "C5": (16384, 16384, [L.FMT_YCOCG, L.FMT_RGTC1], [64, 64], 1)}
+
+
+@pytest.mark.parametrize("cfg", ["C2", "C3", "C4", "C5"])
 def test_full_size_configs_round_trip(ctx, hap, cfg):
-    """BASELINE.json configs at full size on the device: encode -> decode round trip, the
-    decoded texture equals the block encoder's output (checked by checksum-free tensor equality)
-    and one frame is cross-checked against the CPU oracle decoder."""
+    """BASELINE.json configs at full size on the device (C5 = the north-star's 16K Hap Q Alpha target: two textures,
+    8-byte outer 0x0D header + 8-byte section headers, hap.c:562-598): encode -> decode round trip of EVERY texture
+    index, the decoded texture equals the block encoder's output, and frame 0 is decoded again by the CPU checkers
+    (the oracle and, where built, the unmodified reference) from the bytes the GPU wrote."""
     from hap_amd import synth
-    w, h, fmts, chunks, nf = {"C2": (3840, 2160, [L.FMT_DXT1], [1], 1),
-                              "C3": (3840, 2160, [L.FMT_DXT5], [8], 1),
-                              "C4": (7680, 4320, [L.FMT_YCOCG], [24], 3)}[cfg]
+    w, h, fmts, chunks, nf = FULL_SIZE[cfg]
+    count = len(fmts)
     sizes = [(w // 4) * (h // 4) * D.BLOCK_BYTES[f] for f in fmts]
     cap = hap.HapMaxEncodedLength(sizes, fmts, chunks)
     rgba = [synth.rgba_frame(w, h, i, device="cuda") for i in range(nf)]
     outs = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(nf)]
-    tex = [torch.zeros(sizes[0], dtype=torch.uint8, device="cuda") for _ in range(nf)]
+    tex = [[torch.zeros(sizes[t], dtype=torch.uint8, device="cuda") for _ in range(nf)] for t in range(count)]
     torch.cuda.synchronize()      # the context works on its own stream: order torch's fills before it
-    for i in range(nf):
-        assert ctx.compress_rgba(rgba[i], w, h, w * 4, fmts[0], tex[i]) == (0, sizes[0])
-    for flags in (0, hap.ENCODE_FRAGMENT_INDEX):
-        r, used, results = ctx.encode_frames_rgba(rgba, w, h, w * 4, fmts, [1], chunks, outs, flags=flags)
-        assert r == 0 and results == [0] * nf
-        dec = [torch.zeros(sizes[0], dtype=torch.uint8, device="cuda") for _ in range(nf)]
-        torch.cuda.synchronize()
-        r, dused, dfmts, dres = ctx.decode_frames(outs, used, 0, dec)
-        assert r == 0 and dres == [0] * nf and dused == [sizes[0]] * nf
+    for t in range(count):
         for i in range(nf):
-            assert torch.equal(dec[i], tex[i])
-        frame = outs[0][: used[0]].cpu().numpy().tobytes()
-        ro, oo, fo = ORA.decode(frame, 0, sizes[0])
-        assert (ro, fo) == (0, fmts[0]) and oo == tex[0].cpu().numpy().tobytes()
-        assert hap.HapGetFrameTextureChunkCount(frame, 0) == (0, chunks[0])
+            assert ctx.compress_rgba(rgba[i], w, h, w * 4, fmts[t], tex[t][i]) == (0, sizes[t])
+    for flags in (0, hap.ENCODE_FRAGMENT_INDEX):
+        r, used, results = ctx.encode_frames_rgba(rgba, w, h, w * 4, fmts, [1] * count, chunks, outs, flags=flags)
+        assert r == 0 and results == [0] * nf
+        for t in range(count):
+            dec = [torch.zeros(sizes[t], dtype=torch.uint8, device="cuda") for _ in range(nf)]
+            torch.cuda.synchronize()
+            r, dused, dfmts, dres = ctx.decode_frames(outs, used, t, dec)
+            assert r == 0 and dres == [0] * nf and dused == [sizes[t]] * nf and dfmts == [fmts[t]] * nf
+            for i in range(nf):
+                assert torch.equal(dec[i], tex[t][i])
+        frame = outs[0][: used[0]].cpu().numpy()
+        if cfg == "C5":
+            assert frame[3] == 0x0D and bytes(frame[:3]) == b"\0\0\0"            # 8-byte outer header (hap.c:563-576)
+        assert hap.HapGetFrameTextureCount(frame) == (0, count)
+        for t in range(count):
+            assert hap.HapGetFrameTextureFormat(frame, t) == (0, fmts[t])
+            assert hap.HapGetFrameTextureChunkCount(frame, t) == (0, chunks[t])
+        for name, api in CHECKERS:
+            for t in range(count):
+                ro, oo, fo = api.decode_np(frame, t, sizes[t])
+                assert (ro, fo) == (0, fmts[t]), (name, t, ro)
+                assert np.array_equal(oo, tex[t][0].cpu().numpy()), (name, t)
+
+
+@pytest.mark.parametrize("cfg", ["C4", "C5"])
+def test_full_size_frames_from_the_reference_encoder_decode_bit_exactly(ctx, hap, cfg):
+    """G1 at full size: frames written by the CPU checker's HapEncode (the unmodified reference + libsnappy where
+    built: one libsnappy stream per chunk, no private table) decode on the GPU to the bytes the checker itself
+    decodes -- both texture indices for the two-texture C5 frame.  Also through plain hap.h HapDecode with host
+    buffers and a callback, for the 8K frame."""
+    from hap_amd import synth
+    w, h, fmts, chunks, _nf = FULL_SIZE[cfg]
+    count = len(fmts)
+    sizes = [(w // 4) * (h // 4) * D.BLOCK_BYTES[f] for f in fmts]
+    rgba = synth.rgba_frame(w, h, 7, device="cuda")
+    tex = [torch.zeros(sizes[t], dtype=torch.uint8, device="cuda") for t in range(count)]
+    torch.cuda.synchronize()
+    for t in range(count):
+        assert ctx.compress_rgba(rgba, w, h, w * 4, fmts[t], tex[t]) == (0, sizes[t])
+    del rgba
+    host_tex = [t.cpu().numpy() for t in tex]
+    name, api = CHECKERS[-1]                                   # the reference when it exists
+    r, frame = api.encode_np(host_tex, fmts, [1] * count, chunks)
+    assert r == 0 and frame[3] == (0x0D if count == 2 else 0xCF)
+    dframe = torch.from_numpy(frame).cuda()
+    for t in range(count):
+        out = torch.zeros(sizes[t], dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        r, dused, dfmts, dres = ctx.decode_frames([dframe], [frame.size], t, [out])
+        assert (r, dres, dused, dfmts) == (0, [0], [sizes[t]], [fmts[t]])
+        assert torch.equal(out, tex[t])
+        rc, want, fmt = api.decode_np(frame, t, sizes[t])
+        assert (rc, fmt) == (0, fmts[t]) and np.array_equal(want, host_tex[t])
+    if cfg == "C4":
+        out = np.zeros(sizes[0], dtype=np.uint8)
+        calls = []
+        cb = L.CALLBACK(lambda fn, p, n, info: (calls.append(n), [fn(p, i) for i in range(n)]) and None)
+        r, used, fmt = hap.HapDecode(frame, 0, callback=cb, outputBuffer=out)
+        assert (r, used, fmt, calls) == (0, sizes[0], fmts[0], [chunks[0]])
+        assert np.array_equal(out, host_tex[0])
 
 
 # ------------------------------------------ one frame over several GPUs: chunk groups (SURVEY 8e) --

@@ -137,3 +137,36 @@ def test_three_rank_chunk_groups_with_a_band_stored_as_is():
     got = _run_chunk_groups(3, 1)
     assert [g[1] for g in got] == [9, 9, 9]                 # 4 + 1 (as-is band -> one chunk) + 4
     assert all(g[2] and g[4] for g in got) and got[0][3]
+
+
+def test_bench_starts_its_own_ranks_and_splits_the_stream():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks of itself (torch.distributed.run,
+    127.0.0.1), splits the 60-frame stream f -> rank f mod N and reduces the elapsed time with MAX: the launch path
+    of the driver's SCALE runs, here with gloo and a sleep in place of the codec (--selftest-cpu)."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    done = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "2", "--selftest-cpu"], capture_output=True,
+                          text=True, timeout=300, env=env)
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = [json.loads(x) for x in done.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1                                        # rank 0 alone prints
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["frames_per_rank"] == [30, 30]
+    assert line["frames_per_step"] == 60 and 25.0 < line["ms_per_step"] < 200.0      # MAX over ranks of ~30 ms
+    done = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--scaling", "weak", "--frames", "7",
+                           "--selftest-cpu"], capture_output=True, text=True, timeout=300, env=env)
+    line = [json.loads(x) for x in done.stdout.splitlines() if x.startswith("{")][0]
+    assert line["frames_per_rank"] == [7, 7] and line["frames_per_step"] == 14 and line["scaling"] == "weak"
+    # a launcher that started a different number of ranks than --gpus says is an error, not a silent n_gpus
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611")
+    done = subprocess.run([sys.executable, bench, "--gpus", "2", "--selftest-cpu"], capture_output=True, text=True,
+                          timeout=120, env=env2)
+    assert done.returncode != 0 and "rank(s) were started" in done.stderr
+    sys.path.insert(0, os.path.dirname(bench))
+    import bench as B
+    assert [len(B.frames_of_rank(60, r, 8, "strong")) for r in range(8)] == [8, 8, 8, 8, 7, 7, 7, 7]
+    assert sorted(f for r in range(8) for f in B.frames_of_rank(60, r, 8, "strong")) == list(range(60))
+    assert B.frames_of_rank(60, 3, 8, "weak") == list(range(180, 240))
