@@ -41,6 +41,7 @@ def _load():
         "HapGpuDefaultContext": (vp, []),
         "HapGpuSetFragmentLog2": (u, [vp, u]),
         "HapGpuSynchronize": (u, [vp]),
+        "HapGpuTableFallbackCount": (ul, [vp]),
         "HapGpuCompressRGBA": (u, [vp, vp, u, u, ul, u, vp, ul, P(ul)]),
         "HapGpuDecompressRGBA": (u, [vp, vp, ul, u, vp, ul, u, u, vp, ul]),
         "HapGpuEncodeFrames": (u, [vp, u, u, P(vp), P(ul), P(u), P(u), P(u), P(vp), P(ul), P(ul), P(u), u]),

@@ -29,6 +29,7 @@ class HapResult:
 ENCODE_FRAGMENT_INDEX = 0x1
 ENCODE_COARSE_MATCHES = 0x2
 DECODE_IGNORE_FRAGMENT_INDEX = 0x1
+DECODE_IGNORE_HALF_TILES = 0x2
 KERNEL_CLASSES = ["block_encode", "snappy_compress", "frame_pack", "frame_gather", "decode_plan", "snappy_decode",
                   "block_decode"]
 
@@ -254,6 +255,10 @@ class Context:
 
     def synchronize(self):
         return lib.HapGpuSynchronize(self.handle)
+
+    def table_fallbacks(self):
+        """frames decoded a second time because their fragment table did not describe their streams"""
+        return int(lib.HapGpuTableFallbackCount(self.handle))
 
     def compress_rgba(self, rgba, width, height, row_bytes, texture_format, output=None):
         block = 8 if texture_format in (HapTextureFormat.RGB_DXT1, HapTextureFormat.A_RGTC1) else 16

@@ -75,7 +75,9 @@ __device__ unsigned long long block_scan(unsigned long long v, unsigned long lon
 __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames, unsigned frag_log2,
                                                          const uint8_t *__restrict__ slots, unsigned slot_stride,
                                                          const uint32_t *__restrict__ frag_sizes,
-                                                         HapGpuCopyEntry *__restrict__ copies)
+                                                         const uint8_t *__restrict__ tile_sizes,
+                                                         HapGpuCopyEntry *__restrict__ copies, unsigned extra_first,
+                                                         unsigned chunks_per_frame)
 {
     __shared__ unsigned long long scan_lds[4];
     HapGpuFrameEnc &frame = frames[blockIdx.x];
@@ -84,6 +86,7 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
     uint8_t *cursor = (uint8_t *)frame.dst + frame.outer_header_len;
     unsigned long long sections_total = 0;
 
+    unsigned extra_at = extra_first + blockIdx.x * chunks_per_frame;      // this frame's half-tile table moves
     for (unsigned t = 0; t < frame.tex_count; t++) {
         const HapGpuTexEnc tex = frame.tex[t];
         uint8_t *sec = cursor;
@@ -94,7 +97,9 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
 
         if (tex.compressor == 1u) {
             const unsigned vlen = varint_len(cb);
-            const unsigned index_len = tex.emit_index ? 8u + 4u * n * fpc : 0u;
+            // fragment table version 2 (field streams): + 64 half-tile size bytes per fragment
+            const bool with_tiles = tex.emit_index && ((tex.reserved >> 20) & 1u) != 0u && tile_sizes != nullptr;
+            const unsigned index_len = tex.emit_index ? 8u + (with_tiles ? 68u : 4u) * n * fpc : 0u;
             const unsigned ilen = 5u * n + 8u + index_len;
             // pass 1: total stored payload
             unsigned long long total = 0;
@@ -125,12 +130,23 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
                     write_section(sec + hdr + 4u, 4u, n, HAP_SECTION_COMPRESSORS);     // hap.c:438
                     write_section(ctab + n, 4u, 4u * n, HAP_SECTION_SIZES);            // hap.c:440
                     if (tex.emit_index) {
-                        write_section(itab, 4u, 4u + 4u * n * fpc, HAP_SECTION_FRAGMENTS);
-                        itab[4] = (uint8_t)HAP_FRAGMENT_TABLE_VERSION;
+                        write_section(itab, 4u, index_len - 4u, HAP_SECTION_FRAGMENTS);
+                        itab[4] = (uint8_t)(with_tiles ? HAP_FRAGMENT_TABLE_VERSION_FIELDS : HAP_FRAGMENT_TABLE_VERSION);
                         itab[5] = (uint8_t)frag_log2;
-                        itab[6] = (uint8_t)tex.reserved;          // granularity_log2 of the element streams
+                        // granularity_log2 of the element streams (version 2: | fields per block << 4)
+                        itab[6] = (uint8_t)((tex.reserved & 0xFu) | (with_tiles ? ((tex.reserved >> 16) & 7u) << 4 : 0u));
                         itab[7] = (uint8_t)(tex.reserved >> 8);   // match window in 256-byte units, 0 = whole fragment
                     }
+                }
+                // the half-tile size bytes follow the fragment sizes: one move per chunk (consecutive fragments)
+                for (unsigned i = tid; i < n; i += 256u) {
+                    HapGpuCopyEntry e;
+                    e.reserved = 0;
+                    e.src = (uint64_t)(tile_sizes + (size_t)(tex.frag_first + i * fpc) * HAP_HALF_TILES_PER_FRAGMENT);
+                    e.dst = (uint64_t)(itab + 8u + 4u * n * fpc + (size_t)i * fpc * HAP_HALF_TILES_PER_FRAGMENT);
+                    e.len = with_tiles ? fpc * HAP_HALF_TILES_PER_FRAGMENT : 0u;
+                    if (i < chunks_per_frame)
+                        copies[extra_at + i] = e;
                 }
                 // pass 2: positions, tables, moves
                 unsigned long long run = 0;
@@ -181,6 +197,11 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
         if (!complex_frame) {
             // whole texture stored as-is, reference hap.c:490-495
             const unsigned total_frags = n * fpc;
+            for (unsigned i = tid; i < n && i < chunks_per_frame; i += 256u) {
+                HapGpuCopyEntry e;
+                e.reserved = 0; e.src = 0; e.dst = 0; e.len = 0;
+                copies[extra_at + i] = e;
+            }
             for (unsigned f = tid; f < total_frags; f += 256u) {
                 const unsigned i = f / fpc, k = f - i * fpc;
                 const unsigned begin = k << frag_log2;
@@ -200,6 +221,7 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
         }
         cursor += hdr + body;
         sections_total += hdr + body;
+        extra_at += n;
         __syncthreads();
     }
     if (tid == 0) {
@@ -258,12 +280,13 @@ __global__ __launch_bounds__(64) void frame_gather_kernel(const HapGpuCopyEntry 
 
 extern "C" int hapgpu_launch_frame_pack(HapGpuFrameEnc *frames, unsigned frame_count, unsigned frag_log2,
                                         const void *slots, unsigned slot_stride, const uint32_t *frag_sizes,
-                                        HapGpuCopyEntry *copies, hipStream_t stream)
+                                        const uint8_t *tile_sizes, HapGpuCopyEntry *copies, unsigned extra_first,
+                                        unsigned chunks_per_frame, hipStream_t stream)
 {
     if (frame_count == 0)
         return 0;
     hipLaunchKernelGGL(frame_pack_kernel, dim3(frame_count), dim3(256), 0, stream, frames, frag_log2,
-                       (const uint8_t *)slots, slot_stride, frag_sizes, copies);
+                       (const uint8_t *)slots, slot_stride, frag_sizes, tile_sizes, copies, extra_first, chunks_per_frame);
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 

@@ -37,6 +37,7 @@ unsigned int HapGpuCreate(int device, HapGpuContext **context)
         c->byte_granular = ((e && atoi(e) != 0) || getenv("HAP_AMD_COMPRESS_V1")) ? 1u : 0u;
         c->compress_v1 = getenv("HAP_AMD_COMPRESS_V1") ? 1u : 0u;
         c->position_lanes = getenv("HAP_AMD_POSITION_LANES") ? 1u : 0u;
+        c->no_half_tiles = getenv("HAP_AMD_NO_HALF_TILES") ? 1u : 0u;
     }
     *context = c;
     return HapResult_No_Error;
@@ -111,6 +112,17 @@ unsigned int HapGpuSetFragmentLog2(HapGpuContext *context, unsigned int log2_byt
         return HapResult_Bad_Arguments;
     context->frag_log2 = log2_bytes;
     return HapResult_No_Error;
+}
+
+unsigned long HapGpuTableFallbackCount(HapGpuContext *context)
+{
+    unsigned long n;
+    if (!context)
+        return 0;
+    hapgpu_rt_lock(context->rt);
+    n = context->table_fallbacks;
+    hapgpu_rt_unlock(context->rt);
+    return n;
 }
 
 unsigned int HapGpuSynchronize(HapGpuContext *context)

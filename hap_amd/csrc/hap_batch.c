@@ -21,6 +21,7 @@ enum {
     D_FRAMES = 0, D_SLOTS, D_FRAGSIZES, D_COPIES, D_TEX_STAGE, D_FRAME_STAGE, D_BC_TEX, D_RGBA_STAGE,
     D_JOBS, D_CHUNKS, D_UNITS, D_IN_STAGE, D_OUT_STAGE, D_PTRS, D_PREFIX, D_BC_PTRS
 };
+#define D_TILESIZES D_PTRS   /* encode-only arena; D_PTRS is decode-only: one call never needs both */
 enum { P_FRAMES = 0, P_JOBS, P_CHUNKS, P_PREFIX, P_PTRS, P_BC_PTRS };   /* (8, 9: hap_sequence.c) */
 
 #define PREFIX_BYTES 8192u   /* headers + tables of a frame with a few hundred chunks; larger ones are fetched on demand */
@@ -33,7 +34,7 @@ static int is_dev(HapGpuContext *c, const void *p) { return hapgpu_rt_is_device_
 /* ================================================================== encode */
 
 typedef struct tex_geom {
-    unsigned format, compressor, chunk_count, chunk_bytes, header_len, fpc, nibble, gran_log2, field_period;
+    unsigned format, compressor, chunk_count, chunk_bytes, header_len, fpc, nibble, gran_log2, field_period, half_tiles;
     unsigned long bytes;
     size_t bound;        /* hap_max_encoded_length for the requested compressor (hap.c:386) */
 } tex_geom;
@@ -47,7 +48,9 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
 {
     tex_geom g[2];
     unsigned i, f, first_error = HapResult_No_Error;
-    unsigned outer_header = 0, frags_per_frame = 0, max_frags_per_tex = 0, live = 0;
+    unsigned outer_header = 0, frags_per_frame = 0, max_frags_per_tex = 0, live = 0, chunks_per_frame = 0;
+    int any_half_tiles = 0;
+    uint8_t *dtilesizes = NULL;
     unsigned frag_log2 = ctx->frag_log2, frag_bytes = 1u << frag_log2;
     unsigned slot_stride;
     int any_snappy = 0;
@@ -144,13 +147,18 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
                inside the 6 index bytes -- measured 0.25 against 0.45 of the texture size -- which whole-field
                equality cannot see) */
         }
+        /* field streams (fragment table version 2): with the table requested, the [2,6,4,4] compressor also keeps
+           elements inside 128-byte half-tiles and records their sizes for the block-per-lane decoder */
+        t->half_tiles = (t->field_period == 4u && (flags & HAPGPU_ENCODE_FRAGMENT_INDEX) && !ctx->no_half_tiles) ? 1u : 0u;
+        if (t->half_tiles)
+            any_half_tiles = 1;
         if (t->compressor == HapCompressorSnappy)
             gran_mask |= t->field_period == 4u ? 32u : t->field_period == 10u ? 64u : t->field_period == 2u ? 16u : 1u << t->gran_log2;
         if (t->compressor == HapCompressorSnappy) {
             /* header choice uses the layout that will actually be written (hap.c:425-428) */
             size_t ilen = hapf_instructions_length(t->chunk_count);
             if (flags & HAPGPU_ENCODE_FRAGMENT_INDEX)
-                ilen += 8u + 4u * (size_t)t->chunk_count * t->fpc;
+                ilen += 8u + (t->half_tiles ? 68u : 4u) * (size_t)t->chunk_count * t->fpc;
             if (ilen + 4u > 0xFFFFFFu) {          /* instruction container must fit a 24-bit length */
                 for (f = 0; f < frame_count; f++) {
                     results[f] = HapResult_Bad_Arguments;
@@ -164,6 +172,7 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
         if ((size_t)t->chunk_count * t->fpc > max_frags_per_tex)
             max_frags_per_tex = t->chunk_count * t->fpc;
         frags_per_frame += t->chunk_count * t->fpc;
+        chunks_per_frame += t->chunk_count;
         stage_in_bytes += align_up(t->bytes, 256);
         frame_raw_bound += t->header_len + t->bytes;
     }
@@ -237,12 +246,14 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
     dframes = (HapGpuFrameEnc *)hapgpu_rt_device_scratch(rt, D_FRAMES, sizeof(HapGpuFrameEnc) * live);
     dslots = any_snappy ? (uint8_t *)hapgpu_rt_device_scratch(rt, D_SLOTS, (size_t)slot_stride * frags_per_frame * live) : NULL;
     dfragsizes = (uint32_t *)hapgpu_rt_device_scratch(rt, D_FRAGSIZES, sizeof(uint32_t) * (size_t)frags_per_frame * live);
-    dcopies = (HapGpuCopyEntry *)hapgpu_rt_device_scratch(rt, D_COPIES, sizeof(HapGpuCopyEntry) * (size_t)frags_per_frame * live);
+    dcopies = (HapGpuCopyEntry *)hapgpu_rt_device_scratch(rt, D_COPIES, sizeof(HapGpuCopyEntry) * ((size_t)frags_per_frame + chunks_per_frame) * live);
+    if (any_half_tiles)
+        dtilesizes = (uint8_t *)hapgpu_rt_device_scratch(rt, D_TILESIZES, (size_t)HAP_HALF_TILES_PER_FRAGMENT * frags_per_frame * live);
     if (stage_in_bytes)
         tex_stage = (uint8_t *)hapgpu_rt_device_scratch(rt, D_TEX_STAGE, stage_in_bytes);
     if (stage_out_bytes)
         out_stage = (uint8_t *)hapgpu_rt_device_scratch(rt, D_FRAME_STAGE, stage_out_bytes);
-    if (!hframes || !dframes || (any_snappy && !dslots) || !dfragsizes || !dcopies ||
+    if (!hframes || !dframes || (any_snappy && !dslots) || !dfragsizes || !dcopies || (any_half_tiles && !dtilesizes) ||
         (stage_in_bytes && !tex_stage) || (stage_out_bytes && !out_stage)) {
         free(live_index); free(stage_off_in); free(stage_off_out);
         for (f = 0; f < frame_count; f++)
@@ -290,16 +301,18 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
                     const int small_blocks = g[i].format == HapTextureFormat_RGB_DXT1 || g[i].format == HapTextureFormat_A_RGTC1;
                     const int windowed = frag_log2 == 13u && !ctx->compress_v1 &&
                                          g[i].bytes >= (small_blocks ? ((size_t)2u << 20) : ((size_t)1u << 20));
-                    te->reserved = g[i].gran_log2 | (windowed ? (HAP_FRAGMENT_WINDOW_256 << 8) : 0u) | (g[i].field_period << 16);
+                    te->reserved = g[i].gran_log2 | (windowed ? (HAP_FRAGMENT_WINDOW_256 << 8) : 0u) | (g[i].field_period << 16) |
+                                   (g[i].half_tiles << 20);
                 }
             }
         }
         rc |= (unsigned)hapgpu_rt_h2d(rt, dframes, hframes, sizeof(HapGpuFrameEnc) * live);
         if (any_snappy)
             rc |= (unsigned)hapgpu_k_snappy_compress(rt, dframes, live, max_frags_per_tex, frag_log2, dslots, slot_stride, dfragsizes,
-                                                     gran_mask | (count << 8));   /* bits 8..: textures per frame */
-        rc |= (unsigned)hapgpu_k_frame_pack(rt, dframes, live, frag_log2, dslots, slot_stride, dfragsizes, dcopies);
-        rc |= (unsigned)hapgpu_k_frame_gather(rt, dcopies, frags_per_frame * live);
+                                                     dtilesizes, gran_mask | (count << 8));   /* bits 8..: textures per frame */
+        rc |= (unsigned)hapgpu_k_frame_pack(rt, dframes, live, frag_log2, dslots, slot_stride, dfragsizes, dtilesizes, dcopies,
+                                            frags_per_frame * live, chunks_per_frame);
+        rc |= (unsigned)hapgpu_k_frame_gather(rt, dcopies, (frags_per_frame + chunks_per_frame) * live);
         rc |= (unsigned)hapgpu_rt_d2h(rt, hframes, dframes, sizeof(HapGpuFrameEnc) * live);
         rc |= (unsigned)hapgpu_rt_sync(rt);
         if (rc) {
@@ -784,8 +797,12 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                     job->frag_entries = p->frag_entries;
                     job->reserved = p->frag_gran_log2 | (p->frag_window256 << 8);
                     /* bits 0..2: plain fragment kernels needed, bits 4..6: windowed ones (8 KiB fragments whose
-                       table promises offsets of at most 3 KiB) */
-                    if (p->frag_log2 == 13u && p->frag_window256 != 0 && p->frag_window256 <= HAP_FRAGMENT_WINDOW_256)
+                       table promises offsets of at most 3 KiB), bits 8 / 9: field streams (table version 2) */
+                    if (p->frag_tiles_offset && p->frag_fields && !(flags & HAPGPU_DECODE_IGNORE_HALF_TILES)) {
+                        job->fields_period = p->frag_fields;
+                        job->tile_sizes = (uint64_t)(uintptr_t)(frame_dev + p->frag_tiles_offset);
+                        frag_kinds |= p->frag_fields == 4u ? 0x100u : 0x200u;
+                    } else if (p->frag_log2 == 13u && p->frag_window256 != 0 && p->frag_window256 <= HAP_FRAGMENT_WINDOW_256)
                         frag_kinds |= 16u << p->frag_gran_log2;
                     else
                         frag_kinds |= 1u << p->frag_gran_log2;
@@ -900,6 +917,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
             if (results[f] != HAPGPU_STATUS_INDEX_MISMATCH)
                 continue;
             results[f] = HapResult_No_Error;
+            ctx->table_fallbacks += 1;
             if (frame_count == 1 && client_marks) {
                 ctx->preset_marks = client_marks;
                 ctx->preset_count = client_marks_count;

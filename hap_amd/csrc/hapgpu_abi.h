@@ -25,7 +25,10 @@ extern "C" {
 #define HAP_SECTION_SIZES 0x03u
 #define HAP_SECTION_OFFSETS 0x04u
 #define HAP_SECTION_FRAGMENTS 0x46u   /* private: hap_gpu.h */
-#define HAP_FRAGMENT_TABLE_VERSION 1u
+#define HAP_FRAGMENT_TABLE_VERSION 1u       /* fragment sizes only */
+#define HAP_FRAGMENT_TABLE_VERSION_FIELDS 2u /* + one byte per 128-byte half-tile of every fragment: "field streams" */
+#define HAP_HALF_TILE_BYTES 128u
+#define HAP_HALF_TILES_PER_FRAGMENT 64u      /* 8 KiB fragments */
 
 /* internal status codes beyond HapResult (never returned to API callers) */
 #define HAPGPU_STATUS_INDEX_MISMATCH 100u /* fragment index inconsistent: redo without it */
@@ -46,7 +49,9 @@ typedef struct HapGpuTexEnc {
     uint32_t frags_per_chunk;
     uint32_t frag_first;     /* global index of this texture's first fragment */
     uint32_t emit_index;     /* write the fragment-size section */
-    uint32_t reserved;       /* bits 16..19: fields per block for the field-per-lane compressor (0: position per lane,
+    uint32_t reserved;       /* bit 20: "field stream": no element crosses a 128-byte half-tile and the compressor
+                                records every half-tile's compressed size (fragment table version 2);
+                                bits 16..19: fields per block for the field-per-lane compressor (0: position per lane,
                                 2: RGTC1 layout, 4: DXT5 / YCoCg-DXT5, 10: DXT1); bits 8..15: match window in 256-byte units (0 = whole fragment); bits 0..7:
                                 granularity_log2 of the element stream: 0 = bytes, 1 = every position, offset
                                 and length even (lets the decoder move 16 bits per lane) */
@@ -110,7 +115,8 @@ typedef struct HapGpuDecodeJob {
     /* results */
     uint64_t bytes_used;
     uint32_t status;         /* HapResult or HAPGPU_STATUS_* */
-    uint32_t reserved2;
+    uint32_t fields_period;  /* 4 / 2: the table is version 2 and promises [2,6,4,4] / [4,4] field streams; 0 otherwise */
+    uint64_t tile_sizes;     /* device address of the half-tile size bytes inside the frame (64 per fragment entry), or 0 */
 } HapGpuDecodeJob;
 
 #define HAPGPU_UNIT_SKIP 0u
@@ -119,6 +125,8 @@ typedef struct HapGpuDecodeJob {
 #define HAPGPU_UNIT_COPY 3u
 #define HAPGPU_UNIT_SNAPPY_FRAGMENT16 4u /* fragment whose elements are all 16-bit granular */
 #define HAPGPU_UNIT_SNAPPY_FRAGMENT32 5u /* ... all 32-bit granular */
+#define HAPGPU_UNIT_SNAPPY_FIELDS4 6u   /* fragment of a field stream, 16-byte blocks of 2 + 6 + 4 + 4 bytes; aux = its half-tile sizes */
+#define HAPGPU_UNIT_SNAPPY_FIELDS2 7u   /* ... 8-byte blocks of 4 + 4 bytes */
 #define HAPGPU_UNIT_WINDOWED 0x10u       /* flag on the three fragment kinds: every copy offset is <= 3 KiB, so an 8 KiB
                                             fragment decodes through a 4 KiB LDS ring (twice the waves per CU) */
 #define HAP_FRAGMENT_WINDOW_256 12u      /* that window in 256-byte units, as written to the fragment table */
@@ -131,6 +139,8 @@ typedef struct HapGpuDecodeUnit {
     uint32_t dst_len;
     uint32_t kind;           /* HAPGPU_UNIT_* */
     uint32_t job;            /* index of the owning job (status word) */
+    uint64_t aux;            /* FIELDS units: device address of the fragment's 64 half-tile size bytes */
+    uint64_t reserved;
 } HapGpuDecodeUnit;
 
 /* ------------------------------------------------------------------ */
@@ -164,13 +174,17 @@ int hapgpu_k_block_encode_batch(hapgpu_rt *rt, const uint64_t *sources, const ui
                                 unsigned width, unsigned height, size_t row_bytes, unsigned hap_texture_format, int wide);
 int hapgpu_k_block_decode(hapgpu_rt *rt, const void *blocks, const void *alpha, unsigned width, unsigned height,
                           unsigned hap_texture_format, void *rgba, size_t row_bytes);
+/* tile_sizes: 64 bytes per fragment (same indexing as frag_sizes), written for textures whose reserved bit 20 is set */
 int hapgpu_k_snappy_compress(hapgpu_rt *rt, const HapGpuFrameEnc *frames, unsigned frame_count,
                              unsigned max_frags_per_texture, unsigned frag_log2,
-                             void *slots, unsigned slot_stride, uint32_t *frag_sizes,
+                             void *slots, unsigned slot_stride, uint32_t *frag_sizes, uint8_t *tile_sizes,
                              unsigned granularity_mask /* bit g (0..2) set: some position-per-lane texture has granularity_log2 == g; bit 4 / 5 / 6: some texture uses the field-per-lane kernel ([2,6] / [2,6,4,4] / [4,4] fields per block); bits 8..: textures per frame */);
+/* copies: one entry per fragment, then (from index extra_first) chunks_per_frame entries per frame for the
+ * half-tile tables of field streams */
 int hapgpu_k_frame_pack(hapgpu_rt *rt, HapGpuFrameEnc *frames, unsigned frame_count,
                         unsigned frag_log2, const void *slots, unsigned slot_stride,
-                        const uint32_t *frag_sizes, HapGpuCopyEntry *copies);
+                        const uint32_t *frag_sizes, const uint8_t *tile_sizes, HapGpuCopyEntry *copies,
+                        unsigned extra_first, unsigned chunks_per_frame);
 int hapgpu_k_frame_gather(hapgpu_rt *rt, const HapGpuCopyEntry *copies, unsigned count);
 /* first `prefix` bytes of every device-resident frame (0 pointer = skip) -> out_dev + i * prefix */
 int hapgpu_k_gather_prefixes(hapgpu_rt *rt, const uint64_t *frames_dev, const uint64_t *lengths_dev,
@@ -180,6 +194,7 @@ int hapgpu_k_decode_plan(hapgpu_rt *rt, HapGpuDecodeJob *jobs, unsigned job_coun
                          HapGpuDecodeUnit *units, unsigned unit_count);
 /* frag_log2: fragment size of the batch's FRAGMENT units (0: none present);
  * fragment_kinds: bit g set = fragments of granularity_log2 g present */
+/* fragment_kinds bits 8 / 9: field-stream units of [2,6,4,4] / [4,4] blocks present */
 int hapgpu_k_snappy_decode(hapgpu_rt *rt, const HapGpuDecodeUnit *units, unsigned unit_count,
                            HapGpuDecodeJob *jobs, unsigned frag_log2, unsigned fragment_kinds,
                            int any_stream_or_copy_units);

@@ -21,9 +21,10 @@ int hapgpu_launch_block_decode(const void *blocks, const void *alpha, unsigned w
                                unsigned format, void *rgba, size_t row_bytes, hipStream_t stream);
 int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsigned frame_count, unsigned max_frags_per_texture,
                                   unsigned frag_log2, void *slots, unsigned slot_stride, uint32_t *frag_sizes,
-                                  unsigned granularity_mask, hipStream_t stream);
+                                  uint8_t *tile_sizes, unsigned granularity_mask, hipStream_t stream);
 int hapgpu_launch_frame_pack(HapGpuFrameEnc *frames, unsigned frame_count, unsigned frag_log2, const void *slots,
-                             unsigned slot_stride, const uint32_t *frag_sizes, HapGpuCopyEntry *copies,
+                             unsigned slot_stride, const uint32_t *frag_sizes, const uint8_t *tile_sizes,
+                             HapGpuCopyEntry *copies, unsigned extra_first, unsigned chunks_per_frame,
                              hipStream_t stream);
 int hapgpu_launch_frame_gather(const HapGpuCopyEntry *copies, unsigned count, hipStream_t stream);
 int hapgpu_launch_decode_plan(HapGpuDecodeJob *jobs, unsigned job_count, hipStream_t stream);
@@ -369,19 +370,22 @@ extern "C" int hapgpu_k_block_decode(hapgpu_rt *rt, const void *blocks, const vo
 
 extern "C" int hapgpu_k_snappy_compress(hapgpu_rt *rt, const HapGpuFrameEnc *frames, unsigned frame_count,
                                         unsigned max_frags_per_texture, unsigned frag_log2, void *slots,
-                                        unsigned slot_stride, uint32_t *frag_sizes, unsigned granularity_mask)
+                                        unsigned slot_stride, uint32_t *frag_sizes, uint8_t *tile_sizes,
+                                        unsigned granularity_mask)
 {
     scoped_timing st(rt, 1);
     return hapgpu_launch_snappy_compress(frames, frame_count, max_frags_per_texture, frag_log2, slots, slot_stride,
-                                         frag_sizes, granularity_mask, rt->stream);
+                                         frag_sizes, tile_sizes, granularity_mask, rt->stream);
 }
 
 extern "C" int hapgpu_k_frame_pack(hapgpu_rt *rt, HapGpuFrameEnc *frames, unsigned frame_count, unsigned frag_log2,
                                    const void *slots, unsigned slot_stride, const uint32_t *frag_sizes,
-                                   HapGpuCopyEntry *copies)
+                                   const uint8_t *tile_sizes, HapGpuCopyEntry *copies, unsigned extra_first,
+                                   unsigned chunks_per_frame)
 {
     scoped_timing st(rt, 2);
-    return hapgpu_launch_frame_pack(frames, frame_count, frag_log2, slots, slot_stride, frag_sizes, copies, rt->stream);
+    return hapgpu_launch_frame_pack(frames, frame_count, frag_log2, slots, slot_stride, frag_sizes, tile_sizes, copies,
+                                    extra_first, chunks_per_frame, rt->stream);
 }
 
 extern "C" int hapgpu_k_frame_gather(hapgpu_rt *rt, const HapGpuCopyEntry *copies, unsigned count)

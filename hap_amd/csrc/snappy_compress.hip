@@ -709,10 +709,22 @@ __device__ __forceinline__ unsigned field_offset(unsigned j)      // byte positi
     return (j >> 1) * 8u + (COLOUR ? 4u : 2u) * (j & 1u);
 }
 
+// Fixed candidate distances of the field kernel, in blocks, nearest first ("farther wins ties").  The near ones catch
+// neighbouring blocks that share a field; 64 blocks = 1 KiB of 16-byte blocks = one production step of the
+// block-per-lane decoder back: in long runs of equal fields (flat picture areas) every copy then takes its bytes from
+// output that is already complete, instead of forming a chain the decoder has to chase inside its step.
+#ifndef HAP_FIELD_DISTANCES
+#define HAP_FIELD_DISTANCES 1, 2, 3, 4
+#endif
+__device__ constexpr unsigned kFieldDist[] = {HAP_FIELD_DISTANCES};
+constexpr int kFieldFixed = (int)(sizeof(kFieldDist) / sizeof(kFieldDist[0]));
+static_assert(kFieldFixed >= 1 && kFieldFixed <= 7, "priorities are kept in 3 bits");
+
 template <unsigned PERIOD, bool COLOUR = false>
 __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(const HapGpuFrameEnc *__restrict__ frames,
                                                                    uint8_t *__restrict__ slots, unsigned slot_stride,
-                                                                   uint32_t *__restrict__ frag_sizes)
+                                                                   uint32_t *__restrict__ frag_sizes,
+                                                                   uint8_t *__restrict__ tile_sizes)
 {
     constexpr unsigned FL = 13u, kFragBytes = 1u << FL;
     constexpr unsigned kBlock = PERIOD == 4 ? 16u : 8u;
@@ -736,6 +748,12 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
     const unsigned f = tex.frag_first + x;
     uint8_t *out = slots + (size_t)f * slot_stride;
     const unsigned window = ((tex.reserved >> 8) & 0xFFu) ? ((tex.reserved >> 8) & 0xFFu) * 256u : 0xFFFFFFFFu;
+    // "field stream" (fragment table version 2): no element crosses a 128-byte half-tile (32 lanes), and the
+    // compressed size of every half-tile is recorded for the block-per-lane decoder (snappy_decode_fields.hip)
+    const bool halves = ((tex.reserved >> 20) & 1u) != 0u && tile_sizes != nullptr;
+    uint8_t *const my_tiles = tile_sizes + (size_t)f * HAP_HALF_TILES_PER_FRAGMENT;
+    if (halves && tid < HAP_HALF_TILES_PER_FRAGMENT / 4u)
+        reinterpret_cast<uint32_t *>(my_tiles)[tid] = 0u;          // half-tiles beyond a short fragment read as 0
 
     if (((uintptr_t)src & 15u) == 0) {
         uint4 v[3];
@@ -788,7 +806,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
         if (have) {
             const unsigned super_base = kFieldSubs * k * TB;
             const unsigned lanes_in_super = min(64u * kFieldSubs, (n - super_base) / kBlock * PERIOD);
-            unsigned long long eq[kFixed][kFieldSubs], in_mask[kFieldSubs];
+            unsigned long long eq[kFieldFixed][kFieldSubs], in_mask[kFieldSubs];
             unsigned ux[kFieldSubs], vx[kFieldSubs];
 #pragma unroll
             for (int sub = 0; sub < (int)kFieldSubs; sub++) {
@@ -799,13 +817,18 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
                 ux[sub] = xv.x;
                 vx[sub] = xv.y;
 #pragma unroll
-                for (int d = 0; d < kFixed; d++) {
-                    const unsigned dist = (unsigned)(d + 1) * kBlock;
+                for (int d = 0; d < kFieldFixed; d++) {
+                    const unsigned dist = kFieldDist[d] * kBlock;
                     const unsigned at = tile_base + half;
                     const uint2 yv = *reinterpret_cast<const uint2 *>(smem + (at >= dist ? at - dist : 0u));
+                    // lanes whose source lies inside the fragment (and inside the match window)
                     unsigned long long reachable = ~0ull;
-                    if (tile_base == 0u)
-                        reachable = ~0ull << ((unsigned)(d + 1) * PERIOD);
+                    if (tile_base < dist) {
+                        const unsigned first = (dist - tile_base) / kBlock * PERIOD;
+                        reachable = first >= 64u ? 0ull : ~0ull << first;
+                    }
+                    if (dist > window)
+                        reachable = 0ull;
                     eq[d][sub] = ballot64((((xv.x ^ yv.x) & m1) | ((xv.y ^ yv.y) & m2)) == 0u) & in_mask[sub] & reachable;
                 }
             }
@@ -830,7 +853,10 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
             unsigned best_k2[kFieldSubs], best_off2[kFieldSubs];
 #pragma unroll
             for (int sub = 0; sub < (int)kFieldSubs; sub++) {
-                const unsigned room_lanes = lanes_in_super > 64u * sub + lane ? min(16u, lanes_in_super - 64u * sub - lane) : 0u;
+                // lanes a copy starting here may span: up to 16 fields, the end of the data, and (field streams) the
+                // end of this lane's half-tile
+                const unsigned seg_end = min(lanes_in_super, 64u * sub + (halves ? (lane | 31u) + 1u : 64u));
+                const unsigned room_lanes = seg_end > 64u * sub + lane ? min(16u, seg_end - 64u * sub - lane) : 0u;
                 // lanes to the right whose hash candidate lies at the same distance join this one
                 const unsigned next_hd = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hd[sub], 0x130, 0xF, 0xF, false);
                 const unsigned long long same = ballot64(next_hd == hd[sub]) & ballot64(hd[sub] != 0u);
@@ -842,8 +868,9 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
                     const unsigned more = inv ? (unsigned)__builtin_ctz(inv) : 32u;
                     best_key = hd[sub] ? (min(1u + more, room_lanes) << 3) : 0u;
                 }
+                unsigned fixed_off = 0;
 #pragma unroll
-                for (int d = kFixed - 1; d >= 0; d--) {
+                for (int d = kFieldFixed - 1; d >= 0; d--) {
                     const unsigned long long c = eq[d][sub], nx = sub + 1 < (int)kFieldSubs ? eq[d][sub + 1 < (int)kFieldSubs ? sub + 1 : sub] : 0ull;
                     if (c == 0ull)
                         continue;
@@ -854,8 +881,11 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
                     best_key = max(best_key, (l << 3) | (unsigned)(d + 1));            // farther wins ties
                 }
                 const unsigned prio = best_key & 7u;
+#pragma unroll
+                for (int d = 0; d < kFieldFixed; d++)
+                    fixed_off = prio == (unsigned)(d + 1) ? kFieldDist[d] * kBlock : fixed_off;
                 best_k2[sub] = best_key >> 3;
-                best_off2[sub] = prio ? prio * kBlock : hd[sub];
+                best_off2[sub] = prio ? fixed_off : hd[sub];
             }
             unsigned skip = 0;
 #pragma unroll
@@ -872,11 +902,14 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
                 const unsigned long long skipmask = skip >= 64u ? ~0ull : ((1ull << skip) - 1ull);
                 const unsigned long long lit = ~(ballot64((unsigned)reach > lane) | skipmask) & in_mask[sub];
                 skip = carry;
-                const unsigned long long starts = lit & ~(lit << 1);
+                // (field streams: a literal run ends at the half-tile boundary, a new one starts at lane 32)
+                const unsigned long long starts = (lit & ~(lit << 1)) | (halves ? lit & (1ull << 32) : 0ull);
                 unsigned run = 0;                          // literal run length in BYTES
                 if (__builtin_amdgcn_inverse_ballot_w64(starts)) {
                     const unsigned long long a = ~(lit >> lane);
-                    const unsigned r = a ? (unsigned)__builtin_ctzll(a) : 64u;
+                    unsigned r = a ? (unsigned)__builtin_ctzll(a) : 64u;
+                    if (halves && lane < 32u)
+                        r = min(r, 32u - lane);
                     run = field_offset<PERIOD, COLOUR>(lane + r) - my_off;
                 }
                 // this lane's element: literal = [run header] + the field's bytes, copy = 2 or 3 bytes
@@ -919,6 +952,12 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
                 }
                 const int incl = cwave_scan_add((int)cnt);
                 p_at[sub] = total + (unsigned)incl - cnt;
+                if (halves) {
+                    const unsigned lower = (unsigned)__builtin_amdgcn_readlane(incl, 31);
+                    const unsigned both = (unsigned)__builtin_amdgcn_readlane(incl, 63);
+                    if (lane == 0)
+                        *reinterpret_cast<uint16_t *>(my_tiles + 2u * (kFieldSubs * k + sub)) = (uint16_t)(lower | ((both - lower) << 8));
+                }
                 total += (unsigned)__builtin_amdgcn_readlane(incl, 63);
                 p_lo[sub] = vlo;
                 p_hi[sub] = vhi;
@@ -976,8 +1015,8 @@ static unsigned compress_lds_bytes(unsigned frag_log2) { return (1u << frag_log2
 
 extern "C" int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsigned frame_count,
                                              unsigned max_frags_per_texture, unsigned frag_log2, void *slots,
-                                             unsigned slot_stride, uint32_t *frag_sizes, unsigned granularity_mask,
-                                             hipStream_t stream)
+                                             unsigned slot_stride, uint32_t *frag_sizes, uint8_t *tile_sizes,
+                                             unsigned granularity_mask, hipStream_t stream)
 {
     if (frame_count == 0 || max_frags_per_texture == 0)
         return 0;
@@ -1009,13 +1048,13 @@ extern "C" int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsig
         } while (0)
         if (frag_log2 == 13u && (granularity_mask & 16u))
             hipLaunchKernelGGL((snappy_compress_field_kernel<2u>), grid, block, 0, stream, frames, (uint8_t *)slots,
-                               slot_stride, frag_sizes);
+                               slot_stride, frag_sizes, tile_sizes);
         if (frag_log2 == 13u && (granularity_mask & 64u))
             hipLaunchKernelGGL((snappy_compress_field_kernel<2u, true>), grid, block, 0, stream, frames, (uint8_t *)slots,
-                               slot_stride, frag_sizes);
+                               slot_stride, frag_sizes, tile_sizes);
         if (frag_log2 == 13u && (granularity_mask & 32u))
             hipLaunchKernelGGL((snappy_compress_field_kernel<4u>), grid, block, 0, stream, frames, (uint8_t *)slots,
-                               slot_stride, frag_sizes);
+                               slot_stride, frag_sizes, tile_sizes);
         if (granularity_mask & 1u)
             HAP_LAUNCH_COMPRESS(1u);
         if (granularity_mask & 2u)

@@ -63,6 +63,8 @@ __device__ void emit_copy_units(HapGpuDecodeUnit *u, unsigned slots, const uint8
         w.dst_len = w.src_len;
         w.kind = w.src_len ? HAPGPU_UNIT_COPY : HAPGPU_UNIT_SKIP;
         w.job = job;
+        w.aux = 0;
+        w.reserved = 0;
         u[k] = w;
     }
 }
@@ -102,6 +104,7 @@ __global__ __launch_bounds__(64) void decode_plan_kernel(HapGpuDecodeJob *jobs, 
                 w.src = (uint64_t)payload; w.dst = (uint64_t)dst;
                 w.src_len = (unsigned)job->payload_len; w.dst_len = n;
                 w.kind = HAPGPU_UNIT_SNAPPY_STREAM; w.job = j;
+                w.aux = 0; w.reserved = 0;
                 units[0] = w;
                 used = n;
             }
@@ -179,10 +182,18 @@ __global__ __launch_bounds__(64) void decode_plan_kernel(HapGpuDecodeJob *jobs, 
                             w.src_len = fs[k];
                             w.dst_len = min(frag_bytes, out_len - k * frag_bytes);
                             const unsigned gran = job->reserved & 0xFFu, window256 = (job->reserved >> 8) & 0xFFu;
-                            w.kind = gran == 2 ? HAPGPU_UNIT_SNAPPY_FRAGMENT32
-                                   : gran == 1 ? HAPGPU_UNIT_SNAPPY_FRAGMENT16 : HAPGPU_UNIT_SNAPPY_FRAGMENT;
-                            if (job->frag_log2 == 13u && window256 != 0 && window256 <= HAP_FRAGMENT_WINDOW_256)
-                                w.kind |= HAPGPU_UNIT_WINDOWED;
+                            w.aux = 0;
+                            w.reserved = 0;
+                            if (job->fields_period != 0u && job->tile_sizes != 0u) {
+                                // field stream (table version 2): block-per-lane decoder, with this fragment's half-tile sizes
+                                w.kind = job->fields_period == 4u ? HAPGPU_UNIT_SNAPPY_FIELDS4 : HAPGPU_UNIT_SNAPPY_FIELDS2;
+                                w.aux = job->tile_sizes + (uint64_t)(c.frag_first + k) * HAP_HALF_TILES_PER_FRAGMENT;
+                            } else {
+                                w.kind = gran == 2 ? HAPGPU_UNIT_SNAPPY_FRAGMENT32
+                                       : gran == 1 ? HAPGPU_UNIT_SNAPPY_FRAGMENT16 : HAPGPU_UNIT_SNAPPY_FRAGMENT;
+                                if (job->frag_log2 == 13u && window256 != 0 && window256 <= HAP_FRAGMENT_WINDOW_256)
+                                    w.kind |= HAPGPU_UNIT_WINDOWED;
+                            }
                             w.job = j;
                             u[k] = w;
                             at += fs[k];
@@ -202,6 +213,8 @@ __global__ __launch_bounds__(64) void decode_plan_kernel(HapGpuDecodeJob *jobs, 
                     w.dst_len = out_len;
                     w.kind = HAPGPU_UNIT_SNAPPY_STREAM;
                     w.job = j;
+                    w.aux = 0;
+                    w.reserved = 0;
                     u[0] = w;
                 }
             }
@@ -916,12 +929,23 @@ extern "C" int hapgpu_launch_decode_plan(HapGpuDecodeJob *jobs, unsigned job_cou
 // dynamic LDS to request for the v2 kernel: none when its ring + tail fit the static array
 static constexpr unsigned fragment_dynamic_lds(unsigned ring) { return ring + kFragmentTail <= 65536u ? 0u : ring + kFragmentTail; }
 
+extern "C" int hapgpu_launch_snappy_decode_fields(const HapGpuDecodeUnit *units, unsigned unit_count, HapGpuDecodeJob *jobs,
+                                                  unsigned fields_kinds, hipStream_t stream);
+
 extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsigned unit_count, HapGpuDecodeJob *jobs,
                                            unsigned frag_log2, unsigned fragment_kinds, int any_stream_or_copy_units,
                                            hipStream_t stream)
 {
     if (unit_count == 0)
         return 0;
+    // field streams (fragment table version 2): the block-per-lane decoder of snappy_decode_fields.hip
+    if ((fragment_kinds >> 8) & 3u) {
+        if (hapgpu_launch_snappy_decode_fields(units, unit_count, jobs, (fragment_kinds >> 8) & 3u, stream) != 0)
+            return 4;
+        fragment_kinds &= 0xFFu;
+        if (fragment_kinds == 0u)
+            frag_log2 = 0u;
+    }
     static const bool use_v1 = getenv("HAP_AMD_DECODE_V1") != nullptr;
     if (any_stream_or_copy_units) {
         static bool once = false;

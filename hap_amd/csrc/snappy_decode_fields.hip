@@ -1,0 +1,421 @@
+// snappy_decode_fields.hip -- block-per-lane Snappy decoder for "field streams" (gfx950).
+//
+// Replaces hap_decode_chunk's snappy_uncompress (reference hap.c:606-642, call at hap.c:612) for the frames this
+// library writes itself with the fragment table version 2 (private section 0x46, include/hap_gpu.h).  Such a chunk
+// is an ordinary Snappy stream -- the reference decodes it unchanged -- whose elements obey extra rules that the
+// table announces and this kernel VERIFIES while it parses (any violation fails the unit with
+// HAPGPU_STATUS_INDEX_MISMATCH and the host decodes the frame again through the generic kernels):
+//
+//   * the stream is cut into independent 8 KiB fragments (compressed size of each in the table);
+//   * inside a fragment no element crosses a 128-byte "half-tile" of output, and the table holds the compressed size
+//     of every half-tile (one byte each);
+//   * every element starts and ends on a block FIELD boundary -- DXT5 / YCoCg-DXT5 blocks are 2 + 6 + 4 + 4 bytes
+//     (alpha endpoints, alpha indices, colour endpoints, colour indices), DXT1 blocks 4 + 4 -- and every copy offset
+//     is a whole number of blocks.  So each field of each block is produced by exactly one element, either from
+//     literal bytes or from the SAME field of an earlier block.
+//
+// One wavefront decodes one fragment in two phases:
+//
+//   1. PARSE, one lane per half-tile (64 half-tiles = the whole fragment at once): the lane walks its half-tile's
+//      elements serially -- the only serial dependency of Snappy, the element chain, is now 64 independent short
+//      chains -- and leaves per element a 16-bit record {first field, literal?, literal position | block distance}
+//      plus a 32-bit mask of the fields at which an element starts.
+//   2. PRODUCE, one lane per BLOCK, 64 blocks (1 KiB of DXT5) per step: for each of its 4 fields the lane finds the
+//      owning element with one popcount of the start mask, reads the record, and turns it into a source address:
+//      literal bytes in the staged input, or the same field of block (b - distance) in the output ring.  Sources
+//      inside the current step are resolved by pointer doubling on lane indices (ds_bpermute, <= 6 rounds, usually
+//      0-2); then 4 field reads, one 16-byte LDS store (later steps copy from it) and one 16-byte global store.
+//
+// LDS: the output ring (8 KiB) and the staged compressed bytes share one buffer -- the input is parked high enough
+// that output written by step s never reaches the compressed bytes of later steps (positions follow from the
+// half-tile table) -- + 4 KiB of records + masks: 13.8 KiB per wave, 11 waves per CU.
+// HBM traffic: compressed bytes read once, output written once (algorithmic bytes b(1 + c)).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hapgpu_abi.h"
+
+namespace {
+
+constexpr unsigned kFragBytes = 8192u;
+constexpr unsigned kHalf = 128u;                       // bytes of output per half-tile
+constexpr unsigned kHalves = kFragBytes / kHalf;       // 64: one parse lane each
+constexpr unsigned kMaxHalfCompressed = 144u;          // an honest encoder stays <= 130 (all literal + 2 header bytes)
+constexpr unsigned kMaxFragCompressed = kFragBytes + 320u;
+// ring + parked input: worst case max_h(128 h + 144 (64 - h)) + alignment slack (see the S computation below)
+constexpr unsigned kBufBytes = 9344u + 32u;
+constexpr unsigned kRecPerHalf = 32u;
+
+__device__ __forceinline__ int fdpp_shr(int v, int n)
+{
+    switch (n) {
+    case 1: return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);
+    case 2: return __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
+    case 4: return __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
+    default: return __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
+    }
+}
+
+__device__ __forceinline__ int fwave_scan_add(int v)       // inclusive
+{
+    v += fdpp_shr(v, 1);
+    v += fdpp_shr(v, 2);
+    v += fdpp_shr(v, 4);
+    v += fdpp_shr(v, 8);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+__device__ __forceinline__ int fwave_max(int v)            // values >= 0; result in lane 63, returned uniform
+{
+    v = max(v, fdpp_shr(v, 1));
+    v = max(v, fdpp_shr(v, 2));
+    v = max(v, fdpp_shr(v, 4));
+    v = max(v, fdpp_shr(v, 8));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// byte offset of field j counted from a block boundary (PERIOD fields per block)
+template <unsigned PERIOD>
+__device__ __forceinline__ unsigned field_pos(unsigned j)
+{
+    if (PERIOD == 4)
+        return (j >> 2) * 16u + __builtin_amdgcn_ubfe(0x0C080200u, (j & 3u) * 8u, 8u);
+    return j * 4u;
+}
+
+// inverse: field index of byte position p, >= 0x100 when p is not a field boundary
+template <unsigned PERIOD>
+__device__ __forceinline__ unsigned field_at(unsigned p)
+{
+    if (PERIOD == 4) {
+        // inside a block the boundaries are 0, 2, 8, 12: nibble table indexed by (p & 15) >> 1, 0xF = none
+        const unsigned j = __builtin_amdgcn_ubfe(0xF3F2FF10u, (p & 14u) * 2u, 4u);
+        return ((p >> 4) * 4u + j) | ((j & 8u) << 5) | ((p & 1u) << 8);
+    }
+    return (p >> 2) | ((p & 3u) << 8);
+}
+
+// Fails the unit: the host decodes the frame again without the table (generic kernels).
+__device__ __forceinline__ void fail_unit(HapGpuDecodeJob *job, unsigned lane)
+{
+    if (lane == 0)
+        atomicCAS(&job->status, 0u, HAPGPU_STATUS_INDEX_MISMATCH);
+}
+
+// 16 bytes of the unit's input at aligned coordinate x (coordinates are relative to src - shift); bytes outside
+// [shift, in_end) read as zero and are never touched in memory
+__device__ __forceinline__ uint4 load_input16(const uint8_t *src_al, unsigned x, unsigned shift, unsigned in_end)
+{
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (x >= shift && x + 16u <= in_end) {
+        v = *reinterpret_cast<const uint4 *>(src_al + x);
+    } else if (x < in_end && x + 16u > shift) {
+        unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll 1
+        for (unsigned k = 0; k < 16u; k++) {
+            const unsigned y = x + k;
+            if (y >= shift && y < in_end)
+                w[k >> 2] |= (unsigned)src_al[y] << (8u * (k & 3u));
+        }
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    return v;
+}
+
+template <unsigned PERIOD>
+__global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDecodeUnit *__restrict__ units,
+                                                                  unsigned unit_count, HapGpuDecodeJob *jobs)
+{
+    constexpr unsigned kBlock = PERIOD == 4 ? 16u : 8u;
+    constexpr unsigned kBlocksPerHalf = kHalf / kBlock;            // 8 or 16
+    constexpr unsigned kStepBytes = 64u * kBlock;                  // 1024 or 512
+    constexpr unsigned kHalvesPerStep = kStepBytes / kHalf;        // 8 or 4
+    constexpr unsigned kPosShift = PERIOD == 4 ? 1u : 2u;          // element start positions are kept in 2- / 4-byte units
+    constexpr unsigned kLitBias = kHalf;
+    __shared__ __attribute__((aligned(16))) uint8_t buf[kBufBytes];
+    __shared__ __attribute__((aligned(4))) uint16_t rec[kHalves * kRecPerHalf];
+    __shared__ __attribute__((aligned(8))) uint2 masks[kHalves];
+    __shared__ uint16_t coffs[kHalves + 2u];
+    const uint32_t *bufw = reinterpret_cast<const uint32_t *>(buf);
+
+    const unsigned lane = threadIdx.x;
+    if (blockIdx.x >= unit_count)
+        return;
+    const HapGpuDecodeUnit u = units[blockIdx.x];
+    if (u.kind != (PERIOD == 4 ? HAPGPU_UNIT_SNAPPY_FIELDS4 : HAPGPU_UNIT_SNAPPY_FIELDS2))
+        return;
+    HapGpuDecodeJob *job = &jobs[u.job];
+    const uint8_t *src = (const uint8_t *)u.src;
+    uint8_t *dst = (uint8_t *)u.dst;
+    const uint8_t *tile_sizes = (const uint8_t *)u.aux;
+    const unsigned total = u.src_len, out_len = u.dst_len;
+    if (out_len == 0u || out_len > kFragBytes || (out_len % kBlock) != 0u || total > kMaxFragCompressed || !tile_sizes) {
+        fail_unit(job, lane);
+        return;
+    }
+    const unsigned nhalf = (out_len + kHalf - 1u) / kHalf;
+
+    // everything the unit needs from memory is requested at once: the job's status word, the half-tile table and
+    // the first 4 KiB of input (what comes later is fetched by the loop below)
+    const unsigned shift = (unsigned)((uintptr_t)src & 15u);
+    const uint8_t *src_al = src - shift;
+    const unsigned in_end = shift + total;
+    const unsigned job_status = __builtin_nontemporal_load(&job->status);
+    const unsigned tsz = lane < nhalf ? (unsigned)tile_sizes[lane] : 0u;
+    uint4 early[4];
+#pragma unroll
+    for (unsigned i = 0; i < 4u; i++)
+        early[i] = load_input16(src_al, i * 1024u + lane * 16u, shift, in_end);
+    if (job_status != 0u)
+        return;
+
+    // ---- half-tile table -> compressed offsets, and where to park the input ----
+    const int incl = fwave_scan_add((int)tsz);
+    const unsigned coff = (unsigned)incl - tsz;
+    const bool table_bad = (unsigned)__builtin_amdgcn_readlane(incl, 63) != total ||
+                           __builtin_amdgcn_ballot_w64(tsz > kMaxHalfCompressed) != 0ull;
+    if (table_bad) {
+        fail_unit(job, lane);
+        return;
+    }
+    coffs[lane] = (uint16_t)coff;
+    if (lane == 63u)
+        coffs[64] = (uint16_t)total;
+    // Output of half-tiles < h may overwrite buffer bytes below 128 h; the input of half-tile h sits at S + coff[h].
+    const int lead = lane < nhalf ? (int)(kHalf * lane) - (int)coff : 0;
+    const unsigned S = (((unsigned)fwave_max(max(lead, 0)) + kHalf + 15u - shift) & ~15u) + shift;   // S = shift (mod 16)
+    if (S + total + 16u > kBufBytes) {          // cannot happen within the limits checked above
+        fail_unit(job, lane);
+        return;
+    }
+    {
+        uint8_t *park = buf + (S - shift) + lane * 16u;
+#pragma unroll
+        for (unsigned i = 0; i < 4u; i++)
+            if (i * 1024u < in_end)
+                *reinterpret_cast<uint4 *>(park + i * 1024u) = early[i];
+        for (unsigned x = 4096u; x < in_end; x += 1024u)
+            *reinterpret_cast<uint4 *>(park + x) = load_input16(src_al, x + lane * 16u, shift, in_end);
+    }
+    __syncthreads();
+
+    // ---- 1. parse: lane h walks the elements of half-tile h ----
+    // Straight-line code under the loop's exec mask: the three element kinds are decoded side by side and selected.
+    // Per element one signed 16-bit record,
+    //     literal:  0x8000 | (offset of its bytes in the half-tile's input - its output position + 128)   (negative)
+    //     copy:     4 x distance in blocks                                                                (positive)
+    // and one bit of the start mask (bit = output position in 2- or 4-byte units).  Promise checks are accumulated
+    // and looked at once at the end.
+    constexpr unsigned kRecShift = PERIOD == 4 ? 2u : 1u;         // byte offset -> 4 x blocks
+    {
+        const unsigned h = lane;
+        const unsigned hbytes = h < nhalf ? min(kHalf, out_len - kHalf * h) : 0u;
+        const unsigned cbase = S + coff;
+        unsigned cp = cbase;
+        const unsigned cend = cbase + tsz;
+        const unsigned obase = kHalf * h;                 // output position of the half-tile inside the fragment
+        const unsigned litk = 1u + kLitBias + 0x8000u - cbase;
+        unsigned p = 0, mlo = 0, mhi = 0;
+        unsigned recp = 0;                                 // byte offset into this half-tile's records
+        unsigned acc_or = 0;                               // OR of copy offsets (low bits) and start positions << 16
+        unsigned acc_bad = 0;                              // any bit set = the stream breaks a promise
+        unsigned min_off = 0xFFFFu, max_up = 0;            // smallest copy offset, largest literal length code
+        uint8_t *const recb = reinterpret_cast<uint8_t *>(rec) + h * (kRecPerHalf * 2u);
+        // (every element advances p by at least one byte, so the walk is bounded; elements that start off a field
+        // boundary -- the only way to have more than 32 of them -- are caught below, and the record index is masked)
+        while (__builtin_amdgcn_ballot_w64(p < hbytes) != 0ull) {
+            if (p < hbytes) {
+                const unsigned aw = cp >> 2;
+                #ifdef DBG_OLDALIGN
+                const unsigned w = __builtin_amdgcn_alignbyte(bufw[aw + 1u], bufw[aw], cp & 3u);
+#else
+                const unsigned w = __builtin_amdgcn_alignbyte(bufw[aw + 1u], bufw[aw], cp);     // bytes cp .. cp+3
+#endif
+                const unsigned kind = w & 3u, up = __builtin_amdgcn_ubfe(w, 2u, 6u);
+                const unsigned b1 = __builtin_amdgcn_ubfe(w, 8u, 8u);
+                const bool is_lit = kind == 0u, is_c1 = kind == 1u;
+                const bool lng = is_lit && up == 60u;
+                const unsigned lngv = lng ? 1u : 0u;
+                // length - 1: literal / copy-2: tag >> 2 (long literal: the next byte); copy-1: 3 + 3 bits
+                unsigned lm1 = lng ? b1 : up;
+                lm1 = is_c1 ? __builtin_amdgcn_ubfe(w, 2u, 3u) + 3u : lm1;
+                const unsigned adv = is_lit ? lm1 + lngv + 2u : kind + 1u;
+                const unsigned off = is_c1 ? (((w << 3) & 0x700u) | b1) : __builtin_amdgcn_ubfe(w, 8u, 16u);
+                const unsigned litrec = (cp - p) + lngv + litk;                 // 0x8000 | 1 .. 128 + 146
+                // promises: whole blocks back (low offset bits 0), at least one, not before the fragment; no copy-4
+                // (kind 3); no literal with 2..4 length bytes (tag >> 2 in 61..63); starts on 2- / 4-byte positions
+                acc_or |= (is_lit ? 0u : off) | (p << 16);
+                min_off = min(min_off, is_lit ? 0xFFFFu : off);
+                max_up = max(max_up, is_lit ? up : 0u);
+                acc_bad |= (w & (w >> 1) & 1u) | ((!is_lit && off > obase + p) ? 1u : 0u);
+                *reinterpret_cast<uint16_t *>(recb + (recp & (kRecPerHalf * 2u - 2u))) = (uint16_t)(is_lit ? litrec : off >> kRecShift);
+                recp += 2u;
+                const unsigned long long bit = 1ull << (p >> kPosShift);
+                mlo |= (unsigned)bit;
+                mhi |= (unsigned)(bit >> 32);
+                p += lm1 + 1u;
+                cp += adv;
+            }
+        }
+        // an element that overshoots its half-tile or the table's byte count ends up with p / cp off the mark;
+        // starts off a field boundary show in the mask (16-byte blocks: fields begin at bytes 0, 2, 8, 12)
+        bool bad = acc_bad != 0u || (acc_or & (kBlock - 1u)) != 0u || ((acc_or >> 16) & ((1u << kPosShift) - 1u)) != 0u ||
+                   min_off < kBlock || max_up > 60u || (h < nhalf && (cp != cend || p != hbytes));
+        if (PERIOD == 4)
+            bad = bad || ((mlo | mhi) & ~0x53535353u) != 0u;
+        masks[h] = make_uint2(mlo, mhi);
+        if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
+            fail_unit(job, lane);
+            return;
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. produce: lane = block, 64 blocks per step ----
+    const bool dst_wide = ((uintptr_t)dst & (kBlock - 1u)) == 0u;
+    // per-lane constants: the block's place inside its half-tile, and for each of its fields the mask of start bits
+    // at or below it (in the 32-bit half of the start mask that covers the block)
+    const unsigned b = lane & (kBlocksPerHalf - 1u);
+    const unsigned hsub = lane / kBlocksPerHalf;                           // half-tile of the step
+    const bool upper = PERIOD == 4 && b >= 4u;                             // PERIOD 2: 32 four-byte positions, one word
+    unsigned le[PERIOD], fbias[PERIOD];
+#pragma unroll
+    for (unsigned k = 0; k < PERIOD; k++) {
+        const unsigned fb = b * kBlock + field_pos<PERIOD>(k);             // byte position of the field in the half-tile
+        const unsigned q = (fb >> kPosShift) & 31u;
+        le[k] = (2u << q) - 1u;
+        fbias[k] = fb - kLitBias + 0x8000u + S;                            // + coff[half-tile] + record = literal address
+    }
+    const unsigned lane4s = lane * 4u + 0x80000000u;
+    // 2a. every step's fields -> source descriptors ("state"): >= 0 an address in buf (literal bytes, or the ring for a
+    //     copy whose source block lies in an earlier step), < 0 pending: sign bit | 4 x (source lane in the same step).
+    //     All steps are looked up before anything is produced: the LDS round trips of the 8 steps overlap.
+    constexpr unsigned kMaxSteps = kFragBytes / kStepBytes;               // 8 or 16
+    int state[kMaxSteps][PERIOD];
+#pragma unroll
+    for (unsigned s = 0; s < kMaxSteps; s++) {
+        const unsigned opos = (64u * s + lane) * kBlock;                   // output position = ring address
+        const bool active = opos < out_len;
+        const unsigned hh = s * kHalvesPerStep + hsub;
+        const uint2 m = masks[hh];
+        const int cof = (int)(unsigned)coffs[hh];
+        const unsigned msel = upper ? m.y : m.x;
+        const int ebase = upper ? (int)__builtin_popcount(m.x) - 1 : -1;
+        const int16_t *rb = reinterpret_cast<const int16_t *>(rec) + hh * kRecPerHalf;
+#pragma unroll
+        for (unsigned k = 0; k < PERIOD; k++) {
+            const int e = (int)__builtin_popcount(msel & le[k]) + ebase;  // ordinal of the element that owns the field
+            const int r = (int)rb[e & (int)(kRecPerHalf - 1u)];
+            const int lit_addr = cof + (int)fbias[k] + r;                  // (r = record - 0x10000 for literals)
+            // copy: source = same field, r / 4 blocks back.  Inside this step (r / 4 <= lane): pending, sign bit |
+            // 4 x source lane; else an address in the ring (the walk above made sure it is not before the fragment)
+            const int pend = (int)(lane4s - (unsigned)r);              // (unsigned: the wrap-around is the point)
+            const int ring_addr = (int)(opos + field_pos<PERIOD>(k)) - r * (int)(kBlock / 4u);
+            const int cpy = pend < 0 ? pend : ring_addr;
+            const int st = r < 0 ? lit_addr : cpy;
+            state[s][k] = active ? st : 0;
+        }
+    }
+    // 2b. sources produced in the same step: follow the chains to a literal or to an earlier step by pointer doubling
+    //     (<= 6 rounds); the columns of all steps advance together, so a round is up to 32 independent ds_bpermutes in
+    //     flight instead of one dependent LDS round trip per step and round
+    for (;;) {
+        int any_all = 0;
+#pragma unroll
+        for (unsigned s = 0; s < kMaxSteps; s++) {
+            int any = state[s][0];
+#pragma unroll
+            for (unsigned k = 1; k < PERIOD; k++)
+                any |= state[s][k];
+            any_all |= any;
+            if (__builtin_amdgcn_ballot_w64(any < 0) == 0ull)
+                continue;                                                   // (uniform) this step is resolved
+#pragma unroll
+            for (unsigned k = 0; k < PERIOD; k++) {
+#ifdef DBG_SAFEIDX
+                const int g = __builtin_amdgcn_ds_bpermute(state[s][k] < 0 ? (state[s][k] & 0xFC) : (int)(lane * 4u), state[s][k]);
+#else
+                const int g = __builtin_amdgcn_ds_bpermute(state[s][k] & 0xFC, state[s][k]);
+#endif
+                state[s][k] = state[s][k] < 0 ? g : state[s][k];
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(any_all < 0) == 0ull)
+            break;
+    }
+    // 2c. field bytes -> 16-byte block -> ring (later steps copy from it) and memory, step after step
+    const unsigned nsteps = (out_len + kStepBytes - 1u) / kStepBytes;
+#pragma unroll
+    for (unsigned s = 0; s < kMaxSteps; s++) {
+        if (s >= nsteps)
+            break;
+        const unsigned opos = (64u * s + lane) * kBlock;
+        const bool active = opos < out_len;
+        unsigned out[PERIOD == 4 ? 4 : 2];
+        if (PERIOD == 4) {
+            unsigned lo[4], hi1 = 0;
+#pragma unroll
+            for (unsigned k = 0; k < 4; k++) {
+                const unsigned a = (unsigned)state[s][k], aw = a >> 2, sh = a & 3u;
+                const unsigned d0 = bufw[aw], d1 = bufw[aw + 1u];
+                lo[k] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+                if (k == 1) {
+                    const unsigned d2 = bufw[aw + 2u];
+                    hi1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                }
+            }
+            out[0] = (lo[0] & 0xFFFFu) | (lo[1] << 16);
+            out[1] = (lo[1] >> 16) | (hi1 << 16);
+            out[2] = lo[2];
+            out[3] = lo[3];
+        } else {
+#pragma unroll
+            for (unsigned k = 0; k < 2; k++) {
+                const unsigned a = (unsigned)state[s][k], aw = a >> 2, sh = a & 3u;
+                out[k] = __builtin_amdgcn_alignbyte(bufw[aw + 1u], bufw[aw], sh);
+            }
+        }
+        if (active) {
+            if (PERIOD == 4) {
+                const uint4 v = make_uint4(out[0], out[1], out[2], out[3]);
+                *reinterpret_cast<uint4 *>(buf + opos) = v;
+                if (dst_wide) {
+                    *reinterpret_cast<uint4 *>(dst + opos) = v;
+                } else {
+#pragma unroll 1
+                    for (unsigned k = 0; k < 16u; k++)
+                        dst[opos + k] = (uint8_t)(out[k >> 2] >> (8u * (k & 3u)));
+                }
+            } else {
+                const uint2 v = make_uint2(out[0], out[1]);
+                *reinterpret_cast<uint2 *>(buf + opos) = v;
+                if (dst_wide) {
+                    *reinterpret_cast<uint2 *>(dst + opos) = v;
+                } else {
+#pragma unroll 1
+                    for (unsigned k = 0; k < 8u; k++)
+                        dst[opos + k] = (uint8_t)(out[k >> 2] >> (8u * (k & 3u)));
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+} // namespace
+
+// fields_kinds: bit 0 = [2, 6, 4, 4] units present (DXT5 / YCoCg-DXT5), bit 1 = [4, 4] units (DXT1)
+extern "C" int hapgpu_launch_snappy_decode_fields(const HapGpuDecodeUnit *units, unsigned unit_count, HapGpuDecodeJob *jobs,
+                                                  unsigned fields_kinds, hipStream_t stream)
+{
+    if (unit_count == 0)
+        return 0;
+    if (fields_kinds & 1u)
+        hipLaunchKernelGGL((snappy_decode_fields_kernel<4u>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs);
+    if (fields_kinds & 2u)
+        hipLaunchKernelGGL((snappy_decode_fields_kernel<2u>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs);
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}

@@ -27,6 +27,15 @@
  * it (reference hap.c:701-703, HapVideoDRAFT.md:34), hap_amd's decoder uses it
  * to decode one chunk with many wavefronts.  The table also records the
  * granularity (1, 2 or 4 bytes) that every element of the streams honours.
+ *
+ * Section 0x46, version 1:  [1][log2 F][granularity log2][match window / 256 B][LE32 compressed size x fragments]
+ *               version 2:  [2][13][granularity log2 | fields per block << 4][window][LE32 size x fragments]
+ *                           [u8 compressed size x 64 half-tiles x fragments]
+ * Version 2 ("field streams": DXT5 / YCoCg-DXT5 textures, 8 KiB fragments) adds the compressed size of every
+ * 128-byte half-tile of output and promises that no element crosses a half-tile, that every element starts and
+ * ends on a block field boundary (2 + 6 + 4 + 4 bytes) and that every copy offset is a whole number of blocks:
+ * the decoder then parses 64 half-tiles at once and produces one block per lane.  Every promise is checked while
+ * decoding; a frame whose table lies is decoded again without it.
  */
 #ifndef HAP_AMD_HAP_GPU_H
 #define HAP_AMD_HAP_GPU_H
@@ -47,6 +56,8 @@ typedef struct HapGpuContext HapGpuContext;
 
 /* Decode flags */
 #define HAPGPU_DECODE_IGNORE_FRAGMENT_INDEX 0x1u /* decode as a decoder unaware of section 0x46 would */
+#define HAPGPU_DECODE_IGNORE_HALF_TILES 0x2u     /* use a version-2 table's fragment sizes only (the generic
+                                                    fragment decoder), not its half-tile sizes: for A/B measurements */
 
 /* Creates a context on HIP device `device` (-1: the current device) with its
  * own non-blocking stream and growable scratch.  Returns a HapResult. */
@@ -63,6 +74,10 @@ unsigned int HapGpuSetFragmentLog2(HapGpuContext *context, unsigned int log2_byt
 
 /* Blocks until everything enqueued on the context's stream has finished. */
 unsigned int HapGpuSynchronize(HapGpuContext *context);
+
+/* Number of frames this context has decoded a second time because their fragment table (section 0x46) did not
+ * describe their streams: the table is only ever a hint, results are the same either way.  For tests and tools. */
+unsigned long HapGpuTableFallbackCount(HapGpuContext *context);
 
 /* RGBA8 (row-major, rowBytes stride, width/height multiples of 4) -> block
  * compressed texture.  textureFormat is one of RGB_DXT1, RGBA_DXT5,

@@ -28,6 +28,16 @@ def ctx(hap):
     c.close()
 
 
+def find_fragment_table(frame, start=0, stop=400):
+    """(offset of the 0x46 type byte, version, header bytes) of the private fragment table; version 1:
+    [ver][log2 F][granularity log2][window], version 2 (field streams): [2][13][granularity | fields << 4][window]."""
+    for ver in (1, 2):
+        at = bytes(frame).find(bytes([0x46, ver, 13]), start, stop)
+        if at > 0:
+            return at, ver, bytes(frame[at + 1: at + 5])
+    return -1, 0, b""
+
+
 ORA = L.oracle_api()
 REF = L.ref_api()
 CHECKERS = [("oracle", ORA)] + ([("reference", REF)] if REF is not None else [])
@@ -666,7 +676,8 @@ def test_corrupt_fragment_table_falls_back(ctx, hap):
     out = np.zeros(cap, dtype=np.uint8)
     r, used, _ = ctx.encode_frames([[tex]], [L.FMT_DXT5], [1], [4], [out], flags=hap.ENCODE_FRAGMENT_INDEX)
     frame = bytearray(out[: used[0]].tobytes())
-    pos = frame.find(bytes([0x46, 1, 13]), 0, 200) + 5      # type, version, log2 fragment, granularity, 0
+    at, _ver, _hdr = find_fragment_table(frame, 0, 200)
+    pos = at + 5                                            # type, version, log2 fragment, granularity, window
     assert pos > 5
     e0 = int.from_bytes(frame[pos:pos + 4], "little")
     e1 = int.from_bytes(frame[pos + 4:pos + 8], "little")
@@ -929,10 +940,10 @@ def test_coarse_matches_flag_round_trips(ctx, hap, fmt):
             r, du, df, dr = ctx.decode_frames([frame], [len(frame)], 0, [dec], flags=dflags)
             assert (r, du, df, dr) == (0, [len(tex)], [fmt], [0]) and dec.tobytes() == tex
         if flags & hap.ENCODE_FRAGMENT_INDEX:
-            at = frame.find(bytes([0x46, 1, 13]))        # section type, version, log2(8 KiB)
+            at, _ver, _hdr = find_fragment_table(frame)     # section type, version, log2(8 KiB)
             import os
             byte_only = bool(os.environ.get("HAP_AMD_COMPRESS_V1") or os.environ.get("HAP_AMD_BYTE_GRANULAR"))
-            assert at > 0 and frame[at + 3] == (0 if byte_only else 2 if flags & hap.ENCODE_COARSE_MATCHES else 1)
+            assert at > 0 and frame[at + 3] & 15 == (0 if byte_only else 2 if flags & hap.ENCODE_COARSE_MATCHES else 1)
     assert sizes[hap.ENCODE_FRAGMENT_INDEX | hap.ENCODE_COARSE_MATCHES] < 1.25 * sizes[hap.ENCODE_FRAGMENT_INDEX]
 
 
@@ -997,8 +1008,8 @@ def test_match_window_promise_is_checked_and_optional(ctx, hap):
     r, used, res = ctx.encode_frames([[tex]], [L.FMT_YCOCG], [1], [2], [out], flags=hap.ENCODE_FRAGMENT_INDEX)
     assert r == 0
     frame = bytearray(out[: used[0]].tobytes())
-    at = frame.find(bytes([0x46, 1, 13, 1, 12]))
-    assert at > 0
+    at, ver, hdr = find_fragment_table(frame)
+    assert at > 0 and ver == 2 and hdr == bytes([2, 13, 0x41, 12])     # field stream, 16-bit granular, 3 KiB window
     assert hap.HapDecode(bytes(frame), 0, outputBufferBytes=len(tex)) == (0, tex, L.FMT_YCOCG)
     for name, api in CHECKERS:
         assert api.decode(bytes(frame), 0, len(tex)) == (0, tex, L.FMT_YCOCG), name
@@ -1013,7 +1024,7 @@ def test_match_window_promise_is_checked_and_optional(ctx, hap):
     # small textures keep the whole fragment as their window (their block rows are short enough to matter)
     small = tex[: 16 * 64 * 96]
     r, used, res = ctx.encode_frames([[small]], [L.FMT_YCOCG], [1], [2], [out], flags=hap.ENCODE_FRAGMENT_INDEX)
-    assert r == 0 and out[: used[0]].tobytes().find(bytes([0x46, 1, 13, 1, 0])) > 0
+    assert r == 0 and find_fragment_table(out[: used[0]].tobytes())[2] == bytes([2, 13, 0x41, 0])
     assert hap.HapDecode(out[: used[0]].tobytes(), 0, outputBufferBytes=len(small)) == (0, small, L.FMT_YCOCG)
     # a hand-made fragment whose copy reaches 6 KiB back, filed under a table that promises 3 KiB
     lit = bytes(range(256)) * 24                                     # 6144 literal bytes
@@ -1033,3 +1044,164 @@ def test_match_window_promise_is_checked_and_optional(ctx, hap):
     honest = bytearray(lying)
     honest[honest.find(bytes([0x46, 1, 13, 0, 12])) + 4] = 0
     assert hap.HapDecode(bytes(honest), 0, outputBufferBytes=8192) == (0, want, L.FMT_DXT5)
+
+
+# ------------------------------------------------ field streams: fragment table version 2 --
+def _half_tile_table(frame):
+    """(offset of the LE32 fragment sizes, number of entries, offset of the half-tile bytes) of a version-2 table."""
+    at, ver, _hdr = find_fragment_table(frame, 0, 4000)
+    assert ver == 2
+    ln = int.from_bytes(frame[at - 3: at], "little")
+    n = (ln - 4) // 68
+    return at + 5, n, at + 5 + 4 * n
+
+
+def test_field_stream_table_is_described_exactly_and_every_lie_falls_back(ctx, hap):
+    """Frames of DXT5 / YCoCg-DXT5 textures written with the fragment table carry version 2 of it: the compressed
+    size of every 128-byte half-tile of every 8 KiB fragment, with the promise that no element crosses a half-tile,
+    elements start and end on field boundaries and copy offsets are whole blocks (include/hap_gpu.h).  The table is
+    checked against the streams by parsing them on the CPU; then every promise is broken in turn -- the block-per-
+    lane decoder must notice and the frame must still decode to the right bytes through the generic kernels."""
+    tex = D.oracle_bc_encode(D.rgba(1024, 256, frame=6), L.FMT_YCOCG)          # 256 KiB of real blocks
+    out = np.zeros(hap.HapMaxEncodedLength([len(tex)], [L.FMT_YCOCG], [4]) + 65536, dtype=np.uint8)
+    r, used, res = ctx.encode_frames([[tex]], [L.FMT_YCOCG], [1], [4], [out], flags=hap.ENCODE_FRAGMENT_INDEX)
+    assert r == 0 and res == [0]
+    frame = out[: used[0]].tobytes()
+    for name, api in CHECKERS:
+        assert api.decode(frame, 0, len(tex)) == (0, tex, L.FMT_YCOCG), name
+    fs_at, n, ht_at = _half_tile_table(frame)
+    assert n == 4 * 8                                                            # 4 chunks x 64 KiB / 8 KiB
+    frag_sizes = [int.from_bytes(frame[fs_at + 4 * i: fs_at + 4 * i + 4], "little") for i in range(n)]
+    half = np.frombuffer(frame, dtype=np.uint8, count=64 * n, offset=ht_at).reshape(n, 64)
+    assert [int(x) for x in half.sum(axis=1)] == frag_sizes
+    # walk the element streams with the table: every half-tile boundary is an element boundary, offsets are whole blocks
+    payload = ht_at + 64 * n
+    sizes_at = frame.find(bytes([16, 0, 0, 3]), 0, 64) + 4
+    chunk_sizes = [int.from_bytes(frame[sizes_at + 4 * i: sizes_at + 4 * i + 4], "little") for i in range(4)]
+    at = payload
+    for c in range(4):
+        q = at + 3                                                               # varint(65536) is 3 bytes
+        for f in range(8):
+            for h in range(64):
+                end, produced = q + int(half[c * 8 + f][h]), 0
+                while q < end:
+                    tag = frame[q]
+                    kind = tag & 3
+                    if kind == 0:
+                        ln = (tag >> 2) + 1
+                        hd = 1
+                        if ln == 61:
+                            ln, hd = frame[q + 1] + 1, 2
+                        assert ln <= 256
+                        q += hd + ln
+                    else:
+                        assert kind in (1, 2)
+                        ln = 4 + ((tag >> 2) & 7) if kind == 1 else (tag >> 2) + 1
+                        off = ((tag >> 5) << 8) | frame[q + 1] if kind == 1 else frame[q + 1] | (frame[q + 2] << 8)
+                        assert off % 16 == 0 and 16 <= off <= 8192 - 16        # (a small texture: no match window)
+                        q += 1 + kind
+                    assert produced % 16 in (0, 2, 8, 12)
+                    produced += ln
+                assert q == end and produced == 128
+        at += chunk_sizes[c]
+    # decoding: the field-stream path, the generic fragment path on the same table, and no table at all agree
+    before = ctx.table_fallbacks()
+    for flags in (0, hap.DECODE_IGNORE_HALF_TILES, hap.DECODE_IGNORE_FRAGMENT_INDEX):
+        dec = np.zeros(len(tex), dtype=np.uint8)
+        r, du, df, dr = ctx.decode_frames([frame], [len(frame)], 0, [dec], flags=flags)
+        assert (r, du, df, dr) == (0, [len(tex)], [L.FMT_YCOCG], [0]) and dec.tobytes() == tex
+    assert ctx.table_fallbacks() == before                                       # the table was believed every time
+    # lies: half-tile sizes that move a boundary, that no longer add up, that exceed the limit; a wrong field count
+    def decodes(data):
+        canary = np.full(len(tex), 0x5A, dtype=np.uint8)
+        n0 = ctx.table_fallbacks()
+        r, u2, f2, res = ctx.decode_frames([bytes(data)], [len(data)], 0, [canary])
+        return (r, u2, f2, res) == (0, [len(tex)], [L.FMT_YCOCG], [0]) and canary.tobytes() == tex and \
+            ctx.table_fallbacks() == n0 + 1                                      # noticed, and decoded the generic way
+    k = int(np.argmax(half[3] > 8))                                              # a half-tile with a few elements
+    for delta_a, delta_b in ((1, -1), (-2, 2), (3, 0), (0, 200)):
+        bad = bytearray(frame)
+        bad[ht_at + 3 * 64 + k] = (bad[ht_at + 3 * 64 + k] + delta_a) & 0xFF
+        bad[ht_at + 3 * 64 + k + 1] = (bad[ht_at + 3 * 64 + k + 1] + delta_b) & 0xFF
+        assert decodes(bad), (delta_a, delta_b)
+    bad = bytearray(frame)
+    bad[ht_at - 4 * n - 2] = (bad[ht_at - 4 * n - 2] & 15) | 0x20                    # [4, 4] fields claimed for 16-byte blocks
+    assert decodes(bad)
+    bad = bytearray(frame)
+    bad[ht_at: ht_at + 64] = bytes(64)                                           # a fragment with an all-zero table
+    assert decodes(bad)
+
+
+def test_field_stream_promises_are_checked_on_hand_made_streams(ctx, hap):
+    """One 8 KiB fragment written by hand under a version-2 table: the honest stream decodes; then streams that are
+    valid Snappy (the checker decodes them) but break one promise each -- a copy offset that is not a whole block,
+    an element that starts off a field boundary, an element that crosses a half-tile, a copy-4 element, a literal
+    with a 2-byte length -- must come out right all the same (generic path) and never take the process down."""
+    rng = np.random.default_rng(77)
+    def lit(b):
+        assert 1 <= len(b) <= 60
+        return bytes([(len(b) - 1) << 2]) + b
+    def copy2(n, off):
+        return bytes([2 | ((n - 1) << 2)]) + off.to_bytes(2, "little")
+    def copy1(n, off):
+        return bytes([1 | ((n - 4) << 2) | ((off >> 8) << 5), off & 255])
+
+    def frame_of(halves):
+        """halves: 64 lists of element byte strings, each producing 128 bytes."""
+        stream = b"".join(b"".join(h) for h in halves)
+        table = bytes(len(b"".join(h)) for h in halves)
+        chunk = bytes([0x80, 0x40]) + stream
+        tables = bytes([1, 0, 0, 2, 0x0B]) + bytes([4, 0, 0, 3]) + len(chunk).to_bytes(4, "little") + \
+            bytes([72, 0, 0, 0x46, 2, 13, 0x41, 0]) + len(stream).to_bytes(4, "little") + table
+        body = len(tables).to_bytes(3, "little") + bytes([1]) + tables + chunk
+        return len(body).to_bytes(3, "little") + bytes([0xCE]) + body
+
+    def honest_half(h):
+        els = []
+        if h == 0:
+            els += [lit(rng.integers(0, 256, 48, dtype=np.uint8).tobytes()), lit(rng.integers(0, 256, 48, dtype=np.uint8).tobytes())]
+            els += [copy2(16, 96), copy1(8, 16), lit(b"\x11\x22\x33\x44"), copy1(4, 32)]     # 96+16+8+4+4 = 128
+        else:
+            els += [copy2(64, 128), lit(rng.integers(0, 256, 2, dtype=np.uint8).tobytes()), copy1(6, 16 * (1 + h % 4)),
+                    copy1(8, 16), lit(rng.integers(0, 256, 16, dtype=np.uint8).tobytes()), copy2(32, 16 * (2 + h % 5))]
+        return els
+
+    halves = [honest_half(h) for h in range(64)]
+    honest = frame_of(halves)
+    rc, want, fmt = ORA.decode(honest, 0, 8192)
+    assert (rc, fmt) == (0, L.FMT_DXT5) and len(want) == 8192
+    assert hap.HapDecode(honest, 0, outputBufferBytes=8192) == (0, want, L.FMT_DXT5)
+
+    def through_context(data):
+        dec = np.full(8192, 0xA5, dtype=np.uint8)
+        n0 = ctx.table_fallbacks()
+        r, du, df, dr = ctx.decode_frames([data], [len(data)], 0, [dec])
+        return (r, dr[0], dec.tobytes() if r == 0 else None, ctx.table_fallbacks() - n0)
+    assert through_context(honest) == (0, 0, want, 0)          # decoded by the block-per-lane kernel, no second pass
+
+    def variant(h, els):
+        v = [list(x) for x in halves]
+        v[h] = els
+        return frame_of(v)
+    lies = {
+        "offset not a whole block": variant(5, [copy2(64, 128 + 8)] + halves[5][1:]),
+        "start off a field boundary": variant(6, [copy2(62, 128), lit(b"\x01\x02\x03\x04"), copy1(6, 16), copy1(8, 16),
+                                                 lit(bytes(16)), copy2(32, 32)]),
+        "copy-4": variant(7, [bytes([3 | (63 << 2)]) + (128).to_bytes(4, "little")] + halves[7][1:]),
+        "long literal form": variant(8, [bytes([61 << 2]) + (63).to_bytes(2, "little") + bytes(range(64))] + halves[8][1:]),
+        "offset 0 blocks would be offset 16 minus": variant(9, [copy2(64, 128), lit(b"ab"), copy1(6, 16), copy1(8, 16),
+                                                                lit(bytes(16)), copy2(32, 2048 + 64 * 9)]),
+    }
+    # an element that crosses the boundary between half-tiles 10 and 11 (sizes in the table still add up)
+    v = [list(x) for x in halves]
+    v[10] = halves[10][:-1] + [copy2(48, 48)]
+    v[11] = [copy2(48, 128)] + halves[11][1:]
+    lies["element across a half-tile"] = frame_of(v)
+    for name, data in lies.items():
+        rc, expect, _f = ORA.decode(data, 0, 8192)
+        got = hap.HapDecode(data, 0, outputBufferBytes=8192)
+        if rc == 0:
+            assert got == (0, expect, L.FMT_DXT5), name
+            assert through_context(data) == (0, 0, expect, 1), name     # the lie was noticed: one fallback
+        else:
+            assert got[0] == rc, name                      # not even Snappy: the reference's verdict
