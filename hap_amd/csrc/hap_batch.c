@@ -129,7 +129,8 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
             /* DXT1 blocks are two 4-byte fields (endpoints, indices): everything repeats on 4-byte
                boundaries.  The alpha-style blocks of RGTC1 / DXT5 / YCoCg start their index bytes at
                byte 2, so those streams are 2-byte granular. */
-            if ((t->format == HapTextureFormat_RGB_DXT1 || (flags & HAPGPU_ENCODE_COARSE_MATCHES)) && (t->chunk_bytes & 3u) == 0)
+            if ((t->format == HapTextureFormat_RGB_DXT1 || (flags & HAPGPU_ENCODE_COARSE_MATCHES) ||
+                 (t->format == HapTextureFormat_A_RGTC1 && ctx->rgtc1_fields && ctx->rgtc1_fields != 26u)) && (t->chunk_bytes & 3u) == 0)
                 t->gran_log2 = 2u;
             else if ((t->chunk_bytes & 1u) == 0)
                 t->gran_log2 = 1u;
@@ -141,15 +142,21 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
             if (t->gran_log2 == 1u && (t->format == HapTextureFormat_RGBA_DXT5 || t->format == HapTextureFormat_YCoCg_DXT5) &&
                 (t->chunk_bytes & 15u) == 0)
                 t->field_period = 4u;
-            else if (t->gran_log2 == 2u && t->format == HapTextureFormat_RGB_DXT1 && (t->chunk_bytes & 7u) == 0)
+            else if (t->gran_log2 == 2u && (t->format == HapTextureFormat_RGB_DXT1 ||
+                                            (t->format == HapTextureFormat_A_RGTC1 && ctx->rgtc1_fields)) && (t->chunk_bytes & 7u) == 0)
                 t->field_period = 10u;      /* 2 fields per block, the [4, 4] layout (code 2 | 8) */
-            /* (RGTC1 alone stays with the position-per-lane kernel: alpha planes are full of matches that start
-               inside the 6 index bytes -- measured 0.25 against 0.45 of the texture size -- which whole-field
-               equality cannot see) */
+            else if (t->gran_log2 == 1u && t->format == HapTextureFormat_A_RGTC1 && ctx->rgtc1_fields == 26u &&
+                     (t->chunk_bytes & 7u) == 0 && t->bytes >= ((size_t)2u << 20))
+                t->field_period = 2u;       /* [2, 6]: endpoints, indices */
+            /* (RGTC1 planes of 2 MiB and more -- block rows longer than a fragment -- take their natural [2, 6] layout:
+               same size as the position-per-lane kernel there (0.171 against 0.169 of an 8K alpha plane).  Smaller
+               ones stay with positions per lane: their matches start inside the index bytes of the row above, which
+               lies inside the fragment -- 0.25 against 0.45 of a 2048 x 512 plane) */
         }
         /* field streams (fragment table version 2): with the table requested, the [2,6,4,4] compressor also keeps
            elements inside 128-byte half-tiles and records their sizes for the block-per-lane decoder */
-        t->half_tiles = (t->field_period == 4u && (flags & HAPGPU_ENCODE_FRAGMENT_INDEX) && !ctx->no_half_tiles) ? 1u : 0u;
+        t->half_tiles = ((t->field_period == 4u || t->field_period == 10u || t->field_period == 2u) && (flags & HAPGPU_ENCODE_FRAGMENT_INDEX) &&
+                         !ctx->no_half_tiles) ? 1u : 0u;
         if (t->half_tiles)
             any_half_tiles = 1;
         if (t->compressor == HapCompressorSnappy)
@@ -801,7 +808,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                     if (p->frag_tiles_offset && p->frag_fields && !(flags & HAPGPU_DECODE_IGNORE_HALF_TILES)) {
                         job->fields_period = p->frag_fields;
                         job->tile_sizes = (uint64_t)(uintptr_t)(frame_dev + p->frag_tiles_offset);
-                        frag_kinds |= p->frag_fields == 4u ? 0x100u : 0x200u;
+                        frag_kinds |= p->frag_fields == 4u ? 0x100u : p->frag_fields == 2u ? 0x200u : 0x400u;
                     } else if (p->frag_log2 == 13u && p->frag_window256 != 0 && p->frag_window256 <= HAP_FRAGMENT_WINDOW_256)
                         frag_kinds |= 16u << p->frag_gran_log2;
                     else

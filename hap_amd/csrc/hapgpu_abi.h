@@ -115,7 +115,7 @@ typedef struct HapGpuDecodeJob {
     /* results */
     uint64_t bytes_used;
     uint32_t status;         /* HapResult or HAPGPU_STATUS_* */
-    uint32_t fields_period;  /* 4 / 2: the table is version 2 and promises [2,6,4,4] / [4,4] field streams; 0 otherwise */
+    uint32_t fields_period;  /* 4 / 2 / 6: the table is version 2 and promises [2,6,4,4] / [4,4] / [2,6] field streams; 0 otherwise */
     uint64_t tile_sizes;     /* device address of the half-tile size bytes inside the frame (64 per fragment entry), or 0 */
 } HapGpuDecodeJob;
 
@@ -127,6 +127,7 @@ typedef struct HapGpuDecodeJob {
 #define HAPGPU_UNIT_SNAPPY_FRAGMENT32 5u /* ... all 32-bit granular */
 #define HAPGPU_UNIT_SNAPPY_FIELDS4 6u   /* fragment of a field stream, 16-byte blocks of 2 + 6 + 4 + 4 bytes; aux = its half-tile sizes */
 #define HAPGPU_UNIT_SNAPPY_FIELDS2 7u   /* ... 8-byte blocks of 4 + 4 bytes */
+#define HAPGPU_UNIT_SNAPPY_FIELDS26 8u  /* ... 8-byte blocks of 2 + 6 bytes */
 #define HAPGPU_UNIT_WINDOWED 0x10u       /* flag on the three fragment kinds: every copy offset is <= 3 KiB, so an 8 KiB
                                             fragment decodes through a 4 KiB LDS ring (twice the waves per CU) */
 #define HAP_FRAGMENT_WINDOW_256 12u      /* that window in 256-byte units, as written to the fragment table */
@@ -194,7 +195,7 @@ int hapgpu_k_decode_plan(hapgpu_rt *rt, HapGpuDecodeJob *jobs, unsigned job_coun
                          HapGpuDecodeUnit *units, unsigned unit_count);
 /* frag_log2: fragment size of the batch's FRAGMENT units (0: none present);
  * fragment_kinds: bit g set = fragments of granularity_log2 g present */
-/* fragment_kinds bits 8 / 9: field-stream units of [2,6,4,4] / [4,4] blocks present */
+/* fragment_kinds bits 8 / 9 / 10: field-stream units of [2,6,4,4] / [4,4] / [2,6] blocks present */
 int hapgpu_k_snappy_decode(hapgpu_rt *rt, const HapGpuDecodeUnit *units, unsigned unit_count,
                            HapGpuDecodeJob *jobs, unsigned frag_log2, unsigned fragment_kinds,
                            int any_stream_or_copy_units);

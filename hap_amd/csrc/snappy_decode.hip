@@ -186,8 +186,13 @@ __global__ __launch_bounds__(64) void decode_plan_kernel(HapGpuDecodeJob *jobs, 
                             w.reserved = 0;
                             if (job->fields_period != 0u && job->tile_sizes != 0u) {
                                 // field stream (table version 2): block-per-lane decoder, with this fragment's half-tile sizes
-                                w.kind = job->fields_period == 4u ? HAPGPU_UNIT_SNAPPY_FIELDS4 : HAPGPU_UNIT_SNAPPY_FIELDS2;
+                                w.kind = job->fields_period == 4u ? HAPGPU_UNIT_SNAPPY_FIELDS4
+                                       : job->fields_period == 2u ? HAPGPU_UNIT_SNAPPY_FIELDS2 : HAPGPU_UNIT_SNAPPY_FIELDS26;
                                 w.aux = job->tile_sizes + (uint64_t)(c.frag_first + k) * HAP_HALF_TILES_PER_FRAGMENT;
+                                // bytes of the texture section that follow the fragment (up to 15): the decoder may
+                                // fetch its last 16-byte piece whole when they exist
+                                const uint64_t after = job->payload_len - ((uint64_t)c.src_off + at + fs[k]);
+                                w.reserved = after < 15u ? after : 15u;
                             } else {
                                 w.kind = gran == 2 ? HAPGPU_UNIT_SNAPPY_FRAGMENT32
                                        : gran == 1 ? HAPGPU_UNIT_SNAPPY_FRAGMENT16 : HAPGPU_UNIT_SNAPPY_FRAGMENT;
@@ -939,8 +944,8 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
     if (unit_count == 0)
         return 0;
     // field streams (fragment table version 2): the block-per-lane decoder of snappy_decode_fields.hip
-    if ((fragment_kinds >> 8) & 3u) {
-        if (hapgpu_launch_snappy_decode_fields(units, unit_count, jobs, (fragment_kinds >> 8) & 3u, stream) != 0)
+    if ((fragment_kinds >> 8) & 7u) {
+        if (hapgpu_launch_snappy_decode_fields(units, unit_count, jobs, (fragment_kinds >> 8) & 7u, stream) != 0)
             return 4;
         fragment_kinds &= 0xFFu;
         if (fragment_kinds == 0u)

@@ -77,26 +77,28 @@ __device__ __forceinline__ int fwave_max(int v)            // values >= 0; resul
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-// byte offset of field j counted from a block boundary (PERIOD fields per block)
-template <unsigned PERIOD>
-__device__ __forceinline__ unsigned field_pos(unsigned j)
+// Block layouts ("fields per block" nibble of the fragment table, include/hap_gpu.h):
+//   4: 16-byte blocks of 2 + 6 + 4 + 4 bytes (DXT5, YCoCg-DXT5);  2: 8-byte blocks of 4 + 4 (DXT1);
+//   6: 8-byte blocks of 2 + 6 (RGTC1)
+template <unsigned LAYOUT> struct layout_of;
+template <> struct layout_of<4u> { static constexpr unsigned fields = 4u, block = 16u, pos_shift = 1u, unit_kind = HAPGPU_UNIT_SNAPPY_FIELDS4; };
+template <> struct layout_of<2u> { static constexpr unsigned fields = 2u, block = 8u, pos_shift = 2u, unit_kind = HAPGPU_UNIT_SNAPPY_FIELDS2; };
+template <> struct layout_of<6u> { static constexpr unsigned fields = 2u, block = 8u, pos_shift = 1u, unit_kind = HAPGPU_UNIT_SNAPPY_FIELDS26; };
+
+// byte offset of field k inside a block
+template <unsigned LAYOUT>
+__device__ __forceinline__ constexpr unsigned field_pos(unsigned k)
 {
-    if (PERIOD == 4)
-        return (j >> 2) * 16u + __builtin_amdgcn_ubfe(0x0C080200u, (j & 3u) * 8u, 8u);
-    return j * 4u;
+    return LAYOUT == 4u ? (k == 0u ? 0u : k == 1u ? 2u : k == 2u ? 8u : 12u) : LAYOUT == 2u ? 4u * k : 2u * k;
 }
 
-// inverse: field index of byte position p, >= 0x100 when p is not a field boundary
-template <unsigned PERIOD>
-__device__ __forceinline__ unsigned field_at(unsigned p)
-{
-    if (PERIOD == 4) {
-        // inside a block the boundaries are 0, 2, 8, 12: nibble table indexed by (p & 15) >> 1, 0xF = none
-        const unsigned j = __builtin_amdgcn_ubfe(0xF3F2FF10u, (p & 14u) * 2u, 4u);
-        return ((p >> 4) * 4u + j) | ((j & 8u) << 5) | ((p & 1u) << 8);
-    }
-    return (p >> 2) | ((p & 3u) << 8);
-}
+// positions (in units of 1 << pos_shift bytes) at which an element may start, as a mask over one 32-bit word of the
+// start mask: 16-byte blocks are 8 positions with fields at 0, 1, 4, 6; [2, 6] blocks 4 positions with fields at 0, 1
+template <unsigned LAYOUT>
+__device__ __forceinline__ constexpr unsigned start_positions() { return LAYOUT == 4u ? 0x53535353u : LAYOUT == 6u ? 0x33333333u : 0xFFFFFFFFu; }
+
+// waits for every outstanding LDS operation of the wave (one wait for a batch of reads instead of one per use)
+__device__ __forceinline__ void lds_wait() { __builtin_amdgcn_s_waitcnt(0xC07F); }     // lgkmcnt(0), vmcnt / expcnt untouched
 
 // Fails the unit: the host decodes the frame again without the table (generic kernels).
 __device__ __forceinline__ void fail_unit(HapGpuDecodeJob *job, unsigned lane)
@@ -107,12 +109,14 @@ __device__ __forceinline__ void fail_unit(HapGpuDecodeJob *job, unsigned lane)
 
 // 16 bytes of the unit's input at aligned coordinate x (coordinates are relative to src - shift); bytes outside
 // [shift, in_end) read as zero and are never touched in memory
-__device__ __forceinline__ uint4 load_input16(const uint8_t *src_al, unsigned x, unsigned shift, unsigned in_end)
+// (bytes below `shift` belong to the same frame -- its headers precede every chunk -- and are fetched with the piece;
+// `readable_end` = in_end + the bytes known to follow the fragment inside the texture section)
+__device__ __forceinline__ uint4 load_input16(const uint8_t *src_al, unsigned x, unsigned shift, unsigned in_end, unsigned readable_end)
 {
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (x >= shift && x + 16u <= in_end) {
+    if (x < in_end && x + 16u <= readable_end) {
         v = *reinterpret_cast<const uint4 *>(src_al + x);
-    } else if (x < in_end && x + 16u > shift) {
+    } else if (x < in_end) {
         unsigned w[4] = {0, 0, 0, 0};
 #pragma unroll 1
         for (unsigned k = 0; k < 16u; k++) {
@@ -125,15 +129,16 @@ __device__ __forceinline__ uint4 load_input16(const uint8_t *src_al, unsigned x,
     return v;
 }
 
-template <unsigned PERIOD>
+template <unsigned LAYOUT>
 __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDecodeUnit *__restrict__ units,
                                                                   unsigned unit_count, HapGpuDecodeJob *jobs)
 {
-    constexpr unsigned kBlock = PERIOD == 4 ? 16u : 8u;
+    constexpr unsigned PERIOD = layout_of<LAYOUT>::fields;
+    constexpr unsigned kBlock = layout_of<LAYOUT>::block;
     constexpr unsigned kBlocksPerHalf = kHalf / kBlock;            // 8 or 16
     constexpr unsigned kStepBytes = 64u * kBlock;                  // 1024 or 512
     constexpr unsigned kHalvesPerStep = kStepBytes / kHalf;        // 8 or 4
-    constexpr unsigned kPosShift = PERIOD == 4 ? 1u : 2u;          // element start positions are kept in 2- / 4-byte units
+    constexpr unsigned kPosShift = layout_of<LAYOUT>::pos_shift;    // element start positions are kept in 2- / 4-byte units
     constexpr unsigned kLitBias = kHalf;
     __shared__ __attribute__((aligned(16))) uint8_t buf[kBufBytes];
     __shared__ __attribute__((aligned(4))) uint16_t rec[kHalves * kRecPerHalf];
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
     if (blockIdx.x >= unit_count)
         return;
     const HapGpuDecodeUnit u = units[blockIdx.x];
-    if (u.kind != (PERIOD == 4 ? HAPGPU_UNIT_SNAPPY_FIELDS4 : HAPGPU_UNIT_SNAPPY_FIELDS2))
+    if (u.kind != layout_of<LAYOUT>::unit_kind)
         return;
     HapGpuDecodeJob *job = &jobs[u.job];
     const uint8_t *src = (const uint8_t *)u.src;
@@ -163,12 +168,13 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
     const unsigned shift = (unsigned)((uintptr_t)src & 15u);
     const uint8_t *src_al = src - shift;
     const unsigned in_end = shift + total;
+    const unsigned readable_end = in_end + (unsigned)(u.reserved & 15u);
     const unsigned job_status = __builtin_nontemporal_load(&job->status);
     const unsigned tsz = lane < nhalf ? (unsigned)tile_sizes[lane] : 0u;
     uint4 early[4];
 #pragma unroll
     for (unsigned i = 0; i < 4u; i++)
-        early[i] = load_input16(src_al, i * 1024u + lane * 16u, shift, in_end);
+        early[i] = load_input16(src_al, i * 1024u + lane * 16u, shift, in_end, readable_end);
     if (job_status != 0u)
         return;
 
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
             if (i * 1024u < in_end)
                 *reinterpret_cast<uint4 *>(park + i * 1024u) = early[i];
         for (unsigned x = 4096u; x < in_end; x += 1024u)
-            *reinterpret_cast<uint4 *>(park + x) = load_input16(src_al, x + lane * 16u, shift, in_end);
+            *reinterpret_cast<uint4 *>(park + x) = load_input16(src_al, x + lane * 16u, shift, in_end, readable_end);
     }
     __syncthreads();
 
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
     //     copy:     4 x distance in blocks                                                                (positive)
     // and one bit of the start mask (bit = output position in 2- or 4-byte units).  Promise checks are accumulated
     // and looked at once at the end.
-    constexpr unsigned kRecShift = PERIOD == 4 ? 2u : 1u;         // byte offset -> 4 x blocks
+    constexpr unsigned kRecShift = kBlock == 16u ? 2u : 1u;       // byte offset -> 4 x blocks
     {
         const unsigned h = lane;
         const unsigned hbytes = h < nhalf ? min(kHalf, out_len - kHalf * h) : 0u;
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
         uint8_t *const recb = reinterpret_cast<uint8_t *>(rec) + h * (kRecPerHalf * 2u);
         // (every element advances p by at least one byte, so the walk is bounded; elements that start off a field
         // boundary -- the only way to have more than 32 of them -- are caught below, and the record index is masked)
-        while (__builtin_amdgcn_ballot_w64(p < hbytes) != 0ull) {
+        do {
             if (p < hbytes) {
                 const unsigned aw = cp >> 2;
                 #ifdef DBG_OLDALIGN
@@ -259,13 +265,12 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
                 p += lm1 + 1u;
                 cp += adv;
             }
-        }
+        } while (__builtin_amdgcn_ballot_w64(p < hbytes) != 0ull);
         // an element that overshoots its half-tile or the table's byte count ends up with p / cp off the mark;
         // starts off a field boundary show in the mask (16-byte blocks: fields begin at bytes 0, 2, 8, 12)
         bool bad = acc_bad != 0u || (acc_or & (kBlock - 1u)) != 0u || ((acc_or >> 16) & ((1u << kPosShift) - 1u)) != 0u ||
                    min_off < kBlock || max_up > 60u || (h < nhalf && (cp != cend || p != hbytes));
-        if (PERIOD == 4)
-            bad = bad || ((mlo | mhi) & ~0x53535353u) != 0u;
+        bad = bad || ((mlo | mhi) & ~start_positions<LAYOUT>()) != 0u;
         masks[h] = make_uint2(mlo, mhi);
         if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
             fail_unit(job, lane);
@@ -280,71 +285,105 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
     // at or below it (in the 32-bit half of the start mask that covers the block)
     const unsigned b = lane & (kBlocksPerHalf - 1u);
     const unsigned hsub = lane / kBlocksPerHalf;                           // half-tile of the step
-    const bool upper = PERIOD == 4 && b >= 4u;                             // PERIOD 2: 32 four-byte positions, one word
+    // (64 positions per half-tile in two words when positions are 2 bytes; 32 four-byte positions fit one word)
+    const bool upper = kPosShift == 1u && b >= kBlocksPerHalf / 2u;
     unsigned le[PERIOD], fbias[PERIOD];
 #pragma unroll
     for (unsigned k = 0; k < PERIOD; k++) {
-        const unsigned fb = b * kBlock + field_pos<PERIOD>(k);             // byte position of the field in the half-tile
+        const unsigned fb = b * kBlock + field_pos<LAYOUT>(k);             // byte position of the field in the half-tile
         const unsigned q = (fb >> kPosShift) & 31u;
         le[k] = (2u << q) - 1u;
         fbias[k] = fb - kLitBias + 0x8000u + S;                            // + coff[half-tile] + record = literal address
     }
     const unsigned lane4s = lane * 4u + 0x80000000u;
+    unsigned ring_k[PERIOD];                                               // ring address of the lane's fields in step 0
+#pragma unroll
+    for (unsigned k = 0; k < PERIOD; k++)
+        ring_k[k] = lane * kBlock + field_pos<LAYOUT>(k);
     // 2a. every step's fields -> source descriptors ("state"): >= 0 an address in buf (literal bytes, or the ring for a
     //     copy whose source block lies in an earlier step), < 0 pending: sign bit | 4 x (source lane in the same step).
     //     All steps are looked up before anything is produced: the LDS round trips of the 8 steps overlap.
+    //     (Lanes beyond the end of a short fragment compute garbage that nothing reads: sources are always lower lanes.)
     constexpr unsigned kMaxSteps = kFragBytes / kStepBytes;               // 8 or 16
     int state[kMaxSteps][PERIOD];
+    {
+        // (phases with one wait each: all mask / offset reads, then all record reads, then arithmetic -- instead of a
+        // wait in front of every use)
+        unsigned mx[kMaxSteps], my[kMaxSteps];
+        int cof[kMaxSteps];
 #pragma unroll
-    for (unsigned s = 0; s < kMaxSteps; s++) {
-        const unsigned opos = (64u * s + lane) * kBlock;                   // output position = ring address
-        const bool active = opos < out_len;
-        const unsigned hh = s * kHalvesPerStep + hsub;
-        const uint2 m = masks[hh];
-        const int cof = (int)(unsigned)coffs[hh];
-        const unsigned msel = upper ? m.y : m.x;
-        const int ebase = upper ? (int)__builtin_popcount(m.x) - 1 : -1;
-        const int16_t *rb = reinterpret_cast<const int16_t *>(rec) + hh * kRecPerHalf;
+        for (unsigned s = 0; s < kMaxSteps; s++) {
+            const unsigned hh = s * kHalvesPerStep + hsub;
+            const uint2 m = masks[hh];
+            mx[s] = m.x;
+            my[s] = m.y;
+            cof[s] = (int)(unsigned)coffs[hh];
+        }
+        lds_wait();
+        int r[kMaxSteps][PERIOD];
 #pragma unroll
-        for (unsigned k = 0; k < PERIOD; k++) {
-            const int e = (int)__builtin_popcount(msel & le[k]) + ebase;  // ordinal of the element that owns the field
-            const int r = (int)rb[e & (int)(kRecPerHalf - 1u)];
-            const int lit_addr = cof + (int)fbias[k] + r;                  // (r = record - 0x10000 for literals)
-            // copy: source = same field, r / 4 blocks back.  Inside this step (r / 4 <= lane): pending, sign bit |
-            // 4 x source lane; else an address in the ring (the walk above made sure it is not before the fragment)
-            const int pend = (int)(lane4s - (unsigned)r);              // (unsigned: the wrap-around is the point)
-            const int ring_addr = (int)(opos + field_pos<PERIOD>(k)) - r * (int)(kBlock / 4u);
-            const int cpy = pend < 0 ? pend : ring_addr;
-            const int st = r < 0 ? lit_addr : cpy;
-            state[s][k] = active ? st : 0;
+        for (unsigned s = 0; s < kMaxSteps; s++) {
+            const unsigned hh = s * kHalvesPerStep + hsub;
+            const unsigned msel = upper ? my[s] : mx[s];
+            const int ebase = upper ? (int)__builtin_popcount(mx[s]) - 1 : -1;
+            const int16_t *rb = reinterpret_cast<const int16_t *>(rec) + hh * kRecPerHalf;
+#pragma unroll
+            for (unsigned k = 0; k < PERIOD; k++) {
+                // ordinal of the element that owns the field (a parsed half-tile always starts with an element: >= 0)
+                const int e = (int)__builtin_popcount(msel & le[k]) + ebase;
+                r[s][k] = (int)rb[e];
+            }
+            if ((s & 3u) == 3u)
+                lds_wait();                                                 // (at most 16 LDS results outstanding)
+        }
+        lds_wait();
+#pragma unroll
+        for (unsigned s = 0; s < kMaxSteps; s++) {
+#pragma unroll
+            for (unsigned k = 0; k < PERIOD; k++) {
+                const int rr = r[s][k];
+                const int lit_addr = cof[s] + (int)fbias[k] + rr;          // (rr = record - 0x10000 for literals)
+                // copy: source = same field, rr / 4 blocks back.  Inside this step (rr / 4 <= lane): pending = sign bit
+                // | 4 x source lane (negative); else lane4s - rr wraps to a huge positive number and the minimum is
+                // the ring address (the walk above made sure it does not lie before the fragment)
+                const int pend = (int)(lane4s - (unsigned)rr);
+                const int ring_addr = (int)(ring_k[k] + s * kStepBytes) - rr * (int)(kBlock / 4u);
+                const int cpy = min(pend, ring_addr);
+                const int lit_mask = rr >> 31;                              // all ones: literal
+                state[s][k] = (lit_addr & lit_mask) | (cpy & ~lit_mask);
+            }
         }
     }
     // 2b. sources produced in the same step: follow the chains to a literal or to an earlier step by pointer doubling
-    //     (<= 6 rounds); the columns of all steps advance together, so a round is up to 32 independent ds_bpermutes in
-    //     flight instead of one dependent LDS round trip per step and round
-    for (;;) {
-        int any_all = 0;
+    //     (a chain is at most 63 links long: 6 rounds); the columns of all steps advance together, so a round is 32
+    //     independent ds_bpermutes in flight instead of one dependent LDS round trip per step and round
+#pragma unroll 1
+    for (unsigned round = 0; round < 6u; round++) {
+        int any = state[0][0];
 #pragma unroll
-        for (unsigned s = 0; s < kMaxSteps; s++) {
-            int any = state[s][0];
+        for (unsigned s = 0; s < kMaxSteps; s++)
 #pragma unroll
-            for (unsigned k = 1; k < PERIOD; k++)
+            for (unsigned k = 0; k < PERIOD; k++)
                 any |= state[s][k];
-            any_all |= any;
-            if (__builtin_amdgcn_ballot_w64(any < 0) == 0ull)
-                continue;                                                   // (uniform) this step is resolved
-#pragma unroll
-            for (unsigned k = 0; k < PERIOD; k++) {
-#ifdef DBG_SAFEIDX
-                const int g = __builtin_amdgcn_ds_bpermute(state[s][k] < 0 ? (state[s][k] & 0xFC) : (int)(lane * 4u), state[s][k]);
-#else
-                const int g = __builtin_amdgcn_ds_bpermute(state[s][k] & 0xFC, state[s][k]);
-#endif
-                state[s][k] = state[s][k] < 0 ? g : state[s][k];
-            }
-        }
-        if (__builtin_amdgcn_ballot_w64(any_all < 0) == 0ull)
+        if (__builtin_amdgcn_ballot_w64(any < 0 && lane * kBlock < out_len) == 0ull)
             break;
+#pragma unroll
+        for (unsigned s0 = 0; s0 < kMaxSteps; s0 += 4u) {
+            int g[4][PERIOD];
+#pragma unroll
+            for (unsigned s = 0; s < 4u; s++)
+#pragma unroll
+                for (unsigned k = 0; k < PERIOD; k++)
+                    g[s][k] = __builtin_amdgcn_ds_bpermute(state[s0 + s][k], state[s0 + s][k]);   // (lane = address bits 7..2)
+            lds_wait();
+#pragma unroll
+            for (unsigned s = 0; s < 4u; s++)
+#pragma unroll
+                for (unsigned k = 0; k < PERIOD; k++) {
+                    const int pm = state[s0 + s][k] >> 31;                  // all ones: still pending
+                    state[s0 + s][k] = (g[s][k] & pm) | (state[s0 + s][k] & ~pm);
+                }
+        }
     }
     // 2c. field bytes -> 16-byte block -> ring (later steps copy from it) and memory, step after step
     const unsigned nsteps = (out_len + kStepBytes - 1u) / kStepBytes;
@@ -354,11 +393,12 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
             break;
         const unsigned opos = (64u * s + lane) * kBlock;
         const bool active = opos < out_len;
-        unsigned out[PERIOD == 4 ? 4 : 2];
-        if (PERIOD == 4) {
-            unsigned lo[4], hi1 = 0;
+        unsigned out[kBlock / 4u];
+        if (LAYOUT == 4u || LAYOUT == 6u) {
+            // [2, 6 (, 4, 4)]: field 1 is 6 bytes at any byte address: three dwords
+            unsigned lo[PERIOD], hi1 = 0;
 #pragma unroll
-            for (unsigned k = 0; k < 4; k++) {
+            for (unsigned k = 0; k < PERIOD; k++) {
                 const unsigned a = (unsigned)state[s][k], aw = a >> 2, sh = a & 3u;
                 const unsigned d0 = bufw[aw], d1 = bufw[aw + 1u];
                 lo[k] = __builtin_amdgcn_alignbyte(d1, d0, sh);
@@ -369,8 +409,10 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
             }
             out[0] = (lo[0] & 0xFFFFu) | (lo[1] << 16);
             out[1] = (lo[1] >> 16) | (hi1 << 16);
-            out[2] = lo[2];
-            out[3] = lo[3];
+            if (LAYOUT == 4u) {
+                out[2] = lo[2 % PERIOD];
+                out[3] = lo[3 % PERIOD];
+            }
         } else {
 #pragma unroll
             for (unsigned k = 0; k < 2; k++) {
@@ -379,8 +421,8 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
             }
         }
         if (active) {
-            if (PERIOD == 4) {
-                const uint4 v = make_uint4(out[0], out[1], out[2], out[3]);
+            if (kBlock == 16u) {
+                const uint4 v = make_uint4(out[0], out[1], out[2 % (kBlock / 4u)], out[3 % (kBlock / 4u)]);
                 *reinterpret_cast<uint4 *>(buf + opos) = v;
                 if (dst_wide) {
                     *reinterpret_cast<uint4 *>(dst + opos) = v;
@@ -407,7 +449,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
 
 } // namespace
 
-// fields_kinds: bit 0 = [2, 6, 4, 4] units present (DXT5 / YCoCg-DXT5), bit 1 = [4, 4] units (DXT1)
+// fields_kinds: bit 0 = [2, 6, 4, 4] units present (DXT5 / YCoCg-DXT5), bit 1 = [4, 4] units (DXT1), bit 2 = [2, 6] (RGTC1)
 extern "C" int hapgpu_launch_snappy_decode_fields(const HapGpuDecodeUnit *units, unsigned unit_count, HapGpuDecodeJob *jobs,
                                                   unsigned fields_kinds, hipStream_t stream)
 {
@@ -417,5 +459,7 @@ extern "C" int hapgpu_launch_snappy_decode_fields(const HapGpuDecodeUnit *units,
         hipLaunchKernelGGL((snappy_decode_fields_kernel<4u>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs);
     if (fields_kinds & 2u)
         hipLaunchKernelGGL((snappy_decode_fields_kernel<2u>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs);
+    if (fields_kinds & 4u)
+        hipLaunchKernelGGL((snappy_decode_fields_kernel<6u>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs);
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }

@@ -17,7 +17,8 @@ import _libs as L
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C4"
 nf = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 w, h, fmts, chunks = {"C4": (7680, 4320, [0x01], [24]), "C3": (3840, 2160, [0x83F3], [8]),
-                      "C5": (16384, 16384, [0x01, 0x8DBB], [64, 64]), "S": (512, 256, [0x01], [4])}[cfg]
+                      "C5": (16384, 16384, [0x01, 0x8DBB], [64, 64]), "S": (512, 256, [0x01], [4]),
+                      "C2": (3840, 2160, [0x83F0], [1]), "A8": (7680, 4320, [0x8DBB], [24]), "A2": (2048, 512, [0x8DBB], [4]), "S1": (512, 256, [0x83F0], [2])}[cfg]
 bb = {0x01: 16, 0x83F3: 16, 0x8DBB: 8, 0x83F0: 8}
 ctx = hap_amd.Context(0)
 sizes = [(w // 4) * (h // 4) * bb[f] for f in fmts]
