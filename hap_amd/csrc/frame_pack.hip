@@ -5,12 +5,14 @@
 // `compressed_data += chunk_packed_length`).  On the GPU every fragment is compressed at once
 // into a worst-case slot, then:
 //
-//   frame_pack_kernel    one workgroup per frame: sums fragment sizes per chunk, decides per
-//                        chunk "store raw iff compressed >= chunk size" (hap.c:460-471) and per
-//                        texture "store the whole texture raw iff no gain" (hap.c:478-495),
-//                        prefix-sums the chunk positions, and writes every header and table of
-//                        the frame (hap.c:436-440, 497-501, 598) plus, optionally, the private
-//                        fragment-size section 0x46.  It also emits one move per fragment.
+//   frame_chunk_sums_kernel  one wavefront per chunk: sums its fragments' compressed sizes.
+//   frame_pack_kernel    one workgroup per frame: decides per chunk "store raw iff compressed >=
+//                        chunk size" (hap.c:460-471) and per texture "store the whole texture raw
+//                        iff no gain" (hap.c:478-495), prefix-sums the chunk positions, and writes
+//                        every header and table of the frame (hap.c:436-440, 497-501, 598) plus,
+//                        optionally, the private fragment-size section 0x46.
+//   frame_moves_kernel   one wavefront per chunk: one move per fragment (prefix sum of the sizes)
+//                        and the per-fragment entries of the private table.
 //   frame_gather_kernel  one wavefront per move: slot (or raw texture bytes) -> final position.
 //
 // No host round trip: the only thing the host reads back is bytes_used / status per frame.
@@ -72,26 +74,63 @@ __device__ unsigned long long block_scan(unsigned long long v, unsigned long lon
     return before + incl - v;
 }
 
+// [device-only] what the three pack kernels hand to each other about one chunk
+struct ChunkPack {
+    uint64_t dst;        // where the chunk's stored bytes begin in the frame (kernel 2 -> 3)
+    uint64_t itab;       // where its fragment-size entries go, 0 = no table (kernel 2 -> 3)
+    uint32_t csize;      // varint + sum of its fragments' compressed sizes (kernel 1 -> 2)
+    uint32_t how;        // 0: compressed chunk, 1: chunk stored raw, 2: whole texture stored raw (kernel 2 -> 3)
+};
+
+// 1. one wavefront per chunk: compressed size of the chunk = varint + sum over its fragments
+__global__ __launch_bounds__(64) void frame_chunk_sums_kernel(const HapGpuFrameEnc *frames, const uint32_t *__restrict__ frag_sizes,
+                                                              ChunkPack *__restrict__ packs, unsigned chunks_per_frame)
+{
+    const HapGpuFrameEnc &frame = frames[blockIdx.z];
+    const unsigned t = blockIdx.y, i = blockIdx.x, lane = threadIdx.x;
+    if (t >= frame.tex_count)
+        return;
+    const HapGpuTexEnc &tex = frame.tex[t];
+    if (i >= tex.chunk_count)
+        return;
+    ChunkPack *pk = packs + (size_t)blockIdx.z * chunks_per_frame + (t ? frame.tex[0].chunk_count : 0u) + i;
+    unsigned long long sum = 0;
+    if (tex.compressor == 1u) {
+        const uint32_t *fs = frag_sizes + tex.frag_first + (size_t)i * tex.frags_per_chunk;
+        for (unsigned k = lane; k < tex.frags_per_chunk; k += 64u)
+            sum += fs[k];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1)
+            sum += __shfl_xor(sum, d);
+        sum += varint_len(tex.chunk_bytes);
+    }
+    if (lane == 0) {
+        pk->csize = (uint32_t)(sum > 0xFFFFFFFFull ? 0xFFFFFFFFull : sum);
+        pk->dst = 0;
+        pk->itab = 0;
+        pk->how = 2u;
+    }
+}
+
+// 2. one workgroup per frame: store-raw decisions, chunk positions (prefix sums over the chunk sizes of kernel 1),
+//    every header and table except the per-fragment entries
 __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames, unsigned frag_log2,
-                                                         const uint8_t *__restrict__ slots, unsigned slot_stride,
-                                                         const uint32_t *__restrict__ frag_sizes,
                                                          const uint8_t *__restrict__ tile_sizes,
                                                          HapGpuCopyEntry *__restrict__ copies, unsigned extra_first,
-                                                         unsigned chunks_per_frame)
+                                                         ChunkPack *__restrict__ packs, unsigned chunks_per_frame)
 {
     __shared__ unsigned long long scan_lds[4];
     HapGpuFrameEnc &frame = frames[blockIdx.x];
     const unsigned tid = threadIdx.x;
-    const unsigned frag_bytes = 1u << frag_log2;
     uint8_t *cursor = (uint8_t *)frame.dst + frame.outer_header_len;
     unsigned long long sections_total = 0;
-
     unsigned extra_at = extra_first + blockIdx.x * chunks_per_frame;      // this frame's half-tile table moves
+    ChunkPack *pk = packs + (size_t)blockIdx.x * chunks_per_frame;
+
     for (unsigned t = 0; t < frame.tex_count; t++) {
         const HapGpuTexEnc tex = frame.tex[t];
         uint8_t *sec = cursor;
         const unsigned n = tex.chunk_count, fpc = tex.frags_per_chunk, cb = tex.chunk_bytes, hdr = tex.header_len;
-        const uint8_t *tsrc = (const uint8_t *)tex.src;
         unsigned long long body = tex.bytes;
         bool complex_frame = false;
 
@@ -107,10 +146,7 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
                 const unsigned i = base + tid;
                 unsigned long long stored = 0;
                 if (i < n) {
-                    unsigned long long c = vlen;
-                    const uint32_t *fs = frag_sizes + tex.frag_first + (size_t)i * fpc;
-                    for (unsigned k = 0; k < fpc; k++)
-                        c += fs[k];
+                    const unsigned long long c = pk[i].csize;
                     stored = c >= cb ? cb : c;                                   // hap.c:460-466
                 }
                 unsigned long long tile_total;
@@ -133,33 +169,20 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
                         write_section(itab, 4u, index_len - 4u, HAP_SECTION_FRAGMENTS);
                         itab[4] = (uint8_t)(with_tiles ? HAP_FRAGMENT_TABLE_VERSION_FIELDS : HAP_FRAGMENT_TABLE_VERSION);
                         itab[5] = (uint8_t)frag_log2;
-                        // granularity_log2 of the element streams (version 2: | fields per block << 4)
-                        // (layout nibble: compressor code 4 -> 4 = [2,6,4,4], 10 -> 2 = [4,4], 2 -> 6 = [2,6])
+                        // granularity_log2 of the element streams (version 2: | block layout << 4;
+                        // compressor code 4 -> 4 = [2,6,4,4], 10 -> 2 = [4,4], 2 -> 6 = [2,6])
                         const unsigned code = (tex.reserved >> 16) & 0xFu;
                         itab[6] = (uint8_t)((tex.reserved & 0xFu) | (with_tiles ? (code == 4u ? 4u : code == 10u ? 2u : 6u) << 4 : 0u));
                         itab[7] = (uint8_t)(tex.reserved >> 8);   // match window in 256-byte units, 0 = whole fragment
                     }
                 }
-                // the half-tile size bytes follow the fragment sizes: one move per chunk (consecutive fragments)
-                for (unsigned i = tid; i < n; i += 256u) {
-                    HapGpuCopyEntry e;
-                    e.reserved = 0;
-                    e.src = (uint64_t)(tile_sizes + (size_t)(tex.frag_first + i * fpc) * HAP_HALF_TILES_PER_FRAGMENT);
-                    e.dst = (uint64_t)(itab + 8u + 4u * n * fpc + (size_t)i * fpc * HAP_HALF_TILES_PER_FRAGMENT);
-                    e.len = with_tiles ? fpc * HAP_HALF_TILES_PER_FRAGMENT : 0u;
-                    if (i < chunks_per_frame)
-                        copies[extra_at + i] = e;
-                }
-                // pass 2: positions, tables, moves
+                // pass 2: positions and the per-chunk table entries
                 unsigned long long run = 0;
                 for (unsigned base = 0; base < n; base += 256u) {
                     const unsigned i = base + tid;
                     unsigned long long csize = 0, stored = 0;
-                    const uint32_t *fs = frag_sizes + tex.frag_first + (size_t)i * fpc;
                     if (i < n) {
-                        csize = vlen;
-                        for (unsigned k = 0; k < fpc; k++)
-                            csize += fs[k];
+                        csize = pk[i].csize;
                         stored = csize >= cb ? cb : csize;
                     }
                     unsigned long long tile_total;
@@ -174,47 +197,29 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
                             write_varint(at, cb);
                             at += vlen;
                         }
-                        for (unsigned k = 0; k < fpc; k++) {
-                            const unsigned f = tex.frag_first + i * fpc + k;
-                            HapGpuCopyEntry e;
-                            e.reserved = 0;
-                            if (raw) {
-                                const unsigned begin = k << frag_log2;
-                                e.src = (uint64_t)(tsrc + (size_t)i * cb + begin);
-                                e.len = begin < cb ? min(frag_bytes, cb - begin) : 0u;
-                            } else {
-                                e.src = (uint64_t)(slots + (size_t)f * slot_stride);
-                                e.len = fs[k];
-                            }
-                            e.dst = (uint64_t)at;
-                            at += e.len;
-                            copies[f] = e;
-                            if (tex.emit_index)
-                                put32(itab + 8u + 4u * (i * fpc + k), raw ? 0u : fs[k]);
-                        }
+                        pk[i].dst = (uint64_t)at;
+                        pk[i].itab = tex.emit_index ? (uint64_t)(itab + 8u + 4u * (size_t)i * fpc) : 0u;
+                        pk[i].how = raw ? 1u : 0u;
+                        // the half-tile size bytes follow the fragment sizes: one move per chunk (consecutive fragments)
+                        HapGpuCopyEntry e;
+                        e.reserved = 0;
+                        e.src = (uint64_t)(tile_sizes + (size_t)(tex.frag_first + i * fpc) * HAP_HALF_TILES_PER_FRAGMENT);
+                        e.dst = (uint64_t)(itab + 8u + 4u * n * fpc + (size_t)i * fpc * HAP_HALF_TILES_PER_FRAGMENT);
+                        e.len = with_tiles ? fpc * HAP_HALF_TILES_PER_FRAGMENT : 0u;
+                        copies[extra_at + i] = e;
                     }
                 }
             }
         }
         if (!complex_frame) {
             // whole texture stored as-is, reference hap.c:490-495
-            const unsigned total_frags = n * fpc;
-            for (unsigned i = tid; i < n && i < chunks_per_frame; i += 256u) {
+            for (unsigned i = tid; i < n; i += 256u) {
                 HapGpuCopyEntry e;
                 e.reserved = 0; e.src = 0; e.dst = 0; e.len = 0;
                 copies[extra_at + i] = e;
-            }
-            for (unsigned f = tid; f < total_frags; f += 256u) {
-                const unsigned i = f / fpc, k = f - i * fpc;
-                const unsigned begin = k << frag_log2;
-                HapGpuCopyEntry e;
-                e.reserved = 0;
-                e.len = begin < cb ? min(frag_bytes, cb - begin) : 0u;
-                if (f + 1u == total_frags)      // bytes not divisible by the chunk count: keep the tail
-                    e.len = tex.bytes - (i * cb + begin);
-                e.src = (uint64_t)(tsrc + (size_t)i * cb + begin);
-                e.dst = (uint64_t)(sec + hdr + (size_t)i * cb + begin);
-                copies[tex.frag_first + f] = e;
+                pk[i].dst = (uint64_t)(sec + hdr + (size_t)i * cb);
+                pk[i].itab = 0;
+                pk[i].how = 2u;
             }
         }
         if (tid == 0) {
@@ -224,6 +229,7 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
         cursor += hdr + body;
         sections_total += hdr + body;
         extra_at += n;
+        pk += n;
         __syncthreads();
     }
     if (tid == 0) {
@@ -231,6 +237,63 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
             write_section((uint8_t *)frame.dst, frame.outer_header_len, (unsigned)sections_total, HAP_SECTION_MULTI);   // hap.c:598
         frame.bytes_used = frame.outer_header_len + sections_total;
         frame.status = 0;
+    }
+}
+
+// 3. one wavefront per chunk: one move per fragment (slot -> its place in the chunk: prefix sum over the fragment
+//    sizes) and the fragment-size entries of the private table
+__global__ __launch_bounds__(64) void frame_moves_kernel(const HapGpuFrameEnc *frames, unsigned frag_log2,
+                                                         const uint8_t *__restrict__ slots, unsigned slot_stride,
+                                                         const uint32_t *__restrict__ frag_sizes,
+                                                         HapGpuCopyEntry *__restrict__ copies,
+                                                         const ChunkPack *__restrict__ packs, unsigned chunks_per_frame)
+{
+    const HapGpuFrameEnc &frame = frames[blockIdx.z];
+    const unsigned t = blockIdx.y, i = blockIdx.x, lane = threadIdx.x;
+    if (t >= frame.tex_count)
+        return;
+    const HapGpuTexEnc &tex = frame.tex[t];
+    if (i >= tex.chunk_count)
+        return;
+    const ChunkPack pk = packs[(size_t)blockIdx.z * chunks_per_frame + (t ? frame.tex[0].chunk_count : 0u) + i];
+    const unsigned fpc = tex.frags_per_chunk, cb = tex.chunk_bytes, frag_bytes = 1u << frag_log2;
+    const uint8_t *tsrc = (const uint8_t *)tex.src;
+    const uint32_t *fs = frag_sizes + tex.frag_first + (size_t)i * fpc;
+    const bool last_chunk = i + 1u == tex.chunk_count;
+    unsigned long long run = 0;
+    for (unsigned base = 0; base < fpc; base += 64u) {
+        const unsigned k = base + lane;
+        const unsigned begin = k << frag_log2;
+        unsigned len = 0;
+        if (k < fpc) {
+            if (pk.how == 0u) {
+                len = fs[k];
+            } else {
+                len = begin < cb ? min(frag_bytes, cb - begin) : 0u;
+                if (pk.how == 2u && last_chunk && k + 1u == fpc)      // bytes not divisible by the chunk count: keep the tail
+                    len = tex.bytes - (i * cb + begin);
+            }
+        }
+        unsigned long long incl = len;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long up = __shfl_up(incl, d);
+            if ((int)lane >= d)
+                incl += up;
+        }
+        const unsigned long long at = run + incl - len;
+        run += __shfl(incl, 63);
+        if (k < fpc) {
+            const unsigned f = tex.frag_first + i * fpc + k;
+            HapGpuCopyEntry e;
+            e.reserved = 0;
+            e.src = pk.how == 0u ? (uint64_t)(slots + (size_t)f * slot_stride) : (uint64_t)(tsrc + (size_t)i * cb + begin);
+            e.dst = pk.dst + at;
+            e.len = len;
+            copies[f] = e;
+            if (pk.itab)
+                put32((uint8_t *)pk.itab + 4u * k, pk.how == 0u ? len : 0u);
+        }
     }
 }
 
@@ -280,15 +343,26 @@ __global__ __launch_bounds__(64) void frame_gather_kernel(const HapGpuCopyEntry 
 
 } // namespace
 
+// pack_scratch: frame_count * chunks_per_frame * hapgpu_pack_scratch_bytes_per_chunk() bytes of device memory
+extern "C" unsigned hapgpu_pack_scratch_bytes_per_chunk(void) { return (unsigned)sizeof(ChunkPack); }
+
 extern "C" int hapgpu_launch_frame_pack(HapGpuFrameEnc *frames, unsigned frame_count, unsigned frag_log2,
                                         const void *slots, unsigned slot_stride, const uint32_t *frag_sizes,
                                         const uint8_t *tile_sizes, HapGpuCopyEntry *copies, unsigned extra_first,
-                                        unsigned chunks_per_frame, hipStream_t stream)
+                                        unsigned chunks_per_frame, unsigned max_chunks_per_texture, unsigned textures,
+                                        void *pack_scratch, hipStream_t stream)
 {
     if (frame_count == 0)
         return 0;
-    hipLaunchKernelGGL(frame_pack_kernel, dim3(frame_count), dim3(256), 0, stream, frames, frag_log2,
-                       (const uint8_t *)slots, slot_stride, frag_sizes, tile_sizes, copies, extra_first, chunks_per_frame);
+    if (!pack_scratch || max_chunks_per_texture == 0 || textures == 0)
+        return 1;
+    ChunkPack *packs = (ChunkPack *)pack_scratch;
+    const dim3 per_chunk(max_chunks_per_texture, textures, frame_count);
+    hipLaunchKernelGGL(frame_chunk_sums_kernel, per_chunk, dim3(64), 0, stream, frames, frag_sizes, packs, chunks_per_frame);
+    hipLaunchKernelGGL(frame_pack_kernel, dim3(frame_count), dim3(256), 0, stream, frames, frag_log2, tile_sizes, copies,
+                       extra_first, packs, chunks_per_frame);
+    hipLaunchKernelGGL(frame_moves_kernel, per_chunk, dim3(64), 0, stream, frames, frag_log2, (const uint8_t *)slots,
+                       slot_stride, frag_sizes, copies, packs, chunks_per_frame);
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 

@@ -21,7 +21,8 @@ enum {
     D_FRAMES = 0, D_SLOTS, D_FRAGSIZES, D_COPIES, D_TEX_STAGE, D_FRAME_STAGE, D_BC_TEX, D_RGBA_STAGE,
     D_JOBS, D_CHUNKS, D_UNITS, D_IN_STAGE, D_OUT_STAGE, D_PTRS, D_PREFIX, D_BC_PTRS
 };
-#define D_TILESIZES D_PTRS   /* encode-only arena; D_PTRS is decode-only: one call never needs both */
+#define D_TILESIZES D_PTRS   /* encode-only arenas in decode-only slots: one call never needs both */
+#define D_PACK D_PREFIX
 enum { P_FRAMES = 0, P_JOBS, P_CHUNKS, P_PREFIX, P_PTRS, P_BC_PTRS };   /* (8, 9: hap_sequence.c) */
 
 #define PREFIX_BYTES 8192u   /* headers + tables of a frame with a few hundred chunks; larger ones are fetched on demand */
@@ -51,6 +52,8 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
     unsigned outer_header = 0, frags_per_frame = 0, max_frags_per_tex = 0, live = 0, chunks_per_frame = 0;
     int any_half_tiles = 0;
     uint8_t *dtilesizes = NULL;
+    void *dpack = NULL;
+    unsigned max_chunks_per_tex = 0;
     unsigned frag_log2 = ctx->frag_log2, frag_bytes = 1u << frag_log2;
     unsigned slot_stride;
     int any_snappy = 0;
@@ -180,6 +183,8 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
             max_frags_per_tex = t->chunk_count * t->fpc;
         frags_per_frame += t->chunk_count * t->fpc;
         chunks_per_frame += t->chunk_count;
+        if (t->chunk_count > max_chunks_per_tex)
+            max_chunks_per_tex = t->chunk_count;
         stage_in_bytes += align_up(t->bytes, 256);
         frame_raw_bound += t->header_len + t->bytes;
     }
@@ -254,13 +259,14 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
     dslots = any_snappy ? (uint8_t *)hapgpu_rt_device_scratch(rt, D_SLOTS, (size_t)slot_stride * frags_per_frame * live) : NULL;
     dfragsizes = (uint32_t *)hapgpu_rt_device_scratch(rt, D_FRAGSIZES, sizeof(uint32_t) * (size_t)frags_per_frame * live);
     dcopies = (HapGpuCopyEntry *)hapgpu_rt_device_scratch(rt, D_COPIES, sizeof(HapGpuCopyEntry) * ((size_t)frags_per_frame + chunks_per_frame) * live);
+    dpack = hapgpu_rt_device_scratch(rt, D_PACK, (size_t)hapgpu_pack_scratch_bytes_per_chunk() * chunks_per_frame * live);
     if (any_half_tiles)
         dtilesizes = (uint8_t *)hapgpu_rt_device_scratch(rt, D_TILESIZES, (size_t)HAP_HALF_TILES_PER_FRAGMENT * frags_per_frame * live);
     if (stage_in_bytes)
         tex_stage = (uint8_t *)hapgpu_rt_device_scratch(rt, D_TEX_STAGE, stage_in_bytes);
     if (stage_out_bytes)
         out_stage = (uint8_t *)hapgpu_rt_device_scratch(rt, D_FRAME_STAGE, stage_out_bytes);
-    if (!hframes || !dframes || (any_snappy && !dslots) || !dfragsizes || !dcopies || (any_half_tiles && !dtilesizes) ||
+    if (!hframes || !dframes || (any_snappy && !dslots) || !dfragsizes || !dcopies || !dpack || (any_half_tiles && !dtilesizes) ||
         (stage_in_bytes && !tex_stage) || (stage_out_bytes && !out_stage)) {
         free(live_index); free(stage_off_in); free(stage_off_out);
         for (f = 0; f < frame_count; f++)
@@ -318,7 +324,7 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
             rc |= (unsigned)hapgpu_k_snappy_compress(rt, dframes, live, max_frags_per_tex, frag_log2, dslots, slot_stride, dfragsizes,
                                                      dtilesizes, gran_mask | (count << 8));   /* bits 8..: textures per frame */
         rc |= (unsigned)hapgpu_k_frame_pack(rt, dframes, live, frag_log2, dslots, slot_stride, dfragsizes, dtilesizes, dcopies,
-                                            frags_per_frame * live, chunks_per_frame);
+                                            frags_per_frame * live, chunks_per_frame, max_chunks_per_tex, count, dpack);
         rc |= (unsigned)hapgpu_k_frame_gather(rt, dcopies, (frags_per_frame + chunks_per_frame) * live);
         rc |= (unsigned)hapgpu_rt_d2h(rt, hframes, dframes, sizeof(HapGpuFrameEnc) * live);
         rc |= (unsigned)hapgpu_rt_sync(rt);
@@ -582,7 +588,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     hapf_reader *readers;
     fetch_ctx *fetchers;
     unsigned f, live = 0, first_error = HapResult_No_Error, total_units = 0, total_chunks = 0;
-    unsigned frag_log2_seen = 0, frag_kinds = 0;
+    unsigned frag_log2_seen = 0, frag_kinds = 0, max_chunks = 0;
     int any_stream = 0, need_retry = 0;
     uint8_t *prefix = NULL, *in_stage = NULL, *out_stage = NULL;
     size_t in_stage_bytes = 0, out_stage_bytes = 0;
@@ -731,6 +737,8 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                 }
             }
             total_chunks += (unsigned)p->chunk_count;
+            if ((unsigned)p->chunk_count > max_chunks)
+                max_chunks = (unsigned)p->chunk_count;
         } else if (p->mode == HAPGPU_JOB_RAW) {
             units = p->section_length ? (p->section_length + COPY_PIECE - 1) / COPY_PIECE : 1u;
             any_stream = 1;
@@ -826,7 +834,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
         rc |= hapgpu_rt_h2d(rt, djobs, hjobs, sizeof(HapGpuDecodeJob) * live);
         if (total_chunks)
             rc |= hapgpu_rt_h2d(rt, dchunks, hchunks, sizeof(HapGpuChunkIn) * total_chunks);
-        rc |= hapgpu_k_decode_plan(rt, djobs, live, dunits, total_units);
+        rc |= hapgpu_k_decode_plan(rt, djobs, live, dunits, total_units, frag_log2_seen ? max_chunks : 0u);
 
         /* hap.h callback contract (single-frame HapDecode only): the client is asked to "run" the
            chunks once planning succeeded and there is more than one (reference hap.c:852-862) */

@@ -90,6 +90,13 @@ typedef struct HapGpuChunkIn {
     uint32_t unit_first;     /* first unit slot of this chunk (relative to the job) */
     uint32_t unit_count;     /* slots reserved for it */
     uint32_t frag_first;     /* first fragment-table entry of this chunk, if the frame has one */
+    /* written by the plan kernel for the expansion kernel (one wavefront per chunk turns the chunk's
+       fragment-table entries into units) */
+    uint32_t plan_expand;    /* 1: expand with the fragment table */
+    uint32_t plan_hdr;       /* bytes of the chunk's varint length prefix */
+    uint32_t plan_out_len;   /* decoded bytes of the chunk */
+    uint32_t reserved;
+    uint64_t plan_out_off;   /* where they go, relative to the job's dst */
 } HapGpuChunkIn;
 
 #define HAPGPU_JOB_COMPLEX 0u
@@ -185,14 +192,17 @@ int hapgpu_k_snappy_compress(hapgpu_rt *rt, const HapGpuFrameEnc *frames, unsign
 int hapgpu_k_frame_pack(hapgpu_rt *rt, HapGpuFrameEnc *frames, unsigned frame_count,
                         unsigned frag_log2, const void *slots, unsigned slot_stride,
                         const uint32_t *frag_sizes, const uint8_t *tile_sizes, HapGpuCopyEntry *copies,
-                        unsigned extra_first, unsigned chunks_per_frame);
+                        unsigned extra_first, unsigned chunks_per_frame, unsigned max_chunks_per_texture,
+                        unsigned textures, void *pack_scratch);
+/* bytes of pack_scratch needed per chunk (frame_count * chunks_per_frame of them) */
+unsigned hapgpu_pack_scratch_bytes_per_chunk(void);
 int hapgpu_k_frame_gather(hapgpu_rt *rt, const HapGpuCopyEntry *copies, unsigned count);
 /* first `prefix` bytes of every device-resident frame (0 pointer = skip) -> out_dev + i * prefix */
 int hapgpu_k_gather_prefixes(hapgpu_rt *rt, const uint64_t *frames_dev, const uint64_t *lengths_dev,
                              unsigned count, unsigned prefix, void *out_dev);
-/* clears `units` (all SKIP) then plans every job */
+/* clears `units` (all SKIP) then plans every job; max_chunks: largest chunk_count among the jobs */
 int hapgpu_k_decode_plan(hapgpu_rt *rt, HapGpuDecodeJob *jobs, unsigned job_count,
-                         HapGpuDecodeUnit *units, unsigned unit_count);
+                         HapGpuDecodeUnit *units, unsigned unit_count, unsigned max_chunks);
 /* frag_log2: fragment size of the batch's FRAGMENT units (0: none present);
  * fragment_kinds: bit g set = fragments of granularity_log2 g present */
 /* fragment_kinds bits 8 / 9 / 10: field-stream units of [2,6,4,4] / [4,4] / [2,6] blocks present */

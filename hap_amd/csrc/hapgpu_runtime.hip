@@ -25,9 +25,9 @@ int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsigned frame_c
 int hapgpu_launch_frame_pack(HapGpuFrameEnc *frames, unsigned frame_count, unsigned frag_log2, const void *slots,
                              unsigned slot_stride, const uint32_t *frag_sizes, const uint8_t *tile_sizes,
                              HapGpuCopyEntry *copies, unsigned extra_first, unsigned chunks_per_frame,
-                             hipStream_t stream);
+                             unsigned max_chunks_per_texture, unsigned textures, void *pack_scratch, hipStream_t stream);
 int hapgpu_launch_frame_gather(const HapGpuCopyEntry *copies, unsigned count, hipStream_t stream);
-int hapgpu_launch_decode_plan(HapGpuDecodeJob *jobs, unsigned job_count, hipStream_t stream);
+int hapgpu_launch_decode_plan(HapGpuDecodeJob *jobs, unsigned job_count, unsigned max_chunks, hipStream_t stream);
 int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsigned unit_count, HapGpuDecodeJob *jobs,
                                 unsigned frag_log2, unsigned fragment_kinds, int any_stream_or_copy_units,
                                 hipStream_t stream);
@@ -381,11 +381,12 @@ extern "C" int hapgpu_k_snappy_compress(hapgpu_rt *rt, const HapGpuFrameEnc *fra
 extern "C" int hapgpu_k_frame_pack(hapgpu_rt *rt, HapGpuFrameEnc *frames, unsigned frame_count, unsigned frag_log2,
                                    const void *slots, unsigned slot_stride, const uint32_t *frag_sizes,
                                    const uint8_t *tile_sizes, HapGpuCopyEntry *copies, unsigned extra_first,
-                                   unsigned chunks_per_frame)
+                                   unsigned chunks_per_frame, unsigned max_chunks_per_texture, unsigned textures,
+                                   void *pack_scratch)
 {
     scoped_timing st(rt, 2);
     return hapgpu_launch_frame_pack(frames, frame_count, frag_log2, slots, slot_stride, frag_sizes, tile_sizes, copies,
-                                    extra_first, chunks_per_frame, rt->stream);
+                                    extra_first, chunks_per_frame, max_chunks_per_texture, textures, pack_scratch, rt->stream);
 }
 
 extern "C" int hapgpu_k_frame_gather(hapgpu_rt *rt, const HapGpuCopyEntry *copies, unsigned count)
@@ -395,13 +396,13 @@ extern "C" int hapgpu_k_frame_gather(hapgpu_rt *rt, const HapGpuCopyEntry *copie
 }
 
 extern "C" int hapgpu_k_decode_plan(hapgpu_rt *rt, HapGpuDecodeJob *jobs, unsigned job_count,
-                                    HapGpuDecodeUnit *units, unsigned unit_count)
+                                    HapGpuDecodeUnit *units, unsigned unit_count, unsigned max_chunks)
 {
     // unit slots the planner does not reach (it stops at the first malformed chunk) must read as SKIP
     if (unit_count && hipMemsetAsync(units, 0, (size_t)unit_count * sizeof(HapGpuDecodeUnit), rt->stream) != hipSuccess)
         return 4;
     scoped_timing st(rt, 4);
-    return hapgpu_launch_decode_plan(jobs, job_count, rt->stream);
+    return hapgpu_launch_decode_plan(jobs, job_count, max_chunks, rt->stream);
 }
 
 extern "C" int hapgpu_k_snappy_decode(hapgpu_rt *rt, const HapGpuDecodeUnit *units, unsigned unit_count,

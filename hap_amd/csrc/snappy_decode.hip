@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64) void decode_plan_kernel(HapGpuDecodeJob *jobs, 
     }
 
     // complex: reference hap.c:794-843
-    const HapGpuChunkIn *chunks = (const HapGpuChunkIn *)job->chunks;
+    HapGpuChunkIn *chunks = (HapGpuChunkIn *)job->chunks;
     const unsigned n = job->chunk_count;
     const uint32_t *frag_sizes = (const uint32_t *)job->frag_sizes;
     const unsigned frag_bytes = 1u << job->frag_log2;
@@ -165,46 +165,16 @@ __global__ __launch_bounds__(64) void decode_plan_kernel(HapGpuDecodeJob *jobs, 
             } else if (codec == HAP_NIBBLE_NONE) {
                 emit_copy_units(u, c.unit_count, payload + c.src_off, dst + my_off, c.src_len, j);
             } else if (codec == HAP_NIBBLE_SNAPPY) {
-                bool indexed = false;
-                if (per_chunk && c.unit_count == per_chunk &&
-                    (unsigned long long)per_chunk * frag_bytes >= out_len &&
-                    (unsigned long long)(per_chunk - 1) * frag_bytes < out_len) {
-                    const uint32_t *fs = frag_sizes + c.frag_first;
-                    unsigned long long total = hdr;
-                    for (unsigned k = 0; k < per_chunk; k++)
-                        total += fs[k];
-                    if (total == c.src_len) {
-                        unsigned at = hdr;
-                        for (unsigned k = 0; k < per_chunk; k++) {
-                            HapGpuDecodeUnit w;
-                            w.src = (uint64_t)(payload + c.src_off + at);
-                            w.dst = (uint64_t)(dst + my_off + (unsigned long long)k * frag_bytes);
-                            w.src_len = fs[k];
-                            w.dst_len = min(frag_bytes, out_len - k * frag_bytes);
-                            const unsigned gran = job->reserved & 0xFFu, window256 = (job->reserved >> 8) & 0xFFu;
-                            w.aux = 0;
-                            w.reserved = 0;
-                            if (job->fields_period != 0u && job->tile_sizes != 0u) {
-                                // field stream (table version 2): block-per-lane decoder, with this fragment's half-tile sizes
-                                w.kind = job->fields_period == 4u ? HAPGPU_UNIT_SNAPPY_FIELDS4
-                                       : job->fields_period == 2u ? HAPGPU_UNIT_SNAPPY_FIELDS2 : HAPGPU_UNIT_SNAPPY_FIELDS26;
-                                w.aux = job->tile_sizes + (uint64_t)(c.frag_first + k) * HAP_HALF_TILES_PER_FRAGMENT;
-                                // bytes of the texture section that follow the fragment (up to 15): the decoder may
-                                // fetch its last 16-byte piece whole when they exist
-                                const uint64_t after = job->payload_len - ((uint64_t)c.src_off + at + fs[k]);
-                                w.reserved = after < 15u ? after : 15u;
-                            } else {
-                                w.kind = gran == 2 ? HAPGPU_UNIT_SNAPPY_FRAGMENT32
-                                       : gran == 1 ? HAPGPU_UNIT_SNAPPY_FRAGMENT16 : HAPGPU_UNIT_SNAPPY_FRAGMENT;
-                                if (job->frag_log2 == 13u && window256 != 0 && window256 <= HAP_FRAGMENT_WINDOW_256)
-                                    w.kind |= HAPGPU_UNIT_WINDOWED;
-                            }
-                            w.job = j;
-                            u[k] = w;
-                            at += fs[k];
-                        }
-                        indexed = true;
-                    }
+                // chunks with a fragment table are expanded into units by decode_expand_kernel (one wavefront per
+                // chunk); here only the chunk-level facts are recorded
+                const bool indexed = per_chunk && c.unit_count == per_chunk &&
+                                     (unsigned long long)per_chunk * frag_bytes >= out_len &&
+                                     (unsigned long long)(per_chunk - 1) * frag_bytes < out_len;
+                if (indexed) {
+                    chunks[i].plan_expand = 1u;
+                    chunks[i].plan_hdr = hdr;
+                    chunks[i].plan_out_len = out_len;
+                    chunks[i].plan_out_off = my_off;
                 }
                 if (!indexed) {
                     // a table is present but does not describe this chunk: the host redoes the whole
@@ -240,6 +210,73 @@ __global__ __launch_bounds__(64) void decode_plan_kernel(HapGpuDecodeJob *jobs, 
         job->bytes_used = run;
         job->status = status;
     }
+}
+
+// One wavefront per chunk that carries fragment-table entries: compressed offsets by a prefix sum over the entries,
+// one unit per fragment.  (The planner above walks chunks; a 16K texture has 512 fragments per chunk.)
+__global__ __launch_bounds__(64) void decode_expand_kernel(HapGpuDecodeJob *jobs, unsigned job_count)
+{
+    const unsigned j = blockIdx.y, i = blockIdx.x, lane = threadIdx.x;
+    if (j >= job_count)
+        return;
+    HapGpuDecodeJob *job = &jobs[j];
+    if (job->mode != HAPGPU_JOB_COMPLEX || i >= job->chunk_count)
+        return;
+    const HapGpuChunkIn c = ((const HapGpuChunkIn *)job->chunks)[i];
+    if (!c.plan_expand)
+        return;
+    const unsigned n = job->chunk_count;
+    const uint32_t *frag_sizes = (const uint32_t *)job->frag_sizes;
+    const unsigned frag_bytes = 1u << job->frag_log2;
+    const unsigned per_chunk = job->frag_entries / n;
+    const uint32_t *fs = frag_sizes + c.frag_first;
+    const uint8_t *payload = (const uint8_t *)job->payload;
+    uint8_t *dst = (uint8_t *)job->dst;
+    HapGpuDecodeUnit *u = (HapGpuDecodeUnit *)job->units + c.unit_first;
+    const unsigned gran = job->reserved & 0xFFu, window256 = (job->reserved >> 8) & 0xFFu;
+    unsigned kind = gran == 2 ? HAPGPU_UNIT_SNAPPY_FRAGMENT32 : gran == 1 ? HAPGPU_UNIT_SNAPPY_FRAGMENT16 : HAPGPU_UNIT_SNAPPY_FRAGMENT;
+    if (job->frag_log2 == 13u && window256 != 0 && window256 <= HAP_FRAGMENT_WINDOW_256)
+        kind |= HAPGPU_UNIT_WINDOWED;
+    const bool fields = job->fields_period != 0u && job->tile_sizes != 0u;
+    if (fields)       // field stream (table version 2): block-per-lane decoder, with the fragment's half-tile sizes
+        kind = job->fields_period == 4u ? HAPGPU_UNIT_SNAPPY_FIELDS4
+             : job->fields_period == 2u ? HAPGPU_UNIT_SNAPPY_FIELDS2 : HAPGPU_UNIT_SNAPPY_FIELDS26;
+    unsigned long long run = c.plan_hdr;
+    for (unsigned base = 0; base < per_chunk; base += 64u) {
+        const unsigned k = base + lane;
+        const unsigned sz = k < per_chunk ? fs[k] : 0u;
+        unsigned long long incl = sz;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long up = __shfl_up(incl, d);
+            if ((int)lane >= d)
+                incl += up;
+        }
+        const unsigned long long at = run + incl - sz;
+        run += __shfl(incl, 63);
+        if (k < per_chunk) {
+            HapGpuDecodeUnit w;
+            w.src = (uint64_t)(payload + c.src_off + at);
+            w.dst = (uint64_t)(dst + c.plan_out_off + (unsigned long long)k * frag_bytes);
+            w.src_len = sz;
+            w.dst_len = min(frag_bytes, c.plan_out_len - k * frag_bytes);
+            w.kind = kind;
+            w.job = j;
+            w.aux = fields ? job->tile_sizes + (uint64_t)(c.frag_first + k) * HAP_HALF_TILES_PER_FRAGMENT : 0u;
+            // bytes of the texture section that follow the fragment (up to 15): the decoder may fetch its last
+            // 16-byte piece whole when they exist
+            const uint64_t end = (uint64_t)c.src_off + at + sz;
+            const uint64_t after = job->payload_len > end ? job->payload_len - end : 0u;
+            w.reserved = after < 15u ? after : 15u;
+            // a table whose entries run past the chunk is caught below; keep the unit harmless until then
+            if (end > (uint64_t)c.src_off + c.src_len)
+                w.kind = HAPGPU_UNIT_SKIP;
+            u[k] = w;
+        }
+    }
+    // the entries must add up to the chunk: otherwise the host redoes the whole texture without the table
+    if (lane == 0 && run != c.src_len)
+        atomicCAS(&job->status, 0u, HAPGPU_STATUS_INDEX_MISMATCH);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -922,11 +959,13 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
 
 } // namespace
 
-extern "C" int hapgpu_launch_decode_plan(HapGpuDecodeJob *jobs, unsigned job_count, hipStream_t stream)
+extern "C" int hapgpu_launch_decode_plan(HapGpuDecodeJob *jobs, unsigned job_count, unsigned max_chunks, hipStream_t stream)
 {
     if (job_count == 0)
         return 0;
     hipLaunchKernelGGL(decode_plan_kernel, dim3(job_count), dim3(64), 0, stream, jobs, job_count);
+    if (max_chunks)
+        hipLaunchKernelGGL(decode_expand_kernel, dim3(max_chunks, job_count), dim3(64), 0, stream, jobs, job_count);
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 
