@@ -719,6 +719,14 @@ __device__ __forceinline__ unsigned field_offset(unsigned j)      // byte positi
 __device__ constexpr unsigned kFieldDist[] = {HAP_FIELD_DISTANCES};
 constexpr int kFieldFixed = (int)(sizeof(kFieldDist) / sizeof(kFieldDist[0]));
 static_assert(kFieldFixed >= 1 && kFieldFixed <= 7, "priorities are kept in 3 bits");
+constexpr bool field_distances_consecutive()
+{
+    for (int d = 0; d < kFieldFixed; d++)
+        if (kFieldDist[d] != (unsigned)(d + 1))
+            return false;
+    return true;
+}
+constexpr bool kFieldConsecutive = field_distances_consecutive();
 
 template <unsigned PERIOD, bool COLOUR = false>
 __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(const HapGpuFrameEnc *__restrict__ frames,
@@ -827,7 +835,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
                         const unsigned first = (dist - tile_base) / kBlock * PERIOD;
                         reachable = first >= 64u ? 0ull : ~0ull << first;
                     }
-                    if (dist > window)
+                    if (dist > 256u && dist > window)       // (the window is never below one tile)
                         reachable = 0ull;
                     eq[d][sub] = ballot64((((xv.x ^ yv.x) & m1) | ((xv.y ^ yv.y) & m2)) == 0u) & in_mask[sub] & reachable;
                 }
@@ -881,9 +889,13 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
                     best_key = max(best_key, (l << 3) | (unsigned)(d + 1));            // farther wins ties
                 }
                 const unsigned prio = best_key & 7u;
+                if (kFieldConsecutive) {
+                    fixed_off = prio * kBlock;
+                } else {
 #pragma unroll
-                for (int d = 0; d < kFieldFixed; d++)
-                    fixed_off = prio == (unsigned)(d + 1) ? kFieldDist[d] * kBlock : fixed_off;
+                    for (int d = 0; d < kFieldFixed; d++)
+                        fixed_off = prio == (unsigned)(d + 1) ? kFieldDist[d] * kBlock : fixed_off;
+                }
                 best_k2[sub] = best_key >> 3;
                 best_off2[sub] = prio ? fixed_off : hd[sub];
             }

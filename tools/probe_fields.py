@@ -41,6 +41,7 @@ for flags, name in ((0, "fields"), (hap_amd.DECODE_IGNORE_HALF_TILES, "generic-f
     for t in range(len(fmts)):
         dec = [torch.zeros(sizes[t], dtype=torch.uint8, device="cuda") for _ in range(nf)]
         torch.cuda.synchronize()
+        ctx.decode_frames(frames, used, t, dec, flags=flags)        # warm-up (module load, scratch growth)
         ctx.set_profiling(True); ctx.collect_profile()
         r, dused, dfm, dres = ctx.decode_frames(frames, used, t, dec, flags=flags)
         prof = ctx.collect_profile(); ctx.set_profiling(False)
