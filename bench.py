@@ -62,6 +62,9 @@ def parse_args():
                     help="also time decoding of N frames made by the CPU reference encoder (no fragment table); 0 = skip")
     ap.add_argument("--c5-frames", type=int, default=2,
                     help="also time N frames of C5 (16K Hap Q Alpha, the north-star's target config) at N=1; 0 = skip")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="the timed pipeline only: no size-for-speed option, texture->RGBA, host-pointer, foreign-frame, CPU "
+                         "or C5 legs (what tools/prof_bench.sh profiles, so that every dispatch belongs to the headline)")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="launch / rank / reduction logic only, gloo on CPU, a sleep in place of the codec (tests)")
     return ap.parse_args()
@@ -286,8 +289,10 @@ def main():
         line["encode_only"] = {"rgba_GBps": round(nf * rgba_bytes / (enc_ms * 1e-3) / 1e9, 2), "ms": round(enc_ms, 3)}
         line["decode_only"] = {"rgba_GBps": round(nf * rgba_bytes / (dec_ms * 1e-3) / 1e9, 2), "ms": round(dec_ms, 3),
                                "texture_GBps": round(nf * bsum / (dec_ms * 1e-3) / 1e9, 2)}
-        line["texture_to_rgba"] = texture_to_rgba(stream, dev)
-        line["coarse_matches_option"] = coarse_option(stream, hap_amd)
+        if args.no_extras:
+            args.no_cpu_baseline, args.c5_frames = True, 0
+        line["texture_to_rgba"] = None if args.no_extras else texture_to_rgba(stream, dev)
+        line["coarse_matches_option"] = None if args.no_extras else coarse_option(stream, hap_amd)
         stream.used = stream.encode()
         extras = {}
         if not args.no_cpu_baseline:

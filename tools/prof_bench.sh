@@ -1,0 +1,22 @@
+#!/bin/bash
+# Round-2 profiling recipe (gpurun box): kernel trace + stats, SQ counters and HBM traffic counters of bench.py's
+# own command, per config -- counters in their own runs, never combined with other trace domains.
+#   tools/prof_bench.sh C4 30        -> gpurun_out/prof_c4/{kernel_stats.csv, pmc_summary.txt, traffic_summary.txt, bench_*.json}
+export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+CFG=${1:-C4}; FRAMES=${2:-30}
+tag=$(echo $CFG | tr A-Z a-z)
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
+rm -rf $OUT; mkdir -p $OUT
+CMD="python bench.py --config $CFG --steps 2 --warmup 1 --frames $FRAMES --no-extras"
+echo "$CMD" > $OUT/command.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb_trace -o r -- $CMD > $OUT/bench_trace.json 2> /tmp/pb_trace.err
+cp $(find /tmp/pb_trace -name "*kernel_stats.csv") $OUT/kernel_stats.csv
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d /tmp/pb_pmc1 -o r -- $CMD > /dev/null 2> /tmp/pb_pmc1.err
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --output-format csv -d /tmp/pb_pmc2 -o r -- $CMD > /dev/null 2> /tmp/pb_pmc2.err
+python tools/summarize_pmc.py $(find /tmp/pb_pmc1 -name "*counter_collection.csv") $(find /tmp/pb_pmc2 -name "*counter_collection.csv") > $OUT/pmc_summary.txt
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pb_fetch -o r -- $CMD > /dev/null 2> /tmp/pb_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pb_write -o r -- $CMD > $OUT/bench_traffic.json 2> /tmp/pb_write.err
+python tools/summarize_pmc.py $(find /tmp/pb_fetch -name "*counter_collection.csv") $(find /tmp/pb_write -name "*counter_collection.csv") > $OUT/traffic_summary.txt
+tail -2 /tmp/pb_trace.err /tmp/pb_pmc1.err /tmp/pb_fetch.err > $OUT/errs.txt 2>&1
+grep -c . $OUT/kernel_stats.csv $OUT/pmc_summary.txt $OUT/traffic_summary.txt
