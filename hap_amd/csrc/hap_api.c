@@ -34,8 +34,7 @@ unsigned int HapGpuCreate(int device, HapGpuContext **context)
     }
     {
         const char *e = getenv("HAP_AMD_BYTE_GRANULAR");
-        c->byte_granular = ((e && atoi(e) != 0) || getenv("HAP_AMD_COMPRESS_V1")) ? 1u : 0u;
-        c->compress_v1 = getenv("HAP_AMD_COMPRESS_V1") ? 1u : 0u;
+        c->byte_granular = (e && atoi(e) != 0) ? 1u : 0u;
         c->position_lanes = getenv("HAP_AMD_POSITION_LANES") ? 1u : 0u;
         c->no_half_tiles = getenv("HAP_AMD_NO_HALF_TILES") ? 1u : 0u;
         /* RGTC1 planes of large textures go through the [2, 6] field kernel (block-per-lane decodable: 2.9x the decode

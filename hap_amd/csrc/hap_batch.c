@@ -141,7 +141,7 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
         /* alpha-style blocks (2 endpoint + 6 index bytes [+ 4 + 4 of the colour half]) go to the field-per-lane
            compressor when everything lines up: default fragment size, whole blocks per chunk, 16-bit streams */
         t->field_period = 0u;
-        if (t->compressor == HapCompressorSnappy && frag_log2 == 13u && !ctx->compress_v1 && !ctx->position_lanes) {
+        if (t->compressor == HapCompressorSnappy && frag_log2 == 13u && !ctx->position_lanes) {
             if (t->gran_log2 == 1u && (t->format == HapTextureFormat_RGBA_DXT5 || t->format == HapTextureFormat_YCoCg_DXT5) &&
                 (t->chunk_bytes & 15u) == 0)
                 t->field_period = 4u;
@@ -312,7 +312,7 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
                    (rows of up to ~5 KiB: below 1080p for 16-byte blocks, below 4K for 8-byte blocks) */
                 {
                     const int small_blocks = g[i].format == HapTextureFormat_RGB_DXT1 || g[i].format == HapTextureFormat_A_RGTC1;
-                    const int windowed = frag_log2 == 13u && !ctx->compress_v1 &&
+                    const int windowed = frag_log2 == 13u &&
                                          g[i].bytes >= (small_blocks ? ((size_t)2u << 20) : ((size_t)1u << 20));
                     te->reserved = g[i].gran_log2 | (windowed ? (HAP_FRAGMENT_WINDOW_256 << 8) : 0u) | (g[i].field_period << 16) |
                                    (g[i].half_tiles << 20);

@@ -13,7 +13,6 @@ struct HapGpuContext {
     hapgpu_rt *rt;
     unsigned frag_log2;
     unsigned byte_granular;   /* HAP_AMD_BYTE_GRANULAR=1: never emit 16-bit granular element streams */
-    unsigned compress_v1;     /* HAP_AMD_COMPRESS_V1: the first-generation compressor (no match window) */
     unsigned position_lanes;  /* HAP_AMD_POSITION_LANES: never use the field-per-lane compressor */
     unsigned rgtc1_fields;    /* RGTC1 planes through the [4, 4] field kernel (default; HAP_AMD_RGTC1_POSITIONS=1: position lanes) */
     unsigned no_half_tiles;   /* HAP_AMD_NO_HALF_TILES: fragment table version 1 even for field streams (A/B runs) */

@@ -9,20 +9,16 @@
 // differ from libsnappy's (Snappy encoding is not unique); parity is defined as: the reference
 // decoder reproduces the input exactly.
 //
-// Two kernels:
-//   snappy_compress_wg_kernel  (default)  four wavefronts per fragment, 1/2/4 bytes per lane, see below;
-//   snappy_compress_kernel     (HAP_AMD_COMPRESS_V1=1, kept for A/B runs)  one wavefront per fragment,
-//                              one byte per lane:
-// Per 64-byte tile, lane l owns input position p = tile*64 + l:
-//   1. match finding, all lanes at once: (a) hash of the 4 bytes at p -> most recent earlier
-//      position with that hash (LDS u16 table, updated after the lookup), verified and extended
-//      up to 64 bytes; (b) fixed distances 8 and 16 (the block pitch of DXT data) through wave
-//      ballots: equality bit per position, run length = count-trailing-ones of the shifted mask.
-//   2. greedy selection: the scalar unit walks the ballot of "match >= 4" left to right,
-//      skipping the bytes each chosen copy covers (v_readlane for the length).
-//   3. emission, all lanes at once: uncovered positions are literal bytes; every lane knows the
-//      number of bytes it emits (0..3), offsets come from two ballots + mbcnt, and each lane
-//      stores its own tag/data bytes.
+// Kernels (one 256-thread workgroup per fragment, fragment + hash table in LDS, synchronous rounds):
+//   snappy_compress_field_kernel  block textures: a lane owns one block FIELD (DXT5 / YCoCg-DXT5 [2,6,4,4],
+//                                 DXT1 [4,4], large RGTC1 planes [2,6]); with the fragment table requested it
+//                                 writes "field streams" (half-tile sizes, see snappy_decode_fields.hip);
+//   snappy_compress_wg_kernel     everything else: a lane owns a 1 / 2 / 4-byte position.
+// Per tile: (a) candidates, all lanes at once: the most recent earlier position / field with the same hash
+// (LDS table, updated between rounds), and fixed block-pitch distances through wave ballots (equality bit per
+// lane, run length = count-trailing-ones of the shifted mask); (b) greedy left-to-right selection on the
+// scalar unit; (c) emission, all lanes at once: every lane knows the bytes it emits, offsets come from a DPP
+// prefix sum, each lane stores its own element bytes at their final place in the fragment's slot.
 // HBM traffic: fragment read once, compressed bytes written once.
 #include <hip/hip_runtime.h>
 #include <type_traits>
@@ -32,17 +28,7 @@
 
 namespace {
 
-#ifndef HAP_HASH_BITS
-#define HAP_HASH_BITS 12
-#endif
-constexpr unsigned kHashBits = HAP_HASH_BITS;
-constexpr unsigned kHashEntries = 1u << kHashBits;
 
-__device__ __forceinline__ unsigned uniform(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
-{
-    return ((unsigned long long)uniform((unsigned)(v >> 32)) << 32) | uniform((unsigned)v);
-}
 
 // 4 bytes at an arbitrary LDS byte offset (two aligned dword reads + byte align)
 __device__ __forceinline__ unsigned lds_load32(const uint32_t *words, unsigned byte_off)
@@ -79,178 +65,6 @@ __device__ __forceinline__ unsigned run_from(unsigned long long cur, unsigned lo
         r = avail + (b ? (unsigned)__builtin_ctzll(b) : 64u);
     }
     return min(r, 64u);
-}
-
-__global__ __launch_bounds__(64) void snappy_compress_kernel(const HapGpuFrameEnc *__restrict__ frames,
-                                                             unsigned frag_log2, uint8_t *__restrict__ slots,
-                                                             unsigned slot_stride, uint32_t *__restrict__ frag_sizes)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const unsigned frag_bytes = 1u << frag_log2;
-    uint32_t *dataw = reinterpret_cast<uint32_t *>(smem);                 // frag_bytes + 16
-    const uint8_t *data = smem;
-    uint16_t *table = reinterpret_cast<uint16_t *>(smem + frag_bytes + 16);
-
-    const unsigned lane = threadIdx.x;
-    const HapGpuFrameEnc &frame = frames[blockIdx.z];
-    if (blockIdx.y >= frame.tex_count)
-        return;
-    const HapGpuTexEnc &tex = frame.tex[blockIdx.y];
-    if (tex.compressor != 1u)
-        return;
-    const unsigned x = blockIdx.x;
-    if (x >= tex.chunk_count * tex.frags_per_chunk)
-        return;
-    const unsigned chunk = x / tex.frags_per_chunk, j = x - chunk * tex.frags_per_chunk;
-    const unsigned begin = j << frag_log2;
-    const unsigned n = min(frag_bytes, tex.chunk_bytes - begin);
-    const uint8_t *src = (const uint8_t *)tex.src + (size_t)chunk * tex.chunk_bytes + begin;
-    const unsigned f = tex.frag_first + x;
-    uint8_t *out = slots + (size_t)f * slot_stride;
-
-    // ---- stage the fragment and clear the hash table ----
-    if (((uintptr_t)src & 15u) == 0) {
-        for (unsigned i = lane * 16u; i < n + 16u; i += 1024u) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (i + 16u <= n) {
-                v = *reinterpret_cast<const uint4 *>(src + i);
-            } else if (i < n) {
-                unsigned w[4] = {0, 0, 0, 0};
-                for (unsigned k = 0; i + k < n; k++)
-                    w[k >> 2] |= (unsigned)src[i + k] << (8 * (k & 3));
-                v = make_uint4(w[0], w[1], w[2], w[3]);
-            }
-            *reinterpret_cast<uint4 *>(smem + i) = v;
-        }
-    } else {
-        for (unsigned i = lane; i < n + 16u; i += 64u)
-            smem[i] = i < n ? src[i] : (uint8_t)0;
-    }
-    for (unsigned i = lane; i < kHashEntries / 2; i += 64u)
-        reinterpret_cast<uint32_t *>(table)[i] = 0u;
-    __syncthreads();
-
-    const unsigned tiles = (n + 63u) / 64u;
-    unsigned out_pos = 0;       // bytes emitted so far
-    unsigned skip = 0;          // leading positions of the current tile covered by an earlier copy
-
-    // equality ballots for the fixed distances, one tile ahead
-    auto eq_mask = [&](unsigned tile, unsigned d) -> unsigned long long {
-        const unsigned p = tile * 64u + lane;
-        const bool e = tile < tiles && p >= d && p < n && data[p] == data[p - d];
-        return __ballot(e);
-    };
-    unsigned long long m8 = eq_mask(0, 8), m16 = eq_mask(0, 16);
-
-    for (unsigned t = 0; t < tiles; t++) {
-        const unsigned p = t * 64u + lane;
-        const bool in_range = p < n;
-        const unsigned room = in_range ? min(64u, n - p) : 0u;      // longest match allowed here
-        const unsigned long long n8 = eq_mask(t + 1, 8), n16 = eq_mask(t + 1, 16);
-
-        // ---- (a) hash candidate ----
-        unsigned best_len = 0, best_off = 0, my_hash = 0xFFFFFFFFu;
-        if (p + 4u <= n) {
-            const unsigned cur = lds_load32(dataw, p);
-            const unsigned h = (cur * 0x1e35a7bdu) >> (32u - kHashBits);
-            const unsigned cand = table[h];
-            my_hash = h;
-            if (cand < p && lds_load32(dataw, cand) == cur) {
-                unsigned l = 4;
-                while (l < room) {
-                    const unsigned diff = lds_load32(dataw, cand + l) ^ lds_load32(dataw, p + l);
-                    if (diff) {
-                        l += (unsigned)__builtin_ctz(diff) >> 3;
-                        break;
-                    }
-                    l += 4;
-                }
-                best_len = min(l, room);
-                best_off = p - cand;
-            }
-        }
-        // ---- (b) fixed distances ----
-        {
-            const unsigned l8 = min(run_from(m8, n8, lane), room);
-            const unsigned l16 = min(run_from(m16, n16, lane), room);
-            if (l16 > best_len) { best_len = l16; best_off = 16; }
-            if (l8 >= best_len && l8 >= 4) { best_len = l8; best_off = 8; }
-        }
-        m8 = n8;
-        m16 = n16;
-
-        // ---- greedy selection on the scalar unit ----
-        const unsigned long long cand_mask = __ballot(in_range && best_len >= 4u);
-        unsigned long long sel = 0, covered = skip >= 64u ? ~0ull : ((1ull << skip) - 1ull);
-        unsigned cursor = min(skip, 64u);
-        unsigned carry = skip >= 64u ? skip - 64u : 0u;
-        while (cursor < 64u) {
-            const unsigned long long rest = cand_mask >> cursor;
-            if (!rest)
-                break;
-            const unsigned s = cursor + (unsigned)__builtin_ctzll(rest);
-            const unsigned len = (unsigned)__builtin_amdgcn_readlane((int)best_len, (int)s);
-            sel |= 1ull << s;
-            const unsigned e = s + len;
-            covered |= (e >= 64u ? ~0ull : ((1ull << e) - 1ull)) & ~((1ull << s) - 1ull);
-            cursor = e;
-            if (e >= 64u) {
-                carry = e - 64u;
-                break;
-            }
-        }
-        skip = carry;
-        sel = uniform64(sel);
-        covered = uniform64(covered);
-
-        // ---- emission ----
-        const unsigned long long valid = n - t * 64u >= 64u ? ~0ull : ((1ull << (n - t * 64u)) - 1ull);
-        const unsigned long long lit = ~covered & valid;
-        const unsigned long long starts = lit & ~(lit << 1);
-        const bool is_lit = (lit >> lane) & 1ull;
-        const bool is_start = (starts >> lane) & 1ull;
-        const bool is_copy = (sel >> lane) & 1ull;
-        unsigned run = 0;
-        if (is_start) {
-            const unsigned long long a = ~(lit >> lane);
-            run = a ? (unsigned)__builtin_ctzll(a) : 64u;
-        }
-        const bool copy1 = best_len < 12u && best_off < 2048u;
-        unsigned emit = 0;
-        if (is_lit)
-            emit = 1u + (is_start ? (run > 60u ? 2u : 1u) : 0u);
-        else if (is_copy)
-            emit = copy1 ? 2u : 3u;
-        const unsigned long long e0 = __ballot(emit & 1u), e1 = __ballot(emit & 2u);
-        unsigned at = out_pos + bits_below(e0) + 2u * bits_below(e1);
-        if (is_lit) {
-            if (is_start) {
-                if (run > 60u) {
-                    out[at++] = (uint8_t)(60u << 2);
-                    out[at++] = (uint8_t)(run - 1u);
-                } else {
-                    out[at++] = (uint8_t)((run - 1u) << 2);
-                }
-            }
-            out[at] = data[p];
-        } else if (is_copy) {
-            if (copy1) {
-                out[at] = (uint8_t)(1u | ((best_len - 4u) << 2) | ((best_off >> 8) << 5));
-                out[at + 1] = (uint8_t)best_off;
-            } else {
-                out[at] = (uint8_t)(2u | ((best_len - 1u) << 2));
-                out[at + 1] = (uint8_t)best_off;
-                out[at + 2] = (uint8_t)(best_off >> 8);
-            }
-        }
-        out_pos += (unsigned)__popcll(e0) + 2u * (unsigned)__popcll(e1);
-        // remember only positions where an element starts (as libsnappy does): bytes inside a
-        // copy would otherwise evict the older, still useful entries of a small table
-        if ((is_lit || is_copy) && my_hash != 0xFFFFFFFFu)
-            table[my_hash] = (uint16_t)p;
-    }
-    if (lane == 0)
-        frag_sizes[f] = out_pos;
 }
 
 
@@ -1022,9 +836,6 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
 
 } // namespace
 
-// LDS bytes needed per workgroup for a fragment size
-static unsigned compress_lds_bytes(unsigned frag_log2) { return (1u << frag_log2) + 16u + kHashEntries * 2u; }
-
 extern "C" int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsigned frame_count,
                                              unsigned max_frags_per_texture, unsigned frag_log2, void *slots,
                                              unsigned slot_stride, uint32_t *frag_sizes, uint8_t *tile_sizes,
@@ -1034,8 +845,7 @@ extern "C" int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsig
         return 0;
     if (frag_log2 < 10 || frag_log2 > 16)
         return 1;
-    static const bool use_v1 = getenv("HAP_AMD_COMPRESS_V1") != nullptr;
-    if (!use_v1) {
+    {
         const unsigned lds2 = (1u << frag_log2) + 32u + kWgHashEntries * 4u + kWgWaves * 4u;
         if (lds2 > 65536u) {
             static bool once2 = false;
@@ -1076,16 +886,4 @@ extern "C" int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsig
 #undef HAP_LAUNCH_COMPRESS
         return hipGetLastError() == hipSuccess ? 0 : 4;
     }
-    const unsigned lds = compress_lds_bytes(frag_log2);
-    if (lds > 65536u) {
-        static bool once = false;
-        if (!once) {
-            if (hipFuncSetAttribute((const void *)snappy_compress_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return 4;
-            once = true;
-        }
-    }
-    hipLaunchKernelGGL(snappy_compress_kernel, dim3(max_frags_per_texture, 2, frame_count), dim3(64), lds, stream,
-                       frames, frag_log2, (uint8_t *)slots, slot_stride, frag_sizes);
-    return hipGetLastError() == hipSuccess ? 0 : 4;
 }

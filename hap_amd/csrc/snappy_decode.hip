@@ -1,23 +1,28 @@
-// snappy_decode.hip -- decode planner + per-unit Snappy decoder for gfx950.
+// snappy_decode.hip -- decode planner + the generic per-unit Snappy decoder for gfx950.
 //
 // Replaces, for HapDecode, the reference's planning loop (hap.c:794-838: per-chunk
 // snappy_uncompressed_length + running output offsets), its HapDecodeCallback fan-out
 // (hap.c:852-862), and the worker hap_decode_chunk (hap.c:606-642: snappy_uncompress | memcpy).
 //
-//   decode_plan_kernel   one wavefront per texture: reads every chunk's varint, prefix-sums the
-//                        output offsets, applies the reference's error precedence, and expands
-//                        chunks into decode units (whole stream, independent fragment, raw copy).
-//   snappy_decode_kernel one wavefront per unit.  The element chain of a Snappy stream is serial,
-//                        so a wave walks it element by element (tag parsed from an LDS staging
-//                        window with broadcast reads, wave-uniform control flow) and all 64 lanes
-//                        move the element's bytes.  The most recent RING bytes of output live in
-//                        LDS, so back-references are LDS->LDS; finished 4 KiB segments are written
-//                        to HBM with 16-byte-per-lane stores.  HBM traffic = compressed bytes read
-//                        once + output written once.
+//   decode_plan_kernel    one wavefront per texture: reads every chunk's varint, prefix-sums the
+//                         output offsets, applies the reference's error precedence, and emits the
+//                         units of chunks without a fragment table (whole stream, raw copy).
+//   decode_expand_kernel  one wavefront per chunk that has fragment-table entries: one unit per
+//                         fragment (prefix sum over the entries).
+//   snappy_decode_fragment_kernel
+//                         the generic decoder, one wavefront per unit, any valid Snappy stream:
+//                         a 64-byte window of compressed bytes is parsed speculatively at every byte
+//                         position, the real element chain is found by pointer doubling, and the
+//                         window's output is produced 64 units (bytes, or 2 / 4 bytes when the table
+//                         promises such granularity) per step through an owner map; the last RING
+//                         bytes of output live in LDS so that back-references are LDS -> LDS.
+//                         Used for frames from other encoders (one unit per chunk, 32 KiB ring,
+//                         older bytes re-read from memory), for fragment tables of version 1, and as
+//                         the fallback whenever a table turns out not to describe its streams.
 //
-// Parallelism comes from the number of units: chunks x frames for foreign frames, and
-// fragments (16 KiB of output each) x chunks x frames for frames carrying hap_amd's fragment
-// table (section 0x46, see include/hap_gpu.h).
+// Frames written by this library with the version-2 table ("field streams": DXT5, YCoCg-DXT5, DXT1,
+// large RGTC1 planes) are decoded by the block-per-lane kernel of snappy_decode_fields.hip instead.
+// HBM traffic: compressed bytes read once + output written once.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(64) void decode_expand_kernel(HapGpuDecodeJob *jobs
 // decode
 // ------------------------------------------------------------------------------------------
 
-constexpr unsigned kInBytes = 2048, kInGranule = 1024, kSegment = 4096;
+constexpr unsigned kSegment = 4096;
 
 __device__ __forceinline__ unsigned uniform(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -346,215 +351,13 @@ __device__ void flush_ring(const uint8_t *ring, uint8_t *dst, unsigned from, uns
         dst[at + lane] = ring[(at + lane) & (RING - 1)];
 }
 
-template <unsigned RING, bool FRAGMENT>
-__global__ __launch_bounds__(64) void snappy_decode_kernel(const HapGpuDecodeUnit *__restrict__ units,
-                                                           unsigned unit_count, HapGpuDecodeJob *jobs)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *ring = smem;
-    uint32_t *inw = reinterpret_cast<uint32_t *>(smem + RING);
-    const uint8_t *inb = smem + RING;
-
-    const unsigned lane = threadIdx.x;
-    if (blockIdx.x >= unit_count)
-        return;
-    const HapGpuDecodeUnit u = units[blockIdx.x];
-    if (u.kind == HAPGPU_UNIT_SKIP)
-        return;
-    HapGpuDecodeJob *job = &jobs[u.job];
-    if (job->status != 0)
-        return;
-    if (u.kind == HAPGPU_UNIT_COPY) {
-        if (!FRAGMENT)      // raw copies ride with the stream-kernel launch
-            wave_copy((uint8_t *)u.dst, (const uint8_t *)u.src, u.src_len, lane);
-        return;
-    }
-    const unsigned plain_kind = u.kind & ~HAPGPU_UNIT_WINDOWED;       // (this kernel always holds whole fragments)
-    if ((plain_kind == HAPGPU_UNIT_SNAPPY_FRAGMENT || plain_kind == HAPGPU_UNIT_SNAPPY_FRAGMENT16 ||
-         plain_kind == HAPGPU_UNIT_SNAPPY_FRAGMENT32) != FRAGMENT)
-        return;
-
-    const uint8_t *src = (const uint8_t *)u.src;
-    uint8_t *dst = (uint8_t *)u.dst;
-    // stream coordinates are relative to the 16-byte aligned address at or below src
-    const unsigned shift = (unsigned)((uintptr_t)src & 15u);
-    const uint8_t *src_al = src - shift;
-    const unsigned in_end = shift + u.src_len;          // one past the last valid coordinate
-    const unsigned out_len = u.dst_len;
-
-    // Loads one 1 KiB granule (coordinate g*1024) into registers; bytes outside the unit read as 0.
-    auto load_granule = [&](unsigned g) -> uint4 {
-        const unsigned x = g * kInGranule + lane * 16u;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (x >= shift && x + 16u <= in_end) {
-            v = *reinterpret_cast<const uint4 *>(src_al + x);
-        } else if (x + 16u > shift && x < in_end) {
-            unsigned w[4] = {0, 0, 0, 0};
-            for (unsigned k = 0; k < 16; k++) {
-                const unsigned y = x + k;
-                if (y >= shift && y < in_end)
-                    w[k >> 2] |= (unsigned)src_al[y] << (8 * (k & 3));
-            }
-            v = make_uint4(w[0], w[1], w[2], w[3]);
-        }
-        return v;
-    };
-    auto store_granule = [&](unsigned g, uint4 v) {
-        *reinterpret_cast<uint4 *>(smem + RING + ((g & 1u) * kInGranule) + lane * 16u) = v;
-    };
-
-    unsigned ip = shift;
-    const unsigned granules = (in_end + kInGranule - 1) / kInGranule;
-    // staged window: granules next_g-2 and next_g-1, i.e. coordinates [in_hi-2048, in_hi)
-    store_granule(0, load_granule(0));
-    store_granule(1, load_granule(1));
-    unsigned next_g = 2, in_hi = 2 * kInGranule;
-    uint4 pend = make_uint4(0, 0, 0, 0);
-    bool pend_valid = false;
-    __syncthreads();
-
-    bool failed = false;
-    unsigned op = 0, flushed = 0;
-
-    if (!FRAGMENT) {
-        // skip the length prefix (validated by the plan kernel)
-        unsigned b;
-        do {
-            b = inb[ip & (kInBytes - 1)];
-            ip++;
-        } while ((b & 0x80u) && ip < in_end);
-        ip = uniform(ip);
-    }
-
-    while (ip < in_end) {
-        // ---- keep >= 256 staged bytes ahead of ip (or everything up to the end of the unit) ----
-        if (!pend_valid && next_g < granules && ip + 3 * (kInGranule / 2) >= in_hi) {
-            pend = load_granule(next_g);          // prefetch: consumed when the window slides
-            pend_valid = true;
-        }
-        if (ip + 256u > in_hi && next_g < granules + 1 && in_hi < granules * kInGranule) {
-            const unsigned g = ip / kInGranule;
-            if (g + 1 == next_g) {                // ip is in the newer staged granule: slide by one
-                store_granule(next_g, pend_valid ? pend : load_granule(next_g));
-                next_g += 1;
-            } else if (g >= next_g) {             // a long literal jumped past the window
-                store_granule(g, load_granule(g));
-                store_granule(g + 1, load_granule(g + 1));
-                next_g = g + 2;
-            }
-            pend_valid = false;
-            in_hi = next_g * kInGranule;
-            __syncthreads();
-        }
-        // ---- 8 bytes at ip, broadcast from LDS ----
-        const unsigned wi = ip >> 2;
-        const unsigned w0 = inw[wi & 511u], w1 = inw[(wi + 1) & 511u], w2 = inw[(wi + 2) & 511u];
-        const unsigned sh = (ip & 3u) * 8u;
-        const unsigned lo = uniform(sh ? (w0 >> sh) | (w1 << (32 - sh)) : w0);
-        const unsigned hi = uniform(sh ? (w1 >> sh) | (w2 << (32 - sh)) : w1);
-        const unsigned tag = lo & 0xFFu;
-        const unsigned kind = tag & 3u;
-        if (kind == 0) {
-            unsigned len = (tag >> 2) + 1u, hdr = 1;
-            if (len > 60u) {
-                const unsigned extra = len - 60u;                    // 1..4 length bytes
-                const unsigned long long field = (((unsigned long long)hi << 32) | lo) >> 8;
-                const unsigned v = (unsigned)(extra == 4 ? field : (field & ((1ull << (8 * extra)) - 1ull)));
-                hdr = 1 + extra;
-                if (hdr > in_end - ip || v == 0xFFFFFFFFu) { failed = true; break; }
-                len = v + 1u;
-            }
-            if (len > in_end - ip - hdr || len > out_len - op) { failed = true; break; }
-            ip += hdr;
-            // literal payload: from the staging window when it is inside, else straight from memory
-            for (unsigned done = 0; done < len; done += 64u) {
-                const unsigned n = min(64u, len - done);
-                const bool staged = ip + done + n <= in_hi;
-                if (lane < n) {
-                    const unsigned x = ip + done + lane;
-                    const uint8_t b = staged ? inb[x & (kInBytes - 1)] : src_al[x];
-                    ring[(op + lane) & (RING - 1)] = b;
-                }
-                op += n;
-                if (!FRAGMENT && op - flushed >= 2 * kSegment) {
-                    const unsigned upto = op & ~(kSegment - 1);
-                    flush_ring<RING>(ring, dst, flushed, upto, lane);
-                    flushed = upto;
-                }
-            }
-            ip += len;
-        } else {
-            unsigned len, off, hdr;
-            if (kind == 1) {
-                len = 4u + ((tag >> 2) & 7u);
-                off = ((tag >> 5) << 8) | ((lo >> 8) & 0xFFu);
-                hdr = 2;
-            } else if (kind == 2) {
-                len = (tag >> 2) + 1u;
-                off = (lo >> 8) & 0xFFFFu;
-                hdr = 3;
-            } else {
-                len = (tag >> 2) + 1u;
-                off = (lo >> 8) | (hi << 24);
-                hdr = 5;
-            }
-            if (hdr > in_end - ip || off == 0 || off > op || len > out_len - op) { failed = true; break; }
-            ip += hdr;
-            const unsigned from = op - off;
-            if (FRAGMENT || off + 64u <= RING) {
-                // source bytes live in the LDS ring (a fragment never wraps it)
-                if (lane < len) {
-                    unsigned rel = lane;
-                    if (off < len) {
-                        const unsigned q = (lane * ((65536u / off) + 1u)) >> 16;   // lane / off, exact for lane < 64
-                        rel = lane - q * off;
-                    }
-                    const uint8_t b = ring[(from + rel) & (RING - 1)];
-                    ring[(op + lane) & (RING - 1)] = b;
-                }
-            } else {
-                // far back-reference (> ring): the source bytes are in memory once everything
-                // produced so far is flushed; bypass this CU's L1 for the read-back
-                if (op > flushed) {
-                    flush_ring<RING>(ring, dst, flushed, op, lane);
-                    flushed = op;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                if (lane < len) {
-                    const uint8_t b = __hip_atomic_load(dst + from + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ring[(op + lane) & (RING - 1)] = b;
-                }
-            }
-            op += len;
-            if (!FRAGMENT && op - flushed >= 2 * kSegment) {
-                const unsigned upto = op & ~(kSegment - 1);
-                flush_ring<RING>(ring, dst, flushed, upto, lane);
-                flushed = upto;
-            }
-        }
-    }
-    if (!failed && op != out_len)
-        failed = true;
-    if (failed) {
-        if (lane == 0) {
-            const unsigned code = FRAGMENT ? HAPGPU_STATUS_INDEX_MISMATCH
-                                           : (job->mode == HAPGPU_JOB_SNAPPY ? kResInternal : kResBadFrame);
-            atomicCAS(&job->status, 0u, code);
-        }
-        return;
-    }
-    if (op > flushed)
-        flush_ring<RING>(ring, dst, flushed, op, lane);
-}
-
 
 // ------------------------------------------------------------------------------------------
 // window-parallel fragment decoder
 // ------------------------------------------------------------------------------------------
 //
-// The element-by-element kernel above spends ~40 scalar instructions and several dependent LDS
-// round trips per element.  This one works on a 64-byte window of compressed bytes at a time:
+// Walking a stream element by element costs ~40 scalar instructions and several dependent LDS round
+// trips per element.  This kernel works on a 64-byte window of compressed bytes at a time:
 //
 //   1. every lane parses "the element that would start at my byte" (speculatively, in parallel);
 //   2. which of those are real is a chain from lane 0: two rounds of pointer doubling with
@@ -567,8 +370,8 @@ __global__ __launch_bounds__(64) void snappy_decode_kernel(const HapGpuDecodeUni
 //      64-byte step are chased with pointer jumping in registers (<= 6 rounds) before one LDS
 //      gather + one LDS store.
 //
-// Same results and failure semantics as the serial kernel: any malformed element, bad offset or
-// length mismatch fails the unit.  Used for FRAGMENT units (output never wraps the ring).
+// Failure semantics of snappy_uncompress: any malformed element, bad offset or length mismatch fails
+// the unit (hap.c:617-628: Bad_Frame / Internal_Error; a fragment unit: table mismatch -> fallback).
 
 #ifndef HAP_V2_IN_BYTES
 #define HAP_V2_IN_BYTES 1024
@@ -990,31 +793,25 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
         if (fragment_kinds == 0u)
             frag_log2 = 0u;
     }
-    static const bool use_v1 = getenv("HAP_AMD_DECODE_V1") != nullptr;
     if (any_stream_or_copy_units) {
         static bool once = false;
         static unsigned ring_log2 = 15;
         if (!once) {
-            (void)hipFuncSetAttribute((const void *)snappy_decode_kernel<65536u, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes);
             (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, true, 1u>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kFragmentTail);
             const char *e = getenv("HAP_AMD_STREAM_RING_LOG2");
             if (e && atoi(e) >= 14 && atoi(e) <= 16)
                 ring_log2 = (unsigned)atoi(e);
             once = true;
         }
-        if (use_v1)
-            hipLaunchKernelGGL((snappy_decode_kernel<65536u, false>), dim3(unit_count), dim3(64), 65536 + kInBytes, stream, units, unit_count, jobs);
-        else if (ring_log2 == 14)
+        if (ring_log2 == 14)
             hipLaunchKernelGGL((snappy_decode_fragment_kernel<16384u, true, 1u>), dim3(unit_count), dim3(64), fragment_dynamic_lds(16384u), stream, units, unit_count, jobs);
         else if (ring_log2 == 15)
             hipLaunchKernelGGL((snappy_decode_fragment_kernel<32768u, true, 1u>), dim3(unit_count), dim3(64), fragment_dynamic_lds(32768u), stream, units, unit_count, jobs);
         else
             hipLaunchKernelGGL((snappy_decode_fragment_kernel<65536u, true, 1u>), dim3(unit_count), dim3(64), fragment_dynamic_lds(65536u), stream, units, unit_count, jobs);
     }
-    const unsigned extra = kInBytes + (use_v1 ? 0u : kOwnerBytes + 64u);
     static bool once16 = false;
     if (!once16 && frag_log2 == 16) {
-        (void)hipFuncSetAttribute((const void *)snappy_decode_kernel<65536u, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kInBytes);
         (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, false, 1u>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kFragmentTail);
         (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, false, 2u>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kFragmentTail);
         (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, false, 4u>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kFragmentTail);
@@ -1022,23 +819,18 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
     }
 #define HAP_LAUNCH_FRAGMENT(RINGBYTES)                                                                                          \
     do {                                                                                                                        \
-        if (use_v1) {                                                                                                           \
-            hipLaunchKernelGGL((snappy_decode_kernel<RINGBYTES, true>), dim3(unit_count), dim3(64), RINGBYTES + extra, stream,  \
-                               units, unit_count, jobs);                                                                        \
-        } else {                                                                                                                \
-            if (fragment_kinds & 1u)                                                                                            \
-                hipLaunchKernelGGL((snappy_decode_fragment_kernel<RINGBYTES, false, 1u>), dim3(unit_count), dim3(64),           \
-                                   fragment_dynamic_lds(RINGBYTES), stream, units, unit_count, jobs);                       \
-            if (fragment_kinds & 2u)                                                                                            \
-                hipLaunchKernelGGL((snappy_decode_fragment_kernel<RINGBYTES, false, 2u>), dim3(unit_count), dim3(64),           \
-                                   fragment_dynamic_lds(RINGBYTES), stream, units, unit_count, jobs);                       \
-            if (fragment_kinds & 4u)                                                                                            \
-                hipLaunchKernelGGL((snappy_decode_fragment_kernel<RINGBYTES, false, 4u>), dim3(unit_count), dim3(64),           \
-                                   fragment_dynamic_lds(RINGBYTES), stream, units, unit_count, jobs);                       \
-        }                                                                                                                       \
+        if (fragment_kinds & 1u)                                                                                                \
+            hipLaunchKernelGGL((snappy_decode_fragment_kernel<RINGBYTES, false, 1u>), dim3(unit_count), dim3(64),               \
+                               fragment_dynamic_lds(RINGBYTES), stream, units, unit_count, jobs);                               \
+        if (fragment_kinds & 2u)                                                                                                \
+            hipLaunchKernelGGL((snappy_decode_fragment_kernel<RINGBYTES, false, 2u>), dim3(unit_count), dim3(64),               \
+                               fragment_dynamic_lds(RINGBYTES), stream, units, unit_count, jobs);                               \
+        if (fragment_kinds & 4u)                                                                                                \
+            hipLaunchKernelGGL((snappy_decode_fragment_kernel<RINGBYTES, false, 4u>), dim3(unit_count), dim3(64),               \
+                               fragment_dynamic_lds(RINGBYTES), stream, units, unit_count, jobs);                               \
     } while (0)
     // 8 KiB fragments whose table promises a 3 KiB match window: 4 KiB ring, twice the waves per CU
-    if (!use_v1 && frag_log2 == 13u) {
+    if (frag_log2 == 13u) {
         if (fragment_kinds & 16u)
             hipLaunchKernelGGL((snappy_decode_fragment_kernel<4096u, false, 1u, true>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs);
         if (fragment_kinds & 32u)

@@ -10,7 +10,7 @@
  *   osnappy_*   Snappy block format (google/snappy, not vendored by the
  *               reference; call sites /root/reference/source/hap.c:313,453,
  *               612,813,890,899).  Pinned here against libsnappy 1.1.8:
- *               tests/test_oracle_vs_reference.py checks byte-identical
+ *               tests/test_oracle_pinning.py checks byte-identical
  *               compressed streams and identical decode results/status codes.
  *   ohap_*      Hap frame container + chunked second stage
  *               (/root/reference/source/hap.c:324-1188).  Pinned against the

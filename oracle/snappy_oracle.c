@@ -19,7 +19,7 @@
  *   misses), 15-byte input margin, copies emitted as copy-1 when len < 12 and
  *   offset < 2048, otherwise copy-2 pieces of <= 64.
  *
- * Pinning: tests/test_oracle_vs_reference.py requires osnappy_compress to be
+ * Pinning: tests/test_oracle_pinning.py requires osnappy_compress to be
  * BYTE-IDENTICAL to libsnappy 1.1.8's snappy_compress, and osnappy_uncompress
  * to agree with snappy_uncompress on output bytes and status for valid,
  * truncated and corrupted streams.

@@ -942,7 +942,7 @@ def test_coarse_matches_flag_round_trips(ctx, hap, fmt):
         if flags & hap.ENCODE_FRAGMENT_INDEX:
             at, _ver, _hdr = find_fragment_table(frame)     # section type, version, log2(8 KiB)
             import os
-            byte_only = bool(os.environ.get("HAP_AMD_COMPRESS_V1") or os.environ.get("HAP_AMD_BYTE_GRANULAR"))
+            byte_only = bool(os.environ.get("HAP_AMD_BYTE_GRANULAR"))
             assert at > 0 and frame[at + 3] & 15 == (0 if byte_only else 2 if flags & hap.ENCODE_COARSE_MATCHES else 1)
     assert sizes[hap.ENCODE_FRAGMENT_INDEX | hap.ENCODE_COARSE_MATCHES] < 1.25 * sizes[hap.ENCODE_FRAGMENT_INDEX]
 
@@ -1001,8 +1001,8 @@ def test_match_window_promise_is_checked_and_optional(ctx, hap):
     4 KiB ring.  Frames without the promise (older files, joined frames of mixed origin) take the full-size ring;
     a frame whose promise is a lie (a hand-made far copy) is detected and decoded the generic way."""
     import os
-    if os.environ.get("HAP_AMD_COMPRESS_V1") or os.environ.get("HAP_AMD_BYTE_GRANULAR"):
-        pytest.skip("the first-generation compressor keeps no match window")
+    if os.environ.get("HAP_AMD_BYTE_GRANULAR"):
+        pytest.skip("byte-granular streams keep no match window")
     tex = D.stream_bytes(16 * 64 * 1024, "mixed", seed=41)          # 1 MiB: large enough for the window to be used
     out = np.zeros(hap.HapMaxEncodedLength([len(tex)], [L.FMT_YCOCG], [2]) + 4096, dtype=np.uint8)
     r, used, res = ctx.encode_frames([[tex]], [L.FMT_YCOCG], [1], [2], [out], flags=hap.ENCODE_FRAGMENT_INDEX)
