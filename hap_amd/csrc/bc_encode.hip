@@ -16,6 +16,7 @@
 namespace {
 
 constexpr int kFmtDXT1 = 0, kFmtDXT5 = 1, kFmtYCoCg = 2, kFmtRGTC1 = 3;
+constexpr int kFmtYCoCgAlpha = 4;      // Hap Q Alpha: scaled YCoCg-DXT5 + RGTC1 alpha plane from one read of the RGBA
 
 // clamp(t, lo, hi) with lo <= hi: one v_med3_i32
 __device__ __forceinline__ int imed3(int t, int lo, int hi)
@@ -65,23 +66,39 @@ __device__ __forceinline__ uint2 alpha_block(const int (&a)[16])
     const int a0 = hi - inset, a1 = lo + inset;
     unsigned lo24 = 0, hi24 = 0;       // 3-bit codes of pixels 0..7 and 8..15
     if (a0 != a1) {
-        int t[7];
-        int prev = a0;
+        // oracle/bc_oracle.c: ramp position r = #{ j < 7 : 2a < q_j + q_{j+1} } with q_j = floor(((7-j) a0 + j a1) / 7).
+        // With u = a0 - a (clamped to 0..d, d = a0 - a1) and c_j = a0 - q_j = ceil(j d / 7) that is
+        // r = #{ j : u > H_j }, H_j = floor((c_j + c_{j+1}) / 2) -- thresholds that grow with j.  Instead of testing all
+        // seven, estimate from below, r_lo = floor(7 (u - 1) / d) (never more than one short: checked for every d, u),
+        // and test the one threshold that decides: r = r_lo + (u > H[r_lo]), H_7 = 255.
+        const int d = a0 - a1;
+        int c[8];
+        c[0] = 0;
 #pragma unroll
-        for (int j = 1; j < 8; j++) {
-            const int q = div7((7 - j) * a0 + j * a1);
-            t[j - 1] = prev + q;      // q_{j-1} + q_j
-            prev = q;
+        for (int j = 1; j < 7; j++)
+            c[j] = div7(j * d + 6);
+        c[7] = d;
+        unsigned h_lo = 0, h_hi = 0xFF000000u;
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const unsigned h = (unsigned)(c[j] + c[j + 1]) >> 1;
+            if (j < 4)
+                h_lo |= h << (8 * j);
+            else
+                h_hi |= h << (8 * (j - 4));
         }
+        // floor(x / d) = (x * (floor(2^19 / d) + 1)) >> 19 for x <= 7 * 254; the reciprocal from v_rcp_f32, made exact
+        unsigned q = (unsigned)(524288.0f * __builtin_amdgcn_rcpf((float)d));
+        const int rem = 524288 - (int)__umul24(q, (unsigned)d);
+        q += (rem >= d ? 1u : 0u) - (rem < 0 ? 1u : 0u);
+        const unsigned r7 = 7u * (q + 1u);
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const int v2 = 2 * a[i];
-            // r = number of thresholds above v2: med3(t, v2, v2 + 1) is v2 + (v2 < t ? 1 : 0) for integers
-            const int m0 = imed3(t[0], v2, v2 + 1), m1 = imed3(t[1], v2, v2 + 1);
-            const int m2 = imed3(t[2], v2, v2 + 1), m3 = imed3(t[3], v2, v2 + 1);
-            const int m4 = imed3(t[4], v2, v2 + 1), m5 = imed3(t[5], v2, v2 + 1);
-            const int m6 = imed3(t[6], v2, v2 + 1);
-            const unsigned r = (unsigned)((m0 + m1 + m2) + (m3 + m4 + m5) + mad24k<-14>(a[i], m6));
+            const int u = imed3(a0 - a[i], 0, d);
+            const unsigned r_lo = __umul24((unsigned)max(u - 1, 0), r7) >> 19;
+            // H[r_lo]: one byte of the 8-byte table (selector bytes 1..3 = 0x0C give zero)
+            const unsigned th = __builtin_amdgcn_perm(h_hi, h_lo, r_lo | 0x0C0C0C00u);
+            const unsigned r = r_lo + ((unsigned)u > th ? 1u : 0u);
             // ramp position -> S3TC code: 0->0, 7->1, r->r+1 (byte table 00 02 03 04 | 05 06 07 01, one v_perm)
             const unsigned code = __builtin_amdgcn_perm(0x01070605u, 0x04030200u, r);
             // three bits in from the top: after 8 pixels the codes occupy bits 31:8, pixel 0 lowest
@@ -219,7 +236,7 @@ __device__ __forceinline__ uint2 ycocg_colour_block(const int (&co)[16], const i
 
 template <int FMT, bool WIDE>
 __device__ __forceinline__ void encode_block(const uint8_t *__restrict__ rgba, size_t row_bytes, unsigned blocks_x,
-                                             uint8_t *__restrict__ out)
+                                             uint8_t *__restrict__ out, uint8_t *__restrict__ out2 = nullptr)
 {
     // one wavefront per 64 blocks of one block row: the row's address is scalar, no division per lane
     const unsigned by = blockIdx.y, bx = blockIdx.x * 64u + threadIdx.x;
@@ -273,6 +290,13 @@ __device__ __forceinline__ void encode_block(const uint8_t *__restrict__ rgba, s
         }
         const uint2 ab = alpha_block(y), cb = ycocg_colour_block(co, cg);
         *reinterpret_cast<uint4 *>(out + id * 16u) = make_uint4(ab.x, ab.y, cb.x, cb.y);
+        if (FMT == kFmtYCoCgAlpha) {
+            int a[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                a[i] = (int)(p[i] >> 24);
+            *reinterpret_cast<uint2 *>(out2 + id * 8u) = alpha_block(a);
+        }
     }
 }
 
@@ -296,6 +320,20 @@ __global__ __launch_bounds__(64) void bc_encode_batch_kernel(const uint64_t *__r
     if (!rgba || !out)
         return;
     encode_block<FMT, WIDE>(rgba, row_bytes, blocks_x, out);
+}
+
+// Hap Q Alpha: both textures of a picture in one pass over its RGBA (64 + 16 + 8 bytes per block)
+template <bool WIDE>
+__global__ __launch_bounds__(64) void bc_encode_batch2_kernel(const uint64_t *__restrict__ sources,
+                                                              const uint64_t *__restrict__ colour_outputs,
+                                                              const uint64_t *__restrict__ alpha_outputs, size_t row_bytes,
+                                                              unsigned blocks_x)
+{
+    const uint8_t *rgba = (const uint8_t *)sources[blockIdx.z];
+    uint8_t *out = (uint8_t *)colour_outputs[blockIdx.z], *out2 = (uint8_t *)alpha_outputs[blockIdx.z];
+    if (!rgba || !out || !out2)
+        return;
+    encode_block<kFmtYCoCgAlpha, WIDE>(rgba, row_bytes, blocks_x, out, out2);
 }
 
 template <int FMT>
@@ -361,5 +399,23 @@ extern "C" int hapgpu_launch_block_encode_batch(const uint64_t *sources, const u
     case 0x8DBB: launch_batch<kFmtRGTC1>(sources, outputs, pictures, row_bytes, bx, by, wide != 0, stream); break;
     default: return 1;
     }
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}
+
+// Hap Q Alpha batch: scaled YCoCg-DXT5 to colour_outputs[i] and the RGTC1 alpha plane to alpha_outputs[i], one read of
+// every RGBA picture.  Same argument rules as above.
+extern "C" int hapgpu_launch_block_encode_batch_ycocg_alpha(const uint64_t *sources, const uint64_t *colour_outputs,
+                                                            const uint64_t *alpha_outputs, unsigned pictures, unsigned width,
+                                                            unsigned height, size_t row_bytes, int wide, hipStream_t stream)
+{
+    if (!sources || !colour_outputs || !alpha_outputs || pictures == 0 || width == 0 || height == 0 || (width & 3u) ||
+        (height & 3u) || row_bytes < (size_t)width * 4u || (row_bytes & 3u) || pictures > 65535u || height / 4u > 65535u)
+        return 1;
+    const unsigned bx = width / 4u, by = height / 4u;
+    const dim3 grid((bx + 63u) / 64u, by, pictures), block(64);
+    if (wide)
+        hipLaunchKernelGGL((bc_encode_batch2_kernel<true>), grid, block, 0, stream, sources, colour_outputs, alpha_outputs, row_bytes, bx);
+    else
+        hipLaunchKernelGGL((bc_encode_batch2_kernel<false>), grid, block, 0, stream, sources, colour_outputs, alpha_outputs, row_bytes, bx);
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }

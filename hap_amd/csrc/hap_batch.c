@@ -534,6 +534,13 @@ unsigned hapb_encode_rgba(HapGpuContext *ctx, unsigned frame_count, const void *
     }
     /* one launch per texture format over the whole batch (addresses travel as a small device table) */
     if (hapgpu_rt_h2d(rt, dsrc, hsrc, sizeof(uint64_t) * (size_t)(1u + count) * frame_count) == 0) {
+        /* Hap Q Alpha: both textures from one pass over the RGBA (64 + 16 + 8 bytes per block) */
+        if (count == 2 && formats[0] == HapTextureFormat_YCoCg_DXT5 && formats[1] == HapTextureFormat_A_RGTC1) {
+            if (hapgpu_k_block_encode_batch_ycocg_alpha(rt, dsrc, dsrc + frame_count, dsrc + 2u * (size_t)frame_count, frame_count,
+                                                        width, height, row_bytes, wide) != 0)
+                for (f = 0; f < (unsigned)frame_count * count; f++)
+                    tex_ptrs[f] = NULL;
+        } else
         for (i = 0; i < count; i++)
             if (hapgpu_k_block_encode_batch(rt, dsrc, dsrc + (size_t)(1u + i) * frame_count, frame_count, width, height,
                                             row_bytes, formats[i], wide) != 0)

@@ -180,6 +180,10 @@ int hapgpu_k_block_encode(hapgpu_rt *rt, const void *rgba, unsigned width, unsig
 /* pictures of one geometry in one launch; sources / outputs: DEVICE arrays of device addresses (0 = skip) */
 int hapgpu_k_block_encode_batch(hapgpu_rt *rt, const uint64_t *sources, const uint64_t *outputs, unsigned pictures,
                                 unsigned width, unsigned height, size_t row_bytes, unsigned hap_texture_format, int wide);
+/* Hap Q Alpha: scaled YCoCg-DXT5 + RGTC1 alpha plane of every picture from one read of its RGBA */
+int hapgpu_k_block_encode_batch_ycocg_alpha(hapgpu_rt *rt, const uint64_t *sources, const uint64_t *colour_outputs,
+                                            const uint64_t *alpha_outputs, unsigned pictures, unsigned width,
+                                            unsigned height, size_t row_bytes, int wide);
 int hapgpu_k_block_decode(hapgpu_rt *rt, const void *blocks, const void *alpha, unsigned width, unsigned height,
                           unsigned hap_texture_format, void *rgba, size_t row_bytes);
 /* tile_sizes: 64 bytes per fragment (same indexing as frag_sizes), written for textures whose reserved bit 20 is set */

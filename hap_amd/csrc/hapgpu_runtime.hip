@@ -17,6 +17,9 @@ int hapgpu_launch_block_encode(const void *rgba, unsigned width, unsigned height
 int hapgpu_launch_block_encode_batch(const uint64_t *sources, const uint64_t *outputs, unsigned pictures,
                                      unsigned width, unsigned height, size_t row_bytes, unsigned format,
                                      int wide, hipStream_t stream);
+int hapgpu_launch_block_encode_batch_ycocg_alpha(const uint64_t *sources, const uint64_t *colour_outputs,
+                                                 const uint64_t *alpha_outputs, unsigned pictures, unsigned width,
+                                                 unsigned height, size_t row_bytes, int wide, hipStream_t stream);
 int hapgpu_launch_block_decode(const void *blocks, const void *alpha, unsigned width, unsigned height,
                                unsigned format, void *rgba, size_t row_bytes, hipStream_t stream);
 int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsigned frame_count, unsigned max_frags_per_texture,
@@ -359,6 +362,15 @@ extern "C" int hapgpu_k_block_encode_batch(hapgpu_rt *rt, const uint64_t *source
     scoped_timing st(rt, 0);
     return hapgpu_launch_block_encode_batch(sources, outputs, pictures, width, height, row_bytes, hap_texture_format,
                                             wide, rt->stream);
+}
+
+extern "C" int hapgpu_k_block_encode_batch_ycocg_alpha(hapgpu_rt *rt, const uint64_t *sources, const uint64_t *colour_outputs,
+                                                       const uint64_t *alpha_outputs, unsigned pictures, unsigned width,
+                                                       unsigned height, size_t row_bytes, int wide)
+{
+    scoped_timing st(rt, 0);
+    return hapgpu_launch_block_encode_batch_ycocg_alpha(sources, colour_outputs, alpha_outputs, pictures, width, height,
+                                                        row_bytes, wide, rt->stream);
 }
 
 extern "C" int hapgpu_k_block_decode(hapgpu_rt *rt, const void *blocks, const void *alpha, unsigned width,
