@@ -12,7 +12,7 @@ _API_NAMES = (
     "HapCompressorNone", "HapCompressorSnappy", "HapResult", "HapTextureFormat",
     "HapDecode", "HapEncode", "HapGetFrameTextureChunkCount", "HapGetFrameTextureCount",
     "HapGetFrameTextureFormat", "HapMaxEncodedLength", "Context", "ENCODE_FRAGMENT_INDEX", "ENCODE_COARSE_MATCHES",
-    "DECODE_IGNORE_FRAGMENT_INDEX", "DECODE_IGNORE_HALF_TILES", "KERNEL_CLASSES", "HapGpuGetFrameTextureChunkLayout", "HapGpuJoinChunkGroups", "SequenceWriter", "SequenceReader", "BufferList",
+    "DECODE_IGNORE_FRAGMENT_INDEX", "DECODE_IGNORE_HALF_TILES", "DECODE_NO_BLOCK_SCAN", "KERNEL_CLASSES", "HapGpuGetFrameTextureChunkLayout", "HapGpuJoinChunkGroups", "SequenceWriter", "SequenceReader", "BufferList",
 )
 
 

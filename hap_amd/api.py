@@ -30,8 +30,9 @@ ENCODE_FRAGMENT_INDEX = 0x1
 ENCODE_COARSE_MATCHES = 0x2
 DECODE_IGNORE_FRAGMENT_INDEX = 0x1
 DECODE_IGNORE_HALF_TILES = 0x2
+DECODE_NO_BLOCK_SCAN = 0x4
 KERNEL_CLASSES = ["block_encode", "snappy_compress", "frame_pack", "frame_gather", "decode_plan", "snappy_decode",
-                  "block_decode"]
+                  "block_decode", "block_scan"]
 
 
 def _addr_len(buf):

@@ -23,6 +23,8 @@ enum {
 };
 #define D_TILESIZES D_PTRS   /* encode-only arenas in decode-only slots: one call never needs both */
 #define D_PACK D_PREFIX
+#define D_SCAN D_SLOTS       /* ... and the decoder's block-scan arena in an encode-only one */
+#define P_SCAN P_FRAMES
 enum { P_FRAMES = 0, P_JOBS, P_CHUNKS, P_PREFIX, P_PTRS, P_BC_PTRS };   /* (8, 9: hap_sequence.c) */
 
 #define PREFIX_BYTES 8192u   /* headers + tables of a frame with a few hundred chunks; larger ones are fetched on demand */
@@ -584,6 +586,41 @@ static void mark_chunk(void *p, unsigned index)
         m->requested[index] = 1;
 }
 
+/* Unit slots to reserve behind a whole-stream unit for the block scan (snappy_decode.hip): one per 64 KiB of output.
+   The output length is on the device (the stream's varint); bound it by the client's buffer and by the format's
+   largest expansion (a 3-byte copy element produces 64 bytes).  Streams of one block need none. */
+static void scan_entry(HapGpuScanChunk *e, unsigned unit, unsigned long src_len, unsigned slots, uint32_t *dbpos,
+                       unsigned *seg_cursor, unsigned *word_cursor);
+
+static unsigned stream_scan_segments(unsigned long src_len)
+{
+    return (unsigned)(((unsigned long long)src_len + 15u + HAPGPU_SCAN_SEGMENT - 1u) / HAPGPU_SCAN_SEGMENT);
+}
+
+static unsigned stream_block_slots(unsigned long src_len, unsigned long dst_cap)
+{
+    unsigned long long bound = (unsigned long long)src_len * 22u;
+    if (bound > dst_cap)
+        bound = dst_cap;
+    if (bound <= 65536u)
+        return 0u;
+    bound = (bound + 65535u) / 65536u;
+    return bound > 4096u ? 4096u : (unsigned)bound;
+}
+
+static void scan_entry(HapGpuScanChunk *e, unsigned unit, unsigned long src_len, unsigned slots, uint32_t *dbpos,
+                       unsigned *seg_cursor, unsigned *word_cursor)
+{
+    memset(e, 0, sizeof(*e));
+    e->unit = unit;
+    e->seg_first = *seg_cursor;
+    e->seg_count = stream_scan_segments(src_len);
+    e->slots = slots;
+    e->bpos = (uint64_t)(uintptr_t)(dbpos + *word_cursor);
+    *seg_cursor += e->seg_count;
+    *word_cursor += slots + 1u;
+}
+
 unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const *inputs,
                      const unsigned long *input_bytes, unsigned index, void *const *outputs,
                      const unsigned long *output_bytes, unsigned long *output_used,
@@ -597,12 +634,18 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     unsigned f, live = 0, first_error = HapResult_No_Error, total_units = 0, total_chunks = 0;
     unsigned frag_log2_seen = 0, frag_kinds = 0, max_chunks = 0;
     int any_stream = 0, need_retry = 0;
+    unsigned scan_chunks = 0, scan_segs = 0, scan_words = 0;   /* streams with BLOCK slots; their segments; bpos words */
+    const int block_scan = !(flags & HAPGPU_DECODE_NO_BLOCK_SCAN) && !ctx->no_block_scan;
     uint8_t *prefix = NULL, *in_stage = NULL, *out_stage = NULL;
     size_t in_stage_bytes = 0, out_stage_bytes = 0;
     size_t *in_off, *out_off;
     HapGpuDecodeJob *hjobs, *djobs;
     HapGpuChunkIn *hchunks, *dchunks;
     HapGpuDecodeUnit *dunits;
+    HapGpuScanChunk *hscan = NULL, *dscan = NULL;
+    HapGpuScanSegment *dsegs = NULL;
+    uint32_t *dbpos = NULL;
+    uint8_t *drecs = NULL;
     unsigned *job_of_frame;
     unsigned char *in_dev = NULL, *out_dev = NULL;     /* pointer classification, done once per buffer */
     unsigned char *client_marks = NULL;                /* what the client's callback asked for (single-frame path) */
@@ -715,7 +758,8 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                 ch->unit_first = units;
                 ch->frag_first = per_chunk * (unsigned)c;
                 if (codec == HAP_NIBBLE_SNAPPY)
-                    ch->unit_count = per_chunk ? per_chunk : 1u;
+                    ch->unit_count = per_chunk ? per_chunk
+                                               : 1u + (block_scan ? stream_block_slots(ch->src_len, output_bytes[f]) : 0u);
                 else if (codec == HAP_NIBBLE_NONE)
                     ch->unit_count = ch->src_len ? (ch->src_len + COPY_PIECE - 1) / COPY_PIECE : 1u;
                 else
@@ -734,7 +778,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                     for (c = 0; c < p->chunk_count; c++) {
                         HapGpuChunkIn *ch = &p->chunks[c];
                         if ((ch->codec & 0xFFu) == HAP_NIBBLE_SNAPPY)
-                            ch->unit_count = 1u;
+                            ch->unit_count = 1u + (block_scan ? stream_block_slots(ch->src_len, output_bytes[f]) : 0u);
                         ch->unit_first = units;
                         units += ch->unit_count;
                     }
@@ -743,6 +787,13 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                     frag_log2_seen = p->frag_log2;
                 }
             }
+            if (!p->frag_table_offset)
+                for (c = 0; c < p->chunk_count; c++)
+                    if ((p->chunks[c].codec & 0xFFu) == HAP_NIBBLE_SNAPPY && p->chunks[c].unit_count > 1u) {
+                        scan_chunks += 1u;
+                        scan_segs += stream_scan_segments(p->chunks[c].src_len);
+                        scan_words += p->chunks[c].unit_count;          /* slots + 1 */
+                    }
             total_chunks += (unsigned)p->chunk_count;
             if ((unsigned)p->chunk_count > max_chunks)
                 max_chunks = (unsigned)p->chunk_count;
@@ -750,7 +801,12 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
             units = p->section_length ? (p->section_length + COPY_PIECE - 1) / COPY_PIECE : 1u;
             any_stream = 1;
         } else {
-            units = 1;
+            units = 1u + (block_scan ? stream_block_slots(p->section_length, output_bytes[f]) : 0u);
+            if (units > 1u) {
+                scan_chunks += 1u;
+                scan_segs += stream_scan_segments(p->section_length);
+                scan_words += units;
+            }
             any_stream = 1;
         }
         job_of_frame[f] = live++;
@@ -780,8 +836,24 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
         rc = 1;
         goto fail_alloc;
     }
+    if (scan_chunks) {
+        /* one arena: chunk table | segment summaries | block positions | window records */
+        const size_t o_segs = align_up(sizeof(HapGpuScanChunk) * scan_chunks, 64);
+        const size_t o_bpos = o_segs + sizeof(HapGpuScanSegment) * scan_segs;
+        const size_t o_recs = align_up(o_bpos + sizeof(uint32_t) * scan_words, 64);
+        uint8_t *arena = (uint8_t *)hapgpu_rt_device_scratch(rt, D_SCAN, o_recs + (size_t)512u * scan_segs);
+        hscan = (HapGpuScanChunk *)hapgpu_rt_pinned_scratch(rt, P_SCAN, sizeof(HapGpuScanChunk) * scan_chunks);
+        if (!arena || !hscan) {
+            rc = 1;
+            goto fail_alloc;
+        }
+        dscan = (HapGpuScanChunk *)arena;
+        dsegs = (HapGpuScanSegment *)(arena + o_segs);
+        dbpos = (uint32_t *)(arena + o_bpos);
+        drecs = arena + o_recs;
+    }
     {
-        unsigned chunk_cursor = 0, unit_cursor = 0;
+        unsigned chunk_cursor = 0, unit_cursor = 0, scan_cursor = 0, seg_cursor = 0, word_cursor = 0;
         request_marks marks;
         marks.count = 0;
         marks.requested = NULL;
@@ -832,9 +904,22 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                 if (p->chunk_count > 0)
                     memcpy(hchunks + chunk_cursor, p->chunks, sizeof(HapGpuChunkIn) * (size_t)p->chunk_count);
                 chunk_cursor += (unsigned)p->chunk_count;
+                if (scan_chunks && !p->frag_table_offset) {
+                    int c;
+                    for (c = 0; c < p->chunk_count; c++) {
+                        const HapGpuChunkIn *ch = &p->chunks[c];
+                        if ((ch->codec & 0xFFu) != HAP_NIBBLE_SNAPPY || ch->unit_count <= 1u)
+                            continue;
+                        scan_entry(&hscan[scan_cursor++], unit_cursor + ch->unit_first, ch->src_len, ch->unit_count - 1u,
+                                   dbpos, &seg_cursor, &word_cursor);
+                    }
+                }
             } else {
                 job->payload = (uint64_t)(uintptr_t)(frame_dev + p->section_offset);
                 job->payload_len = p->section_length;
+                if (scan_chunks && p->mode == HAPGPU_JOB_SNAPPY && units > 1u)
+                    scan_entry(&hscan[scan_cursor++], unit_cursor, p->section_length, units - 1u, dbpos, &seg_cursor,
+                               &word_cursor);
             }
             unit_cursor += units;
         }
@@ -897,7 +982,13 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                 }
             }
         }
-        rc |= hapgpu_k_snappy_decode(rt, dunits, total_units, djobs, frag_log2_seen, frag_kinds, any_stream);
+        /* streams of other encoders (no fragment table): find their independent 64 KiB blocks first */
+        if (scan_chunks && scan_cursor == scan_chunks) {
+            rc |= hapgpu_rt_h2d(rt, dscan, hscan, sizeof(HapGpuScanChunk) * scan_chunks);
+            rc |= hapgpu_k_scan_blocks(rt, dunits, djobs, dscan, scan_chunks, dsegs, drecs, scan_segs);
+        }
+        rc |= hapgpu_k_snappy_decode(rt, dunits, total_units, djobs, frag_log2_seen, frag_kinds,
+                                     any_stream ? (scan_chunks ? 2 : 1) : 0);
         rc |= hapgpu_rt_d2h(rt, hjobs, djobs, sizeof(HapGpuDecodeJob) * live);
         rc |= hapgpu_rt_sync(rt);
         if (rc)
@@ -946,7 +1037,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
             }
             hapb_decode(ctx, 1, &inputs[f], &input_bytes[f], index, &outputs[f], &output_bytes[f],
                         output_used ? &output_used[f] : NULL, output_formats ? &output_formats[f] : NULL,
-                        &results[f], flags | HAPGPU_DECODE_IGNORE_FRAGMENT_INDEX,
+                        &results[f], flags | HAPGPU_DECODE_IGNORE_FRAGMENT_INDEX | HAPGPU_DECODE_NO_BLOCK_SCAN,
                         frame_count == 1 ? callback : NULL, callback_info);
             ctx->preset_marks = NULL;
             ctx->preset_count = 0;

@@ -135,9 +135,38 @@ typedef struct HapGpuDecodeJob {
 #define HAPGPU_UNIT_SNAPPY_FIELDS4 6u   /* fragment of a field stream, 16-byte blocks of 2 + 6 + 4 + 4 bytes; aux = its half-tile sizes */
 #define HAPGPU_UNIT_SNAPPY_FIELDS2 7u   /* ... 8-byte blocks of 4 + 4 bytes */
 #define HAPGPU_UNIT_SNAPPY_FIELDS26 8u  /* ... 8-byte blocks of 2 + 6 bytes */
+#define HAPGPU_UNIT_SNAPPY_BLOCK 9u     /* one 64 KiB block of another encoder's stream, found by the block scan: bare
+                                           elements, copies stay inside the block; decoded by the whole-stream kernel.
+                                           aux = its HapGpuScanChunk, reserved = block number, src = the stream */
 #define HAPGPU_UNIT_WINDOWED 0x10u       /* flag on the three fragment kinds: every copy offset is <= 3 KiB, so an 8 KiB
                                             fragment decodes through a 4 KiB LDS ring (twice the waves per CU) */
 #define HAP_FRAGMENT_WINDOW_256 12u      /* that window in 256-byte units, as written to the fragment table */
+
+/* Block scan of another encoder's Snappy stream (snappy_decode.hip): the stream's compressed bytes are looked at in
+   segments of HAPGPU_SCAN_SEGMENT bytes (of the 16-byte aligned address range that holds them). */
+#define HAPGPU_SCAN_SEGMENT 4096u
+typedef struct HapGpuScanChunk {
+    /* filled by the host */
+    uint32_t unit;           /* index of the stream's whole-stream unit in the call's unit array */
+    uint32_t seg_first;      /* first of its seg_count segment records */
+    uint32_t seg_count;      /* >= segments the stream can touch: (src_len + 15 + 4095) / 4096 */
+    uint32_t slots;          /* unit slots reserved behind the stream unit (one per 64 KiB block) */
+    uint64_t bpos;           /* device address of slots + 1 words: compressed position where each block begins */
+    /* written by the device (the host sends zeros) */
+    uint32_t ok;             /* the element chain was followed to the stream's end and the lengths agree */
+    uint32_t expected;       /* blocks */
+    uint32_t found;          /* block starts that fall on an element boundary: all of them = BLOCK units run */
+    uint32_t reserved;
+} HapGpuScanChunk;
+
+typedef struct HapGpuScanSegment {   /* device only */
+    uint32_t exit_coord;     /* where the segment's (guessed) chain left the segment */
+    uint32_t cum_total;      /* output bytes that chain produced from its start to there */
+    uint32_t flags;          /* 1: the chain met something that is not an element; 2: it reached the end of the input */
+    uint32_t merge_window;   /* window in which the true chain joined the recorded one (0xFFFFFFFF: never) */
+    uint32_t base_op;        /* absolute output position of the recorded chain's zero */
+    uint32_t reserved[3];
+} HapGpuScanSegment;
 
 /* [device] one wavefront's worth of decode work */
 typedef struct HapGpuDecodeUnit {
@@ -147,7 +176,10 @@ typedef struct HapGpuDecodeUnit {
     uint32_t dst_len;
     uint32_t kind;           /* HAPGPU_UNIT_* */
     uint32_t job;            /* index of the owning job (status word) */
-    uint64_t aux;            /* FIELDS units: device address of the fragment's 64 half-tile size bytes */
+    uint64_t aux;            /* FIELDS units: device address of the fragment's 64 half-tile size bytes;
+                                STREAM units: number of SKIP slots that follow for the block scan's BLOCK units */
+    /* reserved: fragment units: readable bytes after the fragment (<= 15); STREAM units: 0 or the HapGpuScanChunk
+       that decides whether the stream unit or its BLOCK units run */
     uint64_t reserved;
 } HapGpuDecodeUnit;
 
@@ -207,9 +239,16 @@ int hapgpu_k_gather_prefixes(hapgpu_rt *rt, const uint64_t *frames_dev, const ui
 /* clears `units` (all SKIP) then plans every job; max_chunks: largest chunk_count among the jobs */
 int hapgpu_k_decode_plan(hapgpu_rt *rt, HapGpuDecodeJob *jobs, unsigned job_count,
                          HapGpuDecodeUnit *units, unsigned unit_count, unsigned max_chunks);
+/* splits whole-stream units that consist of independent 64 KiB blocks (what libsnappy writes) into BLOCK units,
+ * using the slots reserved behind them; streams that do not qualify stay as they are.  chunks: one entry per stream
+ * (host-filled part copied to the device by the caller); segs / recs: device scratch of seg_total entries /
+ * seg_total * 64 words of 8 bytes */
+int hapgpu_k_scan_blocks(hapgpu_rt *rt, HapGpuDecodeUnit *units, const HapGpuDecodeJob *jobs, HapGpuScanChunk *chunks,
+                         unsigned chunk_count, HapGpuScanSegment *segs, void *recs, unsigned seg_total);
 /* frag_log2: fragment size of the batch's FRAGMENT units (0: none present);
  * fragment_kinds: bit g set = fragments of granularity_log2 g present */
 /* fragment_kinds bits 8 / 9 / 10: field-stream units of [2,6,4,4] / [4,4] / [2,6] blocks present */
+/* any_stream_or_copy_units: 0 none, 1 whole streams / raw copies, 2 the same with block-scanned streams among them */
 int hapgpu_k_snappy_decode(hapgpu_rt *rt, const HapGpuDecodeUnit *units, unsigned unit_count,
                            HapGpuDecodeJob *jobs, unsigned frag_log2, unsigned fragment_kinds,
                            int any_stream_or_copy_units);

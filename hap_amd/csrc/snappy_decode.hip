@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64) void decode_plan_kernel(HapGpuDecodeJob *jobs, 
                 w.src = (uint64_t)payload; w.dst = (uint64_t)dst;
                 w.src_len = (unsigned)job->payload_len; w.dst_len = n;
                 w.kind = HAPGPU_UNIT_SNAPPY_STREAM; w.job = j;
-                w.aux = 0; w.reserved = 0;
+                w.aux = job->unit_count - 1u; w.reserved = 0;       // slots for the block scan
                 units[0] = w;
                 used = n;
             }
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64) void decode_plan_kernel(HapGpuDecodeJob *jobs, 
                     w.dst_len = out_len;
                     w.kind = HAPGPU_UNIT_SNAPPY_STREAM;
                     w.job = j;
-                    w.aux = 0;
+                    w.aux = c.unit_count - 1u;                    // slots for the block scan
                     w.reserved = 0;
                     u[0] = w;
                 }
@@ -454,20 +454,36 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
             wave_copy((uint8_t *)u.dst, (const uint8_t *)u.src, u.src_len, lane);
         return;
     }
-    if (STREAM ? u.kind != HAPGPU_UNIT_SNAPPY_STREAM
+    if (STREAM ? (u.kind != HAPGPU_UNIT_SNAPPY_STREAM && u.kind != HAPGPU_UNIT_SNAPPY_BLOCK)
                : u.kind != ((GRAN == 4 ? HAPGPU_UNIT_SNAPPY_FRAGMENT32
                                        : GRAN == 2 ? HAPGPU_UNIT_SNAPPY_FRAGMENT16 : HAPGPU_UNIT_SNAPPY_FRAGMENT) |
                             (SLIDE ? HAPGPU_UNIT_WINDOWED : 0u)))
         return;
-    constexpr bool kFlushEarly = STREAM || SLIDE;
-    constexpr unsigned kFlushSegment = SLIDE ? 1024u : kSegment;
-    constexpr unsigned kFlushAt = SLIDE ? 1024u : 2u * kSegment;
-
     const uint8_t *src = (const uint8_t *)u.src;
+    unsigned src_len = u.src_len;
+    if (STREAM && (u.kind == HAPGPU_UNIT_SNAPPY_BLOCK || u.reserved != 0u)) {
+        // a stream the block scan looked at: its BLOCK units run when every block start was found, else the stream unit
+        const HapGpuScanChunk *scan = (const HapGpuScanChunk *)(u.kind == HAPGPU_UNIT_SNAPPY_BLOCK ? u.aux : u.reserved);
+        const bool split = scan->ok != 0u && scan->found == scan->expected;
+        if (split != (u.kind == HAPGPU_UNIT_SNAPPY_BLOCK))
+            return;
+        if (split) {
+            const uint32_t *bpos = (const uint32_t *)scan->bpos;
+            const unsigned from = bpos[u.reserved], to = bpos[u.reserved + 1u];
+            src += from;
+            src_len = to >= from ? to - from : 0u;
+        }
+    }
+    constexpr bool kFlushEarly = STREAM || SLIDE;
+    // rings below 16 KiB (windowed fragments; streams decoded with many waves per CU) give finished output back in
+    // 1 KiB pieces
+    constexpr unsigned kFlushSegment = (SLIDE || RING < 16384u) ? 1024u : kSegment;
+    constexpr unsigned kFlushAt = (SLIDE || RING < 16384u) ? 1024u : 2u * kSegment;
+
     uint8_t *dst = (uint8_t *)u.dst;
     const unsigned shift = (unsigned)((uintptr_t)src & 15u);
     const uint8_t *src_al = src - shift;
-    const unsigned in_end = shift + u.src_len;
+    const unsigned in_end = shift + src_len;
     const unsigned out_len = u.dst_len;
 
     auto load_granule = [&](unsigned g) -> uint4 {
@@ -504,8 +520,8 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
 
     bool failed = !kFlushEarly && out_len > RING;
     unsigned op = 0, flushed = 0;
-    if (STREAM) {
-        // skip the length prefix (validated by the plan kernel)
+    if (STREAM && u.kind == HAPGPU_UNIT_SNAPPY_STREAM) {
+        // skip the length prefix (validated by the plan kernel); BLOCK units are bare elements
         unsigned b;
         do {
             b = smem[RING + (ip & (kV2InBytes - 1))];
@@ -750,14 +766,469 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
         failed = true;
     if (failed) {
         if (lane == 0) {
-            const unsigned code = !STREAM ? HAPGPU_STATUS_INDEX_MISMATCH
-                                          : (job->mode == HAPGPU_JOB_SNAPPY ? kResInternal : kResBadFrame);
+            // (a BLOCK unit that fails -- a copy reaching before its block -- has the frame decoded again whole)
+            const unsigned code = (!STREAM || u.kind == HAPGPU_UNIT_SNAPPY_BLOCK)
+                                      ? HAPGPU_STATUS_INDEX_MISMATCH
+                                      : (job->mode == HAPGPU_JOB_SNAPPY ? kResInternal : kResBadFrame);
             atomicCAS(&job->status, 0u, code);
         }
         return;
     }
     if (op > flushed)
         flush_ring<RING>(ring, dst, flushed, op, lane);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// block scan for streams from other encoders
+// ------------------------------------------------------------------------------------------
+//
+// libsnappy -- what the reference's HapEncode calls (hap.c:453) -- compresses independent 64 KiB blocks: no element
+// crosses a multiple of 64 KiB of output and no copy reaches before the start of its block.  A chunk
+// of such a stream (1.38 MB at 8K, 4 MiB at 16K) therefore is 22 / 64 independently decodable pieces -- if one knows
+// where in the compressed bytes they begin.  Finding out means walking the element chain, which is serial; three
+// kernels make it parallel, all built on the window parser of the decoder above (speculative parse of 64 byte
+// positions, chain membership by pointer doubling) and none producing any output:
+//
+//   scan_walk_kernel   one wavefront per 4 KiB of COMPRESSED bytes (a "segment").  It starts 5 windows before its
+//                      segment on a guess -- the element chain from an arbitrary byte joins the true chain within a
+//                      few elements -- and records, for each of the segment's 64 windows, at which byte the chain
+//                      entered it and how much output the chain had produced by then; plus where it left the segment.
+//   scan_merge_kernel  one wavefront per chunk follows the TRUE chain from the stream's first element, but only until
+//                      it stands on a byte the segment's record also entered: from there the record is the true
+//                      chain, and the walk continues at the record's exit in the next segment (where, thanks to the
+//                      warm-up, it usually matches at once).  This gives every segment its absolute output position.
+//   scan_find_kernel   one wavefront per segment looks up which of its windows holds each multiple of 64 KiB of
+//                      output, parses that one window again and notes the compressed position of the element that
+//                      starts exactly there (none: an element straddles the boundary, the stream is not splittable).
+//
+// When every boundary of a chunk was found, its BLOCK units (written by the merge kernel into the slots the host
+// reserved behind the stream unit) decode it, one wavefront per 64 KiB block, in the whole-stream kernel below with a
+// small ring; otherwise they return at once and the stream unit runs as before.  What the scan does not check -- a
+// copy reaching before its block -- the BLOCK unit's own offset check catches: the frame is then decoded again
+// without the scan, as after a fragment table that lied.  An 8K frame's 24 chunks become 528 units.
+constexpr unsigned kScanSegment = HAPGPU_SCAN_SEGMENT;
+constexpr unsigned kScanWarmWindows = 5u;                     // > the longest element that is not a "long literal" (258 bytes)
+constexpr unsigned kScanLds = kScanSegment + 64u * kScanWarmWindows + 128u;
+constexpr unsigned kBlockOut = 65536u;
+constexpr unsigned kRecNone = 0xFFu;
+
+// One 16-byte / 4-byte piece of the stream at aligned coordinate c, without touching bytes at or after in_end.
+__device__ __forceinline__ uint4 scan_load16(const uint8_t *src_al, unsigned c, unsigned in_end)
+{
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (c + 16u <= in_end) {
+        v = *reinterpret_cast<const uint4 *>(src_al + c);
+    } else if (c < in_end) {
+        unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll 1
+        for (unsigned k = 0; k < 16u && c + k < in_end; k++)
+            w[k >> 2] |= (unsigned)src_al[c + k] << (8 * (k & 3));
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    return v;
+}
+
+__device__ __forceinline__ unsigned scan_load4(const uint8_t *src_al, unsigned c, unsigned in_end)
+{
+    unsigned v = 0;
+    if (c + 4u <= in_end) {
+        v = *reinterpret_cast<const uint32_t *>(src_al + c);
+    } else if (c < in_end) {
+#pragma unroll 1
+        for (unsigned k = 0; k < 4u && c + k < in_end; k++)
+            v |= (unsigned)src_al[c + k] << (8 * k);
+    }
+    return v;
+}
+
+// The element that would start at coordinate x, from the five bytes there (lo: bytes x..x+3, hi: byte x+4).
+struct ScanElement {
+    unsigned len;        // output bytes
+    unsigned tokbytes;   // input bytes
+    bool stopper;        // not an element the window parser takes: a literal with 2..4 length bytes, or cut off by the input's end
+};
+
+__device__ __forceinline__ ScanElement scan_parse(unsigned lo, unsigned x, unsigned in_end)
+{
+    const unsigned tag = lo & 0xFFu, kind = tag & 3u;
+    unsigned len, hdr;
+    bool special = false;
+    if (kind == 0) {
+        len = (tag >> 2) + 1u;
+        hdr = 1;
+        if (len == 61u) {
+            len = ((lo >> 8) & 0xFFu) + 1u;
+            hdr = 2;
+        } else if (len > 61u) {
+            special = true;
+            hdr = 1u + (len - 60u);
+        }
+    } else if (kind == 1) {
+        len = 4u + ((tag >> 2) & 7u);
+        hdr = 2;
+    } else if (kind == 2) {
+        len = (tag >> 2) + 1u;
+        hdr = 3;
+    } else {
+        len = (tag >> 2) + 1u;
+        hdr = 5;
+    }
+    ScanElement el;
+    el.len = len;
+    el.tokbytes = hdr + (kind == 0 ? len : 0u);
+    el.stopper = special || x >= in_end || el.tokbytes > in_end - x;
+    return el;
+}
+
+// Lanes on the element chain that starts at lane `from` of a 64-byte window (0: the element at `from` is a stopper).
+__device__ __forceinline__ unsigned long long scan_chain(const ScanElement &el, unsigned lane, unsigned from)
+{
+    const unsigned nxt = el.stopper ? 64u : min(lane + el.tokbytes, 64u);
+    unsigned long long mask1 = el.stopper ? 0ull : (1ull << lane);
+    unsigned j1 = nxt;
+    unsigned g_j = (unsigned)lane_gather((int)j1, j1 & 63u);
+    unsigned g_lo = (unsigned)lane_gather((int)(unsigned)mask1, j1 & 63u);
+    unsigned g_hi = (unsigned)lane_gather((int)(unsigned)(mask1 >> 32), j1 & 63u);
+    unsigned long long mask2 = mask1 | (j1 < 64u ? (((unsigned long long)g_hi << 32) | g_lo) : 0ull);
+    unsigned j2 = j1 < 64u ? g_j : 64u;
+    g_j = (unsigned)lane_gather((int)j2, j2 & 63u);
+    g_lo = (unsigned)lane_gather((int)(unsigned)mask2, j2 & 63u);
+    g_hi = (unsigned)lane_gather((int)(unsigned)(mask2 >> 32), j2 & 63u);
+    const unsigned long long mask4 = mask2 | (j2 < 64u ? (((unsigned long long)g_hi << 32) | g_lo) : 0ull);
+    const unsigned j4 = j2 < 64u ? g_j : 64u;
+    unsigned long long T = 0;
+    for (unsigned s = from; s < 64u;) {
+        const unsigned m_lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mask4, (int)s);
+        const unsigned m_hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mask4 >> 32), (int)s);
+        T |= ((unsigned long long)m_hi << 32) | m_lo;
+        s = (unsigned)__builtin_amdgcn_readlane((int)j4, (int)s);
+    }
+    return T;
+}
+
+// The long literal (2..4 length bytes) at coordinate p, from its first five bytes: header and payload sizes.
+// false: not a long literal, or it does not fit the input.
+__device__ __forceinline__ bool scan_long_literal(unsigned lo0, unsigned hi0, unsigned p, unsigned in_end, unsigned *hdr, unsigned *llen)
+{
+    const unsigned tag0 = lo0 & 0xFFu;
+    if ((tag0 & 3u) != 0 || (tag0 >> 2) < 61u || p >= in_end)
+        return false;
+    const unsigned extra = (tag0 >> 2) - 59u;
+    const unsigned long long field = (((unsigned long long)hi0 << 32) | lo0) >> 8;
+    const unsigned v = (unsigned)(extra == 4 ? field : (field & ((1ull << (8 * extra)) - 1ull)));
+    const unsigned h = 1u + extra;
+    if (h > in_end - p || v == 0xFFFFFFFFu || v + 1u > in_end - p - h)
+        return false;
+    *hdr = h;
+    *llen = v + 1u;
+    return true;
+}
+
+// chunk of global segment g: the last chunk whose seg_first is <= g
+__device__ __forceinline__ unsigned scan_chunk_of(const HapGpuScanChunk *chunks, unsigned chunk_count, unsigned g)
+{
+    unsigned lo = 0, hi = chunk_count;
+    while (hi - lo > 1u) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (chunks[mid].seg_first <= g)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ bool scan_unit_wanted(const HapGpuDecodeUnit &u, const HapGpuDecodeJob *jobs)
+{
+    return u.kind == HAPGPU_UNIT_SNAPPY_STREAM && u.aux != 0u && jobs[u.job].status == 0u && u.dst_len > kBlockOut;
+}
+
+__global__ __launch_bounds__(64) void scan_walk_kernel(const HapGpuDecodeUnit *units, const HapGpuDecodeJob *jobs,
+                                                       const HapGpuScanChunk *chunks, unsigned chunk_count,
+                                                       HapGpuScanSegment *segs, unsigned long long *recs, unsigned seg_total)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t smem[kScanLds];
+    const uint32_t *inw = reinterpret_cast<const uint32_t *>(smem);
+    const unsigned lane = threadIdx.x, g = blockIdx.x;
+    if (g >= seg_total)
+        return;
+    const HapGpuScanChunk sc = chunks[scan_chunk_of(chunks, chunk_count, g)];
+    const unsigned s = g - sc.seg_first;
+    const HapGpuDecodeUnit u = units[sc.unit];
+    const unsigned shift = (unsigned)(u.src & 15u);
+    const uint8_t *src_al = (const uint8_t *)u.src - shift;
+    const unsigned in_end = shift + u.src_len;
+    const unsigned seg_begin = s * kScanSegment, seg_end = seg_begin + kScanSegment;
+    unsigned long long rec = kRecNone;
+    unsigned flags = 1u, cum = 0, p = 0;
+    if (scan_unit_wanted(u, jobs) && s < sc.seg_count && seg_begin < in_end) {
+        const unsigned warm = s == 0 ? 0u : kScanWarmWindows;
+        const unsigned stage_begin = seg_begin - 64u * warm;
+        const unsigned stage_end = min(seg_end + 64u, (in_end + 15u) & ~15u);
+        for (unsigned c = stage_begin + lane * 16u; c < stage_end; c += 1024u)
+            *reinterpret_cast<uint4 *>(smem + (c - stage_begin)) = scan_load16(src_al, c, in_end);
+        __syncthreads();
+        p = stage_begin;
+        if (s == 0) {      // the stream's first element follows its length prefix (validated by the plan kernel)
+            unsigned b;
+            p = shift;
+            do {
+                b = smem[p];
+                p++;
+            } while ((b & 0x80u) && p < in_end);
+            p = uniform(p);
+        }
+        flags = 0;
+        unsigned seen = 0xFFFFFFFFu;            // window whose entry is on record
+        while (p < seg_end) {
+            if (p >= in_end) {
+                flags = 2u;                      // (advances never pass in_end)
+                break;
+            }
+            const unsigned wi = (p - stage_begin) >> 6, ws = stage_begin + wi * 64u, e = p - ws;
+            if (wi != seen && wi >= warm && lane == wi - warm)
+                rec = ((unsigned long long)cum << 8) | e;
+            seen = wi;
+            const unsigned x = ws + lane, xi = (x - stage_begin) >> 2, sh = x & 3u;
+            const unsigned w0 = inw[xi], w1 = inw[xi + 1u];
+            const unsigned lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
+            const unsigned hi = (w1 >> (8u * sh)) & 0xFFu;
+            const ScanElement el = scan_parse(lo, x, in_end);
+            const unsigned long long T = scan_chain(el, lane, e);
+            if (T == 0ull) {
+                unsigned h = 0, llen = 0;
+                const bool is_long = scan_long_literal((unsigned)__builtin_amdgcn_readlane((int)lo, (int)e),
+                                                       (unsigned)__builtin_amdgcn_readlane((int)hi, (int)e), p, in_end, &h, &llen);
+                if (p < seg_begin) {             // still guessing: try again from the next window
+                    p = ws + 64u;
+                    continue;
+                }
+                if (!is_long) {
+                    flags = 1u;                  // not an element: if this is the true chain, the stream is broken
+                    break;
+                }
+                p += h + llen;
+                cum += llen;
+                continue;
+            }
+            const bool is_tok = __builtin_amdgcn_inverse_ballot_w64(T);
+            const int incl = wave_scan_add(is_tok ? (int)el.len : 0);
+            const unsigned last = 63u - (unsigned)__builtin_clzll(T);
+            cum += (unsigned)__builtin_amdgcn_readlane(incl, 63);
+            p = ws + last + (unsigned)__builtin_amdgcn_readlane((int)el.tokbytes, (int)last);
+        }
+        if (flags == 0u && p >= in_end)
+            flags = 2u;
+    }
+    recs[(size_t)g * 64u + lane] = rec;
+    if (lane == 0) {
+        HapGpuScanSegment sg;
+        sg.exit_coord = p;
+        sg.cum_total = cum;
+        sg.flags = flags;
+        sg.merge_window = 0xFFFFFFFFu;
+        sg.base_op = 0;
+        sg.reserved[0] = sg.reserved[1] = sg.reserved[2] = 0;
+        segs[g] = sg;
+    }
+}
+
+// A window read straight from memory (the merge and find kernels visit few windows).
+__device__ __forceinline__ void scan_window_bytes(const uint8_t *src_al, unsigned x, unsigned in_end, unsigned *lo, unsigned *hi)
+{
+    const unsigned c = x & ~3u, sh = x & 3u;
+    const unsigned w0 = scan_load4(src_al, c, in_end), w1 = scan_load4(src_al, c + 4u, in_end);
+    *lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
+    *hi = (w1 >> (8u * sh)) & 0xFFu;
+}
+
+__global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units, const HapGpuDecodeJob *jobs,
+                                                        HapGpuScanChunk *chunks, unsigned chunk_count,
+                                                        HapGpuScanSegment *segs, const unsigned long long *recs)
+{
+    const unsigned lane = threadIdx.x, c = blockIdx.x;
+    if (c >= chunk_count)
+        return;
+    const HapGpuScanChunk sc = chunks[c];
+    const HapGpuDecodeUnit u = units[sc.unit];
+    const unsigned out_len = u.dst_len;
+    const unsigned nblk = (out_len + kBlockOut - 1u) / kBlockOut;
+    if (!scan_unit_wanted(u, jobs) || nblk > sc.slots)
+        return;                                   // (ok stays 0: the host sent zeros)
+    const unsigned shift = (unsigned)(u.src & 15u);
+    const uint8_t *src_al = (const uint8_t *)u.src - shift;
+    const unsigned in_end = shift + u.src_len;
+    uint32_t *bpos = (uint32_t *)sc.bpos;
+    unsigned p = shift;
+    {
+        unsigned b;
+        do {
+            b = src_al[p];
+            p++;
+        } while ((b & 0x80u) && p < in_end);
+        p = uniform(p);
+    }
+    unsigned op = 0, found = 0, cur = 0xFFFFFFFFu;
+    unsigned long long rec = kRecNone;
+    HapGpuScanSegment sg = {};
+    bool ok = true;
+    while (p < in_end) {
+        const unsigned s = p / kScanSegment, wi = (p % kScanSegment) >> 6, e = p & 63u;
+        if (s != cur) {
+            rec = recs[(size_t)(sc.seg_first + s) * 64u + lane];
+            sg = segs[sc.seg_first + s];
+            cur = s;
+        }
+        const unsigned r_lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)rec, (int)wi);
+        const unsigned r_hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rec >> 32), (int)wi);
+        if ((r_lo & 0xFFu) == e) {
+            // the record's chain entered this window where the true chain stands: the rest of the segment is on record
+            if (sg.flags & 1u) {
+                ok = false;
+                break;
+            }
+            const unsigned at_entry = (r_lo >> 8) | (r_hi << 24);
+            const unsigned base_op = op - at_entry;
+            if (lane == 0) {
+                segs[sc.seg_first + s].merge_window = wi;
+                segs[sc.seg_first + s].base_op = base_op;
+            }
+            p = sg.exit_coord;
+            op = base_op + sg.cum_total;
+            continue;
+        }
+        // not yet: one window of the true chain, parsed here
+        const unsigned ws = p - e, x = ws + lane;
+        unsigned lo, hi;
+        scan_window_bytes(src_al, x, in_end, &lo, &hi);
+        const ScanElement el = scan_parse(lo, x, in_end);
+        const unsigned long long T = scan_chain(el, lane, e);
+        if (T == 0ull) {
+            unsigned h = 0, llen = 0;
+            if (!scan_long_literal((unsigned)__builtin_amdgcn_readlane((int)lo, (int)e),
+                                   (unsigned)__builtin_amdgcn_readlane((int)hi, (int)e), p, in_end, &h, &llen)) {
+                ok = false;
+                break;
+            }
+            if ((op & (kBlockOut - 1u)) == 0u && op < out_len) {
+                if (lane == 0)
+                    bpos[op / kBlockOut] = p;
+                found += 1u;
+            }
+            p += h + llen;
+            op += llen;
+            continue;
+        }
+        const bool is_tok = __builtin_amdgcn_inverse_ballot_w64(T);
+        const int incl = wave_scan_add(is_tok ? (int)el.len : 0);
+        const unsigned at = op + (unsigned)incl - (is_tok ? el.len : 0u);
+        const bool starts_block = is_tok && (at & (kBlockOut - 1u)) == 0u && at < out_len;
+        if (starts_block)
+            bpos[at / kBlockOut] = x;
+        found += (unsigned)__builtin_popcountll(ballot64(starts_block));
+        const unsigned last = 63u - (unsigned)__builtin_clzll(T);
+        op += (unsigned)__builtin_amdgcn_readlane(incl, 63);
+        p = ws + last + (unsigned)__builtin_amdgcn_readlane((int)el.tokbytes, (int)last);
+        if (op > out_len) {
+            ok = false;
+            break;
+        }
+    }
+    if (!ok || p != in_end || op != out_len)
+        return;
+    HapGpuScanChunk *state = chunks + c;
+    for (unsigned b = lane; b < nblk; b += 64u) {
+        HapGpuDecodeUnit w;
+        w.src = (uint64_t)src_al;
+        w.dst = u.dst + (uint64_t)b * kBlockOut;
+        w.src_len = 0;
+        w.dst_len = min(kBlockOut, out_len - b * kBlockOut);
+        w.kind = HAPGPU_UNIT_SNAPPY_BLOCK;
+        w.job = u.job;
+        w.aux = (uint64_t)state;
+        w.reserved = b;
+        units[sc.unit + 1u + b] = w;
+    }
+    if (lane == 0) {
+        bpos[nblk] = in_end;
+        units[sc.unit].reserved = (uint64_t)state;
+        state->expected = nblk;
+        atomicAdd(&state->found, found);
+        state->ok = 1u;
+    }
+}
+
+__global__ __launch_bounds__(64) void scan_find_kernel(const HapGpuDecodeUnit *units, HapGpuScanChunk *chunks, unsigned chunk_count,
+                                                       const HapGpuScanSegment *segs, const unsigned long long *recs,
+                                                       unsigned seg_total)
+{
+    const unsigned lane = threadIdx.x, g = blockIdx.x;
+    if (g >= seg_total)
+        return;
+    const unsigned c = scan_chunk_of(chunks, chunk_count, g);
+    const HapGpuScanChunk sc = chunks[c];
+    const HapGpuScanSegment sg = segs[g];
+    if (!sc.ok || sg.merge_window >= 64u)
+        return;
+    const HapGpuDecodeUnit u = units[sc.unit];
+    const unsigned shift = (unsigned)(u.src & 15u);
+    const uint8_t *src_al = (const uint8_t *)u.src - shift;
+    const unsigned in_end = shift + u.src_len, out_len = u.dst_len;
+    uint32_t *bpos = (uint32_t *)sc.bpos;
+    const unsigned seg_begin = (g - sc.seg_first) * kScanSegment;
+    const unsigned long long rec = recs[(size_t)g * 64u + lane];
+    const unsigned entry = (unsigned)rec & 0xFFu;
+    const unsigned abs_op = sg.base_op + (unsigned)(rec >> 8);           // output position at this window's entry
+    const bool usable = lane >= sg.merge_window && entry != kRecNone;
+    const unsigned first_op = (unsigned)__builtin_amdgcn_readlane((int)abs_op, (int)sg.merge_window);
+    const unsigned exit_op = sg.base_op + sg.cum_total;
+    unsigned found = 0;
+    // block starts V with first_op <= V < exit_op belong to elements that start in this segment's recorded windows
+    for (unsigned long long V = ((unsigned long long)first_op + kBlockOut - 1u) / kBlockOut * kBlockOut;
+         V < exit_op && V < out_len; V += kBlockOut) {
+        const unsigned long long m = ballot64(usable && abs_op <= (unsigned)V);
+        if (m == 0ull)
+            continue;
+        const unsigned k = 63u - (unsigned)__builtin_clzll(m);          // the last window entered at or before V
+        const unsigned ws = seg_begin + 64u * k;
+        unsigned p = ws + (unsigned)__builtin_amdgcn_readlane((int)entry, (int)k);
+        unsigned op = (unsigned)__builtin_amdgcn_readlane((int)abs_op, (int)k);
+        const unsigned x = ws + lane;
+        unsigned lo, hi;
+        scan_window_bytes(src_al, x, in_end, &lo, &hi);
+        const ScanElement el = scan_parse(lo, x, in_end);
+        while (p < ws + 64u && p < in_end && op <= (unsigned)V) {
+            const unsigned e = p - ws;
+            const unsigned long long T = scan_chain(el, lane, e);
+            if (T == 0ull) {
+                unsigned h = 0, llen = 0;
+                if (!scan_long_literal((unsigned)__builtin_amdgcn_readlane((int)lo, (int)e),
+                                       (unsigned)__builtin_amdgcn_readlane((int)hi, (int)e), p, in_end, &h, &llen))
+                    break;
+                if (op == (unsigned)V) {
+                    if (lane == 0)
+                        bpos[V / kBlockOut] = p;
+                    found += 1u;
+                }
+                p += h + llen;
+                op += llen;
+                continue;
+            }
+            const bool is_tok = __builtin_amdgcn_inverse_ballot_w64(T);
+            const int incl = wave_scan_add(is_tok ? (int)el.len : 0);
+            const unsigned at = op + (unsigned)incl - (is_tok ? el.len : 0u);
+            const bool hit = is_tok && at == (unsigned)V;
+            if (hit)
+                bpos[V / kBlockOut] = x;
+            found += (unsigned)__builtin_popcountll(ballot64(hit));
+            const unsigned last = 63u - (unsigned)__builtin_clzll(T);
+            op += (unsigned)__builtin_amdgcn_readlane(incl, 63);
+            p = ws + last + (unsigned)__builtin_amdgcn_readlane((int)el.tokbytes, (int)last);
+        }
+    }
+    if (lane == 0 && found)
+        atomicAdd(&chunks[c].found, found);
 }
 
 } // namespace
@@ -779,6 +1250,23 @@ static constexpr unsigned fragment_dynamic_lds(unsigned ring) { return ring + kF
 extern "C" int hapgpu_launch_snappy_decode_fields(const HapGpuDecodeUnit *units, unsigned unit_count, HapGpuDecodeJob *jobs,
                                                   unsigned fields_kinds, hipStream_t stream);
 
+// Finds the 64 KiB blocks of the whole-stream units listed in `chunks` (see the block scan above) and writes their
+// BLOCK units; the decode launch that follows must include the stream kernel.
+extern "C" int hapgpu_launch_scan_blocks(HapGpuDecodeUnit *units, const HapGpuDecodeJob *jobs, HapGpuScanChunk *chunks,
+                                         unsigned chunk_count, HapGpuScanSegment *segs, void *recs, unsigned seg_total,
+                                         hipStream_t stream)
+{
+    if (chunk_count == 0 || seg_total == 0)
+        return 0;
+    hipLaunchKernelGGL(scan_walk_kernel, dim3(seg_total), dim3(64), 0, stream, units, jobs, chunks, chunk_count, segs,
+                       (unsigned long long *)recs, seg_total);
+    hipLaunchKernelGGL(scan_merge_kernel, dim3(chunk_count), dim3(64), 0, stream, units, jobs, chunks, chunk_count, segs,
+                       (const unsigned long long *)recs);
+    hipLaunchKernelGGL(scan_find_kernel, dim3(seg_total), dim3(64), 0, stream, units, chunks, chunk_count, segs,
+                       (const unsigned long long *)recs, seg_total);
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}
+
 extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsigned unit_count, HapGpuDecodeJob *jobs,
                                            unsigned frag_log2, unsigned fragment_kinds, int any_stream_or_copy_units,
                                            hipStream_t stream)
@@ -794,16 +1282,23 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
             frag_log2 = 0u;
     }
     if (any_stream_or_copy_units) {
+        // any_stream_or_copy_units == 2: most units are 64 KiB blocks found by the block scan -- a 4 KiB ring (copies
+        // from further back re-read the output from memory) lets 28 wavefronts share a CU instead of 4
         static bool once = false;
-        static unsigned ring_log2 = 15;
+        static unsigned ring_forced = 0;
         if (!once) {
             (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, true, 1u>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kFragmentTail);
             const char *e = getenv("HAP_AMD_STREAM_RING_LOG2");
-            if (e && atoi(e) >= 14 && atoi(e) <= 16)
-                ring_log2 = (unsigned)atoi(e);
+            if (e && atoi(e) >= 12 && atoi(e) <= 16)
+                ring_forced = (unsigned)atoi(e);
             once = true;
         }
-        if (ring_log2 == 14)
+        const unsigned ring_log2 = ring_forced ? ring_forced : any_stream_or_copy_units == 2 ? 12u : 15u;
+        if (ring_log2 == 12)
+            hipLaunchKernelGGL((snappy_decode_fragment_kernel<4096u, true, 1u>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs);
+        else if (ring_log2 == 13)
+            hipLaunchKernelGGL((snappy_decode_fragment_kernel<8192u, true, 1u>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs);
+        else if (ring_log2 == 14)
             hipLaunchKernelGGL((snappy_decode_fragment_kernel<16384u, true, 1u>), dim3(unit_count), dim3(64), fragment_dynamic_lds(16384u), stream, units, unit_count, jobs);
         else if (ring_log2 == 15)
             hipLaunchKernelGGL((snappy_decode_fragment_kernel<32768u, true, 1u>), dim3(unit_count), dim3(64), fragment_dynamic_lds(32768u), stream, units, unit_count, jobs);

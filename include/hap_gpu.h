@@ -58,6 +58,9 @@ typedef struct HapGpuContext HapGpuContext;
 #define HAPGPU_DECODE_IGNORE_FRAGMENT_INDEX 0x1u /* decode as a decoder unaware of section 0x46 would */
 #define HAPGPU_DECODE_IGNORE_HALF_TILES 0x2u     /* use a version-2 table's fragment sizes only (the generic
                                                     fragment decoder), not its half-tile sizes: for A/B measurements */
+#define HAPGPU_DECODE_NO_BLOCK_SCAN 0x4u         /* decode other encoders' Snappy streams with one wavefront per
+                                                    stream instead of looking for their 64 KiB blocks first: for A/B
+                                                    measurements (environment HAP_AMD_NO_BLOCK_SCAN does the same) */
 
 /* Creates a context on HIP device `device` (-1: the current device) with its
  * own non-blocking stream and growable scratch.  Returns a HapResult. */
@@ -205,7 +208,8 @@ enum HapGpuKernelClass {
     HapGpuKernel_DecodePlan = 4,
     HapGpuKernel_SnappyDecode = 5,
     HapGpuKernel_BlockDecode = 6,
-    HapGpuKernel_ClassCount = 7
+    HapGpuKernel_BlockScan = 7,       /* finding the 64 KiB blocks of other encoders' Snappy streams */
+    HapGpuKernel_ClassCount = 8
 };
 
 /* enable != 0: record a start/stop event pair around every kernel launch. */

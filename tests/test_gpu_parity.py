@@ -1205,3 +1205,154 @@ def test_field_stream_promises_are_checked_on_hand_made_streams(ctx, hap):
             assert through_context(data) == (0, 0, expect, 1), name     # the lie was noticed: one fallback
         else:
             assert got[0] == rc, name                      # not even Snappy: the reference's verdict
+
+
+# ------------------------------------------ other encoders' streams: block scan, then one unit per 64 KiB block --
+def _varint(v):
+    out = bytearray()
+    while v >= 0x80:
+        out.append((v & 0x7F) | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def _frame_of_streams(streams, fmt_byte=0xCE):
+    """A Hap frame whose texture is these Snappy streams, one chunk each (decode instructions container with
+    compressor and size tables)."""
+    n = len(streams)
+    comp = bytes([n & 255, n >> 8 & 255, n >> 16, 2]) + bytes([0x0B] * n)
+    sizes = bytes([(4 * n) & 255, (4 * n) >> 8 & 255, (4 * n) >> 16, 3]) + b"".join(len(s).to_bytes(4, "little") for s in streams)
+    tables = comp + sizes
+    body = len(tables).to_bytes(3, "little") + bytes([1]) + tables + b"".join(streams)
+    if len(body) < (1 << 24):
+        return len(body).to_bytes(3, "little") + bytes([fmt_byte]) + body
+    return bytes([0, 0, 0, fmt_byte]) + len(body).to_bytes(4, "little") + body
+
+
+def test_block_scan_decodes_what_the_whole_stream_decoder_decodes(ctx, hap):
+    """Streams without a fragment table are looked over for libsnappy's independent 64 KiB blocks first and then
+    decoded one wavefront per block.  Frames made by the checker's encoder (the reference + libsnappy where built)
+    and hand-made streams that follow or break the block rule in every way the scan checks: the bytes (and the
+    result codes of broken streams) are those of the whole-stream path and of the checker."""
+    rng = np.random.default_rng(2024)
+
+    def lit(b):
+        n = len(b)
+        if n <= 60:
+            return bytes([(n - 1) << 2]) + b
+        if n <= 256:
+            return bytes([60 << 2, n - 1]) + b
+        if n <= 65536:
+            return bytes([61 << 2]) + (n - 1).to_bytes(2, "little") + b
+        return bytes([62 << 2]) + (n - 1).to_bytes(3, "little") + b
+
+    def copy2(n, off):
+        return bytes([2 | ((n - 1) << 2)]) + off.to_bytes(2, "little")
+
+    def copy1(n, off):
+        return bytes([1 | ((n - 4) << 2) | ((off >> 8) << 5), off & 255])
+
+    def copy4(n, off):
+        return bytes([3 | ((n - 1) << 2)]) + off.to_bytes(4, "little")
+
+    def block(total, seed, first_far=False):
+        """Elements producing exactly `total` bytes with every copy inside the block."""
+        r = np.random.default_rng(seed)
+        els, made = [], 0
+        while made < total:
+            left = total - made
+            pick = r.integers(0, 8)
+            if made < 64 or pick == 0:
+                n = int(min(left, r.integers(1, 61)))
+                els.append(lit(r.integers(0, 256, n, dtype=np.uint8).tobytes()))
+            elif pick == 1:
+                n = int(min(left, r.integers(61, 257)))
+                els.append(lit(r.integers(0, 256, n, dtype=np.uint8).tobytes()))
+            elif pick == 2 and left >= 300:
+                n = int(min(left, r.integers(300, 3000)))
+                els.append(lit(r.integers(0, 256, n, dtype=np.uint8).tobytes()))
+            elif pick in (3, 4):
+                n = int(min(left, r.integers(4, 12)))
+                if n < 4:
+                    els.append(lit(bytes(n)))
+                else:
+                    els.append(copy1(n, int(r.integers(1, min(made, 2047) + 1))))
+            elif pick == 7:
+                n = int(min(left, r.integers(1, 65)))
+                els.append(copy4(n, int(r.integers(1, made + 1))))
+            else:
+                n = int(min(left, r.integers(1, 65)))
+                els.append(copy2(n, made if first_far and made < 65536 else int(r.integers(1, min(made, 65535) + 1))))
+            made += n
+        return b"".join(els)
+
+    def check(frame, nbytes, what, expect_ok=True):
+        rc, want, fmt = ORA.decode(frame, 0, nbytes)
+        assert (rc == 0) == expect_ok, (what, rc)
+        got = {}
+        for flags in (0, hap_amd_flags.DECODE_NO_BLOCK_SCAN):
+            out = np.full(nbytes, 0x5A, dtype=np.uint8)
+            r, used, fmts, res = ctx.decode_frames([frame], [len(frame)], 0, [out], flags)
+            got[flags] = (r, res[0], used[0] if r == 0 else 0, out.tobytes() if r == 0 else None)
+        assert got[0] == got[hap_amd_flags.DECODE_NO_BLOCK_SCAN], what
+        if rc == 0:
+            assert got[0] == (0, 0, nbytes, want), what
+            assert hap.HapDecode(frame, 0, outputBufferBytes=nbytes) == (0, want, fmt), what
+        else:
+            assert got[0][0] == rc and got[0][1] == rc, (what, got[0][:2], rc)
+
+    import hap_amd as hap_amd_flags
+    K = 65536
+    # 1. honest streams: 1..5 blocks, last one short / exactly full / one byte; several chunks of different length
+    for name, lens in [("two full", [K, K]), ("short tail", [K, K, 1000]), ("one byte tail", [K, K, K, 1]),
+                       ("five", [K] * 4 + [K - 1]), ("single", [K]), ("just over", [K, 1])]:
+        stream = _varint(sum(lens)) + b"".join(block(n, 100 + i) for i, n in enumerate(lens))
+        check(_frame_of_streams([stream]), sum(lens), name)
+    many = [_varint(3 * K + 77 * c) + block(K, c) + block(K, c + 50) + block(K, c + 90) + block(77 * c, c + 7)
+            for c in range(1, 6)]
+    check(_frame_of_streams(many), sum(3 * K + 77 * c for c in range(1, 6)), "five chunks")
+    # 2. valid Snappy that is not made of independent blocks: stays with the whole-stream decoder
+    head = block(K - 10, 9)
+    straddle = _varint(2 * K) + head + lit(rng.integers(0, 256, 20, dtype=np.uint8).tobytes()) + block(K - 10, 10)
+    check(_frame_of_streams([straddle]), 2 * K, "literal across a block end")
+    straddle = _varint(2 * K) + head + copy2(20, 500) + block(K - 10, 11)
+    check(_frame_of_streams([straddle]), 2 * K, "copy across a block end")
+    reach = _varint(2 * K) + block(K, 12) + lit(b"abcdefgh") + copy2(40, 4000) + block(K - 48, 13)
+    check(_frame_of_streams([reach]), 2 * K, "copy from the previous block")
+    reach = _varint(2 * K) + block(K, 12) + copy1(8, 8) + block(K - 8, 13)
+    check(_frame_of_streams([reach]), 2 * K, "a block that begins with a copy")
+    big = _varint(2 * K + 5) + lit(rng.integers(0, 256, 2 * K + 5, dtype=np.uint8).tobytes())
+    check(_frame_of_streams([big]), 2 * K + 5, "one literal of three blocks")
+    # 3. broken streams: the reference's verdict either way (hap.c:637-640 -> Bad_Frame)
+    good = _varint(3 * K) + block(K, 20) + block(K, 21) + block(K, 22)
+    check(_frame_of_streams([good[:-3]]), 3 * K, "truncated", expect_ok=False)
+    check(_frame_of_streams([good + lit(b"xy")]), 3 * K, "too long", expect_ok=False)
+    bad = _varint(3 * K) + block(K, 20) + block(K, 21) + lit(b"0123") + copy2(8, 9) + block(K - 12, 22)
+    check(_frame_of_streams([bad]), 3 * K, "offset before the block", expect_ok=True)
+    bad = _varint(2 * K) + lit(b"0123") + copy2(8, 9) + block(2 * K - 12, 23)
+    check(_frame_of_streams([bad]), 2 * K, "offset before the stream", expect_ok=False)
+    bad = _varint(2 * K) + block(K, 24) + lit(b"0123") + copy2(8, 0) + block(K - 12, 25)
+    check(_frame_of_streams([bad]), 2 * K, "offset zero", expect_ok=False)
+    # 4. the checker's encoder: block-structured by construction (libsnappy / its restatement), 1 and 7 chunks,
+    #    and the scan must pay off: the decode kernels take less than half the time on a 4 MiB texture
+    tex = D.oracle_bc_encode(D.rgba(4096, 1024, frame=3), L.FMT_DXT5)
+    for name, api in CHECKERS:
+        for chunks in (1, 7):
+            r, frame = api.encode([tex], [L.FMT_DXT5], [L.COMP_SNAPPY], [chunks])
+            assert r == 0
+            check(frame, len(tex), (name, chunks))
+    dframe = torch.from_numpy(np.frombuffer(frame, dtype=np.uint8).copy()).cuda()
+    out = torch.zeros(len(tex), dtype=torch.uint8, device="cuda")
+    times = {}
+    for flags in (hap_amd_flags.DECODE_NO_BLOCK_SCAN, 0):
+        ctx.decode_frames([dframe], [len(frame)], 0, [out], flags)
+        ctx.set_profiling(True)
+        ctx.collect_profile()
+        for _ in range(3):
+            assert ctx.decode_frames([dframe], [len(frame)], 0, [out], flags)[0] == 0
+        prof = ctx.collect_profile()
+        ctx.set_profiling(False)
+        times[flags] = prof["snappy_decode"][1] + prof["block_scan"][1]
+        assert (prof["block_scan"][0] > 0) == (flags == 0)
+    assert times[0] < 0.5 * times[hap_amd_flags.DECODE_NO_BLOCK_SCAN], times
