@@ -293,6 +293,7 @@ def main():
             args.no_cpu_baseline, args.c5_frames = True, 0
         line["texture_to_rgba"] = None if args.no_extras else texture_to_rgba(stream, dev)
         line["coarse_matches_option"] = None if args.no_extras else coarse_option(stream, hap_amd)
+        line["smaller_files_option"] = None if args.no_extras else smaller_option(stream, hap_amd)
         stream.used = stream.encode()
         extras = {}
         if not args.no_cpu_baseline:
@@ -403,6 +404,26 @@ def coarse_option(stream, hap_amd):
     return {"rgba_GBps": round(stream.nf * stream.rgba_bytes / (c_ms * 1e-3) / 1e9, 2), "ms": round(c_ms, 3),
             "snappy_ratio": round(sum(cused) / stream.nf / sum(stream.tex_bytes), 4),
             "note": "encode+decode with 32-bit granular element streams for every format"}
+
+
+def smaller_option(stream, hap_amd):
+    """the speed-for-size option (HAPGPU_ENCODE_SMALLER_FILES: 64 KiB fragments, no private table), reported beside the
+    default; never `value`"""
+    if not hasattr(hap_amd, "ENCODE_SMALLER_FILES"):
+        return None
+    sflags = hap_amd.ENCODE_SMALLER_FILES
+    stream.encode(sflags)
+    stream.ctx.timer_start()
+    sused = stream.encode(sflags)
+    enc_ms = stream.ctx.timer_stop()
+    stream.decode(sused)
+    stream.ctx.timer_start()
+    stream.decode(sused)
+    dec_ms = stream.ctx.timer_stop()
+    return {"snappy_ratio": round(sum(sused) / stream.nf / sum(stream.tex_bytes), 4),
+            "encode_ms": round(enc_ms, 3), "decode_ms": round(dec_ms, 3),
+            "rgba_GBps": round(stream.nf * stream.rgba_bytes / ((enc_ms + dec_ms) * 1e-3) / 1e9, 2),
+            "note": "encode / decode of the same frames with 64 KiB Snappy fragments and no fragment table"}
 
 
 def c5_target(hap_amd, ctx, dev, frames, flags, fence, steps=3):

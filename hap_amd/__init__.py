@@ -11,7 +11,7 @@ no Python or CPU implementation behind it -- a missing library raises ImportErro
 _API_NAMES = (
     "HapCompressorNone", "HapCompressorSnappy", "HapResult", "HapTextureFormat",
     "HapDecode", "HapEncode", "HapGetFrameTextureChunkCount", "HapGetFrameTextureCount",
-    "HapGetFrameTextureFormat", "HapMaxEncodedLength", "Context", "ENCODE_FRAGMENT_INDEX", "ENCODE_COARSE_MATCHES",
+    "HapGetFrameTextureFormat", "HapMaxEncodedLength", "Context", "ENCODE_FRAGMENT_INDEX", "ENCODE_COARSE_MATCHES", "ENCODE_SMALLER_FILES",
     "DECODE_IGNORE_FRAGMENT_INDEX", "DECODE_IGNORE_HALF_TILES", "DECODE_NO_BLOCK_SCAN", "KERNEL_CLASSES", "HapGpuGetFrameTextureChunkLayout", "HapGpuJoinChunkGroups", "SequenceWriter", "SequenceReader", "BufferList",
 )
 

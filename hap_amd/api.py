@@ -28,6 +28,7 @@ class HapResult:
 
 ENCODE_FRAGMENT_INDEX = 0x1
 ENCODE_COARSE_MATCHES = 0x2
+ENCODE_SMALLER_FILES = 0x4
 DECODE_IGNORE_FRAGMENT_INDEX = 0x1
 DECODE_IGNORE_HALF_TILES = 0x2
 DECODE_NO_BLOCK_SCAN = 0x4

@@ -161,9 +161,10 @@ unsigned long HapMaxEncodedLength(unsigned int count, unsigned long *lengths,
 
 static unsigned env_encode_flags(void)
 {
-    const char *e = getenv("HAP_AMD_FRAGMENT_INDEX"), *c = getenv("HAP_AMD_COARSE_MATCHES");
+    const char *e = getenv("HAP_AMD_FRAGMENT_INDEX"), *c = getenv("HAP_AMD_COARSE_MATCHES"), *s = getenv("HAP_AMD_SMALLER_FILES");
     return ((e && atoi(e) != 0) ? HAPGPU_ENCODE_FRAGMENT_INDEX : 0u) |
-           ((c && atoi(c) != 0) ? HAPGPU_ENCODE_COARSE_MATCHES : 0u);
+           ((c && atoi(c) != 0) ? HAPGPU_ENCODE_COARSE_MATCHES : 0u) |
+           ((s && atoi(s) != 0) ? HAPGPU_ENCODE_SMALLER_FILES : 0u);
 }
 
 /* reference hap.c:506-604 */

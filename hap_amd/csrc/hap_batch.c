@@ -56,7 +56,10 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
     uint8_t *dtilesizes = NULL;
     void *dpack = NULL;
     unsigned max_chunks_per_tex = 0;
-    unsigned frag_log2 = ctx->frag_log2, frag_bytes = 1u << frag_log2;
+    /* HAPGPU_ENCODE_SMALLER_FILES: 64 KiB fragments (a match may lie 64 KiB back, like libsnappy's), elements on
+       16-bit positions anywhere instead of whole block fields, and no fragment table */
+    const int smaller = (flags & HAPGPU_ENCODE_SMALLER_FILES) != 0;
+    unsigned frag_log2 = smaller ? 16u : ctx->frag_log2, frag_bytes = 1u << frag_log2;
     unsigned slot_stride;
     int any_snappy = 0;
     unsigned gran_mask = 0;
@@ -97,6 +100,8 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
             return rc;
         }
     }
+    if (smaller)
+        flags &= ~HAPGPU_ENCODE_FRAGMENT_INDEX;
     /* geometry shared by every frame of the batch */
     if (count == 2) {
         size_t worst = 0;                                             /* hap.c:563-576 */
@@ -143,7 +148,7 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
         /* alpha-style blocks (2 endpoint + 6 index bytes [+ 4 + 4 of the colour half]) go to the field-per-lane
            compressor when everything lines up: default fragment size, whole blocks per chunk, 16-bit streams */
         t->field_period = 0u;
-        if (t->compressor == HapCompressorSnappy && frag_log2 == 13u && !ctx->position_lanes) {
+        if (t->compressor == HapCompressorSnappy && frag_log2 == 13u && !ctx->position_lanes && !smaller) {
             if (t->gran_log2 == 1u && (t->format == HapTextureFormat_RGBA_DXT5 || t->format == HapTextureFormat_YCoCg_DXT5) &&
                 (t->chunk_bytes & 15u) == 0)
                 t->field_period = 4u;

@@ -1282,19 +1282,21 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
             frag_log2 = 0u;
     }
     if (any_stream_or_copy_units) {
-        // any_stream_or_copy_units == 2: most units are 64 KiB blocks found by the block scan -- a 4 KiB ring (copies
-        // from further back re-read the output from memory) lets 28 wavefronts share a CU instead of 4
+        // any_stream_or_copy_units == 2: most units are 64 KiB blocks found by the block scan -- a 2 KiB ring (copies
+        // from further back re-read the output from memory) lets 32 wavefronts share a CU instead of 4
         static bool once = false;
         static unsigned ring_forced = 0;
         if (!once) {
             (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, true, 1u>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kFragmentTail);
             const char *e = getenv("HAP_AMD_STREAM_RING_LOG2");
-            if (e && atoi(e) >= 12 && atoi(e) <= 16)
+            if (e && atoi(e) >= 11 && atoi(e) <= 16)
                 ring_forced = (unsigned)atoi(e);
             once = true;
         }
-        const unsigned ring_log2 = ring_forced ? ring_forced : any_stream_or_copy_units == 2 ? 12u : 15u;
-        if (ring_log2 == 12)
+        const unsigned ring_log2 = ring_forced ? ring_forced : any_stream_or_copy_units == 2 ? 11u : 15u;
+        if (ring_log2 == 11)
+            hipLaunchKernelGGL((snappy_decode_fragment_kernel<2048u, true, 1u>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs);
+        else if (ring_log2 == 12)
             hipLaunchKernelGGL((snappy_decode_fragment_kernel<4096u, true, 1u>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs);
         else if (ring_log2 == 13)
             hipLaunchKernelGGL((snappy_decode_fragment_kernel<8192u, true, 1u>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs);

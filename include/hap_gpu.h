@@ -51,8 +51,15 @@ typedef struct HapGpuContext HapGpuContext;
 /* Encode flags */
 #define HAPGPU_ENCODE_FRAGMENT_INDEX 0x1u   /* emit the private fragment-size section (type 0x46) */
 #define HAPGPU_ENCODE_COARSE_MATCHES 0x2u   /* Snappy elements on 32-bit boundaries for every texture format, not just
-                                               DXT1 (whose blocks are two 32-bit fields): about 1.7x the compress and
-                                               1.15x the decompress rate for about 5 % more bytes on YCoCg-DXT5 */
+                                               DXT1 (whose blocks are two 32-bit fields).  Kept for formats without a
+                                               field layout (BC7, BC6H); for DXT5 / YCoCg-DXT5 / RGTC1 the default
+                                               field streams are both smaller and faster since round 2 */
+
+#define HAPGPU_ENCODE_SMALLER_FILES 0x4u    /* smaller frames, slower: Snappy fragments of 64 KiB (matches up to 64 KiB back,
+                                               as in libsnappy's blocks) with elements at any 16-bit position, and no
+                                               private section.  8K YCoCg-DXT5: 0.360 of the texture size against 0.395
+                                               (libsnappy: 0.336), compressing at a fifth of the default rate; such frames
+                                               decode like another encoder's (block scan, about 300 GB/s of texture) */
 
 /* Decode flags */
 #define HAPGPU_DECODE_IGNORE_FRAGMENT_INDEX 0x1u /* decode as a decoder unaware of section 0x46 would */

@@ -1356,3 +1356,64 @@ def test_block_scan_decodes_what_the_whole_stream_decoder_decodes(ctx, hap):
         times[flags] = prof["snappy_decode"][1] + prof["block_scan"][1]
         assert (prof["block_scan"][0] > 0) == (flags == 0)
     assert times[0] < 0.5 * times[hap_amd_flags.DECODE_NO_BLOCK_SCAN], times
+
+
+def _instruction_section_types(frame):
+    """Section types inside the decode instructions container of every texture of a frame."""
+    def header(at):
+        n = int.from_bytes(frame[at:at + 3], "little")
+        if n:
+            return 4, n, frame[at + 3]
+        return 8, int.from_bytes(frame[at + 4:at + 8], "little"), frame[at + 3]
+    h, n, t = header(0)
+    tops = []
+    if t == 0x0D:
+        at = h
+        while at < h + n:
+            h2, n2, _t2 = header(at)
+            tops.append(at)
+            at += h2 + n2
+    else:
+        tops.append(0)
+    found = []
+    for top in tops:
+        h, n, t = header(top)
+        assert t >> 4 == 0xC
+        h2, n2, t2 = header(top + h)
+        assert t2 == 1
+        at, end, kinds = top + h + h2, top + h + h2 + n2, []
+        while at < end:
+            h3, n3, t3 = header(at)
+            kinds.append(t3)
+            at += h3 + n3
+        found.append(kinds)
+    return found
+
+
+def test_smaller_files_flag_round_trips(ctx, hap):
+    """HAPGPU_ENCODE_SMALLER_FILES: 64 KiB fragments and no private section -- a plain Hap frame, smaller than the
+    default one, that the checker / reference decode and that comes back through the block scan."""
+    img = D.rgba(2048, 1024, frame=5)
+    for fmt, formats in ((L.FMT_YCOCG, [L.FMT_YCOCG]), (L.FMT_DXT5, [L.FMT_DXT5, L.FMT_RGTC1])):
+        tex = [D.oracle_bc_encode(img, f) for f in formats]
+        count = len(tex)
+        sizes = {}
+        for flags in (hap.ENCODE_FRAGMENT_INDEX, hap.ENCODE_SMALLER_FILES, hap.ENCODE_SMALLER_FILES | hap.ENCODE_FRAGMENT_INDEX):
+            out = np.zeros(hap.HapMaxEncodedLength([len(t) for t in tex], formats, [4] * count) + 65536, dtype=np.uint8)
+            r, used, res = ctx.encode_frames([tex], formats, [1] * count, [4] * count, [out], flags=flags)
+            assert r == 0 and res == [0]
+            frame = out[: used[0]].tobytes()
+            sizes[flags] = len(frame)
+            if flags & hap.ENCODE_SMALLER_FILES:
+                assert _instruction_section_types(frame) == [[2, 3]] * count
+                assert hap.HapGetFrameTextureChunkCount(frame, 0) == (0, 4)
+            for t in range(count):
+                for name, api in CHECKERS:
+                    assert api.decode(frame, t, len(tex[t])) == (0, tex[t], formats[t]), (name, t)
+                n0 = ctx.table_fallbacks()
+                dec = np.zeros(len(tex[t]), dtype=np.uint8)
+                r, du, df, dr = ctx.decode_frames([frame], [len(frame)], t, [dec])
+                assert (r, du, df, dr) == (0, [len(tex[t])], [formats[t]], [0]) and dec.tobytes() == tex[t]
+                assert ctx.table_fallbacks() == n0                     # every block start found: no second pass
+        assert sizes[hap.ENCODE_SMALLER_FILES] < 0.97 * sizes[hap.ENCODE_FRAGMENT_INDEX], sizes
+        assert sizes[hap.ENCODE_SMALLER_FILES] == sizes[hap.ENCODE_SMALLER_FILES | hap.ENCODE_FRAGMENT_INDEX]
