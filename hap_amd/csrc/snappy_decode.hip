@@ -423,6 +423,34 @@ __device__ __forceinline__ int lane_gather(int v, unsigned src_lane)
     return __builtin_amdgcn_ds_bpermute((int)(src_lane << 2), v);
 }
 
+// Lanes on the element chain that starts at lane `from` of a 64-byte window (0: the element at `from` is a stopper).
+// nxt: lane of the element after this lane's (64: beyond the window or none).  Pointer doubling gives every lane the
+// set of the next 2^kChainRounds chain elements from it; the scalar unit then hops along the chain that many at a time.
+#ifndef HAP_CHAIN_ROUNDS
+#define HAP_CHAIN_ROUNDS 3
+#endif
+__device__ __forceinline__ unsigned long long window_chain(bool stopper, unsigned nxt, unsigned lane, unsigned from)
+{
+    unsigned long long mask = stopper ? 0ull : (1ull << lane);
+    unsigned j = nxt;
+#pragma unroll
+    for (int round = 0; round < HAP_CHAIN_ROUNDS; round++) {
+        const unsigned g_j = (unsigned)lane_gather((int)j, j & 63u);
+        const unsigned g_lo = (unsigned)lane_gather((int)(unsigned)mask, j & 63u);
+        const unsigned g_hi = (unsigned)lane_gather((int)(unsigned)(mask >> 32), j & 63u);
+        mask |= j < 64u ? (((unsigned long long)g_hi << 32) | g_lo) : 0ull;
+        j = j < 64u ? g_j : 64u;
+    }
+    unsigned long long T = 0;
+    for (unsigned s = from; s < 64u;) {
+        const unsigned m_lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mask, (int)s);
+        const unsigned m_hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mask >> 32), (int)s);
+        T |= ((unsigned long long)m_hi << 32) | m_lo;
+        s = (unsigned)__builtin_amdgcn_readlane((int)j, (int)s);
+    }
+    return T;
+}
+
 // GRAN = 2: every element of the unit has even length and (copies) even offset, so one lane moves
 // 16 bits (FRAGMENT16 units, produced by hap_amd's 16-bit granular compressor).
 // SLIDE: the unit is a fragment larger than the ring whose copies all stay within RING - 1 KiB (promised by the
@@ -589,27 +617,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
         const unsigned nxt = stopper ? 64u : min(lane + tokbytes, 64u);
 
         // ---- 2. chain membership from lane 0 ----
-        unsigned long long mask1 = stopper ? 0ull : (1ull << lane);
-        unsigned j1 = nxt;
-        // round 1: two elements per hop
-        unsigned g_j = (unsigned)lane_gather((int)j1, j1 & 63u);
-        unsigned g_lo = (unsigned)lane_gather((int)(unsigned)mask1, j1 & 63u);
-        unsigned g_hi = (unsigned)lane_gather((int)(unsigned)(mask1 >> 32), j1 & 63u);
-        unsigned long long mask2 = mask1 | (j1 < 64u ? (((unsigned long long)g_hi << 32) | g_lo) : 0ull);
-        unsigned j2 = j1 < 64u ? g_j : 64u;
-        // round 2: four elements per hop
-        g_j = (unsigned)lane_gather((int)j2, j2 & 63u);
-        g_lo = (unsigned)lane_gather((int)(unsigned)mask2, j2 & 63u);
-        g_hi = (unsigned)lane_gather((int)(unsigned)(mask2 >> 32), j2 & 63u);
-        const unsigned long long mask4 = mask2 | (j2 < 64u ? (((unsigned long long)g_hi << 32) | g_lo) : 0ull);
-        const unsigned j4 = j2 < 64u ? g_j : 64u;
-        unsigned long long T = 0;
-        for (unsigned s = 0; s < 64u;) {
-            const unsigned m_lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mask4, (int)s);
-            const unsigned m_hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mask4 >> 32), (int)s);
-            T |= ((unsigned long long)m_hi << 32) | m_lo;
-            s = (unsigned)__builtin_amdgcn_readlane((int)j4, (int)s);
-        }
+        unsigned long long T = window_chain(stopper, nxt, lane, 0u);
 
         if (T == 0) {
             // the element at ip is a long literal (or malformed): serial path, one element
@@ -881,30 +889,9 @@ __device__ __forceinline__ ScanElement scan_parse(unsigned lo, unsigned x, unsig
     return el;
 }
 
-// Lanes on the element chain that starts at lane `from` of a 64-byte window (0: the element at `from` is a stopper).
 __device__ __forceinline__ unsigned long long scan_chain(const ScanElement &el, unsigned lane, unsigned from)
 {
-    const unsigned nxt = el.stopper ? 64u : min(lane + el.tokbytes, 64u);
-    unsigned long long mask1 = el.stopper ? 0ull : (1ull << lane);
-    unsigned j1 = nxt;
-    unsigned g_j = (unsigned)lane_gather((int)j1, j1 & 63u);
-    unsigned g_lo = (unsigned)lane_gather((int)(unsigned)mask1, j1 & 63u);
-    unsigned g_hi = (unsigned)lane_gather((int)(unsigned)(mask1 >> 32), j1 & 63u);
-    unsigned long long mask2 = mask1 | (j1 < 64u ? (((unsigned long long)g_hi << 32) | g_lo) : 0ull);
-    unsigned j2 = j1 < 64u ? g_j : 64u;
-    g_j = (unsigned)lane_gather((int)j2, j2 & 63u);
-    g_lo = (unsigned)lane_gather((int)(unsigned)mask2, j2 & 63u);
-    g_hi = (unsigned)lane_gather((int)(unsigned)(mask2 >> 32), j2 & 63u);
-    const unsigned long long mask4 = mask2 | (j2 < 64u ? (((unsigned long long)g_hi << 32) | g_lo) : 0ull);
-    const unsigned j4 = j2 < 64u ? g_j : 64u;
-    unsigned long long T = 0;
-    for (unsigned s = from; s < 64u;) {
-        const unsigned m_lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mask4, (int)s);
-        const unsigned m_hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mask4 >> 32), (int)s);
-        T |= ((unsigned long long)m_hi << 32) | m_lo;
-        s = (unsigned)__builtin_amdgcn_readlane((int)j4, (int)s);
-    }
-    return T;
+    return window_chain(el.stopper, el.stopper ? 64u : min(lane + el.tokbytes, 64u), lane, from);
 }
 
 // The long literal (2..4 length bytes) at coordinate p, from its first five bytes: header and payload sizes.

@@ -1417,3 +1417,43 @@ def test_smaller_files_flag_round_trips(ctx, hap):
                 assert ctx.table_fallbacks() == n0                     # every block start found: no second pass
         assert sizes[hap.ENCODE_SMALLER_FILES] < 0.97 * sizes[hap.ENCODE_FRAGMENT_INDEX], sizes
         assert sizes[hap.ENCODE_SMALLER_FILES] == sizes[hap.ENCODE_SMALLER_FILES | hap.ENCODE_FRAGMENT_INDEX]
+
+
+def test_block_scan_on_corrupted_streams_matches_the_checker(ctx, hap):
+    """Random damage inside the Snappy payload of checker-made frames (several 64 KiB blocks per chunk): whatever the
+    scan makes of it -- split, not split, split and sent back by a BLOCK unit -- the verdict and, where the damaged
+    stream still is Snappy, the bytes are the checker's."""
+    rng = np.random.default_rng(99)
+    tex = D.oracle_bc_encode(D.rgba(2048, 512, frame=9), L.FMT_DXT5)             # 1 MiB: 2 chunks of 8 blocks
+    r, frame = ORA.encode([tex], [L.FMT_DXT5], [L.COMP_SNAPPY], [2])
+    assert r == 0
+    payload_from = 4 + 4 + (4 + 2) + (4 + 8)
+    agree_ok = agree_bad = 0
+    for trial in range(160):
+        f = bytearray(frame)
+        kind = trial % 4
+        i = int(rng.integers(payload_from, len(f)))
+        if kind == 0:
+            f[i] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            f[i] = int(rng.integers(0, 256))
+        elif kind == 2:                                      # a run of damaged bytes
+            n = int(rng.integers(2, 40))
+            f[i:i + n] = rng.integers(0, 256, len(f[i:i + n]), dtype=np.uint8).tobytes()
+        else:                                                # an element tag turned into a long literal / a copy-4
+            f[i] = int(rng.choice([0xF4, 0xF8, 0xFC, 0xF0, 0x03, 0xFF]))
+        f = bytes(f)
+        ro, oo, fo = ORA.decode(f, 0, len(tex))
+        got = {}
+        for flags in (0, hap.DECODE_NO_BLOCK_SCAN):
+            out = np.zeros(len(tex), dtype=np.uint8)
+            r, used, fmts, res = ctx.decode_frames([f], [len(f)], 0, [out], flags)
+            got[flags] = (r, res[0], out.tobytes() if r == 0 else None)
+        assert got[0] == got[hap.DECODE_NO_BLOCK_SCAN], (trial, i)
+        assert got[0][0] == ro, (trial, i, got[0][:2], ro)
+        if ro == 0:
+            assert got[0][2] == oo, (trial, i)
+            agree_ok += 1
+        else:
+            agree_bad += 1
+    assert agree_ok > 10 and agree_bad > 10, (agree_ok, agree_bad)
