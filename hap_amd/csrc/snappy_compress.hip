@@ -619,18 +619,9 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
 
     const unsigned tiles = (n + TB - 1u) / TB, supers = (tiles + kFieldSubs - 1u) / kFieldSubs;
     unsigned round_base = 0;
-#ifdef HAP_EXP_LOADONLY
-    if (tid == 0)
-        frag_sizes[f] = smem[n - 1] + table[5];
-    return;
-#endif
     for (unsigned base = 0; base < supers; base += kWgWaves) {
         const unsigned k = base + wave;
-#ifdef HAP_EXP_NOPROUNDS
-        const bool have = k < supers && smem[0] == 0x77 && smem[1] == 0x13 && smem[2] == 0x99;
-#else
         const bool have = k < supers;
-#endif
         unsigned p_at[kFieldSubs] = {}, p_lo[kFieldSubs] = {}, p_hi[kFieldSubs] = {}, p_cnt[kFieldSubs] = {}, p_hash[kFieldSubs] = {};
         unsigned long long m_in[kFieldSubs] = {};
         unsigned total = 0;
@@ -672,11 +663,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
                 const unsigned a = ux[sub] & m1, b = vx[sub] & m2;
                 const unsigned z = a ^ __builtin_amdgcn_alignbit(b, b, 19) ^ (t << 29);
                 hh[sub] = (z * 0x9E3779B1u) >> (32u - kWgHashBits);
-#ifdef HAP_EXP_NOHASH
-                const unsigned c = 0xFFFFFFFFu;
-#else
                 const unsigned c = table[hh[sub]];
-#endif
                 const unsigned gap = fi - c;                                     // in fields
                 const unsigned dist = gap / PERIOD * kBlock;
                 const bool valid = __builtin_amdgcn_inverse_ballot_w64(in_mask[sub]) && c < fi &&
@@ -735,11 +722,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
                 unsigned long long sel = 0;
                 unsigned cursor = (unsigned)__builtin_amdgcn_readfirstlane((int)skip);
                 const unsigned next_free = lane + kk;
-#ifdef HAP_EXP_NOGREEDY
-                sel = cand_mask & 0x1111111111111111ull;
-#else
                 greedy_select(cand_mask, next_free, cursor, sel);
-#endif
                 const unsigned carry = cursor > 64u ? cursor - 64u : 0u;
                 const int reach = cwave_scan_max(__builtin_amdgcn_inverse_ballot_w64(sel) ? (int)next_free : 0);
                 const unsigned long long skipmask = skip >= 64u ? ~0ull : ((1ull << skip) - 1ull);
@@ -825,11 +808,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
 #pragma unroll
             for (int sub = 0; sub < (int)kFieldSubs; sub++) {
                 uint8_t *dst = out + my_base + p_at[sub];
-#ifdef HAP_EXP_NOSTORE
-                const unsigned cnt = p_lo[sub] == 0x12345u ? p_cnt[sub] : 0u, vlo = p_lo[sub], vhi = p_hi[sub];
-#else
                 const unsigned cnt = p_cnt[sub], vlo = p_lo[sub], vhi = p_hi[sub];
-#endif
                 if (cnt >= 2u)
                     store16(dst, vlo);
                 if (cnt >= 4u)
@@ -845,10 +824,8 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
                 if (cnt == 7u)
                     dst[6] = (uint8_t)(vhi >> 16);
                 // every field is remembered (candidates are looked up by field, not by element)
-#ifndef HAP_EXP_NOHASH
                 if (__builtin_amdgcn_inverse_ballot_w64(m_in[sub]))
                     atomicMax(&table[p_hash[sub]], (kFieldSubs * k + sub) * TB / kBlock * PERIOD + lane);
-#endif
             }
         }
         lds_barrier();
