@@ -694,13 +694,16 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
             const unsigned elen = ((g0 >> 11) & 0x1FFu) / GRAN;
             const bool lit = ((g0 >> 20) & 1u) != 0;
             unsigned desc;                       // bit 31: resolved (LDS byte address), else output position
-            if (lit) {
-                desc = 0x80000000u | (GRAN >= 2 ? 0x40000000u : 0u) | (RING + ((g1 + GRAN * rel) & (kV2InBytes - 1)));
-            } else {
+            // (both kinds are worked out side by side and selected: a branch on `lit` diverges in most steps)
+            const unsigned desc_lit = 0x80000000u | (GRAN >= 2 ? 0x40000000u : 0u) | (RING + ((g1 + GRAN * rel) & (kV2InBytes - 1)));
+            {
                 unsigned r = rel;
                 const unsigned offu = g2 / GRAN;
-                if (offu < elen) {                               // overlapping copy: periodic pattern
-                    const unsigned q = __umul24(rel, (65536u / offu) + 1u) >> 16;    // rel / offu, exact for rel < 64
+                if (!lit && offu < elen) {                       // overlapping copy: periodic pattern
+                    // rel / offu, exact for rel < 256 and offu < 128: the reciprocal from v_rcp_f32 is exact enough
+                    // (65536 / offu is an integer or at least 1/127 away from one)
+                    const unsigned m = (unsigned)(65536.0f * __builtin_amdgcn_rcpf((float)offu)) + 1u;
+                    const unsigned q = __umul24(rel, m) >> 16;
                     r = rel - __umul24(q, offu);
                 }
                 const unsigned q = g1 / GRAN + r;                // output position (in units) of the source
@@ -711,17 +714,18 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
                 if (STREAM && q + RING < op + kOwnerBytes + 64u)
                     desc = 0xC0000000u | q;
             }
+            desc = lit ? desc_lit : desc;
             if (!active)
                 desc = 0x80000000u;
             // sources inside this 64-byte step: pointer jumping
-            for (int round = 0; round < 7; round++) {
-                const bool pending = (int)desc >= 0;
-                if (ballot64((int)desc >= 0) == 0)
-                    break;
-                const unsigned from = (desc - (opu + B)) & 63u;
-                const unsigned g = (unsigned)lane_gather((int)desc, from);
-                if (pending)
-                    desc = g;
+            if (ballot64((int)desc >= 0) != 0ull) {
+                int round = 0;
+                do {
+                    const bool pending = (int)desc >= 0;
+                    const unsigned from = (desc - (opu + B)) & 63u;
+                    const unsigned g = (unsigned)lane_gather((int)desc, from);
+                    desc = pending ? g : desc;
+                } while (++round < 7 && ballot64((int)desc >= 0) != 0ull);
             }
             const unsigned a0 = desc & 0x3FFFFFFFu;
             const bool far = STREAM && (desc & 0x40000000u) != 0;
