@@ -650,7 +650,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     HapGpuScanChunk *hscan = NULL, *dscan = NULL;
     HapGpuScanSegment *dsegs = NULL;
     uint32_t *dbpos = NULL;
-    uint8_t *drecs = NULL;
+    uint8_t *drecs = NULL, *djoins = NULL;
     unsigned *job_of_frame;
     unsigned char *in_dev = NULL, *out_dev = NULL;     /* pointer classification, done once per buffer */
     unsigned char *client_marks = NULL;                /* what the client's callback asked for (single-frame path) */
@@ -842,10 +842,11 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
         goto fail_alloc;
     }
     if (scan_chunks) {
-        /* one arena: chunk table | segment summaries | block positions | window records */
+        /* one arena: chunk table | segment summaries | block positions | joins | window records */
         const size_t o_segs = align_up(sizeof(HapGpuScanChunk) * scan_chunks, 64);
         const size_t o_bpos = o_segs + sizeof(HapGpuScanSegment) * scan_segs;
-        const size_t o_recs = align_up(o_bpos + sizeof(uint32_t) * scan_words, 64);
+        const size_t o_joins = align_up(o_bpos + sizeof(uint32_t) * scan_words, 64);
+        const size_t o_recs = align_up(o_joins + (size_t)8u * scan_segs, 64);
         uint8_t *arena = (uint8_t *)hapgpu_rt_device_scratch(rt, D_SCAN, o_recs + (size_t)512u * scan_segs);
         hscan = (HapGpuScanChunk *)hapgpu_rt_pinned_scratch(rt, P_SCAN, sizeof(HapGpuScanChunk) * scan_chunks);
         if (!arena || !hscan) {
@@ -855,6 +856,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
         dscan = (HapGpuScanChunk *)arena;
         dsegs = (HapGpuScanSegment *)(arena + o_segs);
         dbpos = (uint32_t *)(arena + o_bpos);
+        djoins = arena + o_joins;
         drecs = arena + o_recs;
     }
     {
@@ -990,7 +992,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
         /* streams of other encoders (no fragment table): find their independent 64 KiB blocks first */
         if (scan_chunks && scan_cursor == scan_chunks) {
             rc |= hapgpu_rt_h2d(rt, dscan, hscan, sizeof(HapGpuScanChunk) * scan_chunks);
-            rc |= hapgpu_k_scan_blocks(rt, dunits, djobs, dscan, scan_chunks, dsegs, drecs, scan_segs);
+            rc |= hapgpu_k_scan_blocks(rt, dunits, djobs, dscan, scan_chunks, dsegs, drecs, djoins, scan_segs);
         }
         rc |= hapgpu_k_snappy_decode(rt, dunits, total_units, djobs, frag_log2_seen, frag_kinds,
                                      any_stream ? (scan_chunks ? 2 : 1) : 0);

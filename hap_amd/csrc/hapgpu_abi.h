@@ -163,10 +163,10 @@ typedef struct HapGpuScanSegment {   /* device only */
     uint32_t exit_coord;     /* where the segment's (guessed) chain left the segment */
     uint32_t cum_total;      /* output bytes that chain produced from its start to there */
     uint32_t flags;          /* 1: the chain met something that is not an element; 2: it reached the end of the input */
-    uint32_t merge_window;   /* window in which the true chain joined the recorded one (0xFFFFFFFF: never) */
-    uint32_t base_op;        /* absolute output position of the recorded chain's zero */
-    uint32_t reserved[3];
+    uint32_t reserved;
 } HapGpuScanSegment;
+/* (per segment, in an array of its own: the window in which the true chain joined the recorded one -- 0xFFFFFFFF:
+   never -- and the absolute output position of the recorded chain's zero, 2 x uint32) */
 
 /* [device] one wavefront's worth of decode work */
 typedef struct HapGpuDecodeUnit {
@@ -241,10 +241,10 @@ int hapgpu_k_decode_plan(hapgpu_rt *rt, HapGpuDecodeJob *jobs, unsigned job_coun
                          HapGpuDecodeUnit *units, unsigned unit_count, unsigned max_chunks);
 /* splits whole-stream units that consist of independent 64 KiB blocks (what libsnappy writes) into BLOCK units,
  * using the slots reserved behind them; streams that do not qualify stay as they are.  chunks: one entry per stream
- * (host-filled part copied to the device by the caller); segs / recs: device scratch of seg_total entries /
- * seg_total * 64 words of 8 bytes */
+ * (host-filled part copied to the device by the caller); segs / recs / joins: device scratch of seg_total entries /
+ * seg_total * 64 words of 8 bytes / seg_total * 8 bytes */
 int hapgpu_k_scan_blocks(hapgpu_rt *rt, HapGpuDecodeUnit *units, const HapGpuDecodeJob *jobs, HapGpuScanChunk *chunks,
-                         unsigned chunk_count, HapGpuScanSegment *segs, void *recs, unsigned seg_total);
+                         unsigned chunk_count, HapGpuScanSegment *segs, void *recs, void *joins, unsigned seg_total);
 /* frag_log2: fragment size of the batch's FRAGMENT units (0: none present);
  * fragment_kinds: bit g set = fragments of granularity_log2 g present */
 /* fragment_kinds bits 8 / 9 / 10: field-stream units of [2,6,4,4] / [4,4] / [2,6] blocks present */

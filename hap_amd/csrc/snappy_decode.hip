@@ -937,7 +937,8 @@ __device__ __forceinline__ bool scan_unit_wanted(const HapGpuDecodeUnit &u, cons
 
 __global__ __launch_bounds__(64) void scan_walk_kernel(const HapGpuDecodeUnit *units, const HapGpuDecodeJob *jobs,
                                                        const HapGpuScanChunk *chunks, unsigned chunk_count,
-                                                       HapGpuScanSegment *segs, unsigned long long *recs, unsigned seg_total)
+                                                       HapGpuScanSegment *__restrict__ segs, unsigned long long *__restrict__ recs,
+                                                       uint2 *__restrict__ joins, unsigned seg_total)
 {
     __shared__ __attribute__((aligned(16))) uint8_t smem[kScanLds];
     const uint32_t *inw = reinterpret_cast<const uint32_t *>(smem);
@@ -1018,10 +1019,9 @@ __global__ __launch_bounds__(64) void scan_walk_kernel(const HapGpuDecodeUnit *u
         sg.exit_coord = p;
         sg.cum_total = cum;
         sg.flags = flags;
-        sg.merge_window = 0xFFFFFFFFu;
-        sg.base_op = 0;
-        sg.reserved[0] = sg.reserved[1] = sg.reserved[2] = 0;
+        sg.reserved = 0;
         segs[g] = sg;
+        joins[g] = make_uint2(0xFFFFFFFFu, 0u);          // (window, output position of the record's zero): not joined yet
     }
 }
 
@@ -1036,7 +1036,8 @@ __device__ __forceinline__ void scan_window_bytes(const uint8_t *src_al, unsigne
 
 __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units, const HapGpuDecodeJob *jobs,
                                                         HapGpuScanChunk *chunks, unsigned chunk_count,
-                                                        HapGpuScanSegment *segs, const unsigned long long *recs)
+                                                        const HapGpuScanSegment *__restrict__ segs,
+                                                        const unsigned long long *__restrict__ recs, uint2 *__restrict__ joins)
 {
     const unsigned lane = threadIdx.x, c = blockIdx.x;
     if (c >= chunk_count)
@@ -1061,15 +1062,25 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
         p = uniform(p);
     }
     unsigned op = 0, found = 0, cur = 0xFFFFFFFFu;
-    unsigned long long rec = kRecNone;
-    HapGpuScanSegment sg = {};
+    unsigned long long rec = kRecNone, rec_ahead = kRecNone;
+    HapGpuScanSegment sg = {}, sg_ahead = {};
     bool ok = true;
     while (p < in_end) {
         const unsigned s = p / kScanSegment, wi = (p % kScanSegment) >> 6, e = p & 63u;
         if (s != cur) {
-            rec = recs[(size_t)(sc.seg_first + s) * 64u + lane];
-            sg = segs[sc.seg_first + s];
+            // the next segment's record was asked for when this one was entered (the chain nearly always goes there)
+            if (s == cur + 1u && cur != 0xFFFFFFFFu) {
+                rec = rec_ahead;
+                sg = sg_ahead;
+            } else {
+                rec = recs[(size_t)(sc.seg_first + s) * 64u + lane];
+                sg = segs[sc.seg_first + s];
+            }
             cur = s;
+            if (s + 1u < sc.seg_count) {
+                rec_ahead = recs[(size_t)(sc.seg_first + s + 1u) * 64u + lane];
+                sg_ahead = segs[sc.seg_first + s + 1u];
+            }
         }
         const unsigned r_lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)rec, (int)wi);
         const unsigned r_hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rec >> 32), (int)wi);
@@ -1081,10 +1092,8 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
             }
             const unsigned at_entry = (r_lo >> 8) | (r_hi << 24);
             const unsigned base_op = op - at_entry;
-            if (lane == 0) {
-                segs[sc.seg_first + s].merge_window = wi;
-                segs[sc.seg_first + s].base_op = base_op;
-            }
+            if (lane == 0)
+                joins[sc.seg_first + s] = make_uint2(wi, base_op);
             p = sg.exit_coord;
             op = base_op + sg.cum_total;
             continue;
@@ -1151,7 +1160,8 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
 }
 
 __global__ __launch_bounds__(64) void scan_find_kernel(const HapGpuDecodeUnit *units, HapGpuScanChunk *chunks, unsigned chunk_count,
-                                                       const HapGpuScanSegment *segs, const unsigned long long *recs,
+                                                       const HapGpuScanSegment *__restrict__ segs,
+                                                       const unsigned long long *__restrict__ recs, const uint2 *__restrict__ joins,
                                                        unsigned seg_total)
 {
     const unsigned lane = threadIdx.x, g = blockIdx.x;
@@ -1160,7 +1170,9 @@ __global__ __launch_bounds__(64) void scan_find_kernel(const HapGpuDecodeUnit *u
     const unsigned c = scan_chunk_of(chunks, chunk_count, g);
     const HapGpuScanChunk sc = chunks[c];
     const HapGpuScanSegment sg = segs[g];
-    if (!sc.ok || sg.merge_window >= 64u)
+    const uint2 join = joins[g];
+    const unsigned merge_window = join.x, base_op = join.y;
+    if (!sc.ok || merge_window >= 64u)
         return;
     const HapGpuDecodeUnit u = units[sc.unit];
     const unsigned shift = (unsigned)(u.src & 15u);
@@ -1170,10 +1182,10 @@ __global__ __launch_bounds__(64) void scan_find_kernel(const HapGpuDecodeUnit *u
     const unsigned seg_begin = (g - sc.seg_first) * kScanSegment;
     const unsigned long long rec = recs[(size_t)g * 64u + lane];
     const unsigned entry = (unsigned)rec & 0xFFu;
-    const unsigned abs_op = sg.base_op + (unsigned)(rec >> 8);           // output position at this window's entry
-    const bool usable = lane >= sg.merge_window && entry != kRecNone;
-    const unsigned first_op = (unsigned)__builtin_amdgcn_readlane((int)abs_op, (int)sg.merge_window);
-    const unsigned exit_op = sg.base_op + sg.cum_total;
+    const unsigned abs_op = base_op + (unsigned)(rec >> 8);              // output position at this window's entry
+    const bool usable = lane >= merge_window && entry != kRecNone;
+    const unsigned first_op = (unsigned)__builtin_amdgcn_readlane((int)abs_op, (int)merge_window);
+    const unsigned exit_op = base_op + sg.cum_total;
     unsigned found = 0;
     // block starts V with first_op <= V < exit_op belong to elements that start in this segment's recorded windows
     for (unsigned long long V = ((unsigned long long)first_op + kBlockOut - 1u) / kBlockOut * kBlockOut;
@@ -1244,17 +1256,17 @@ extern "C" int hapgpu_launch_snappy_decode_fields(const HapGpuDecodeUnit *units,
 // Finds the 64 KiB blocks of the whole-stream units listed in `chunks` (see the block scan above) and writes their
 // BLOCK units; the decode launch that follows must include the stream kernel.
 extern "C" int hapgpu_launch_scan_blocks(HapGpuDecodeUnit *units, const HapGpuDecodeJob *jobs, HapGpuScanChunk *chunks,
-                                         unsigned chunk_count, HapGpuScanSegment *segs, void *recs, unsigned seg_total,
-                                         hipStream_t stream)
+                                         unsigned chunk_count, HapGpuScanSegment *segs, void *recs, void *joins,
+                                         unsigned seg_total, hipStream_t stream)
 {
     if (chunk_count == 0 || seg_total == 0)
         return 0;
     hipLaunchKernelGGL(scan_walk_kernel, dim3(seg_total), dim3(64), 0, stream, units, jobs, chunks, chunk_count, segs,
-                       (unsigned long long *)recs, seg_total);
+                       (unsigned long long *)recs, (uint2 *)joins, seg_total);
     hipLaunchKernelGGL(scan_merge_kernel, dim3(chunk_count), dim3(64), 0, stream, units, jobs, chunks, chunk_count, segs,
-                       (const unsigned long long *)recs);
+                       (const unsigned long long *)recs, (uint2 *)joins);
     hipLaunchKernelGGL(scan_find_kernel, dim3(seg_total), dim3(64), 0, stream, units, chunks, chunk_count, segs,
-                       (const unsigned long long *)recs, seg_total);
+                       (const unsigned long long *)recs, (const uint2 *)joins, seg_total);
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 
