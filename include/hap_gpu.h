@@ -86,7 +86,8 @@ unsigned int HapGpuSetFragmentLog2(HapGpuContext *context, unsigned int log2_byt
 unsigned int HapGpuSynchronize(HapGpuContext *context);
 
 /* Number of frames this context has decoded a second time because their fragment table (section 0x46) did not
- * describe their streams: the table is only ever a hint, results are the same either way.  For tests and tools. */
+ * describe their streams, or because a stream split into 64 KiB blocks by the block scan turned out to copy across a
+ * block start: table and scan are only ever hints, results are the same either way.  For tests and tools. */
 unsigned long HapGpuTableFallbackCount(HapGpuContext *context);
 
 /* RGBA8 (row-major, rowBytes stride, width/height multiples of 4) -> block
