@@ -28,7 +28,11 @@
 //
 // LDS: the output ring (8 KiB) and the staged compressed bytes share one buffer -- the input is parked high enough
 // that output written by step s never reaches the compressed bytes of later steps (positions follow from the
-// half-tile table) -- + 4 KiB of records + masks: 13.8 KiB per wave, 11 waves per CU.
+// half-tile table).  The element records live in the same buffer too, BELOW the parked input, where output only
+// arrives after every record has been read (a half-tile of c compressed bytes has at most c / 2 elements, so their
+// places follow from the table as well); fragments whose records do not fit there -- compressed to more than about
+// half -- keep them in the first bytes of their own output range in memory until production overwrites them.
+// 9.9 KiB per wave, 16 waves per CU (r02 first version: records in 4 KiB of their own, 11 waves).
 // HBM traffic: compressed bytes read once, output written once (algorithmic bytes b(1 + c)).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -141,9 +145,8 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
     constexpr unsigned kPosShift = layout_of<LAYOUT>::pos_shift;    // element start positions are kept in 2- / 4-byte units
     constexpr unsigned kLitBias = kHalf;
     __shared__ __attribute__((aligned(16))) uint8_t buf[kBufBytes];
-    __shared__ __attribute__((aligned(4))) uint16_t rec[kHalves * kRecPerHalf];
     __shared__ __attribute__((aligned(8))) uint2 masks[kHalves];
-    __shared__ uint16_t coffs[kHalves + 2u];
+    __shared__ uint32_t coffs[kHalves + 2u];                       // compressed offset | first record << 16, per half-tile
     const uint32_t *bufw = reinterpret_cast<const uint32_t *>(buf);
 
     const unsigned lane = threadIdx.x;
@@ -187,9 +190,13 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
         fail_unit(job, lane);
         return;
     }
-    coffs[lane] = (uint16_t)coff;
-    if (lane == 63u)
-        coffs[64] = (uint16_t)total;
+    // records: a half-tile of tsz compressed bytes holds at most tsz / 2 elements (and one per field)
+    const unsigned hfields = lane < nhalf ? min(kHalf, out_len - kHalf * lane) / kBlock * PERIOD : 0u;
+    const unsigned nrec = min(min(kRecPerHalf, tsz >> 1), hfields);
+    const int rincl = fwave_scan_add((int)nrec);
+    const unsigned rbase = (unsigned)rincl - nrec;
+    const unsigned rbytes = 2u * (unsigned)__builtin_amdgcn_readlane(rincl, 63);
+    coffs[lane] = coff | (rbase << 16);
     // Output of half-tiles < h may overwrite buffer bytes below 128 h; the input of half-tile h sits at S + coff[h].
     const int lead = lane < nhalf ? (int)(kHalf * lane) - (int)coff : 0;
     const unsigned S = (((unsigned)fwave_max(max(lead, 0)) + kHalf + 15u - shift) & ~15u) + shift;   // S = shift (mod 16)
@@ -197,6 +204,9 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
         fail_unit(job, lane);
         return;
     }
+    // records below the parked input when they fit, else in the unit's own output range (2-byte aligned) in memory
+    const bool rec_in_lds = rbytes <= S - shift;
+    uint8_t *const rec_mem = (uint8_t *)(((uintptr_t)dst + 1u) & ~(uintptr_t)1u);
     {
         uint8_t *park = buf + (S - shift) + lane * 16u;
 #pragma unroll
@@ -229,7 +239,8 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
         unsigned acc_or = 0;                               // OR of copy offsets (low bits) and start positions << 16
         unsigned acc_bad = 0;                              // any bit set = the stream breaks a promise
         unsigned min_off = 0xFFFFu, max_up = 0;            // smallest copy offset, largest literal length code
-        uint8_t *const recb = reinterpret_cast<uint8_t *>(rec) + h * (kRecPerHalf * 2u);
+        uint8_t *const recb = (rec_in_lds ? buf : rec_mem) + 2u * rbase;
+        const unsigned reccap = 2u * nrec;                 // (a stream with more elements than that has left its bytes)
         // (every element advances p by at least one byte, so the walk is bounded; elements that start off a field
         // boundary -- the only way to have more than 32 of them -- are caught below, and the record index is masked)
         do {
@@ -257,7 +268,8 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
                 min_off = min(min_off, is_lit ? 0xFFFFu : off);
                 max_up = max(max_up, is_lit ? up : 0u);
                 acc_bad |= (w & (w >> 1) & 1u) | ((!is_lit && off > obase + p) ? 1u : 0u);
-                *reinterpret_cast<uint16_t *>(recb + (recp & (kRecPerHalf * 2u - 2u))) = (uint16_t)(is_lit ? litrec : off >> kRecShift);
+                if (recp < reccap)
+                    *reinterpret_cast<uint16_t *>(recb + recp) = (uint16_t)(is_lit ? litrec : off >> kRecShift);
                 recp += 2u;
                 const unsigned long long bit = 1ull << (p >> kPosShift);
                 mlo |= (unsigned)bit;
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
         // an element that overshoots its half-tile or the table's byte count ends up with p / cp off the mark;
         // starts off a field boundary show in the mask (16-byte blocks: fields begin at bytes 0, 2, 8, 12)
         bool bad = acc_bad != 0u || (acc_or & (kBlock - 1u)) != 0u || ((acc_or >> 16) & ((1u << kPosShift) - 1u)) != 0u ||
-                   min_off < kBlock || max_up > 60u || (h < nhalf && (cp != cend || p != hbytes));
+                   min_off < kBlock || max_up > 60u || (h < nhalf && (cp != cend || p != hbytes)) || recp > reccap;
         bad = bad || ((mlo | mhi) & ~start_positions<LAYOUT>()) != 0u;
         masks[h] = make_uint2(mlo, mhi);
         if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
@@ -277,6 +289,8 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
             return;
         }
     }
+    if (!rec_in_lds)
+        __threadfence();
     __syncthreads();
 
     // ---- 2. produce: lane = block, 64 blocks per step ----
@@ -317,26 +331,44 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
             const uint2 m = masks[hh];
             mx[s] = m.x;
             my[s] = m.y;
-            cof[s] = (int)(unsigned)coffs[hh];
+            cof[s] = (int)coffs[hh];
         }
         lds_wait();
         int r[kMaxSteps][PERIOD];
+        if (rec_in_lds) {
 #pragma unroll
-        for (unsigned s = 0; s < kMaxSteps; s++) {
-            const unsigned hh = s * kHalvesPerStep + hsub;
-            const unsigned msel = upper ? my[s] : mx[s];
-            const int ebase = upper ? (int)__builtin_popcount(mx[s]) - 1 : -1;
-            const int16_t *rb = reinterpret_cast<const int16_t *>(rec) + hh * kRecPerHalf;
+            for (unsigned s = 0; s < kMaxSteps; s++) {
+                const unsigned msel = upper ? my[s] : mx[s];
+                const int ebase = (upper ? (int)__builtin_popcount(mx[s]) - 1 : -1) + (cof[s] >> 16);
+                const int16_t *rb = reinterpret_cast<const int16_t *>(buf);
 #pragma unroll
-            for (unsigned k = 0; k < PERIOD; k++) {
-                // ordinal of the element that owns the field (a parsed half-tile always starts with an element: >= 0)
-                const int e = (int)__builtin_popcount(msel & le[k]) + ebase;
-                r[s][k] = (int)rb[e];
+                for (unsigned k = 0; k < PERIOD; k++) {
+                    // ordinal of the element that owns the field (a parsed half-tile always starts with an element: >= 0)
+                    const int e = (int)__builtin_popcount(msel & le[k]) + ebase;
+                    r[s][k] = (int)rb[e];
+                }
+                if ((s & 3u) == 3u)
+                    lds_wait();                                             // (at most 16 LDS results outstanding)
             }
-            if ((s & 3u) == 3u)
-                lds_wait();                                                 // (at most 16 LDS results outstanding)
+            lds_wait();
+        } else {
+            // (the wave's own stores, read back past the CU's L1, which may hold these lines as they were before)
+            const int16_t *rb = reinterpret_cast<const int16_t *>(rec_mem);
+#pragma unroll
+            for (unsigned s = 0; s < kMaxSteps; s++) {
+                const unsigned msel = upper ? my[s] : mx[s];
+                const int ebase = (upper ? (int)__builtin_popcount(mx[s]) - 1 : -1) + (cof[s] >> 16);
+#pragma unroll
+                for (unsigned k = 0; k < PERIOD; k++) {
+                    const int e = (int)__builtin_popcount(msel & le[k]) + ebase;
+                    r[s][k] = (int)__hip_atomic_load(rb + ((64u * s + lane) * kBlock < out_len ? e : 0), __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
-        lds_wait();
+#pragma unroll
+        for (unsigned s = 0; s < kMaxSteps; s++)
+            cof[s] &= 0xFFFF;
 #pragma unroll
         for (unsigned s = 0; s < kMaxSteps; s++) {
 #pragma unroll

@@ -1457,3 +1457,42 @@ def test_block_scan_on_corrupted_streams_matches_the_checker(ctx, hap):
         else:
             agree_bad += 1
     assert agree_ok > 10 and agree_bad > 10, (agree_ok, agree_bad)
+
+
+@pytest.mark.parametrize("fmt", [L.FMT_DXT5, L.FMT_DXT1, L.FMT_RGTC1])
+def test_field_streams_that_compress_poorly_keep_their_records_in_memory(ctx, hap, fmt):
+    """Fragments compressed to more than about half have no room for their element records below the parked input
+    in LDS: the block-per-lane decoder then keeps them in the fragment's own output range until production overwrites
+    it.  Textures with constant endpoints and random index bytes (many small elements, ratio ~0.7-0.9), sizes that
+    end in a short fragment and in a short half-tile, aligned and odd output addresses: exact, and no second pass."""
+    rng = np.random.default_rng(4242)
+    block = 16 if fmt == L.FMT_DXT5 else 8
+    nblocks = (2 << 20) // block + (8192 + 3 * 128 + 2 * block) // block if fmt == L.FMT_RGTC1 else 3 * 8192 // block + 700
+    tex = bytearray(rng.integers(0, 256, nblocks * block, dtype=np.uint8).tobytes())
+    for b in range(nblocks):
+        if fmt == L.FMT_DXT5:
+            tex[b * 16: b * 16 + 2] = b"\xf0\x10"                      # alpha endpoints
+            tex[b * 16 + 8: b * 16 + 12] = b"\x12\x34\x56\x78"          # colour endpoints
+        elif fmt == L.FMT_DXT1:
+            tex[b * 8: b * 8 + 4] = b"\x12\x34\x56\x78"
+        else:
+            tex[b * 8 + 2: b * 8 + 8] = b"\x01\x02\x03\x04\x05\x06"     # RGTC1: constant indices, random endpoints
+    tex = bytes(tex)
+    out = np.zeros(hap.HapMaxEncodedLength([len(tex)], [fmt], [1]) + 65536, dtype=np.uint8)
+    r, used, res = ctx.encode_frames([[tex]], [fmt], [1], [1], [out], flags=hap.ENCODE_FRAGMENT_INDEX)
+    assert r == 0 and res == [0]
+    frame = out[: used[0]].tobytes()
+    at, ver, _hdr = find_fragment_table(frame)
+    assert at > 0 and ver == 2 and 0.45 < len(frame) / len(tex) < 1.0, (ver, len(frame) / len(tex))
+    for name, api in CHECKERS:
+        assert api.decode(frame, 0, len(tex)) == (0, tex, fmt), name
+    dframe = torch.from_numpy(np.frombuffer(frame, dtype=np.uint8).copy()).cuda()
+    for odd in (0, 1, 2):
+        n0 = ctx.table_fallbacks()
+        backing = torch.full((len(tex) + 16,), 0x5A, dtype=torch.uint8, device="cuda")
+        dec = backing[odd: odd + len(tex)]
+        torch.cuda.synchronize()
+        r, du, df, dr = ctx.decode_frames([dframe], [len(frame)], 0, [dec])
+        assert (r, du, df, dr) == (0, [len(tex)], [fmt], [0])
+        assert dec.cpu().numpy().tobytes() == tex and ctx.table_fallbacks() == n0
+        assert backing[:odd].cpu().tolist() == [0x5A] * odd and backing[odd + len(tex):].cpu().tolist() == [0x5A] * (16 - odd)
