@@ -101,6 +101,10 @@ __device__ __forceinline__ constexpr unsigned field_pos(unsigned k)
 template <unsigned LAYOUT>
 __device__ __forceinline__ constexpr unsigned start_positions() { return LAYOUT == 4u ? 0x53535353u : LAYOUT == 6u ? 0x33333333u : 0xFFFFFFFFu; }
 
+// (mask & a) | (~mask & b).  (Left to the compiler: a hand-placed v_bfi_b32 made the kernel 7 % slower -- the asm
+// statement keeps the selects from being scheduled between the LDS round trips.)
+__device__ __forceinline__ int bit_select(int mask, int a, int b) { return (mask & a) | (~mask & b); }
+
 // waits for every outstanding LDS operation of the wave (one wait for a batch of reads instead of one per use)
 __device__ __forceinline__ void lds_wait() { __builtin_amdgcn_s_waitcnt(0xC07F); }     // lgkmcnt(0), vmcnt / expcnt untouched
 
@@ -182,20 +186,20 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
         return;
 
     // ---- half-tile table -> compressed offsets, and where to park the input ----
-    const int incl = fwave_scan_add((int)tsz);
-    const unsigned coff = (unsigned)incl - tsz;
-    const bool table_bad = (unsigned)__builtin_amdgcn_readlane(incl, 63) != total ||
+    // (one scan for both prefix sums: sizes in the low half -- at most 64 x 144 -- and record counts in the high half)
+    const unsigned hfields = lane < nhalf ? min(kHalf, out_len - kHalf * lane) / kBlock * PERIOD : 0u;
+    const unsigned nrec = min(min(kRecPerHalf, tsz >> 1), hfields);   // a half-tile of tsz bytes holds at most tsz / 2 elements
+    const unsigned both = (unsigned)fwave_scan_add((int)(tsz | (nrec << 16)));
+    const unsigned incl = both & 0xFFFFu;
+    const unsigned coff = incl - tsz;
+    const bool table_bad = ((unsigned)__builtin_amdgcn_readlane((int)both, 63) & 0xFFFFu) != total ||
                            __builtin_amdgcn_ballot_w64(tsz > kMaxHalfCompressed) != 0ull;
     if (table_bad) {
         fail_unit(job, lane);
         return;
     }
-    // records: a half-tile of tsz compressed bytes holds at most tsz / 2 elements (and one per field)
-    const unsigned hfields = lane < nhalf ? min(kHalf, out_len - kHalf * lane) / kBlock * PERIOD : 0u;
-    const unsigned nrec = min(min(kRecPerHalf, tsz >> 1), hfields);
-    const int rincl = fwave_scan_add((int)nrec);
-    const unsigned rbase = (unsigned)rincl - nrec;
-    const unsigned rbytes = 2u * (unsigned)__builtin_amdgcn_readlane(rincl, 63);
+    const unsigned rbase = (both >> 16) - nrec;
+    const unsigned rbytes = 2u * ((unsigned)__builtin_amdgcn_readlane((int)both, 63) >> 16);
     coffs[lane] = coff | (rbase << 16);
     // Output of half-tiles < h may overwrite buffer bytes below 128 h; the input of half-tile h sits at S + coff[h].
     const int lead = lane < nhalf ? (int)(kHalf * lane) - (int)coff : 0;
@@ -236,9 +240,10 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
         const unsigned litk = 1u + kLitBias + 0x8000u - cbase;
         unsigned p = 0, mlo = 0, mhi = 0;
         unsigned recp = 0;                                 // byte offset into this half-tile's records
-        unsigned acc_or = 0;                               // OR of copy offsets (low bits) and start positions << 16
-        unsigned acc_bad = 0;                              // any bit set = the stream breaks a promise
-        unsigned min_off = 0xFFFFu, max_up = 0;            // smallest copy offset, largest literal length code
+        unsigned acc_or = 0;                               // OR of copy offsets (low bits) and start positions << 17
+        unsigned max_kind = 0;                             // 3 = a copy-4 element
+        int max_reach = 0;                                 // how far before the fragment the farthest copy reaches
+        unsigned min_off = 0xFFFFFu, max_up = 0;           // smallest copy offset, largest literal length code
         uint8_t *const recb = (rec_in_lds ? buf : rec_mem) + 2u * rbase;
         const unsigned reccap = 2u * nrec;                 // (a stream with more elements than that has left its bytes)
         // (every element advances p by at least one byte, so the walk is bounded; elements that start off a field
@@ -264,10 +269,12 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
                 const unsigned litrec = (cp - p) + lngv + litk;                 // 0x8000 | 1 .. 128 + 146
                 // promises: whole blocks back (low offset bits 0), at least one, not before the fragment; no copy-4
                 // (kind 3); no literal with 2..4 length bytes (tag >> 2 in 61..63); starts on 2- / 4-byte positions
-                acc_or |= (is_lit ? 0u : off) | (p << 16);
-                min_off = min(min_off, is_lit ? 0xFFFFu : off);
+                const unsigned offx = is_lit ? 0x10000u : off;                  // (a literal counts as offset 64 Ki: neutral below)
+                acc_or |= offx | (p << 17);
+                min_off = min(min_off, offx);
                 max_up = max(max_up, is_lit ? up : 0u);
-                acc_bad |= (w & (w >> 1) & 1u) | ((!is_lit && off > obase + p) ? 1u : 0u);
+                max_kind = max(max_kind, kind);
+                max_reach = max(max_reach, (int)(offx & 0xFFFFu) - (int)(obase + p));   // > 0: a copy from before the fragment
                 if (recp < reccap)
                     *reinterpret_cast<uint16_t *>(recb + recp) = (uint16_t)(is_lit ? litrec : off >> kRecShift);
                 recp += 2u;
@@ -280,8 +287,8 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
         } while (__builtin_amdgcn_ballot_w64(p < hbytes) != 0ull);
         // an element that overshoots its half-tile or the table's byte count ends up with p / cp off the mark;
         // starts off a field boundary show in the mask (16-byte blocks: fields begin at bytes 0, 2, 8, 12)
-        bool bad = acc_bad != 0u || (acc_or & (kBlock - 1u)) != 0u || ((acc_or >> 16) & ((1u << kPosShift) - 1u)) != 0u ||
-                   min_off < kBlock || max_up > 60u || (h < nhalf && (cp != cend || p != hbytes)) || recp > reccap;
+        bool bad = max_kind == 3u || max_reach > 0 || (acc_or & (kBlock - 1u)) != 0u ||
+                   ((acc_or >> 17) & ((1u << kPosShift) - 1u)) != 0u || min_off < kBlock || max_up > 60u || (h < nhalf && (cp != cend || p != hbytes)) || recp > reccap;
         bad = bad || ((mlo | mhi) & ~start_positions<LAYOUT>()) != 0u;
         masks[h] = make_uint2(mlo, mhi);
         if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
@@ -382,7 +389,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
                 const int ring_addr = (int)(ring_k[k] + s * kStepBytes) - rr * (int)(kBlock / 4u);
                 const int cpy = min(pend, ring_addr);
                 const int lit_mask = rr >> 31;                              // all ones: literal
-                state[s][k] = (lit_addr & lit_mask) | (cpy & ~lit_mask);
+                state[s][k] = bit_select(lit_mask, lit_addr, cpy);
             }
         }
     }
@@ -413,7 +420,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
 #pragma unroll
                 for (unsigned k = 0; k < PERIOD; k++) {
                     const int pm = state[s0 + s][k] >> 31;                  // all ones: still pending
-                    state[s0 + s][k] = (g[s][k] & pm) | (state[s0 + s][k] & ~pm);
+                    state[s0 + s][k] = bit_select(pm, g[s][k], state[s0 + s][k]);
                 }
         }
     }
