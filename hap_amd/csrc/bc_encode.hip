@@ -198,22 +198,32 @@ __device__ __forceinline__ uint2 colour_block(const unsigned (&px)[16])
     return make_uint2(c0 | (c1 << 16), idx);
 }
 
-// Colour half of a scaled YCoCg-DXT5 block; co/cg biased by 128.
-__device__ __forceinline__ uint2 ycocg_colour_block(const int (&co)[16], const int (&cg)[16])
+typedef unsigned short pk_u16 __attribute__((ext_vector_type(2)));
+typedef short pk_i16 __attribute__((ext_vector_type(2)));
+
+// Colour half of a scaled YCoCg-DXT5 block; cc[i] = Co | Cg << 16, both biased by 128 (0..255): the box, the
+// covariance terms and the scaling work on both halves at once (v_pk_min/max_u16, v_pk_mad_i16, v_mad_i32_i16).
+__device__ __forceinline__ uint2 ycocg_colour_block(const unsigned (&cc)[16])
 {
-    int lo_o = co[0], hi_o = co[0], lo_g = cg[0], hi_g = cg[0];
+    pk_u16 lo = __builtin_bit_cast(pk_u16, cc[0]), hi = lo;
 #pragma unroll
     for (int i = 1; i < 16; i++) {
-        lo_o = min(lo_o, co[i]); hi_o = max(hi_o, co[i]);
-        lo_g = min(lo_g, cg[i]); hi_g = max(hi_g, cg[i]);
+        const pk_u16 v = __builtin_bit_cast(pk_u16, cc[i]);
+        lo = __builtin_elementwise_min(lo, v);
+        hi = __builtin_elementwise_max(hi, v);
     }
+    int lo_o = lo.x, hi_o = hi.x, lo_g = lo.y, hi_g = hi.y;
     const int m = max(max(128 - lo_o, hi_o - 128), max(128 - lo_g, hi_g - 128));
     const int s = m <= 31 ? 4 : (m <= 63 ? 2 : 1);
     int cov = 0;
-    const int mo = lo_o + hi_o, mg = lo_g + hi_g;
+    const pk_i16 mid = __builtin_bit_cast(pk_i16, lo + hi);            // (lo + hi per half: at most 510)
 #pragma unroll
-    for (int i = 0; i < 16; i++)
-        cov = mad24(2 * co[i] - mo, 2 * cg[i] - mg, cov);
+    for (int i = 0; i < 16; i++) {
+        const pk_i16 d = __builtin_bit_cast(pk_i16, cc[i]) * (short)2 - mid;  // 2 Co - (lo + hi) | 2 Cg - (lo + hi), |.| <= 255
+        int r;
+        asm("v_mad_i32_i16 %0, %1, %1, %2 op_sel:[0,1,0,0]" : "=v"(r) : "v"(d), "v"(cov));   // low half x high half + cov
+        cov = r;
+    }
     lo_o = (lo_o - 128) * s + 128; hi_o = (hi_o - 128) * s + 128;
     lo_g = (lo_g - 128) * s + 128; hi_g = (hi_g - 128) * s + 128;
     int ins = (hi_o - lo_o) >> 4; lo_o += ins; hi_o -= ins;
@@ -226,9 +236,15 @@ __device__ __forceinline__ uint2 ycocg_colour_block(const int (&co)[16], const i
     if (c0 != c1) {
         unsigned pal[4], px[16];
         palette_from_565(c0, c1, false, pal);
+        // (c - 128) s + 128 for both halves (16-bit arithmetic wraps to the right value), then Co' | Cg' << 8
+        const pk_u16 scale = {(unsigned short)s, (unsigned short)s};
+        const unsigned short bias = (unsigned short)(128 - 128 * s);
+        const pk_u16 off = {bias, bias};
 #pragma unroll
-        for (int i = 0; i < 16; i++)
-            px[i] = pack3((co[i] - 128) * s + 128, (cg[i] - 128) * s + 128, 0);
+        for (int i = 0; i < 16; i++) {
+            const unsigned t = __builtin_bit_cast(unsigned, (pk_u16)(__builtin_bit_cast(pk_u16, cc[i]) * scale + off));
+            px[i] = __builtin_amdgcn_perm(t, t, 0x0C0C0200u);            // bytes: t.0, t.2, zero, zero
+        }
         idx = nearest4(px, pal);
     }
     return make_uint2(c0 | (c1 << 16), idx);
@@ -278,17 +294,19 @@ __device__ __forceinline__ void encode_block(const uint8_t *__restrict__ rgba, s
         const uint2 ab = alpha_block(a), cb = colour_block(px);
         *reinterpret_cast<uint4 *>(out + id * 16u) = make_uint4(ab.x, ab.y, cb.x, cb.y);
     } else {
-        int y[16], co[16], cg[16];
+        int y[16];
+        unsigned cc[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             // Y = (R+2G+B+2)>>2 ; Co = ((R-B+1)>>1)+128 = (R+(255-B)+2)>>1 ; Cg = ((-R+2G-B+2)>>2)+128 =
             // ((255-R)+2G+(255-B)+4)>>2 -- three byte dot products (alpha weight 0), upper clamp only
             const unsigned q = p[i];
             y[i] = (int)(__builtin_amdgcn_udot4(q, 0x00010201u, 2u, false) >> 2);
-            co[i] = (int)min(__builtin_amdgcn_udot4(q ^ 0x00FF0000u, 0x00010001u, 2u, false) >> 1, 255u);
-            cg[i] = (int)min(__builtin_amdgcn_udot4(q ^ 0x00FF00FFu, 0x00010201u, 4u, false) >> 2, 255u);
+            const unsigned co = min(__builtin_amdgcn_udot4(q ^ 0x00FF0000u, 0x00010001u, 2u, false) >> 1, 255u);
+            const unsigned cg = min(__builtin_amdgcn_udot4(q ^ 0x00FF00FFu, 0x00010201u, 4u, false) >> 2, 255u);
+            cc[i] = co | (cg << 16);
         }
-        const uint2 ab = alpha_block(y), cb = ycocg_colour_block(co, cg);
+        const uint2 ab = alpha_block(y), cb = ycocg_colour_block(cc);
         *reinterpret_cast<uint4 *>(out + id * 16u) = make_uint4(ab.x, ab.y, cb.x, cb.y);
         if (FMT == kFmtYCoCgAlpha) {
             int a[16];
