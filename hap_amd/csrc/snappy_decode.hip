@@ -16,9 +16,15 @@
 //                         window's output is produced 64 units (bytes, or 2 / 4 bytes when the table
 //                         promises such granularity) per step through an owner map; the last RING
 //                         bytes of output live in LDS so that back-references are LDS -> LDS.
-//                         Used for frames from other encoders (one unit per chunk, 32 KiB ring,
-//                         older bytes re-read from memory), for fragment tables of version 1, and as
-//                         the fallback whenever a table turns out not to describe its streams.
+//                         Used for frames from other encoders (one unit per 64 KiB block found by the
+//                         scan below with a 2 KiB ring, or one unit per chunk with a 32 KiB ring; older
+//                         bytes are re-read from memory), for fragment tables of version 1, and as the
+//                         fallback whenever a table turns out not to describe its streams.
+//   scan_walk_kernel / scan_merge_kernel / scan_find_kernel
+//                         the block scan: where in the compressed bytes of another encoder's stream
+//                         each 64 KiB block of output begins (libsnappy's blocks are independent),
+//                         found in parallel over 4 KiB segments of compressed bytes without producing
+//                         output -- see the comment in front of them.
 //
 // Frames written by this library with the version-2 table ("field streams": DXT5, YCoCg-DXT5, DXT1,
 // large RGTC1 planes) are decoded by the block-per-lane kernel of snappy_decode_fields.hip instead.
