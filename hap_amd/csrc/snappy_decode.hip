@@ -754,12 +754,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
                 // far sources were written to memory by THIS wave at least RING - 12 KiB of output ago:
                 // drain the wave's own stores, then read back past the CU's L1 (sc1), which may still
                 // hold the line as it was before those stores
-#ifdef HAP_FAR_FENCE
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
                 if (far)
                     value = __hip_atomic_load(dst + a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }

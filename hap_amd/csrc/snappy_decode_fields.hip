@@ -251,11 +251,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
         do {
             if (p < hbytes) {
                 const unsigned aw = cp >> 2;
-                #ifdef DBG_OLDALIGN
-                const unsigned w = __builtin_amdgcn_alignbyte(bufw[aw + 1u], bufw[aw], cp & 3u);
-#else
-                const unsigned w = __builtin_amdgcn_alignbyte(bufw[aw + 1u], bufw[aw], cp);     // bytes cp .. cp+3
-#endif
+                const unsigned w = __builtin_amdgcn_alignbyte(bufw[aw + 1u], bufw[aw], cp);     // bytes cp .. cp+3 (shift = cp & 3)
                 const unsigned kind = w & 3u, up = __builtin_amdgcn_ubfe(w, 2u, 6u);
                 const unsigned b1 = __builtin_amdgcn_ubfe(w, 8u, 8u);
                 const bool is_lit = kind == 0u, is_c1 = kind == 1u;
