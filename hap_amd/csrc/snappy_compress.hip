@@ -613,6 +613,13 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
                       : COLOUR ? (t == 0 ? 0xFFFFFFFFu : 0u) : (t == 0 ? 0x0000FFFFu : 0xFFFF0000u);
     const unsigned m2 = PERIOD == 4 ? ((t & 1u) ? 0xFFFFFFFFu : 0u) : (t == 1 ? 0xFFFFFFFFu : 0u);
     const unsigned size = PERIOD == 4 ? (t == 0 ? 2u : t == 1 ? 6u : 4u) : COLOUR ? 4u : (t == 0 ? 2u : 6u);
+    // how the field's bytes come out of the 8 bytes (ux, vx) read at `half`: [2,6]: field 0 = ux & 0xFFFF, field 1 = the
+    // six bytes from byte 2; the 4-byte fields are ux (field 2 of [2,6,4,4], field 0 of [4,4]) or vx
+    const bool f_from_v = PERIOD == 4 ? t == 3u : (COLOUR && t == 1u);
+    const unsigned f_shift = (!COLOUR && t == 1u) ? 16u : 0u;
+    const unsigned f_mask_lo = (!COLOUR && t == 0u) ? 0xFFFFu : 0xFFFFFFFFu;
+    const unsigned f_mask_hi = (!COLOUR && t == 1u) ? 0xFFFFu : 0u;
+
     const bool upper = lane >= 32u;
     const unsigned lane31 = lane & 31u;
     const unsigned my_off = field_offset<PERIOD, COLOUR>(lane);
@@ -730,52 +737,35 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
                 skip = carry;
                 // (field streams: a literal run ends at the half-tile boundary, a new one starts at lane 32)
                 const unsigned long long starts = (lit & ~(lit << 1)) | (halves ? lit & (1ull << 32) : 0ull);
-                unsigned run = 0;                          // literal run length in BYTES
-                if (__builtin_amdgcn_inverse_ballot_w64(starts)) {
+                // literal run that starts at this lane, in bytes (0: none starts here).  Everything below is worked out for
+                // every lane and selected at the end: branches on lane-varying conditions cost more scalar bookkeeping
+                // than the few instructions they would skip.
+                unsigned r;
+                if (halves) {                              // (uniform) runs end with the half-tile: 32 lanes are enough
+                    const unsigned wlo = upper ? (unsigned)(lit >> 32) : (unsigned)lit;
+                    const unsigned whi = upper ? 0u : (unsigned)(lit >> 32);
+                    const unsigned inv = ~__builtin_amdgcn_alignbit(whi, wlo, lane31);
+                    r = min(inv ? (unsigned)__builtin_ctz(inv) : 32u, 32u - lane31);
+                } else {
                     const unsigned long long a = ~(lit >> lane);
-                    unsigned r = a ? (unsigned)__builtin_ctzll(a) : 64u;
-                    if (halves && lane < 32u)
-                        r = min(r, 32u - lane);
-                    run = field_offset<PERIOD, COLOUR>(lane + r) - my_off;
+                    r = a ? (unsigned)__builtin_ctzll(a) : 64u;
                 }
-                // this lane's element: literal = [run header] + the field's bytes, copy = 2 or 3 bytes
-                unsigned cnt = 0, vlo = 0, vhi = 0;
-                if (__builtin_amdgcn_inverse_ballot_w64(lit)) {
-                    // field bytes, low byte first
-                    unsigned flo, fhi = 0;
-                    if (PERIOD == 4 && t >= 2u) {
-                        flo = t == 2u ? ux[sub] : vx[sub];
-                    } else if (COLOUR) {
-                        flo = t == 0u ? ux[sub] : vx[sub];
-                    } else if (t == 0u) {
-                        flo = ux[sub] & 0xFFFFu;
-                    } else {
-                        flo = (ux[sub] >> 16) | (vx[sub] << 16);
-                        fhi = vx[sub] >> 16;
-                    }
-                    cnt = size;
-                    vlo = flo;
-                    vhi = fhi;
-                    if (run != 0u) {
-                        if (run > 60u) {
-                            vhi = (fhi << 16) | (flo >> 16);
-                            vlo = (flo << 16) | ((run - 1u) << 8) | 0xF0u;
-                            cnt += 2u;
-                        } else {
-                            vhi = (fhi << 8) | (flo >> 24);
-                            vlo = (flo << 8) | ((run - 1u) << 2);
-                            cnt += 1u;
-                        }
-                    }
-                } else if (__builtin_amdgcn_inverse_ballot_w64(sel)) {
-                    if (best_len < 12u && best_off < 2048u) {
-                        vlo = 1u | ((best_len - 4u) << 2) | ((best_off >> 8) << 5) | ((best_off & 0xFFu) << 8);
-                        cnt = 2u;
-                    } else {
-                        vlo = 2u | ((best_len - 1u) << 2) | (best_off << 8);
-                        cnt = 3u;
-                    }
-                }
+                const unsigned run = __builtin_amdgcn_inverse_ballot_w64(starts) ? field_offset<PERIOD, COLOUR>(lane + r) - my_off : 0u;
+                // literal element: [run header] + the field's bytes, low byte first (f_* are per-lane constants)
+                const unsigned fbase = f_from_v ? vx[sub] : ux[sub];
+                const unsigned flo = __builtin_amdgcn_alignbit(vx[sub], fbase, f_shift) & f_mask_lo;
+                const unsigned fhi = (vx[sub] >> 16) & f_mask_hi;
+                const unsigned hdr_len = (run != 0u ? 1u : 0u) + (run > 60u ? 1u : 0u);
+                const unsigned hdr = run == 0u ? 0u : run > 60u ? (0xF0u | ((run - 1u) << 8)) : ((run - 1u) << 2);
+                const unsigned long long lit_bytes = ((((unsigned long long)fhi << 32) | flo) << (8u * hdr_len)) | hdr;
+                // copy element: 2 bytes (copy-1: 4..11 bytes from less than 2 KiB back) or 3
+                const bool c1 = best_len < 12u && best_off < 2048u;
+                const unsigned e1 = 1u | ((best_len - 4u) << 2) | ((best_off >> 8) << 5) | ((best_off & 0xFFu) << 8);
+                const unsigned e2 = 2u | ((best_len - 1u) << 2) | (best_off << 8);
+                const bool is_lit = __builtin_amdgcn_inverse_ballot_w64(lit), is_sel = __builtin_amdgcn_inverse_ballot_w64(sel & ~lit);
+                const unsigned cnt = is_lit ? size + hdr_len : is_sel ? (c1 ? 2u : 3u) : 0u;
+                const unsigned vlo = is_lit ? (unsigned)lit_bytes : (c1 ? e1 : e2);
+                const unsigned vhi = is_lit ? (unsigned)(lit_bytes >> 32) : 0u;
                 const int incl = cwave_scan_add((int)cnt);
                 p_at[sub] = total + (unsigned)incl - cnt;
                 if (halves) {
@@ -817,12 +807,8 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
                     store16(dst + 4, vhi);
                 if (cnt == 8u)
                     store16(dst + 6, vhi >> 16);
-                if (cnt == 3u)
-                    dst[2] = (uint8_t)(vlo >> 16);
-                if (cnt == 5u)
-                    dst[4] = (uint8_t)vhi;
-                if (cnt == 7u)
-                    dst[6] = (uint8_t)(vhi >> 16);
+                if (cnt & 1u)                                // 3, 5 or 7 bytes: the last one on its own
+                    dst[cnt - 1u] = (uint8_t)(cnt == 3u ? vlo >> 16 : cnt == 5u ? vhi : vhi >> 16);
                 // every field is remembered (candidates are looked up by field, not by element)
                 if (__builtin_amdgcn_inverse_ballot_w64(m_in[sub]))
                     atomicMax(&table[p_hash[sub]], (kFieldSubs * k + sub) * TB / kBlock * PERIOD + lane);
