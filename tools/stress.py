@@ -1,0 +1,53 @@
+"""Dev stress run: many random textures through encode -> decode (field streams, records in LDS and in memory,
+generic streams) and checker-made frames through the block scan, batches of several frames, every result compared.
+    python tools/stress.py [seed] [seconds]"""
+import os, sys, time
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _data as D, _libs as L, hap_amd
+ORA = L.oracle_api()
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
+ctx = hap_amd.Context(0)
+FMTS = [(L.FMT_DXT1, 8), (L.FMT_DXT5, 16), (L.FMT_YCOCG, 16), (L.FMT_RGTC1, 8), (L.FMT_BC7, 16)]
+t0 = time.time(); rounds = frames = fails = 0
+while time.time() - t0 < budget:
+    fmt, block = FMTS[int(rng.integers(0, len(FMTS)))]
+    nf = int(rng.integers(1, 5))
+    nblocks = int(rng.integers(1, 40000)) if rng.integers(0, 4) else int(rng.integers(100000, 300000))
+    chunks = int(rng.integers(1, 9))
+    texs = []
+    for i in range(nf):
+        kind = ["zero", "random", "mixed", "runs"][int(rng.integers(0, 4))]
+        t = bytearray(D.stream_bytes(nblocks * block, kind, seed=int(rng.integers(0, 1 << 30))))
+        if rng.integers(0, 2) and block == 16:            # constant endpoints, noisy indices: poorly compressible field streams
+            a = np.frombuffer(bytes(t), dtype=np.uint8).reshape(-1, 16).copy()
+            a[:, 0:2] = 7; a[:, 8:12] = 9
+            a[:, 2:8] = rng.integers(0, 256, (a.shape[0], 6), dtype=np.uint8)
+            t = bytearray(a.tobytes())
+        texs.append(bytes(t))
+    n = nblocks * block
+    cap = hap_amd.HapMaxEncodedLength([n], [fmt], [chunks]) + 4096
+    # ours: encode a batch, decode the batch, compare; the checker must agree on the first frame
+    outs = [np.zeros(cap, dtype=np.uint8) for _ in range(nf)]
+    flags = hap_amd.ENCODE_FRAGMENT_INDEX if rng.integers(0, 4) else 0
+    r, used, res = ctx.encode_frames([[t] for t in texs], [fmt], [1], [chunks], outs, flags=flags)
+    ok = r == 0 and all(x == 0 for x in res)
+    if ok:
+        encoded = [outs[i][: used[i]].tobytes() for i in range(nf)]
+        decs = [np.zeros(n, dtype=np.uint8) for _ in range(nf)]
+        r, du, df, dr = ctx.decode_frames(encoded, [len(e) for e in encoded], 0, decs)
+        ok = r == 0 and all(decs[i].tobytes() == texs[i] for i in range(nf)) and ORA.decode(encoded[0], 0, n) == (0, texs[0], fmt)
+    # the checker's frames: block scan path (several blocks per chunk when the texture is large)
+    if ok:
+        foreign = [ORA.encode([t], [fmt], [1], [chunks])[1] for t in texs]
+        decs = [np.zeros(n, dtype=np.uint8) for _ in range(nf)]
+        r, du, df, dr = ctx.decode_frames(foreign, [len(e) for e in foreign], 0, decs)
+        ok = r == 0 and all(decs[i].tobytes() == texs[i] for i in range(nf))
+    rounds += 1; frames += nf
+    if not ok:
+        fails += 1
+        print("FAIL round", rounds, "fmt", hex(fmt), "blocks", nblocks, "chunks", chunks, "frames", nf, "flags", flags)
+print("stress: %d rounds, %d frames, %d failures, fallbacks %d, %.0f s" % (rounds, frames, fails, ctx.table_fallbacks(), time.time() - t0))
