@@ -542,6 +542,18 @@ constexpr bool field_distances_consecutive()
 }
 constexpr bool kFieldConsecutive = field_distances_consecutive();
 
+// bits lane .. lane + 31 of a wave-wide mask (continued by the next tile's mask), as this lane sees them: with one tile
+// per round a single 64-bit shift of the scalar pair; picking halves per lane and funnel-shifting costs twice as much
+__device__ __forceinline__ unsigned mask_window(unsigned long long cur, unsigned long long next, unsigned lane)
+{
+    if (kFieldSubs == 1u)
+        return (unsigned)(cur >> lane);
+    const bool upper = lane >= 32u;
+    const unsigned lo = upper ? (unsigned)(cur >> 32) : (unsigned)cur;
+    const unsigned hi = upper ? (unsigned)next : (unsigned)(cur >> 32);
+    return __builtin_amdgcn_alignbit(hi, lo, lane & 31u);
+}
+
 template <unsigned PERIOD, bool COLOUR = false>
 __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(const HapGpuFrameEnc *__restrict__ frames,
                                                                    uint8_t *__restrict__ slots, unsigned slot_stride,
@@ -551,7 +563,12 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
     constexpr unsigned FL = 13u, kFragBytes = 1u << FL;
     constexpr unsigned kBlock = PERIOD == 4 ? 16u : 8u;
     constexpr unsigned TB = 64u / PERIOD * kBlock;                // 256 bytes per tile
-    __shared__ __attribute__((aligned(16))) uint8_t smem[kFragBytes + 32u + kWgHashEntries * 4u + kWgWaves * 4u];
+    // (kLead zero bytes in front of the fragment: the candidate 1..4 blocks back is read at a constant offset from the
+    // lane's own position, without a clamp for the first blocks -- whose lanes are masked out of the match anyway)
+    constexpr unsigned kLead = (kFieldDist[kFieldFixed - 1] * 16u + 15u) & ~15u;
+    static_assert(kLead <= 1024u, "candidate distances are ascending and short");
+    __shared__ __attribute__((aligned(16))) uint8_t smem_all[kLead + kFragBytes + 32u + kWgHashEntries * 4u + kWgWaves * 4u];
+    uint8_t *const smem = smem_all + kLead;
     uint32_t *table = reinterpret_cast<uint32_t *>(smem + kFragBytes + 32);
     uint32_t *roundsz = table + kWgHashEntries;
 
@@ -604,6 +621,8 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
     }
     for (unsigned i = tid; i < kWgHashEntries; i += 64u * kWgWaves)
         table[i] = 0u;
+    if (tid * 16u < kLead)
+        *reinterpret_cast<uint4 *>(smem_all + tid * 16u) = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
     // per-lane constants: field type, position of the 8-byte half block that holds the field, compare masks
@@ -620,7 +639,6 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
     const unsigned f_mask_lo = (!COLOUR && t == 0u) ? 0xFFFFu : 0xFFFFFFFFu;
     const unsigned f_mask_hi = (!COLOUR && t == 1u) ? 0xFFFFu : 0u;
 
-    const bool upper = lane >= 32u;
     const unsigned lane31 = lane & 31u;
     const unsigned my_off = field_offset<PERIOD, COLOUR>(lane);
 
@@ -649,7 +667,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
                 for (int d = 0; d < kFieldFixed; d++) {
                     const unsigned dist = kFieldDist[d] * kBlock;
                     const unsigned at = tile_base + half;
-                    const uint2 yv = *reinterpret_cast<const uint2 *>(smem + (at >= dist ? at - dist : 0u));
+                    const uint2 yv = *reinterpret_cast<const uint2 *>(smem + at - dist);     // (may lie in the lead bytes)
                     // lanes whose source lies inside the fragment (and inside the match window)
                     unsigned long long reachable = ~0ull;
                     if (tile_base < dist) {
@@ -691,9 +709,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
                 const unsigned long long same = ballot64(next_hd == hd[sub]) & ballot64(hd[sub] != 0u);
                 unsigned best_key;
                 {
-                    const unsigned lo = upper ? (unsigned)(same >> 32) : (unsigned)same;
-                    const unsigned hi = upper ? 0u : (unsigned)(same >> 32);
-                    const unsigned inv = ~__builtin_amdgcn_alignbit(hi, lo, lane31);
+                    const unsigned inv = ~mask_window(same, 0ull, lane);
                     const unsigned more = inv ? (unsigned)__builtin_ctz(inv) : 32u;
                     best_key = hd[sub] ? (min(1u + more, room_lanes) << 3) : 0u;
                 }
@@ -703,9 +719,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
                     const unsigned long long c = eq[d][sub], nx = sub + 1 < (int)kFieldSubs ? eq[d][sub + 1 < (int)kFieldSubs ? sub + 1 : sub] : 0ull;
                     if (c == 0ull)
                         continue;
-                    const unsigned lo = upper ? (unsigned)(c >> 32) : (unsigned)c;
-                    const unsigned hi = upper ? (unsigned)nx : (unsigned)(c >> 32);
-                    const unsigned inv = ~__builtin_amdgcn_alignbit(hi, lo, lane31);
+                    const unsigned inv = ~mask_window(c, nx, lane);
                     const unsigned l = min(inv ? (unsigned)__builtin_ctz(inv) : 32u, room_lanes);
                     best_key = max(best_key, (l << 3) | (unsigned)(d + 1));            // farther wins ties
                 }
@@ -742,9 +756,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
                 // than the few instructions they would skip.
                 unsigned r;
                 if (halves) {                              // (uniform) runs end with the half-tile: 32 lanes are enough
-                    const unsigned wlo = upper ? (unsigned)(lit >> 32) : (unsigned)lit;
-                    const unsigned whi = upper ? 0u : (unsigned)(lit >> 32);
-                    const unsigned inv = ~__builtin_amdgcn_alignbit(whi, wlo, lane31);
+                    const unsigned inv = ~(unsigned)(lit >> lane);
                     r = min(inv ? (unsigned)__builtin_ctz(inv) : 32u, 32u - lane31);
                 } else {
                     const unsigned long long a = ~(lit >> lane);
