@@ -95,7 +95,7 @@ __device__ __forceinline__ uint2 alpha_block(const int (&a)[16])
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const int u = imed3(a0 - a[i], 0, d);
-            const unsigned r_lo = __umul24((unsigned)max(u - 1, 0), r7) >> 19;
+            const unsigned r_lo = __umul24(__builtin_elementwise_sub_sat((unsigned)u, 1u), r7) >> 19;   // (u - 1, not below 0)
             // H[r_lo]: one byte of the 8-byte table (selector bytes 1..3 = 0x0C give zero)
             const unsigned th = __builtin_amdgcn_perm(h_hi, h_lo, r_lo | 0x0C0C0C00u);
             const unsigned r = r_lo + ((unsigned)u > th ? 1u : 0u);
@@ -117,6 +117,7 @@ __device__ __forceinline__ uint2 alpha_block(const int (&a)[16])
 
 // 2-bit index of the nearest of 4 palette entries for 16 pixels; px and pal are packed
 // bytes (c0 | c1<<8 | c2<<16), top byte zero.  Lowest index wins ties.
+template <bool COMPLEMENTED = false>      // COMPLEMENTED: px already holds 255 - p in its colour bytes
 __device__ __forceinline__ unsigned nearest4(const unsigned (&px)[16], const unsigned (&pal)[4])
 {
     // |p - c_k|^2 orders like |c_k|^2 - 2 p.c_k; scale by 4 and put k in the low bits so that one signed min
@@ -131,7 +132,7 @@ __device__ __forceinline__ unsigned nearest4(const unsigned (&px)[16], const uns
     unsigned idx = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        const unsigned q = px[i] ^ 0x00FFFFFFu;
+        const unsigned q = COMPLEMENTED ? px[i] : px[i] ^ 0x00FFFFFFu;
         const int s0 = (int)(__builtin_amdgcn_udot4(q, pal[0], 0u, false) << 3) + base[0];
         const int s1 = (int)(__builtin_amdgcn_udot4(q, pal[1], 0u, false) << 3) + base[1];
         const int s2 = (int)(__builtin_amdgcn_udot4(q, pal[2], 0u, false) << 3) + base[2];
@@ -236,16 +237,17 @@ __device__ __forceinline__ uint2 ycocg_colour_block(const unsigned (&cc)[16])
     if (c0 != c1) {
         unsigned pal[4], px[16];
         palette_from_565(c0, c1, false, pal);
-        // (c - 128) s + 128 for both halves (16-bit arithmetic wraps to the right value), then Co' | Cg' << 8
-        const pk_u16 scale = {(unsigned short)s, (unsigned short)s};
-        const unsigned short bias = (unsigned short)(128 - 128 * s);
+        // 255 - ((c - 128) s + 128) for both halves (16-bit arithmetic wraps to the right value) -- the index search
+        // multiplies the complement --, then the two bytes side by side
+        const pk_u16 scale = {(unsigned short)(0u - (unsigned)s), (unsigned short)(0u - (unsigned)s)};
+        const unsigned short bias = (unsigned short)(127 + 128 * s);
         const pk_u16 off = {bias, bias};
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const unsigned t = __builtin_bit_cast(unsigned, (pk_u16)(__builtin_bit_cast(pk_u16, cc[i]) * scale + off));
             px[i] = __builtin_amdgcn_perm(t, t, 0x0C0C0200u);            // bytes: t.0, t.2, zero, zero
         }
-        idx = nearest4(px, pal);
+        idx = nearest4<true>(px, pal);
     }
     return make_uint2(c0 | (c1 << 16), idx);
 }
