@@ -304,9 +304,10 @@ __device__ __forceinline__ void encode_block(const uint8_t *__restrict__ rgba, s
             // ((255-R)+2G+(255-B)+4)>>2 -- three byte dot products (alpha weight 0), upper clamp only
             const unsigned q = p[i];
             y[i] = (int)(__builtin_amdgcn_udot4(q, 0x00010201u, 2u, false) >> 2);
-            const unsigned co = min(__builtin_amdgcn_udot4(q ^ 0x00FF0000u, 0x00010001u, 2u, false) >> 1, 255u);
-            const unsigned cg = min(__builtin_amdgcn_udot4(q ^ 0x00FF00FFu, 0x00010201u, 4u, false) >> 2, 255u);
-            cc[i] = co | (cg << 16);
+            const unsigned co = __builtin_amdgcn_udot4(q ^ 0x00FF0000u, 0x00010001u, 2u, false) >> 1;      // 1..256
+            const unsigned cg = __builtin_amdgcn_udot4(q ^ 0x00FF00FFu, 0x00010201u, 4u, false) >> 2;      // 1..256
+            const pk_u16 both = __builtin_bit_cast(pk_u16, co | (cg << 16)), top = {255, 255};
+            cc[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_min(both, top));                      // upper clamp, both at once
         }
         const uint2 ab = alpha_block(y), cb = ycocg_colour_block(cc);
         *reinterpret_cast<uint4 *>(out + id * 16u) = make_uint4(ab.x, ab.y, cb.x, cb.y);
