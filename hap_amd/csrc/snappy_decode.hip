@@ -825,6 +825,7 @@ constexpr unsigned kScanWarmWindows = 5u;                     // > the longest e
 constexpr unsigned kScanLds = kScanSegment + 64u * kScanWarmWindows + 128u;
 constexpr unsigned kBlockOut = 65536u;
 constexpr unsigned kRecNone = 0xFFu;
+constexpr unsigned kMergeSegments = 2048u;                    // segments of one stream the merge kernel tabulates (8 MiB compressed)
 
 // One 16-byte / 4-byte piece of the stream at aligned coordinate c, without touching bytes at or after in_end.
 __device__ __forceinline__ uint4 scan_load16(const uint8_t *src_al, unsigned c, unsigned in_end)
@@ -1066,8 +1067,70 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
     unsigned long long rec = kRecNone, rec_ahead = kRecNone;
     HapGpuScanSegment sg = {}, sg_ahead = {};
     bool ok = true;
+    // The usual case, worked out for all segments at once (one lane per segment): the chain recorded for segment i - 1
+    // leaves it inside segment i at a byte where the chain recorded for segment i entered a window (thanks to the
+    // warm-up it has joined the true chain by then) -- segment i is "good".  Along a run of good segments the recorded
+    // chains are the true chain and the output positions are prefix sums; the walk below takes such runs in one step and
+    // parses windows itself only in the segments that are not good (about one in a hundred).
+    __shared__ uint32_t l_exit[kMergeSegments];             // where segment i's recorded chain leaves it
+    __shared__ uint32_t l_before[kMergeSegments + 1u];      // output of the good segments before i (entry to exit each)
+    __shared__ unsigned long long l_good[kMergeSegments / 64u];
+    const unsigned nseg = (in_end + kScanSegment - 1u) / kScanSegment;
+    const unsigned first_element = p;
+    const bool tabled = nseg <= sc.seg_count && nseg <= kMergeSegments;
+    if (tabled) {
+        unsigned run = 0;
+        for (unsigned base = 0; base < nseg; base += 64u) {
+            const unsigned i = base + lane;
+            const bool mine = i < nseg;
+            unsigned entry = first_element, flags_prev = 0;
+            if (mine && i > 0u) {
+                const HapGpuScanSegment prev = segs[sc.seg_first + i - 1u];
+                entry = prev.exit_coord;
+                flags_prev = prev.flags;
+            }
+            HapGpuScanSegment here = {};
+            unsigned long long r = kRecNone;
+            if (mine)
+                here = segs[sc.seg_first + i];
+            const bool inside = mine && flags_prev == 0u && entry / kScanSegment == i && entry < in_end;
+            if (inside)
+                r = recs[(size_t)(sc.seg_first + i) * 64u + ((entry % kScanSegment) >> 6)];
+            const bool good = inside && ((unsigned)r & 0xFFu) == (entry & 63u) && (here.flags & 1u) == 0u;
+            const unsigned delta = good ? here.cum_total - (unsigned)(r >> 8) : 0u;
+            const unsigned incl = (unsigned)wave_scan_add((int)delta);
+            if (mine) {
+                l_exit[i] = here.exit_coord;
+                l_before[i] = run + incl - delta;
+            }
+            const unsigned long long goods = ballot64(good);
+            if (lane == 0)
+                l_good[base / 64u] = goods;
+            run += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        if (lane == 0)
+            l_before[nseg] = run;
+        __syncthreads();
+    }
     while (p < in_end) {
         const unsigned s = p / kScanSegment, wi = (p % kScanSegment) >> 6, e = p & 63u;
+        if (tabled && p == (s == 0u ? first_element : l_exit[s - 1u]) && ((l_good[s / 64u] >> (s & 63u)) & 1ull)) {
+            // a run of good segments [s, t): all their joins at once, then on to where the last one's chain leaves
+            unsigned t = s + 1u;
+            while (t < nseg && ((l_good[t / 64u] >> (t & 63u)) & 1ull))
+                t++;
+            const unsigned before_run = l_before[s];
+            for (unsigned i = s + lane; i < t; i += 64u) {
+                const unsigned entry = i == 0u ? first_element : l_exit[i - 1u];
+                const unsigned w = (entry % kScanSegment) >> 6;
+                const unsigned at_entry = (unsigned)(recs[(size_t)(sc.seg_first + i) * 64u + w] >> 8);
+                joins[sc.seg_first + i] = make_uint2(w, op + (l_before[i] - before_run) - at_entry);
+            }
+            op += l_before[t] - before_run;
+            p = l_exit[t - 1u];
+            cur = 0xFFFFFFFFu;
+            continue;
+        }
         if (s != cur) {
             // the next segment's record was asked for when this one was entered (the chain nearly always goes there)
             if (s == cur + 1u && cur != 0xFFFFFFFFu) {
