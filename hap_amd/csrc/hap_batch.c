@@ -25,7 +25,7 @@ enum {
 #define D_PACK D_PREFIX
 #define D_SCAN D_SLOTS       /* ... and the decoder's block-scan arena in an encode-only one */
 #define P_SCAN P_FRAMES
-enum { P_FRAMES = 0, P_JOBS, P_CHUNKS, P_PREFIX, P_PTRS, P_BC_PTRS };   /* (8, 9: hap_sequence.c) */
+enum { P_FRAMES = 0, P_JOBS, P_CHUNKS, P_PREFIX, P_PTRS, P_BC_PTRS, P_PREFIX2 };   /* (8, 9: hap_sequence.c) */
 
 #define PREFIX_BYTES 8192u   /* headers + tables of a frame with a few hundred chunks; larger ones are fetched on demand */
 #define COPY_PIECE 65536u
@@ -722,6 +722,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                 fetchers[f].device_frame = (const uint8_t *)inputs[f];
                 readers[f].fetch = fetch_from_device;
                 readers[f].user = &fetchers[f];
+                readers[f].total_len = input_bytes[f];
             } else {
                 hapf_reader_init_host(&readers[f], inputs[f], input_bytes[f]);
                 in_off[f] = in_stage_bytes + 1;
@@ -732,6 +733,49 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
             rc |= hapgpu_rt_sync(rt);
         if (rc)
             goto fail_alloc;
+        /* a later texture of a multi-texture frame begins where the first one ends, far beyond the prefix: the start
+           of its section comes over in a second gather for the whole call instead of one round trip per frame and table */
+        if (device_frames && index > 0) {
+            uint64_t *hptr = (uint64_t *)hapgpu_rt_pinned_scratch(rt, P_PTRS, sizeof(uint64_t) * 2u * frame_count);
+            uint64_t *dptr = (uint64_t *)hapgpu_rt_device_scratch(rt, D_PTRS, sizeof(uint64_t) * 2u * frame_count);
+            uint8_t *dprefix = (uint8_t *)hapgpu_rt_device_scratch(rt, D_PREFIX, (size_t)PREFIX_BYTES * frame_count);
+            uint8_t *prefix2 = (uint8_t *)hapgpu_rt_pinned_scratch(rt, P_PREFIX2, (size_t)PREFIX_BYTES * frame_count);
+            unsigned far = 0;
+            if (hptr && dptr && dprefix && prefix2) {
+                for (f = 0; f < frame_count; f++) {
+                    hapf_section top, first;
+                    uint64_t at;
+                    hptr[f] = 0u;
+                    hptr[frame_count + f] = 0u;
+                    if (results[f] != HapResult_No_Error || !in_dev[f] || readers[f].view_len < 16u)
+                        continue;
+                    if (hapf_read_section(readers[f].view, (uint32_t)input_bytes[f], &top) != HapResult_No_Error ||
+                        top.type != 0x0Du || top.header_len + 8u > readers[f].view_len ||
+                        hapf_read_section(readers[f].view + top.header_len, top.length, &first) != HapResult_No_Error)
+                        continue;                                  /* (the planner reports what is wrong with it) */
+                    at = (uint64_t)top.header_len + first.header_len + first.length;
+                    if (at + 16u <= readers[f].view_len || at >= input_bytes[f])
+                        continue;
+                    hptr[f] = (uint64_t)(uintptr_t)inputs[f] + at;
+                    hptr[frame_count + f] = input_bytes[f] - at;
+                    readers[f].view2_off = at;
+                    far++;
+                }
+                if (far) {
+                    rc |= hapgpu_rt_h2d(rt, dptr, hptr, sizeof(uint64_t) * 2u * frame_count);
+                    rc |= hapgpu_k_gather_prefixes(rt, dptr, dptr + frame_count, frame_count, PREFIX_BYTES, dprefix);
+                    rc |= hapgpu_rt_d2h(rt, prefix2, dprefix, (size_t)PREFIX_BYTES * frame_count);
+                    rc |= hapgpu_rt_sync(rt);
+                    if (rc)
+                        goto fail_alloc;
+                    for (f = 0; f < frame_count; f++)
+                        if (hptr[f]) {
+                            readers[f].view2 = prefix2 + (size_t)PREFIX_BYTES * f;
+                            readers[f].view2_len = hptr[frame_count + f] < PREFIX_BYTES ? hptr[frame_count + f] : PREFIX_BYTES;
+                        }
+                }
+            }
+        }
     }
 
     /* 2. plan on the host: sections and tables only (hap_frame.c) */

@@ -28,23 +28,40 @@ void hapf_reader_free(hapf_reader *r)
     free(r->side);
     r->side = NULL;
     r->side_cap = 0;
+    r->side_len = 0;
 }
 
 const uint8_t *hapf_need(hapf_reader *r, uint64_t offset, uint64_t length)
 {
+    uint64_t want = length;
     if (offset + length <= r->view_len)
         return r->view + offset;
+    if (r->view2 && offset >= r->view2_off && offset + length <= r->view2_off + r->view2_len)
+        return r->view2 + (offset - r->view2_off);
     if (!r->fetch)
         return NULL;
-    if (length > r->side_cap) {
-        uint8_t *n = (uint8_t *)realloc(r->side, (size_t)length + 16);
+    if (r->side && r->side_len && offset >= r->side_off && offset + length <= r->side_off + r->side_len)
+        return r->side + (offset - r->side_off);
+    /* a fetch costs a round trip to the device: bring the neighbourhood too (the tables of a section follow its header) */
+    if (r->total_len && want < 4096u) {
+        want = 4096u;
+        if (offset + want > r->total_len)
+            want = r->total_len > offset ? r->total_len - offset : 0u;
+        if (want < length)
+            want = length;
+    }
+    if (want > r->side_cap) {
+        uint8_t *n = (uint8_t *)realloc(r->side, (size_t)want + 16);
         if (!n)
             return NULL;
         r->side = n;
-        r->side_cap = length;
+        r->side_cap = want;
     }
-    if (r->fetch(r->user, offset, length, r->side) != 0)
+    r->side_len = 0;
+    if (r->fetch(r->user, offset, want, r->side) != 0)
         return NULL;
+    r->side_off = offset;
+    r->side_len = want;
     return r->side;
 }
 

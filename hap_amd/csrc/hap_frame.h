@@ -19,12 +19,15 @@ typedef struct hapf_section {
  * host-visible copy of the first view_len bytes; anything beyond is pulled
  * through `fetch` on demand. */
 typedef struct hapf_reader {
-    const uint8_t *view;
+    const uint8_t *view;     /* host-visible bytes from the start of the frame */
     uint64_t view_len;
+    const uint8_t *view2;    /* optional second host-visible window (a later texture's section, fetched ahead) */
+    uint64_t view2_off, view2_len;
     int (*fetch)(void *user, uint64_t offset, uint64_t length, uint8_t *dst);
     void *user;
-    uint8_t *side;      /* last fetched range */
-    uint64_t side_cap;
+    uint64_t total_len;      /* frame length when known (lets a fetch bring a few KiB around what was asked for), else 0 */
+    uint8_t *side;           /* last fetched range */
+    uint64_t side_cap, side_off, side_len;
 } hapf_reader;
 
 void hapf_reader_init_host(hapf_reader *r, const void *frame, uint64_t length);
