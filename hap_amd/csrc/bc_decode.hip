@@ -98,10 +98,15 @@ __global__ __launch_bounds__(256) void bc_decode_kernel(const uint8_t *__restric
         unsigned co4 = 0, cg4 = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int s = (int)(((pal[2] >> (8 * k)) & 255u) >> 3) + 1;
+            const int s = (int)(((pal[2] >> (8 * k)) & 255u) >> 3) + 1;               // 1..32
             int co = (int)((pal[0] >> (8 * k)) & 255u) - 128, cg = (int)((pal[1] >> (8 * k)) & 255u) - 128;
-            co = co >= 0 ? co / s : -((-co) / s);
-            cg = cg >= 0 ? cg / s : -((-cg) / s);
+            // |x| / s for |x| <= 128 by a 16-bit reciprocal: floor(65536 / s) + 1 from v_rcp_f32 is exact here (the
+            // quotient is an integer for powers of two, else at least 1/31 away from one), and so is the product's
+            // top half for |x| < 516
+            const unsigned m = (unsigned)(65536.0f * __builtin_amdgcn_rcpf((float)s)) + 1u;
+            const int qo = (int)(__umul24((unsigned)abs(co), m) >> 16), qg = (int)(__umul24((unsigned)abs(cg), m) >> 16);
+            co = co >= 0 ? qo : -qo;
+            cg = cg >= 0 ? qg : -qg;
             co4 |= (unsigned)(co + 128) << (8 * k);
             cg4 |= (unsigned)(cg + 128) << (8 * k);
         }
