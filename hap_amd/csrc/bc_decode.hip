@@ -32,11 +32,11 @@ __device__ __forceinline__ void decode_alpha(uint2 blk, int (&out)[16])
     if (a0 > a1) {
 #pragma unroll
         for (int i = 1; i < 7; i++)
-            v[i + 1] = ((7 - i) * a0 + i * a1) / 7;
+            v[i + 1] = (int)(__umul24((unsigned)((7 - i) * a0 + i * a1), 9363u) >> 16);     // / 7, exact below 13107
     } else {
 #pragma unroll
         for (int i = 1; i < 5; i++)
-            v[i + 1] = ((5 - i) * a0 + i * a1) / 5;
+            v[i + 1] = (int)(__umul24((unsigned)((5 - i) * a0 + i * a1), 13108u) >> 16);    // / 5, exact below 3277
         v[6] = 0;
         v[7] = 255;
     }
@@ -61,8 +61,9 @@ __device__ __forceinline__ void decode_palette(uint2 blk, bool dxt1_modes, unsig
     const bool four = !dxt1_modes || c0 > c1;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        const int e2 = four ? (2 * e0[c] + e1[c]) / 3 : (e0[c] + e1[c]) / 2;
-        const int e3 = four ? (e0[c] + 2 * e1[c]) / 3 : 0;
+        // (/ 3 as one full-rate 24-bit multiply: exact below 32768)
+        const int e2 = four ? (int)(__umul24((unsigned)(2 * e0[c] + e1[c]), 21846u) >> 16) : (e0[c] + e1[c]) / 2;
+        const int e3 = four ? (int)(__umul24((unsigned)(e0[c] + 2 * e1[c]), 21846u) >> 16) : 0;
         pal[c] = (unsigned)e0[c] | ((unsigned)e1[c] << 8) | ((unsigned)e2 << 16) | ((unsigned)e3 << 24);
     }
 }
