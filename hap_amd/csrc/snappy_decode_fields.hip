@@ -244,7 +244,9 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
         unsigned max_kind = 0;                             // 3 = a copy-4 element
         int max_reach = 0;                                 // how far before the fragment the farthest copy reaches
         unsigned min_off = 0xFFFFFu, max_up = 0;           // smallest copy offset, largest literal length code
-        uint8_t *const recb = (rec_in_lds ? buf : rec_mem) + 2u * rbase;
+        // (two typed pointers and a uniform branch at the store: one pointer chosen between LDS and memory would make
+        // every record a flat store)
+        uint8_t *const rec_lds = buf + 2u * rbase, *const rec_glb = rec_mem + 2u * rbase;
         const unsigned reccap = 2u * nrec;                 // (a stream with more elements than that has left its bytes)
         // (every element advances p by at least one byte, so the walk is bounded; elements that start off a field
         // boundary -- the only way to have more than 32 of them -- are caught below, and the record index is masked)
@@ -271,8 +273,13 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
                 max_up = max(max_up, is_lit ? up : 0u);
                 max_kind = max(max_kind, kind);
                 max_reach = max(max_reach, (int)(offx & 0xFFFFu) - (int)(obase + p));   // > 0: a copy from before the fragment
-                if (recp < reccap)
-                    *reinterpret_cast<uint16_t *>(recb + recp) = (uint16_t)(is_lit ? litrec : off >> kRecShift);
+                if (recp < reccap) {
+                    const uint16_t record = (uint16_t)(is_lit ? litrec : off >> kRecShift);
+                    if (rec_in_lds)
+                        *reinterpret_cast<uint16_t *>(rec_lds + recp) = record;
+                    else
+                        *reinterpret_cast<uint16_t *>(rec_glb + recp) = record;
+                }
                 recp += 2u;
                 const unsigned long long bit = 1ull << (p >> kPosShift);
                 mlo |= (unsigned)bit;
