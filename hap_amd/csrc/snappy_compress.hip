@@ -834,6 +834,11 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(co
 
 } // namespace
 
+extern "C" int hapgpu_launch_snappy_compress_blocks(const HapGpuFrameEnc *frames, unsigned frame_count,
+                                                    unsigned max_frags_per_texture, unsigned textures, void *slots,
+                                                    unsigned slot_stride, uint32_t *frag_sizes, uint8_t *tile_sizes,
+                                                    unsigned layouts, hipStream_t stream);
+
 extern "C" int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsigned frame_count,
                                              unsigned max_frags_per_texture, unsigned frag_log2, void *slots,
                                              unsigned slot_stride, uint32_t *frag_sizes, uint8_t *tile_sizes,
@@ -866,15 +871,26 @@ extern "C" int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsig
                 hipLaunchKernelGGL((snappy_compress_wg_kernel<G, 0u>), grid, block, lds2, stream, frames, frag_log2,            \
                                    (uint8_t *)slots, slot_stride, frag_sizes);                                                  \
         } while (0)
-        if (frag_log2 == 13u && (granularity_mask & 16u))
-            hipLaunchKernelGGL((snappy_compress_field_kernel<2u>), grid, block, 0, stream, frames, (uint8_t *)slots,
-                               slot_stride, frag_sizes, tile_sizes);
-        if (frag_log2 == 13u && (granularity_mask & 64u))
-            hipLaunchKernelGGL((snappy_compress_field_kernel<2u, true>), grid, block, 0, stream, frames, (uint8_t *)slots,
-                               slot_stride, frag_sizes, tile_sizes);
-        if (frag_log2 == 13u && (granularity_mask & 32u))
-            hipLaunchKernelGGL((snappy_compress_field_kernel<4u>), grid, block, 0, stream, frames, (uint8_t *)slots,
-                               slot_stride, frag_sizes, tile_sizes);
+        // block textures: the block-per-lane kernels of snappy_compress_blocks.hip (HAP_AMD_FIELD_LANES=1 selects the
+        // field-per-lane kernel of this file instead, kept for comparison)
+        static const bool field_lanes = getenv("HAP_AMD_FIELD_LANES") != nullptr && atoi(getenv("HAP_AMD_FIELD_LANES")) != 0;
+        if (frag_log2 == 13u && (granularity_mask & 0x70u) && !field_lanes) {
+            const unsigned layouts = ((granularity_mask & 32u) ? 1u : 0u) | ((granularity_mask & 64u) ? 2u : 0u) |
+                                     ((granularity_mask & 16u) ? 4u : 0u);
+            if (hapgpu_launch_snappy_compress_blocks(frames, frame_count, max_frags_per_texture, textures, slots, slot_stride,
+                                                     frag_sizes, tile_sizes, layouts, stream))
+                return 4;
+        } else if (frag_log2 == 13u) {
+            if (granularity_mask & 16u)
+                hipLaunchKernelGGL((snappy_compress_field_kernel<2u>), grid, block, 0, stream, frames, (uint8_t *)slots,
+                                   slot_stride, frag_sizes, tile_sizes);
+            if (granularity_mask & 64u)
+                hipLaunchKernelGGL((snappy_compress_field_kernel<2u, true>), grid, block, 0, stream, frames, (uint8_t *)slots,
+                                   slot_stride, frag_sizes, tile_sizes);
+            if (granularity_mask & 32u)
+                hipLaunchKernelGGL((snappy_compress_field_kernel<4u>), grid, block, 0, stream, frames, (uint8_t *)slots,
+                                   slot_stride, frag_sizes, tile_sizes);
+        }
         if (granularity_mask & 1u)
             HAP_LAUNCH_COMPRESS(1u);
         if (granularity_mask & 2u)

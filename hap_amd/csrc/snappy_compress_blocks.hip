@@ -1,0 +1,439 @@
+// snappy_compress_blocks.hip -- block-per-lane Snappy compressor for block textures ("field streams"), gfx950.
+//
+// Replaces the snappy_compress call-out of the reference's chunk loop (hap.c:448-476, call at hap.c:453) for DXT5 /
+// YCoCg-DXT5 / DXT1 / RGTC1 textures.  The output is ordinary Snappy (literal / copy-1 / copy-2 elements: the
+// reference decodes it unchanged) that keeps the promises of the private fragment table version 2
+// (include/hap_gpu.h, snappy_decode_fields.hip): 8 KiB fragments, no element crosses a 128-byte half-tile, every
+// element starts and ends on a block-field boundary, copy offsets are whole blocks.  Its bytes are DEFINED by the
+// scalar restatement oracle/field_stream_oracle.c; the tests compare the two byte for byte.
+//
+// One wavefront per fragment, a lane owns a 16-byte UNIT (one DXT5 block or two 8-byte blocks = 4 fields), so one
+// wave-instruction covers 1 KiB ("step"); nothing but two small tables lives in LDS:
+//
+//   1. MATCH, lane = unit, 8 steps: the unit and the bytes 1..4 blocks in front of it come from memory as five
+//      overlapping 16-byte loads per lane; 16 field comparisons per lane give a nibble per distance; index fields
+//      also look up the most recent earlier block with the same value in a 512-entry table whose 64-bit entries
+//      hold block number, field class and the full value (no second read to verify; ds_max_u64 inserts after the
+//      step's lookups: the most recent block wins whatever the lane order).  A three-stage nibble transpose over
+//      groups of 8 lanes (DPP + rotate + bit-field insert) turns "a nibble per distance per lane" into "a 32-bit
+//      mask per distance per half-tile", one dword per lane to LDS.
+//   2. CHOOSE, lane = half-tile (all 64 of the fragment at once), bit-parallel on 32-bit masks: copies are placed left
+//      to right, nearest matching distance first, each running to the end of its match -- per round every uncovered
+//      stretch starts one copy and an integer ADD carries it through its run of ones, so the loop runs as often as
+//      the longest chain of touching copies (1.2 on average), not once per element.  Start, literal, "one more
+//      byte" and distance masks, the half-tile's compressed size (popcounts) and -- one DPP scan -- its offset in
+//      the fragment go back to LDS; the sizes are the fragment table's half-tile bytes.
+//   3. EMIT, lane = unit, 8 steps: popcounts of the masks below the unit give its output offset; each of its 4
+//      fields forms its element bytes (header / copy tag from the distance to the next start bit) and stores
+//      them and its literal bytes at their final place.
+//
+// HBM traffic: texture read once (the neighbour loads hit L1 / L2), compressed bytes written once.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hapgpu_abi.h"
+
+namespace {
+
+constexpr unsigned kFragBytes = 8192u;
+constexpr unsigned kSteps = kFragBytes / 1024u;
+constexpr unsigned kTableBits = 9u;                 // oracle/field_stream_oracle.c: OFS_TABLE_BITS
+constexpr unsigned kDistances = 4u;
+
+// Layout of a 16-byte unit: field k begins at fo(k) and has fs(k) bytes; copy distances are multiples of `block`.
+//   4: DXT5 / YCoCg-DXT5 [2, 6, 4, 4], one block;  2: DXT1 [4, 4] x 2 blocks;  6: RGTC1 [2, 6] x 2 blocks.
+// (`code` is what the host puts into HapGpuTexEnc.reserved bits 16..19 for the layout.)
+template <unsigned LAYOUT> struct unit_layout;
+template <> struct unit_layout<4u> {
+    static constexpr unsigned block = 16u, code = 4u;
+    static constexpr unsigned small32 = 0x11111111u;     // 2-byte fields of a half-tile
+    static constexpr unsigned big32 = 0x22222222u;       // 6-byte fields
+    static constexpr unsigned hashed32 = 0xAAAAAAAAu;    // fields with table candidates
+    static constexpr unsigned run3_12 = 0xBBBBBBBBu;     // starts whose 3-field run has >= 12 bytes
+    static constexpr unsigned run15_61 = 0x22222222u;    // starts whose 15-field run has > 60 bytes
+    __device__ static constexpr unsigned fo(unsigned k) { return k == 0u ? 0u : k == 1u ? 2u : k == 2u ? 8u : 12u; }
+    __device__ static constexpr unsigned fs(unsigned k) { return k == 0u ? 2u : k == 1u ? 6u : 4u; }
+    __device__ static constexpr unsigned cls(unsigned k) { return k == 1u ? 1u : k == 3u ? 3u : 0u; }
+};
+template <> struct unit_layout<2u> {
+    static constexpr unsigned block = 8u, code = 10u;
+    static constexpr unsigned small32 = 0u, big32 = 0u, hashed32 = 0xAAAAAAAAu, run3_12 = 0xFFFFFFFFu, run15_61 = 0u;
+    __device__ static constexpr unsigned fo(unsigned k) { return 4u * k; }
+    __device__ static constexpr unsigned fs(unsigned) { return 4u; }
+    __device__ static constexpr unsigned cls(unsigned k) { return (k & 1u) ? 1u : 0u; }
+};
+template <> struct unit_layout<6u> {
+    static constexpr unsigned block = 8u, code = 2u;
+    static constexpr unsigned small32 = 0x55555555u, big32 = 0xAAAAAAAAu, hashed32 = 0xAAAAAAAAu, run3_12 = 0xAAAAAAAAu,
+                              run15_61 = 0xAAAAAAAAu;
+    __device__ static constexpr unsigned fo(unsigned k) { return k == 0u ? 0u : k == 1u ? 2u : k == 2u ? 8u : 10u; }
+    __device__ static constexpr unsigned fs(unsigned k) { return (k & 1u) ? 6u : 2u; }
+    __device__ static constexpr unsigned cls(unsigned k) { return (k & 1u) ? 1u : 0u; }
+};
+
+// memory accesses at any byte address (the fragment of a client's texture may begin anywhere)
+struct __attribute__((packed)) pk_u16 { uint16_t v; };
+struct __attribute__((packed)) pk_u32 { uint32_t v; };
+struct __attribute__((packed)) pk_u64 { uint32_t a, b; };
+struct __attribute__((packed)) pk_u128 { uint32_t a, b, c, d; };
+__device__ __forceinline__ void put8(uint8_t *p, unsigned v) { *p = (uint8_t)v; }
+__device__ __forceinline__ void put16(uint8_t *p, unsigned v) { reinterpret_cast<pk_u16 *>(p)->v = (uint16_t)v; }
+__device__ __forceinline__ void put32(uint8_t *p, unsigned v) { reinterpret_cast<pk_u32 *>(p)->v = v; }
+__device__ __forceinline__ uint4 get128(const uint8_t *p)
+{
+    const pk_u128 v = *reinterpret_cast<const pk_u128 *>(p);
+    return make_uint4(v.a, v.b, v.c, v.d);
+}
+__device__ __forceinline__ uint2 get64(const uint8_t *p)
+{
+    const pk_u64 v = *reinterpret_cast<const pk_u64 *>(p);
+    return make_uint2(v.a, v.b);
+}
+
+__device__ __forceinline__ unsigned rotr(unsigned v, unsigned n) { return __builtin_amdgcn_alignbit(v, v, n); }
+__device__ __forceinline__ unsigned bfi(unsigned mask, unsigned a, unsigned b) { return (a & mask) | (b & ~mask); }
+__device__ __forceinline__ unsigned popc(unsigned v) { return (unsigned)__builtin_popcount(v); }
+
+__device__ __forceinline__ int scan_add(int v)          // inclusive, across the wavefront
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+
+// value of lane ^ 4 / ^ 2 / ^ 1
+__device__ __forceinline__ unsigned lane_xor4(unsigned v)
+{
+    int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0x5, false);      // lanes 0-3, 8-11 of a row: from lane + 4
+    t = __builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xF, 0xA, false);          // lanes 4-7, 12-15: from lane - 4
+    return (unsigned)t;
+}
+__device__ __forceinline__ unsigned lane_xor2(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false); }
+__device__ __forceinline__ unsigned lane_xor1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); }
+
+// 1 where the field differs, per field of the unit, as a nibble
+template <unsigned LAYOUT>
+__device__ __forceinline__ unsigned differ_nibble(const uint4 x, const uint4 y)
+{
+    const unsigned d0 = x.x ^ y.x, d1 = x.y ^ y.y, d2 = x.z ^ y.z, d3 = x.w ^ y.w;
+    unsigned t0, t1, t2, t3;
+    if (LAYOUT == 4u) {
+        t0 = d0 & 0xFFFFu; t1 = (d0 & 0xFFFF0000u) | d1; t2 = d2; t3 = d3;
+    } else if (LAYOUT == 2u) {
+        t0 = d0; t1 = d1; t2 = d2; t3 = d3;
+    } else {
+        t0 = d0 & 0xFFFFu; t1 = (d0 & 0xFFFF0000u) | d1; t2 = d2 & 0xFFFFu; t3 = (d2 & 0xFFFF0000u) | d3;
+    }
+    return min(t0, 1u) | (min(t1, 1u) << 1) | (min(t2, 1u) << 2) | (min(t3, 1u) << 3);
+}
+
+// value of an index field: low 32 bits and the 16 bits above (0 for 4-byte fields)
+template <unsigned LAYOUT>
+__device__ __forceinline__ void index_field(const uint4 x, unsigned k, unsigned &lo, unsigned &hi)
+{
+    if (LAYOUT == 2u) {
+        lo = k == 1u ? x.y : x.w;
+        hi = 0u;
+    } else if (k == 1u) {
+        lo = __builtin_amdgcn_alignbit(x.y, x.x, 16);
+        hi = x.y >> 16;
+    } else if (LAYOUT == 4u) {
+        lo = x.w;
+        hi = 0u;
+    } else {
+        lo = __builtin_amdgcn_alignbit(x.w, x.z, 16);
+        hi = x.w >> 16;
+    }
+}
+
+__device__ __forceinline__ unsigned table_slot(unsigned lo, unsigned hi, unsigned cls)
+{
+    const unsigned z = lo ^ rotr(hi, 19) ^ (cls << 29);
+    return (z * 0x9E3779B1u) >> (32u - kTableBits);
+}
+
+template <unsigned LAYOUT>
+__global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpuFrameEnc *__restrict__ frames,
+                                                                    uint8_t *__restrict__ slots, unsigned slot_stride,
+                                                                    uint32_t *__restrict__ frag_sizes,
+                                                                    uint8_t *__restrict__ tile_sizes)
+{
+    using UL = unit_layout<LAYOUT>;
+    constexpr unsigned B = UL::block;
+    __shared__ unsigned long long table[1u << kTableBits];
+    __shared__ __attribute__((aligned(16))) uint32_t masks[64u * 8u];
+
+    const unsigned lane = threadIdx.x;
+    const HapGpuTexEnc tex = frames[blockIdx.z].tex[blockIdx.y < 2u ? blockIdx.y : 0u];
+    const unsigned tex_count = frames[blockIdx.z].tex_count;
+    const unsigned x = blockIdx.x;
+    if ((blockIdx.y >= tex_count) | (tex.compressor != 1u) | (((tex.reserved >> 16) & 0xFu) != UL::code) |
+        (x >= tex.chunk_count * tex.frags_per_chunk) | (tex.src == 0) | (tex.chunk_bytes == 0))
+        return;
+    const unsigned chunk = x / tex.frags_per_chunk, fj = x - chunk * tex.frags_per_chunk;
+    const unsigned begin = fj * kFragBytes;
+    const unsigned n = min(kFragBytes, tex.chunk_bytes - begin);          // whole blocks (host-checked)
+    const uint8_t *src = (const uint8_t *)tex.src + (size_t)chunk * tex.chunk_bytes + begin;
+    const unsigned f = tex.frag_first + x;
+    uint8_t *out = slots + (size_t)f * slot_stride;
+    const unsigned window = ((tex.reserved >> 8) & 0xFFu) ? ((tex.reserved >> 8) & 0xFFu) * 256u : 0xFFFFFFFFu;
+    const bool want_sizes = ((tex.reserved >> 20) & 1u) != 0u && tile_sizes != nullptr;
+
+    // table: empty
+    {
+        uint4 *t = reinterpret_cast<uint4 *>(table);
+#pragma unroll
+        for (unsigned i = 0; i < (sizeof(table) / 16u) / 64u; i++)
+            t[i * 64u + lane] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+
+    // per-lane constants of the nibble transpose
+    const unsigned keep4 = (lane & 4u) ? 0xFFFF0000u : 0x0000FFFFu;
+    const unsigned keep2 = (lane & 2u) ? 0xFF00FF00u : 0x00FF00FFu;
+    const unsigned keep1 = (lane & 1u) ? 0xF0F0F0F0u : 0x0F0F0F0Fu;
+    const unsigned rot2 = (lane & 2u) ? 8u : 24u;
+    const unsigned rot1 = (lane & 1u) ? 4u : 28u;
+
+    // ---- 1. match ----
+    uint4 X[kSteps];
+    unsigned HD[kSteps];                 // table candidates of the unit's two index fields: distance in blocks, 0 = none
+#pragma unroll
+    for (unsigned s = 0; s < kSteps; s++) {
+        const unsigned pos = (64u * s + lane) * 16u;
+        X[s] = make_uint4(0, 0, 0, 0);
+        HD[s] = 0u;
+        if (64u * s * 16u >= n) {                  // (uniform) nothing left: half-tiles of this step read as empty
+            masks[64u * s + lane] = 0u;
+            continue;
+        }
+        const bool whole = pos + 16u <= n, part = pos < n;     // (a last unit of 8 bytes: layouts of 8-byte blocks)
+        if (whole) {
+            X[s] = get128(src + pos);
+        } else if (part) {
+            const uint2 v = get64(src + pos);
+            X[s] = make_uint4(v.x, v.y, 0, 0);
+        }
+        uint4 Y[kDistances];
+#pragma unroll
+        for (unsigned d = 0; d < kDistances; d++) {
+            const unsigned back = (d + 1u) * B;
+            Y[d] = make_uint4(0, 0, 0, 0);
+            if (s == 0u) {
+                if (part && pos >= back)
+                    Y[d] = get128(src + pos - back);
+                else if (B == 8u && part && pos + 8u == back) {          // the upper half reaches the fragment's first bytes
+                    const uint2 v = get64(src);
+                    Y[d] = make_uint4(0, 0, v.x, v.y);
+                }
+            } else if (part) {
+                Y[d] = get128(src + pos - back);
+            }
+        }
+        const uint4 xs = X[s];
+        unsigned differ = 0;
+#pragma unroll
+        for (unsigned d = 0; d < kDistances; d++)
+            differ |= differ_nibble<LAYOUT>(xs, Y[d]) << (4u * d);
+        // fields that exist, and (first step) whose source d blocks back lies inside the fragment
+        unsigned ok = whole ? 0xFFFFu : part ? 0x3333u : 0u;
+        if (s == 0u) {
+            unsigned reach = 0;
+#pragma unroll
+            for (unsigned d = 0; d < kDistances; d++)
+#pragma unroll
+                for (unsigned k = 0; k < 4u; k++)
+                    reach |= (pos + UL::fo(k) >= (d + 1u) * B ? 1u : 0u) << (4u * d + k);
+            ok &= reach;
+        }
+        unsigned P = ~differ & ok;
+        // table candidates of the index fields
+        unsigned slot[2], klo[2], khi[2];
+        unsigned long long e[2];
+        bool valid[2];
+#pragma unroll
+        for (unsigned i = 0; i < 2u; i++) {
+            const unsigned k = 2u * i + 1u;
+            unsigned lo, hi;
+            index_field<LAYOUT>(xs, k, lo, hi);
+            klo[i] = lo;
+            khi[i] = hi | (UL::cls(k) << 16);
+            slot[i] = table_slot(lo, hi, UL::cls(k));
+            valid[i] = i == 0u ? part : whole;
+            e[i] = table[slot[i]];
+        }
+        unsigned hd2[2];
+#pragma unroll
+        for (unsigned i = 0; i < 2u; i++) {
+            const unsigned unit = 64u * s + lane;
+            const unsigned blk = B == 16u ? unit : 2u * unit + i;
+            const unsigned elo = (unsigned)e[i], ehi = (unsigned)(e[i] >> 32);
+            const unsigned dist = blk - (ehi >> 18);
+            const bool hit = valid[i] && elo == klo[i] && (ehi & 0x3FFFFu) == khi[i] && dist * B <= window;
+            hd2[i] = hit ? dist : 0u;
+            const unsigned far = hit && dist * B >= 2048u ? 1u : 0u;
+            P |= (hit ? 1u : 0u) << (16u + 2u * i + 1u);
+            P |= far << (20u + 2u * i + 1u);
+            if (valid[i])
+                atomicMax(&table[slot[i]], ((unsigned long long)(khi[i] | (blk << 18)) << 32) | klo[i]);
+        }
+        HD[s] = hd2[0] | (hd2[1] << 16);
+        // nibbles of 8 lanes -> one 32-bit mask per kind: lane j of the group ends up with kind j of its half-tile
+        P = bfi(keep4, P, rotr(lane_xor4(P), 16));
+        P = bfi(keep2, P, rotr(lane_xor2(P), rot2));
+        P = bfi(keep1, P, rotr(lane_xor1(P), rot1));
+        masks[64u * s + lane] = P;
+    }
+    __syncthreads();
+
+    // ---- 2. choose: lane = half-tile ----
+    {
+        const uint4 ma = *reinterpret_cast<const uint4 *>(&masks[lane * 8u]);
+        const uint4 mb = *reinterpret_cast<const uint4 *>(&masks[lane * 8u + 4u]);
+        // valid fields of the half-tile (a prefix)
+        const unsigned fields_total = (n >> 4) * 4u + ((n & 8u) ? 2u : 0u);
+        const unsigned nv = fields_total > 32u * lane ? min(32u, fields_total - 32u * lane) : 0u;
+        const unsigned valid = nv >= 32u ? 0xFFFFFFFFu : ((1u << nv) - 1u);
+        unsigned E[kDistances] = {ma.x, ma.y, ma.z, ma.w}, A[kDistances] = {0u, 0u, 0u, 0u};
+        unsigned U = 0;
+#pragma unroll
+        for (unsigned d = 0; d < kDistances; d++) {
+            E[d] &= ~(UL::small32 & ~(E[d] >> 1));          // a 2-byte field only together with the field behind it
+            U |= E[d];
+        }
+        unsigned front = U & ~(U << 1);
+        while (__builtin_amdgcn_ballot_w64(front != 0u) != 0ull) {
+            unsigned taken = 0, ends = 0;
+#pragma unroll
+            for (unsigned d = 0; d < kDistances; d++) {
+                const unsigned seeds = front & E[d] & ~taken;
+                const unsigned sum = E[d] + seeds;
+                A[d] |= (E[d] & ~sum) | seeds;
+                ends |= sum & ~E[d];
+                taken |= seeds;
+            }
+            front = ends & U;
+        }
+        const unsigned cov = A[0] | A[1] | A[2] | A[3];
+        const unsigned Hm = mb.x & ~cov;
+        const unsigned L = valid & ~(cov | Hm);
+        unsigned S = Hm | (L & ~(L << 1)) | ((1u << 16) & ~L);
+#pragma unroll
+        for (unsigned d = 0; d < kDistances; d++)
+            S |= A[d] & ~(A[d] << 1);
+        S &= valid;
+        const unsigned Sx1 = ((S | ~valid) >> 1) | 0x80000000u;       // bit i: position i + 1 starts an element (or ends the data)
+        const unsigned CS = S & ~L;
+        const unsigned N1 = ~Sx1;
+        // one more byte: copies of >= 12 bytes or from >= 2048 bytes back (copy-2), literal runs of > 60 bytes
+        const unsigned C3 = (CS & N1 & (N1 >> 1) & ((N1 >> 2) | UL::run3_12)) | (Hm & mb.y);
+        const unsigned Cn = L & ~S;
+        const unsigned w2 = Cn & (Cn >> 1), w4 = w2 & (w2 >> 2), w8 = w4 & (w4 >> 4);
+        const unsigned w12 = w8 & (w4 >> 8), w14 = w12 & (w2 >> 12), w15 = w14 & (Cn >> 14);
+        const unsigned LS = S & L & ((w15 >> 1) | ((w14 >> 1) & UL::run15_61));
+        const unsigned X3 = C3 | LS;
+        const unsigned D0 = A[1] | A[3], D1 = A[2] | A[3];       // (distance - 1) of a copy's fields: the A[] are disjoint
+        const unsigned lit_bytes = 4u * popc(L) - 2u * popc(L & UL::small32) + 2u * popc(L & UL::big32);
+        const unsigned total = lit_bytes + popc(S) + popc(CS) + popc(X3);
+        const unsigned incl = (unsigned)scan_add((int)total);
+        const unsigned base = incl - total;
+        *reinterpret_cast<uint4 *>(&masks[lane * 8u]) = make_uint4(S, L, X3, D0);
+        *reinterpret_cast<uint4 *>(&masks[lane * 8u + 4u]) = make_uint4(D1, Hm, Sx1, base);
+        if (want_sizes)
+            tile_sizes[(size_t)f * HAP_HALF_TILES_PER_FRAGMENT + lane] = (uint8_t)total;
+        if (lane == 63u)
+            frag_sizes[f] = incl;
+    }
+    __syncthreads();
+
+    // ---- 3. emit: lane = unit ----
+    const unsigned j4 = 4u * (lane & 7u);
+    const unsigned below = (1u << j4) - 1u;
+#pragma unroll
+    for (unsigned s = 0; s < kSteps; s++) {
+        if (64u * s * 16u >= n)
+            break;
+        const unsigned hh = 8u * s + (lane >> 3);
+        const uint4 ma = *reinterpret_cast<const uint4 *>(&masks[hh * 8u]);
+        const uint4 mb = *reinterpret_cast<const uint4 *>(&masks[hh * 8u + 4u]);
+        const unsigned S = ma.x, L = ma.y, X3 = ma.z, D0 = ma.w, D1 = mb.x, Hm = mb.y, Sx1 = mb.z;
+        const unsigned CS = S & ~L;
+        unsigned off = mb.w + 4u * popc(L & below) + 2u * popc(L & UL::big32 & below) - 2u * popc(L & UL::small32 & below) +
+                       popc(S & below) + popc(CS & below) + popc(X3 & below);
+        const unsigned sj = S >> j4, lj = L >> j4, xj = X3 >> j4, d0j = D0 >> j4, d1j = D1 >> j4, hj = Hm >> j4, nj = Sx1 >> j4;
+        const uint4 xs = X[s];
+#pragma unroll
+        for (unsigned k = 0; k < 4u; k++) {
+            const bool is_s = ((sj >> k) & 1u) != 0u, is_l = ((lj >> k) & 1u) != 0u, x3 = ((xj >> k) & 1u) != 0u;
+            // bytes from this field to the next start: 4 per field, corrected by where the two fields sit in their units
+            const unsigned c = (unsigned)__builtin_ctz(nj >> k);              // fields in between (the mask ends with a set bit)
+            const unsigned q = k + 1u + c;                                    // (next start) mod 4 = q mod 4
+            const unsigned adj_q = LAYOUT == 4u ? ((q & 3u) == 1u ? 2u : 0u) : LAYOUT == 6u ? 2u * (q & 1u) : 0u;
+            const unsigned len = 4u * (c + 1u) + (4u * k - UL::fo(k)) - adj_q;
+            unsigned v;
+            if (is_l) {
+                v = x3 ? (0xF0u | ((len - 1u) << 8)) : ((len - 1u) << 2);
+            } else {
+                unsigned dist = 1u + ((d0j >> k) & 1u) + 2u * ((d1j >> k) & 1u);
+                if ((k & 1u) && ((hj >> k) & 1u))
+                    dist = (HD[s] >> (8u * (k - 1u))) & 0xFFFFu;
+                const unsigned offb = dist * B;
+                v = x3 ? (2u | ((len - 1u) << 2) | (offb << 8))
+                       : (1u | ((len - 4u) << 2) | ((offb >> 8) << 5) | ((offb & 0xFFu) << 8));
+            }
+            uint8_t *p = out + off;
+            if (is_s && (!is_l || x3))
+                put16(p, v);
+            if (is_s && is_l && !x3)
+                put8(p, v);
+            if (is_s && !is_l && x3)
+                put8(p + 2, v >> 16);
+            off += is_s ? (is_l ? 1u : 2u) + (x3 ? 1u : 0u) : 0u;
+            if (is_l) {
+                p = out + off;
+                if (LAYOUT == 2u) {
+                    put32(p, k == 0u ? xs.x : k == 1u ? xs.y : k == 2u ? xs.z : xs.w);
+                } else if (k == 0u) {
+                    put16(p, xs.x);
+                } else if (k == 1u) {
+                    put16(p, xs.x >> 16);
+                    put32(p + 2, xs.y);
+                } else if (LAYOUT == 4u) {
+                    put32(p, k == 2u ? xs.z : xs.w);
+                } else if (k == 2u) {
+                    put16(p, xs.z);
+                } else {
+                    put16(p, xs.z >> 16);
+                    put32(p + 2, xs.w);
+                }
+                off += UL::fs(k);
+            }
+        }
+    }
+}
+
+} // namespace
+
+// layouts: bit 0 = [2,6,4,4] textures present, bit 1 = [4,4], bit 2 = [2,6]
+extern "C" int hapgpu_launch_snappy_compress_blocks(const HapGpuFrameEnc *frames, unsigned frame_count,
+                                                    unsigned max_frags_per_texture, unsigned textures, void *slots,
+                                                    unsigned slot_stride, uint32_t *frag_sizes, uint8_t *tile_sizes,
+                                                    unsigned layouts, hipStream_t stream)
+{
+    if (frame_count == 0 || max_frags_per_texture == 0 || layouts == 0)
+        return 0;
+    const dim3 grid(max_frags_per_texture, textures, frame_count), block(64);
+    if (layouts & 1u)
+        hipLaunchKernelGGL((snappy_compress_blocks_kernel<4u>), grid, block, 0, stream, frames, (uint8_t *)slots, slot_stride,
+                           frag_sizes, tile_sizes);
+    if (layouts & 2u)
+        hipLaunchKernelGGL((snappy_compress_blocks_kernel<2u>), grid, block, 0, stream, frames, (uint8_t *)slots, slot_stride,
+                           frag_sizes, tile_sizes);
+    if (layouts & 4u)
+        hipLaunchKernelGGL((snappy_compress_blocks_kernel<6u>), grid, block, 0, stream, frames, (uint8_t *)slots, slot_stride,
+                           frag_sizes, tile_sizes);
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}

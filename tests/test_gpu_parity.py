@@ -1496,3 +1496,68 @@ def test_field_streams_that_compress_poorly_keep_their_records_in_memory(ctx, ha
         assert (r, du, df, dr) == (0, [len(tex)], [fmt], [0])
         assert dec.cpu().numpy().tobytes() == tex and ctx.table_fallbacks() == n0
         assert backing[:odd].cpu().tolist() == [0x5A] * odd and backing[odd + len(tex):].cpu().tolist() == [0x5A] * (16 - odd)
+
+
+# ------------------------------------------------- block-per-lane compressor --
+def _ofs_fragment(data, layout, window=0):
+    o = L.oracle_lib()
+    o.ofs_compress_fragment.restype = C.c_uint
+    out = (C.c_ubyte * (8192 + 512))()
+    halves = (C.c_ubyte * 64)()
+    n = o.ofs_compress_fragment(bytes(data), C.c_uint(len(data)), C.c_uint(layout), C.c_uint(window), out, halves)
+    return bytes(out[:n]), bytes(halves)
+
+
+def _own_frame_sections(frame, chunks):
+    """(chunk codec bytes, chunk sizes, fragment sizes, half-tile bytes [n, 64], payload offset) of a one-texture frame
+    written with the version-2 fragment table."""
+    fs_at, n, ht_at = _half_tile_table(frame)
+    hdr = 4 if int.from_bytes(frame[0:3], "little") else 8
+    p = hdr + 4
+    assert frame[p + 3] == 0x02
+    codecs = frame[p + 4: p + 4 + chunks]
+    p += 4 + chunks
+    assert frame[p + 3] == 0x03
+    sizes = [int.from_bytes(frame[p + 4 + 4 * i: p + 8 + 4 * i], "little") for i in range(chunks)]
+    frag_sizes = [int.from_bytes(frame[fs_at + 4 * i: fs_at + 4 * i + 4], "little") for i in range(n)]
+    half = np.frombuffer(frame, dtype=np.uint8, count=64 * n, offset=ht_at).reshape(n, 64)
+    return codecs, sizes, frag_sizes, half, ht_at + 64 * n
+
+
+@pytest.mark.parametrize("fmt,layout,shape,chunks", [
+    (L.FMT_YCOCG, 4, (1024, 256), 4), (L.FMT_DXT5, 4, (1000, 260), 5), (L.FMT_YCOCG, 4, (2048, 1024), 3),
+    (L.FMT_DXT1, 2, (1024, 256), 2), (L.FMT_DXT1, 2, (1028, 252), 3), (L.FMT_RGTC1, 6, (4096, 1028), 2)])
+def test_block_compressor_writes_exactly_the_bytes_of_its_scalar_definition(ctx, hap, fmt, layout, shape, chunks):
+    """The Snappy stage for block textures (snappy_compress_blocks.hip, in place of hap.c:453) is defined by
+    oracle/field_stream_oracle.c: every chunk's stream, every fragment size and every half-tile byte of the frame are
+    the scalar code's, for the three unit layouts, short last fragments and 8-byte tails included -- and both checkers
+    decode the frame to the texture."""
+    w, h = shape
+    tex = D.oracle_bc_encode(D.rgba(w, h, frame=3), fmt)
+    out = np.zeros(hap.HapMaxEncodedLength([len(tex)], [fmt], [chunks]) + 65536, dtype=np.uint8)
+    r, used, res = ctx.encode_frames([[tex]], [fmt], [1], [chunks], [out], flags=hap.ENCODE_FRAGMENT_INDEX)
+    assert r == 0 and res == [0]
+    frame = out[: used[0]].tobytes()
+    for name, api in CHECKERS:
+        assert api.decode(frame, 0, len(tex)) == (0, tex, fmt), name
+    limited = ORA.chunk_count(_encode_with(ORA, tex, fmt, L.COMP_SNAPPY, chunks), 0)[1]
+    codecs, sizes, frag_sizes, half, at = _own_frame_sections(frame, limited)
+    cb = len(tex) // limited
+    window = 3072 if len(tex) >= ((2 << 20) if layout != 4 else (1 << 20)) else 0
+    fi = 0
+    for c in range(limited):
+        assert codecs[c] == 0x0B
+        want = _varint(cb)
+        for o in range(0, cb, 8192):
+            piece, halves = _ofs_fragment(tex[c * cb + o: c * cb + min(cb, o + 8192)], layout, window)
+            assert frag_sizes[fi] == len(piece), (c, o)
+            assert half[fi].tobytes() == halves, (c, o)
+            want += piece
+            fi += 1
+        assert sizes[c] == len(want)
+        got = frame[at: at + sizes[c]]
+        if got != want:
+            bad = next(i for i in range(len(want)) if got[i] != want[i])
+            raise AssertionError("chunk %d differs at stream byte %d of %d" % (c, bad, len(want)))
+        at += sizes[c]
+    assert fi == len(frag_sizes) and at == len(frame)

@@ -231,3 +231,66 @@ def test_ycocg_blocks_are_dxt5_blocks_a_hap_q_shader_reconstructs():
         assert D.psnr(rgb, img[..., :3]) > 33.0
         mine = D.oracle_bc_decode(blocks, L.FMT_YCOCG, w, h)
         assert np.abs(rgb.astype(int) - mine[..., :3].astype(int)).max() <= 2
+
+
+# ---- the scalar definition of the GPU's block compressor (oracle/field_stream_oracle.c) ----
+@pytest.mark.parametrize("fmt,layout,block", [(L.FMT_YCOCG, 4, 16), (L.FMT_DXT5, 4, 16), (L.FMT_DXT1, 2, 8), (L.FMT_RGTC1, 6, 8)])
+def test_field_stream_definition_is_snappy_and_keeps_its_promises(fmt, layout, block):
+    """What ofs_compress_fragment writes is an ordinary Snappy stream (libsnappy and the restatement decode it to the
+    input) that keeps the promises of the fragment table version 2: the half-tile bytes add up, no element crosses a
+    128-byte half-tile, elements start on field boundaries, copies reach back whole blocks inside the fragment,
+    literal runs use at most one length byte."""
+    import ctypes as C
+    o = L.oracle_lib()
+    o.ofs_compress_fragment.restype = C.c_uint
+    tex = D.oracle_bc_encode(D.rgba(1024, 512, frame=9), fmt)
+    starts = {4: (0, 2, 8, 12), 2: (0, 4), 6: (0, 2)}[layout]
+    rng = np.random.default_rng(7)
+    sizes = [8192, 8192, 8192, 8192, 4096, 1024 + 3 * block, block, 8192 - block, 128, 128 + block]
+    total_in = total_out = 0
+    for trial, n in enumerate(sizes * 3):
+        at = int(rng.integers(0, (len(tex) - n) // block)) * block
+        data = tex[at: at + n]
+        out = (C.c_ubyte * (8192 + 512))()
+        halves = (C.c_ubyte * 64)()
+        m = o.ofs_compress_fragment(data, C.c_uint(n), C.c_uint(layout), C.c_uint(0 if trial % 2 else 3072), out, halves)
+        stream = bytes(out[:m])
+        assert sum(halves) == m and m <= n + n // 32 + 64
+        head = bytearray()
+        v = n
+        while v >= 128:
+            head.append((v & 127) | 128)
+            v >>= 7
+        head.append(v)
+        assert D.osnappy_uncompress(bytes(head) + stream, n) == (0, data)
+        if L.snappy_lib() is not None:
+            assert D.ref_snappy_uncompress(bytes(head) + stream, n) == (0, data)
+        q = produced_total = 0
+        for h in range((n + 127) // 128):
+            end, produced = q + halves[h], 0
+            while q < end:
+                tag = stream[q]
+                kind = tag & 3
+                assert produced % block in starts
+                if kind == 0:
+                    ln, hd = (tag >> 2) + 1, 1
+                    assert ln <= 61
+                    if ln == 61:
+                        ln, hd = stream[q + 1] + 1, 2
+                        assert ln > 60
+                    q += hd + ln
+                else:
+                    assert kind in (1, 2)
+                    ln = 4 + ((tag >> 2) & 7) if kind == 1 else (tag >> 2) + 1
+                    off = ((tag >> 5) << 8) | stream[q + 1] if kind == 1 else stream[q + 1] | (stream[q + 2] << 8)
+                    assert off % block == 0 and block <= off <= produced_total + produced
+                    if trial % 2 == 0:
+                        assert off <= 3072
+                    q += 1 + kind
+                produced += ln
+            assert q == end and produced == min(128, n - 128 * h)
+            produced_total += produced
+        assert q == m
+        total_in += n
+        total_out += m
+    assert total_out < total_in
