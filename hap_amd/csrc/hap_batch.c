@@ -196,7 +196,7 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
         frame_raw_bound += t->header_len + t->bytes;
     }
     frame_raw_bound += outer_header;
-    slot_stride = (unsigned)align_up(frag_bytes + frag_bytes / 32u + 64u, 16);
+    slot_stride = (unsigned)align_up(frag_bytes + frag_bytes / 32u + 64u + HAPGPU_SLOT_SCRATCH_BYTES, 16);
 
     /* per-frame checks; frames that fail are left out of the launch */
     live_index = (unsigned *)malloc(sizeof(unsigned) * frame_count);

@@ -30,6 +30,11 @@ extern "C" {
 #define HAP_HALF_TILE_BYTES 128u
 #define HAP_HALF_TILES_PER_FRAGMENT 64u      /* 8 KiB fragments */
 
+/* A fragment's slot in the compressor's scratch: at most 130 bytes per half-tile of elements, then a few bytes per
+   lane that stores with nothing to write are pointed at (snappy_compress_blocks.hip) */
+#define HAPGPU_SLOT_DATA_BYTES (HAP_HALF_TILES_PER_FRAGMENT * 130u)
+#define HAPGPU_SLOT_SCRATCH_BYTES 272u
+
 /* internal status codes beyond HapResult (never returned to API callers) */
 #define HAPGPU_STATUS_INDEX_MISMATCH 100u /* fragment index inconsistent: redo without it */
 

@@ -47,7 +47,6 @@ template <> struct unit_layout<4u> {
     static constexpr unsigned block = 16u, code = 4u;
     static constexpr unsigned small32 = 0x11111111u;     // 2-byte fields of a half-tile
     static constexpr unsigned big32 = 0x22222222u;       // 6-byte fields
-    static constexpr unsigned hashed32 = 0xAAAAAAAAu;    // fields with table candidates
     static constexpr unsigned run3_12 = 0xBBBBBBBBu;     // starts whose 3-field run has >= 12 bytes
     static constexpr unsigned run15_61 = 0x22222222u;    // starts whose 15-field run has > 60 bytes
     __device__ static constexpr unsigned fo(unsigned k) { return k == 0u ? 0u : k == 1u ? 2u : k == 2u ? 8u : 12u; }
@@ -56,42 +55,56 @@ template <> struct unit_layout<4u> {
 };
 template <> struct unit_layout<2u> {
     static constexpr unsigned block = 8u, code = 10u;
-    static constexpr unsigned small32 = 0u, big32 = 0u, hashed32 = 0xAAAAAAAAu, run3_12 = 0xFFFFFFFFu, run15_61 = 0u;
+    static constexpr unsigned small32 = 0u, big32 = 0u, run3_12 = 0xFFFFFFFFu, run15_61 = 0u;
     __device__ static constexpr unsigned fo(unsigned k) { return 4u * k; }
     __device__ static constexpr unsigned fs(unsigned) { return 4u; }
     __device__ static constexpr unsigned cls(unsigned k) { return (k & 1u) ? 1u : 0u; }
 };
 template <> struct unit_layout<6u> {
     static constexpr unsigned block = 8u, code = 2u;
-    static constexpr unsigned small32 = 0x55555555u, big32 = 0xAAAAAAAAu, hashed32 = 0xAAAAAAAAu, run3_12 = 0xAAAAAAAAu,
+    static constexpr unsigned small32 = 0x55555555u, big32 = 0xAAAAAAAAu, run3_12 = 0xAAAAAAAAu,
                               run15_61 = 0xAAAAAAAAu;
     __device__ static constexpr unsigned fo(unsigned k) { return k == 0u ? 0u : k == 1u ? 2u : k == 2u ? 8u : 10u; }
     __device__ static constexpr unsigned fs(unsigned k) { return (k & 1u) ? 6u : 2u; }
     __device__ static constexpr unsigned cls(unsigned k) { return (k & 1u) ? 1u : 0u; }
 };
 
-// memory accesses at any byte address (the fragment of a client's texture may begin anywhere)
+// memory accesses at any byte address (the fragment of a client's texture may begin anywhere), in the global address
+// space (pointers that come out of a descriptor as integers would otherwise be accessed with flat instructions,
+// whose waits also stall on the LDS counter)
+typedef const uint8_t __attribute__((address_space(1))) *gsrc_t;
+typedef uint8_t __attribute__((address_space(1))) *gdst_t;
 struct __attribute__((packed)) pk_u16 { uint16_t v; };
 struct __attribute__((packed)) pk_u32 { uint32_t v; };
 struct __attribute__((packed)) pk_u64 { uint32_t a, b; };
 struct __attribute__((packed)) pk_u128 { uint32_t a, b, c, d; };
-__device__ __forceinline__ void put8(uint8_t *p, unsigned v) { *p = (uint8_t)v; }
-__device__ __forceinline__ void put16(uint8_t *p, unsigned v) { reinterpret_cast<pk_u16 *>(p)->v = (uint16_t)v; }
-__device__ __forceinline__ void put32(uint8_t *p, unsigned v) { reinterpret_cast<pk_u32 *>(p)->v = v; }
-__device__ __forceinline__ uint4 get128(const uint8_t *p)
+__device__ __forceinline__ void put8(gdst_t p, unsigned v) { *p = (uint8_t)v; }
+__device__ __forceinline__ void put16(gdst_t p, unsigned v) { reinterpret_cast<pk_u16 __attribute__((address_space(1))) *>(p)->v = (uint16_t)v; }
+__device__ __forceinline__ void put32(gdst_t p, unsigned v) { reinterpret_cast<pk_u32 __attribute__((address_space(1))) *>(p)->v = v; }
+__device__ __forceinline__ uint4 get128(gsrc_t p)
 {
-    const pk_u128 v = *reinterpret_cast<const pk_u128 *>(p);
-    return make_uint4(v.a, v.b, v.c, v.d);
+    const pk_u128 __attribute__((address_space(1))) *q = reinterpret_cast<const pk_u128 __attribute__((address_space(1))) *>(p);
+    return make_uint4(q->a, q->b, q->c, q->d);
 }
-__device__ __forceinline__ uint2 get64(const uint8_t *p)
+__device__ __forceinline__ uint2 get64(gsrc_t p)
 {
-    const pk_u64 v = *reinterpret_cast<const pk_u64 *>(p);
-    return make_uint2(v.a, v.b);
+    const pk_u64 __attribute__((address_space(1))) *q = reinterpret_cast<const pk_u64 __attribute__((address_space(1))) *>(p);
+    return make_uint2(q->a, q->b);
 }
 
 __device__ __forceinline__ unsigned rotr(unsigned v, unsigned n) { return __builtin_amdgcn_alignbit(v, v, n); }
 __device__ __forceinline__ unsigned bfi(unsigned mask, unsigned a, unsigned b) { return (a & mask) | (b & ~mask); }
 __device__ __forceinline__ unsigned popc(unsigned v) { return (unsigned)__builtin_popcount(v); }
+// 0 -> 0, anything else -> 1 (kept out of the compiler's hands: it turns min(x, 1) into a compare and a select
+// through a scalar register pair, two instructions and wait states instead of one)
+__device__ __forceinline__ unsigned nonzero(unsigned v)
+{
+    unsigned r;
+    asm("v_min_u32 %0, 1, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+// all ones if bit `bit` of v is set, else 0
+__device__ __forceinline__ unsigned bit_mask(unsigned v, unsigned bit) { return (unsigned)__builtin_amdgcn_sbfe((int)v, bit, 1u); }
 
 __device__ __forceinline__ int scan_add(int v)          // inclusive, across the wavefront
 {
@@ -114,9 +127,9 @@ __device__ __forceinline__ unsigned lane_xor4(unsigned v)
 __device__ __forceinline__ unsigned lane_xor2(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false); }
 __device__ __forceinline__ unsigned lane_xor1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); }
 
-// 1 where the field differs, per field of the unit, as a nibble
+// 1 where the field differs, per field of the unit, shifted to nibble `d`, OR-ed into acc
 template <unsigned LAYOUT>
-__device__ __forceinline__ unsigned differ_nibble(const uint4 x, const uint4 y)
+__device__ __forceinline__ unsigned differ_nibble(unsigned acc, const uint4 x, const uint4 y, unsigned d)
 {
     const unsigned d0 = x.x ^ y.x, d1 = x.y ^ y.y, d2 = x.z ^ y.z, d3 = x.w ^ y.w;
     unsigned t0, t1, t2, t3;
@@ -127,7 +140,11 @@ __device__ __forceinline__ unsigned differ_nibble(const uint4 x, const uint4 y)
     } else {
         t0 = d0 & 0xFFFFu; t1 = (d0 & 0xFFFF0000u) | d1; t2 = d2 & 0xFFFFu; t3 = (d2 & 0xFFFF0000u) | d3;
     }
-    return min(t0, 1u) | (min(t1, 1u) << 1) | (min(t2, 1u) << 2) | (min(t3, 1u) << 3);
+    acc |= nonzero(t0) << (4u * d);
+    acc |= nonzero(t1) << (4u * d + 1u);
+    acc |= nonzero(t2) << (4u * d + 2u);
+    acc |= nonzero(t3) << (4u * d + 3u);
+    return acc;
 }
 
 // value of an index field: low 32 bits and the 16 bits above (0 for 4-byte fields)
@@ -176,9 +193,9 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
     const unsigned chunk = x / tex.frags_per_chunk, fj = x - chunk * tex.frags_per_chunk;
     const unsigned begin = fj * kFragBytes;
     const unsigned n = min(kFragBytes, tex.chunk_bytes - begin);          // whole blocks (host-checked)
-    const uint8_t *src = (const uint8_t *)tex.src + (size_t)chunk * tex.chunk_bytes + begin;
+    const gsrc_t src = (gsrc_t)(tex.src + (uint64_t)chunk * tex.chunk_bytes + begin);
     const unsigned f = tex.frag_first + x;
-    uint8_t *out = slots + (size_t)f * slot_stride;
+    const gdst_t out = (gdst_t)((uintptr_t)slots + (size_t)f * slot_stride);
     const unsigned window = ((tex.reserved >> 8) & 0xFFu) ? ((tex.reserved >> 8) & 0xFFu) * 256u : 0xFFFFFFFFu;
     const bool want_sizes = ((tex.reserved >> 20) & 1u) != 0u && tile_sizes != nullptr;
 
@@ -197,6 +214,9 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
     const unsigned keep1 = (lane & 1u) ? 0xF0F0F0F0u : 0x0F0F0F0Fu;
     const unsigned rot2 = (lane & 2u) ? 8u : 24u;
     const unsigned rot1 = (lane & 1u) ? 4u : 28u;
+    // the last position a whole 16-byte (layouts of 8-byte blocks: 8-byte) load may start at: lanes beyond the data
+    // load the last unit again (no lane-varying branch around the loads; what they compute is masked out)
+    const unsigned last = n - (B == 16u ? 16u : 8u);
 
     // ---- 1. match ----
     uint4 X[kSteps];
@@ -210,50 +230,48 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
             masks[64u * s + lane] = 0u;
             continue;
         }
-        const bool whole = pos + 16u <= n, part = pos < n;     // (a last unit of 8 bytes: layouts of 8-byte blocks)
-        if (whole) {
-            X[s] = get128(src + pos);
-        } else if (part) {
-            const uint2 v = get64(src + pos);
-            X[s] = make_uint4(v.x, v.y, 0, 0);
-        }
-        uint4 Y[kDistances];
+        const unsigned pc = min(pos, last);
+        uint4 xs, Y[kDistances];
+        if (B == 16u) {
+            xs = get128(src + pc);
 #pragma unroll
-        for (unsigned d = 0; d < kDistances; d++) {
-            const unsigned back = (d + 1u) * B;
-            Y[d] = make_uint4(0, 0, 0, 0);
-            if (s == 0u) {
-                if (part && pos >= back)
-                    Y[d] = get128(src + pos - back);
-                else if (B == 8u && part && pos + 8u == back) {          // the upper half reaches the fragment's first bytes
-                    const uint2 v = get64(src);
-                    Y[d] = make_uint4(0, 0, v.x, v.y);
+            for (unsigned d = 0; d < kDistances; d++) {
+                const unsigned back = (d + 1u) * B;
+                Y[d] = get128(src + (s == 0u ? max(pc, back) - back : pc - back));
+            }
+        } else {
+            const uint2 lo = get64(src + pc), hi = get64(src + min(pos + 8u, last));
+            xs = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+            for (unsigned d = 0; d < kDistances; d++) {
+                const unsigned back = (d + 1u) * B;
+                if (s == 0u) {                     // (the upper half of a unit may reach the fragment's first bytes)
+                    const uint2 ylo = get64(src + max(pc, back) - back), yhi = get64(src + max(pc + 8u, back) - back);
+                    Y[d] = make_uint4(ylo.x, ylo.y, yhi.x, yhi.y);
+                } else {
+                    Y[d] = get128(src + pc - back);
                 }
-            } else if (part) {
-                Y[d] = get128(src + pos - back);
             }
         }
-        const uint4 xs = X[s];
+        X[s] = xs;
         unsigned differ = 0;
 #pragma unroll
         for (unsigned d = 0; d < kDistances; d++)
-            differ |= differ_nibble<LAYOUT>(xs, Y[d]) << (4u * d);
+            differ = differ_nibble<LAYOUT>(differ, xs, Y[d], d);
         // fields that exist, and (first step) whose source d blocks back lies inside the fragment
-        unsigned ok = whole ? 0xFFFFu : part ? 0x3333u : 0u;
+        unsigned ok = pos + 16u <= n ? 0xFFFFu : 0u;
+        if (B == 8u)
+            ok = pos + 16u <= n ? 0xFFFFu : pos + 8u <= n ? 0x3333u : 0u;
         if (s == 0u) {
-            unsigned reach = 0;
-#pragma unroll
-            for (unsigned d = 0; d < kDistances; d++)
-#pragma unroll
-                for (unsigned k = 0; k < 4u; k++)
-                    reach |= (pos + UL::fo(k) >= (d + 1u) * B ? 1u : 0u) << (4u * d + k);
-            ok &= reach;
+            if (B == 16u)
+                ok &= (1u << (4u * min(lane, 4u))) - 1u;
+            else
+                ok &= lane == 0u ? 0x000Cu : lane == 1u ? 0x0CFFu : 0xFFFFu;
         }
         unsigned P = ~differ & ok;
         // table candidates of the index fields
-        unsigned slot[2], klo[2], khi[2];
+        unsigned slot[2], klo[2], khi[2], valid[2];
         unsigned long long e[2];
-        bool valid[2];
 #pragma unroll
         for (unsigned i = 0; i < 2u; i++) {
             const unsigned k = 2u * i + 1u;
@@ -262,7 +280,7 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
             klo[i] = lo;
             khi[i] = hi | (UL::cls(k) << 16);
             slot[i] = table_slot(lo, hi, UL::cls(k));
-            valid[i] = i == 0u ? part : whole;
+            valid[i] = (i == 0u ? pos + 8u <= n : pos + 16u <= n) ? 0xFFFFFFFFu : 0u;
             e[i] = table[slot[i]];
         }
         unsigned hd2[2];
@@ -272,13 +290,12 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
             const unsigned blk = B == 16u ? unit : 2u * unit + i;
             const unsigned elo = (unsigned)e[i], ehi = (unsigned)(e[i] >> 32);
             const unsigned dist = blk - (ehi >> 18);
-            const bool hit = valid[i] && elo == klo[i] && (ehi & 0x3FFFFu) == khi[i] && dist * B <= window;
+            const unsigned miss = (elo ^ klo[i]) | ((ehi & 0x3FFFFu) ^ khi[i]) | ~valid[i];
+            const bool hit = (miss == 0u) & (dist * B <= window);
             hd2[i] = hit ? dist : 0u;
-            const unsigned far = hit && dist * B >= 2048u ? 1u : 0u;
-            P |= (hit ? 1u : 0u) << (16u + 2u * i + 1u);
-            P |= far << (20u + 2u * i + 1u);
-            if (valid[i])
-                atomicMax(&table[slot[i]], ((unsigned long long)(khi[i] | (blk << 18)) << 32) | klo[i]);
+            P |= hit ? (dist * B >= 2048u ? 0x220000u : 0x020000u) << (2u * i) : 0u;
+            // (units beyond the data insert a zero, which changes nothing)
+            atomicMax(&table[slot[i]], ((unsigned long long)((khi[i] | (blk << 18)) & valid[i]) << 32) | (klo[i] & valid[i]));
         }
         HD[s] = hd2[0] | (hd2[1] << 16);
         // nibbles of 8 lanes -> one 32-bit mask per kind: lane j of the group ends up with kind j of its half-tile
@@ -308,7 +325,12 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
         while (__builtin_amdgcn_ballot_w64(front != 0u) != 0ull) {
             unsigned taken = 0, ends = 0;
 #pragma unroll
-            for (unsigned d = 0; d < kDistances; d++) {
+            for (unsigned dd = 0; dd < kDistances; dd++) {
+#ifdef HAP_BLK_FAR_FIRST
+                const unsigned d = kDistances - 1u - dd;
+#else
+                const unsigned d = dd;
+#endif
                 const unsigned seeds = front & E[d] & ~taken;
                 const unsigned sum = E[d] + seeds;
                 A[d] |= (E[d] & ~sum) | seeds;
@@ -350,12 +372,13 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
     __syncthreads();
 
     // ---- 3. emit: lane = unit ----
+    // (values are formed without lane-varying branches; only the stores themselves are predicated)
     const unsigned j4 = 4u * (lane & 7u);
     const unsigned below = (1u << j4) - 1u;
 #pragma unroll
     for (unsigned s = 0; s < kSteps; s++) {
         if (64u * s * 16u >= n)
-            break;
+            continue;
         const unsigned hh = 8u * s + (lane >> 3);
         const uint4 ma = *reinterpret_cast<const uint4 *>(&masks[hh * 8u]);
         const uint4 mb = *reinterpret_cast<const uint4 *>(&masks[hh * 8u + 4u]);
@@ -364,53 +387,52 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
         unsigned off = mb.w + 4u * popc(L & below) + 2u * popc(L & UL::big32 & below) - 2u * popc(L & UL::small32 & below) +
                        popc(S & below) + popc(CS & below) + popc(X3 & below);
         const unsigned sj = S >> j4, lj = L >> j4, xj = X3 >> j4, d0j = D0 >> j4, d1j = D1 >> j4, hj = Hm >> j4, nj = Sx1 >> j4;
+        const unsigned third = sj & ~lj & xj;              // copy-2 elements: a third byte
         const uint4 xs = X[s];
+        const unsigned fw[4] = {xs.x, LAYOUT == 2u ? xs.y : xs.x >> 16, xs.z, LAYOUT == 4u ? xs.w : LAYOUT == 2u ? xs.w : xs.z >> 16};
 #pragma unroll
         for (unsigned k = 0; k < 4u; k++) {
-            const bool is_s = ((sj >> k) & 1u) != 0u, is_l = ((lj >> k) & 1u) != 0u, x3 = ((xj >> k) & 1u) != 0u;
+            const unsigned is_s = bit_mask(sj, k), is_l = bit_mask(lj, k), x3 = bit_mask(xj, k);
             // bytes from this field to the next start: 4 per field, corrected by where the two fields sit in their units
             const unsigned c = (unsigned)__builtin_ctz(nj >> k);              // fields in between (the mask ends with a set bit)
-            const unsigned q = k + 1u + c;                                    // (next start) mod 4 = q mod 4
-            const unsigned adj_q = LAYOUT == 4u ? ((q & 3u) == 1u ? 2u : 0u) : LAYOUT == 6u ? 2u * (q & 1u) : 0u;
-            const unsigned len = 4u * (c + 1u) + (4u * k - UL::fo(k)) - adj_q;
-            unsigned v;
-            if (is_l) {
-                v = x3 ? (0xF0u | ((len - 1u) << 8)) : ((len - 1u) << 2);
-            } else {
-                unsigned dist = 1u + ((d0j >> k) & 1u) + 2u * ((d1j >> k) & 1u);
-                if ((k & 1u) && ((hj >> k) & 1u))
-                    dist = (HD[s] >> (8u * (k - 1u))) & 0xFFFFu;
-                const unsigned offb = dist * B;
-                v = x3 ? (2u | ((len - 1u) << 2) | (offb << 8))
-                       : (1u | ((len - 4u) << 2) | ((offb >> 8) << 5) | ((offb & 0xFFu) << 8));
+            unsigned len4 = 4u * (4u * c + 4u + (4u * k - UL::fo(k)));        // ... times 4, for the tags
+            if (LAYOUT == 4u)
+                len4 -= 8u - 8u * nonzero((c + k) & 3u);                      // the next start is a field 1
+            else if (LAYOUT == 6u)
+                len4 -= 8u * ((c + k + 1u) & 1u);                             // ... an odd field
+            // literal run: tag = len - 1 (60 = one length byte follows); the first data byte rides along, so that every
+            // start stores 16 bits
+            const unsigned lit = bfi(x3, (len4 << 6) - 0x10u, (len4 - 4u) | ((fw[k] & 0xFFu) << 8));
+            // copy: copy-2 tag 2 | (len - 1) << 2, offset in the next two bytes; copy-1 (len 4..11, offset < 2048):
+            // tag 1 | (len - 4) << 2 | (offset >> 8) << 5, then the offset's low byte
+            unsigned dist = 1u + ((d0j >> k) & 1u) + 2u * ((d1j >> k) & 1u);
+            unsigned near_high = 0;
+            if (k & 1u) {
+                const unsigned h = bit_mask(hj, k);
+                const unsigned hd = (HD[s] >> (8u * (k - 1u))) & 0xFFFFu;
+                dist = bfi(h, hd, dist);
+                near_high = (((hd * B) >> 8) << 5) & h;
             }
-            uint8_t *p = out + off;
-            if (is_s && (!is_l || x3))
-                put16(p, v);
-            if (is_s && is_l && !x3)
-                put8(p, v);
-            if (is_s && !is_l && x3)
-                put8(p + 2, v >> 16);
-            off += is_s ? (is_l ? 1u : 2u) + (x3 ? 1u : 0u) : 0u;
+            const unsigned c2 = len4 + (dist * B << 8) - 2u;
+            const unsigned cpy = c2 - (13u & ~x3) + (near_high & ~x3);
+            const unsigned v = bfi(is_l, lit, cpy);
+            if (is_s)
+                put16(out + off, v);
+            if (bit_mask(third, k))
+                put8(out + off + 2, v >> 16);
+            // element bytes: literal header 1 (+1), copy 2 (+1)
+            off += is_s & ((is_l & 1u) + (~is_l & 2u) + (x3 & 1u));
             if (is_l) {
-                p = out + off;
-                if (LAYOUT == 2u) {
-                    put32(p, k == 0u ? xs.x : k == 1u ? xs.y : k == 2u ? xs.z : xs.w);
-                } else if (k == 0u) {
-                    put16(p, xs.x);
-                } else if (k == 1u) {
-                    put16(p, xs.x >> 16);
-                    put32(p + 2, xs.y);
-                } else if (LAYOUT == 4u) {
-                    put32(p, k == 2u ? xs.z : xs.w);
-                } else if (k == 2u) {
-                    put16(p, xs.z);
+                if (UL::fs(k) == 2u) {
+                    put16(out + off, fw[k]);
+                } else if (UL::fs(k) == 4u) {
+                    put32(out + off, fw[k]);
                 } else {
-                    put16(p, xs.z >> 16);
-                    put32(p + 2, xs.w);
+                    put16(out + off, fw[k]);
+                    put32(out + off + 2, k == 1u ? xs.y : xs.w);
                 }
-                off += UL::fs(k);
             }
+            off += is_l & UL::fs(k);
         }
     }
 }
