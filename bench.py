@@ -148,6 +148,19 @@ class Stream:
         self.ctx.set_profiling(False)
         return elapsed, prof
 
+    def bit_exact(self):
+        """After the timed region: every texture the last step decoded equals what the block encoder makes of the same
+        RGBA frame (the encoder itself is pinned to oracle/bc_oracle.c by the -m gpu tests at these sizes)."""
+        ok = True
+        for idx, fmt in enumerate(self.fmts):
+            want = torch.empty(self.tex_bytes[idx], dtype=torch.uint8, device=self.dec[idx][0].device)
+            for i in range(self.nf):
+                torch.cuda.synchronize()
+                r = self.ctx.compress_rgba(self.rgba[i], self.w, self.h, self.w * 4, fmt, want)
+                self.ctx.synchronize()
+                ok = ok and r[0] == 0 and bool(torch.equal(want, self.dec[idx][i]))
+        return ok
+
     def split_rates(self):
         """separate encode / decode wall times of one untimed extra pass (events on the library's stream)"""
         self.ctx.timer_start()
@@ -295,6 +308,8 @@ def main():
         line["coarse_matches_option"] = None if args.no_extras else coarse_option(stream, hap_amd)
         line["smaller_files_option"] = None if args.no_extras else smaller_option(stream, hap_amd)
         stream.used = stream.encode()
+        stream.decode(stream.used)
+        line["bit_exact"] = stream.bit_exact()
         extras = {}
         if not args.no_cpu_baseline:
             for name, fn in (("host_pointer_path", lambda: host_pointer_path(ctx, stream.rgba, stream.frames, stream.used, fmts,
@@ -317,9 +332,14 @@ def main():
             del stream
             torch.cuda.empty_cache()
             try:
-                line["c5"] = c5_target(hap_amd, ctx, dev, args.c5_frames, flags, fence)
+                line["c5"] = side_config(hap_amd, ctx, dev, "C5", args.c5_frames, flags, fence)
             except Exception as exc:
                 line["c5"] = {"error": repr(exc)}
+            for small in ("C2", "C3"):
+                try:
+                    line[small.lower()] = side_config(hap_amd, ctx, dev, small, CONFIGS[small][4], flags, fence)
+                except Exception as exc:
+                    line[small.lower()] = {"error": repr(exc)}
     else:
         per_rank = [len(frames_of_rank(nf_total, r, world, args.scaling)) for r in range(world)]
         line["config"] = {"workload": "%s: %dx%d %s, %s chunks, Snappy, %d-frame stream, device-resident" % (
@@ -426,21 +446,23 @@ def smaller_option(stream, hap_amd):
             "note": "encode / decode of the same frames with 64 KiB Snappy fragments and no fragment table"}
 
 
-def c5_target(hap_amd, ctx, dev, frames, flags, fence, steps=6):
-    """The north-star's target config beside the headline: 16384x16384 Hap Q Alpha (YCoCg-DXT5 + RGTC1, 64 + 64 chunks,
-    two-texture frame), `frames` frames per step on this GPU.  Same step, same timing rules."""
-    s = Stream(hap_amd, ctx, dev, "C5", list(range(frames)), flags)
+def side_config(hap_amd, ctx, dev, config, frames, flags, fence, steps=6):
+    """The other BASELINE.json configs beside the headline, same step and timing rules: C5 = the north-star's target,
+    16384x16384 Hap Q Alpha (YCoCg-DXT5 + RGTC1, 64 + 64 chunks, two-texture frame); C2 / C3 = the 4K configs."""
+    s = Stream(hap_amd, ctx, dev, config, list(range(frames)), flags)
     elapsed, prof = s.timed(steps, 2, fence)
-    kernels, ratio = s.kernel_table(prof, steps, "C5")
+    kernels, ratio = s.kernel_table(prof, steps, config)
     enc_ms, dec_ms = s.split_rates()
     total = frames * steps
-    return {"workload": "C5: 16384x16384 0x1+0x8dbb, 64+64 chunks, Snappy, %d frames per step, device-resident" % frames,
+    return {"workload": "%s: %dx%d %s, %s chunks, Snappy, %d frames per step, device-resident" % (
+                config, s.w, s.h, "+".join("%#x" % f for f in s.fmts), "+".join(map(str, s.chunks)), frames),
             "value": round(total * s.rgba_bytes / elapsed / 1e9, 2), "unit": "GB/s", "fps": round(total / elapsed, 2),
             "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 3), "snappy_ratio": round(ratio, 4),
+            "bit_exact": s.bit_exact(),
             "encode_only": {"rgba_GBps": round(frames * s.rgba_bytes / (enc_ms * 1e-3) / 1e9, 2), "ms": round(enc_ms, 3)},
             "decode_only": {"rgba_GBps": round(frames * s.rgba_bytes / (dec_ms * 1e-3) / 1e9, 2), "ms": round(dec_ms, 3),
                             "texture_GBps": round(frames * sum(s.tex_bytes) / (dec_ms * 1e-3) / 1e9, 2)},
-            "roofline": s.roofline(kernels, "C5", kernel="snappy_decode"),
+            "roofline": s.roofline(kernels, config, kernel="snappy_decode"),
             "kernels": kernels}
 
 

@@ -43,10 +43,6 @@ __device__ __forceinline__ int mad24k(int a, int c)
     return r;
 }
 
-// exact floor(x / 7) for 0 <= x < 13107 and floor(x / 3) for 0 <= x < 32768 with one full-rate 24-bit multiply
-__device__ __forceinline__ int div7(int x) { return (int)(__umul24((unsigned)x, 9363u) >> 16); }
-__device__ __forceinline__ int div3(int x) { return (int)(__umul24((unsigned)x, 21846u) >> 16); }
-
 __device__ __forceinline__ int quant5(int v) { int t = mad24k<31>(v, 128); return (t + (t >> 8)) >> 8; }
 __device__ __forceinline__ int quant6(int v) { int t = mad24k<63>(v, 128); return (t + (t >> 8)) >> 8; }
 __device__ __forceinline__ int expand5(int q) { return (q << 3) | (q >> 2); }
@@ -66,39 +62,24 @@ __device__ __forceinline__ uint2 alpha_block(const int (&a)[16])
     const int a0 = hi - inset, a1 = lo + inset;
     unsigned lo24 = 0, hi24 = 0;       // 3-bit codes of pixels 0..7 and 8..15
     if (a0 != a1) {
-        // oracle/bc_oracle.c: ramp position r = #{ j < 7 : 2a < q_j + q_{j+1} } with q_j = floor(((7-j) a0 + j a1) / 7).
-        // With u = a0 - a (clamped to 0..d, d = a0 - a1) and c_j = a0 - q_j = ceil(j d / 7) that is
-        // r = #{ j : u > H_j }, H_j = floor((c_j + c_{j+1}) / 2) -- thresholds that grow with j.  Instead of testing all
-        // seven, estimate from below, r_lo = floor(7 (u - 1) / d) (never more than one short: checked for every d, u),
-        // and test the one threshold that decides: r = r_lo + (u > H[r_lo]), H_7 = 255.
+        // oracle/bc_oracle.c: with d = a0 - a1 and u = a0 - a clamped to 0..d, the ramp position is
+        // r = ((14 u + max(d - 6, 0)) * m) >> 20, m = floor(2^19 / d) + 1 -- the pixel's place on the ramp rounded to
+        // the nearest of its 8 steps (x * m >> 20 = x / 2d), thresholds moved by the 3/7 the decoder's steps are
+        // rounded down on average.  Per pixel: subtract, clamp, one multiply-add, shift, code, insert.
         const int d = a0 - a1;
-        int c[8];
-        c[0] = 0;
-#pragma unroll
-        for (int j = 1; j < 7; j++)
-            c[j] = div7(j * d + 6);
-        c[7] = d;
-        unsigned h_lo = 0, h_hi = 0xFF000000u;
-#pragma unroll
-        for (int j = 0; j < 7; j++) {
-            const unsigned h = (unsigned)(c[j] + c[j + 1]) >> 1;
-            if (j < 4)
-                h_lo |= h << (8 * j);
-            else
-                h_hi |= h << (8 * (j - 4));
-        }
-        // floor(x / d) = (x * (floor(2^19 / d) + 1)) >> 19 for x <= 7 * 254; the reciprocal from v_rcp_f32, made exact
+        // floor(2^19 / d): the reciprocal from v_rcp_f32, made exact
         unsigned q = (unsigned)(524288.0f * __builtin_amdgcn_rcpf((float)d));
         const int rem = 524288 - (int)__umul24(q, (unsigned)d);
         q += (rem >= d ? 1u : 0u) - (rem < 0 ? 1u : 0u);
-        const unsigned r7 = 7u * (q + 1u);
+        const unsigned m = q + 1u;
+        const unsigned m14 = 14u * m;                                   // < 2^23
+        const unsigned bias = __umul24((unsigned)max(d - 6, 0), m);     // < 2^20
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const int u = imed3(a0 - a[i], 0, d);
-            const unsigned r_lo = __umul24(__builtin_elementwise_sub_sat((unsigned)u, 1u), r7) >> 19;   // (u - 1, not below 0)
-            // H[r_lo]: one byte of the 8-byte table (selector bytes 1..3 = 0x0C give zero)
-            const unsigned th = __builtin_amdgcn_perm(h_hi, h_lo, r_lo | 0x0C0C0C00u);
-            const unsigned r = r_lo + ((unsigned)u > th ? 1u : 0u);
+            unsigned x;
+            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(x) : "v"(u), "v"(m14), "v"(bias));     // <= 255 * 14 m + bias < 2^31
+            const unsigned r = x >> 20;
             // ramp position -> S3TC code: 0->0, 7->1, r->r+1 (byte table 00 02 03 04 | 05 06 07 01, one v_perm)
             const unsigned code = __builtin_amdgcn_perm(0x01070605u, 0x04030200u, r);
             // three bits in from the top: after 8 pixels the codes occupy bits 31:8, pixel 0 lowest
@@ -115,45 +96,76 @@ __device__ __forceinline__ uint2 alpha_block(const int (&a)[16])
     return make_uint2((unsigned)v, (unsigned)(v >> 32));
 }
 
-// 2-bit index of the nearest of 4 palette entries for 16 pixels; px and pal are packed
-// bytes (c0 | c1<<8 | c2<<16), top byte zero.  Lowest index wins ties.
-template <bool COMPLEMENTED = false>      // COMPLEMENTED: px already holds 255 - p in its colour bytes
-__device__ __forceinline__ unsigned nearest4(const unsigned (&px)[16], const unsigned (&pal)[4])
+// 2-bit indices of 16 pixels for the palette p0, p1, (2 p0 + p1) / 3, (p0 + 2 p1) / 3 (oracle/bc_oracle.c,
+// pick_indices): the entries lie at 3/3, 0/3, 2/3, 1/3 of the segment p1 .. p0, so the pixel is projected onto it,
+//     t = (pixel - p1) . dir + len2 / 6 clamped to 0 .. len2 + len2 / 6,   dir = p0 - p1, len2 = |dir|^2,
+//     pos = (t * floor(3 * 2^24 / len2)) >> 24,                            index = {1, 3, 2, 0}[pos].
+// One unsigned byte dot product per pixel: channels whose direction is negative enter complemented (`flip` has 0xFF
+// in those bytes, XOR-ed into the pixel unless FLIPPED says the caller did that already), the constants of the
+// complement and of p1 . dir ride in the dot product's accumulator.  px, p0, p1: packed bytes, top byte zero.
+struct projection {
+    unsigned adir;      // |dir| per channel, packed
+    unsigned flip;      // 0xFF where dir < 0
+    int start;          // accumulator start: len2 / 6 - p1 . dir - 255 * (sum of |dir| over flipped channels)
+    int top;            // len2 + len2 / 6
+    unsigned m24;       // floor(3 * 2^24 / len2)
+};
+
+__device__ __forceinline__ projection make_projection(unsigned p0, unsigned p1)
 {
-    // |p - c_k|^2 orders like |c_k|^2 - 2 p.c_k; scale by 4 and put k in the low bits so that one signed min
-    // picks the smallest distance with the smallest index on ties: s_k = 4|c_k|^2 + k - 8 p.c_k.
-    // With the complemented pixel p' = 255 - p (per byte), p.c_k = 255 sum(c_k) - p'.c_k, so
-    // s_k = (4|c_k|^2 + k - 2040 sum(c_k)) + (p'.c_k << 3): one dot product and one shift-add per entry.
-    int base[4];
+    projection pr;
+    // per-byte |p0 - p1| and the sign bytes: 9-bit lanes of a 32-bit subtraction would borrow across bytes, so per channel
+    int dir[3];
+    unsigned adir = 0, flip = 0;
+    int neg = 0, base = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++)
-        base[k] = 4 * (int)__builtin_amdgcn_udot4(pal[k], pal[k], 0u, false) + k -
-                  2040 * (int)__builtin_amdgcn_udot4(pal[k], 0x00010101u, 0u, false);
+    for (int c = 0; c < 3; c++) {
+        const int a = (int)((p0 >> (8 * c)) & 255u), b = (int)((p1 >> (8 * c)) & 255u);
+        dir[c] = a - b;
+        const int ad = abs(dir[c]);
+        adir |= (unsigned)ad << (8 * c);
+        flip |= (dir[c] < 0 ? 0xFFu : 0u) << (8 * c);
+        neg += dir[c] < 0 ? ad : 0;
+        base = mad24(b, dir[c], base);
+    }
+    const unsigned len2 = __builtin_amdgcn_udot4(adir, adir, 0u, false);                 // 16 .. 195075
+    const unsigned sixth = __umulhi(len2, 0xAAAAAAABu) >> 2;                             // len2 / 6
+    // floor(3 * 2^24 / len2) from the float reciprocal, corrected with the integer remainder (off by one at most)
+    unsigned m = (unsigned)(50331648.0f * __builtin_amdgcn_rcpf((float)len2));
+    const int rem = (int)(50331648u - m * len2);
+    m += (rem >= (int)len2 ? 1u : 0u) - (rem < 0 ? 1u : 0u);
+    pr.adir = adir;
+    pr.flip = flip;
+    pr.start = (int)sixth - base - 255 * neg;
+    pr.top = (int)(len2 + sixth);
+    pr.m24 = m;
+    return pr;
+}
+
+template <bool FLIPPED = false>
+__device__ __forceinline__ unsigned project4(const unsigned (&px)[16], const projection &pr)
+{
     unsigned idx = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        const unsigned q = COMPLEMENTED ? px[i] : px[i] ^ 0x00FFFFFFu;
-        const int s0 = (int)(__builtin_amdgcn_udot4(q, pal[0], 0u, false) << 3) + base[0];
-        const int s1 = (int)(__builtin_amdgcn_udot4(q, pal[1], 0u, false) << 3) + base[1];
-        const int s2 = (int)(__builtin_amdgcn_udot4(q, pal[2], 0u, false) << 3) + base[2];
-        const int s3 = (int)(__builtin_amdgcn_udot4(q, pal[3], 0u, false) << 3) + base[3];
-        const int best = min(min(s0, s1), min(s2, s3));
+        const unsigned q = FLIPPED ? px[i] : px[i] ^ pr.flip;
+        // (clamped by the compiler's own v_med3: an inline-asm reader right behind the dot product would miss its wait states)
+        const int t = min(max((int)__builtin_amdgcn_udot4(q, pr.adir, (unsigned)pr.start, false), 0), pr.top);
+        const unsigned pos = __umul24((unsigned)t, pr.m24) >> 24;        // t < 2^18, m24 < 2^22, product <= 3.5 * 2^24
+        const unsigned code = __builtin_amdgcn_perm(0u, 0x00020301u, pos);  // {1, 3, 2, 0}[pos]
         // shift the two index bits in from the top: after 16 pixels pixel 0 sits in bits 1:0
-        idx = __builtin_amdgcn_alignbit((unsigned)best, idx, 2);
+        idx = __builtin_amdgcn_alignbit(code, idx, 2);
     }
     return idx;
 }
 
 __device__ __forceinline__ unsigned pack3(int a, int b, int c) { return (unsigned)a | ((unsigned)b << 8) | ((unsigned)c << 16); }
 
-__device__ __forceinline__ void palette_from_565(unsigned c0, unsigned c1, bool blue, unsigned (&pal)[4])
+// the two end entries of the palette of a 5:6:5 endpoint pair, packed bytes (the blue field of a scaled YCoCg block
+// carries the scale, not a colour: left out there)
+__device__ __forceinline__ unsigned expand_565(unsigned c, bool blue)
 {
-    const int r0 = expand5(c0 >> 11), g0 = expand6((c0 >> 5) & 63), b0 = blue ? expand5(c0 & 31) : 0;
-    const int r1 = expand5(c1 >> 11), g1 = expand6((c1 >> 5) & 63), b1 = blue ? expand5(c1 & 31) : 0;
-    pal[0] = pack3(r0, g0, b0);
-    pal[1] = pack3(r1, g1, b1);
-    pal[2] = pack3(div3(2 * r0 + r1), div3(2 * g0 + g1), div3(2 * b0 + b1));
-    pal[3] = pack3(div3(r0 + 2 * r1), div3(g0 + 2 * g1), div3(b0 + 2 * b1));
+    return pack3(expand5(c >> 11), expand6((c >> 5) & 63), blue ? expand5(c & 31) : 0);
 }
 
 // DXT1-style colour block from 16 packed RGB pixels (alpha byte already cleared).
@@ -191,11 +203,8 @@ __device__ __forceinline__ uint2 colour_block(const unsigned (&px)[16])
     const unsigned qb = (unsigned)(quant5(br) << 11 | quant6(lo[1]) << 5 | quant5(bb));
     const unsigned c0 = max(qa, qb), c1 = min(qa, qb);
     unsigned idx = 0;
-    if (c0 != c1) {
-        unsigned pal[4];
-        palette_from_565(c0, c1, true, pal);
-        idx = nearest4(px, pal);
-    }
+    if (c0 != c1)
+        idx = project4(px, make_projection(expand_565(c0, true), expand_565(c1, true)));
     return make_uint2(c0 | (c1 << 16), idx);
 }
 
@@ -235,19 +244,21 @@ __device__ __forceinline__ uint2 ycocg_colour_block(const unsigned (&cc)[16])
     const unsigned c0 = max(qa, qb), c1 = min(qa, qb);
     unsigned idx = 0;
     if (c0 != c1) {
-        unsigned pal[4], px[16];
-        palette_from_565(c0, c1, false, pal);
-        // 255 - ((c - 128) s + 128) for both halves (16-bit arithmetic wraps to the right value) -- the index search
-        // multiplies the complement --, then the two bytes side by side
-        const pk_u16 scale = {(unsigned short)(0u - (unsigned)s), (unsigned short)(0u - (unsigned)s)};
-        const unsigned short bias = (unsigned short)(127 + 128 * s);
-        const pk_u16 off = {bias, bias};
+        unsigned px[16];
+        const projection pr = make_projection(expand_565(c0, false), expand_565(c1, false));
+        // the scaled pixel (c - 128) s + 128 of each half -- or its complement 255 - that, where the segment's direction
+        // is negative in that channel (16-bit arithmetic wraps to the right value) --, then the two bytes side by side
+        const unsigned short s_o = (unsigned short)((pr.flip & 0x00FFu) ? 0u - (unsigned)s : (unsigned)s);
+        const unsigned short s_g = (unsigned short)((pr.flip & 0xFF00u) ? 0u - (unsigned)s : (unsigned)s);
+        const unsigned short b_o = (unsigned short)((pr.flip & 0x00FFu) ? 127 + 128 * s : 128 - 128 * s);
+        const unsigned short b_g = (unsigned short)((pr.flip & 0xFF00u) ? 127 + 128 * s : 128 - 128 * s);
+        const pk_u16 scale = {s_o, s_g}, off = {b_o, b_g};
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const unsigned t = __builtin_bit_cast(unsigned, (pk_u16)(__builtin_bit_cast(pk_u16, cc[i]) * scale + off));
             px[i] = __builtin_amdgcn_perm(t, t, 0x0C0C0200u);            // bytes: t.0, t.2, zero, zero
         }
-        idx = nearest4<true>(px, pal);
+        idx = project4<true>(px, pr);
     }
     return make_uint2(c0 | (c1 << 16), idx);
 }

@@ -212,13 +212,16 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
     const bool rec_in_lds = rbytes <= S - shift;
     uint8_t *const rec_mem = (uint8_t *)(((uintptr_t)dst + 1u) & ~(uintptr_t)1u);
     {
+        // (every lane stores only granules that hold input: the last 1 KiB row of stores would otherwise run up to
+        // 1008 bytes past S + total, beyond the buffer for fragments that begin with well-compressed half-tiles)
         uint8_t *park = buf + (S - shift) + lane * 16u;
 #pragma unroll
         for (unsigned i = 0; i < 4u; i++)
-            if (i * 1024u < in_end)
+            if (i * 1024u + lane * 16u < in_end)
                 *reinterpret_cast<uint4 *>(park + i * 1024u) = early[i];
         for (unsigned x = 4096u; x < in_end; x += 1024u)
-            *reinterpret_cast<uint4 *>(park + x) = load_input16(src_al, x + lane * 16u, shift, in_end, readable_end);
+            if (x + lane * 16u < in_end)
+                *reinterpret_cast<uint4 *>(park + x) = load_input16(src_al, x + lane * 16u, shift, in_end, readable_end);
     }
     __syncthreads();
 

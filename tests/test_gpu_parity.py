@@ -332,7 +332,11 @@ def test_decode_dual_texture(hap):
         assert hap.HapDecode(frame, 1, outputBufferBytes=len(b)) == (0, b, L.FMT_RGTC1)
 
 
-def test_decode_malformed_frames_match_oracle(hap):
+@pytest.mark.parametrize("name,api", CHECKERS)
+def test_decode_malformed_frames_match_oracle(hap, name, api):
+    """Truncations, single-bit damage and every value of the section-type byte: the GPU path's result codes (and
+    bytes, where a frame still decodes) are the checker's -- the restatement and the unmodified reference alike."""
+    ORA = api
     rng = np.random.default_rng(3)
     tex = D.stream_bytes(16 * 256, "runs")
     _, frame = ORA.encode([tex], [L.FMT_DXT5], [1], [4])
@@ -757,6 +761,17 @@ def test_byte_granular_streams_and_a_lying_table(hap):
     assert r == 0 and ORA.decode(f16, 0, len(tex)) == (0, tex, L.FMT_YCOCG)
 
 
+def _oracle_bc_encode_threaded(img, fmt, threads=32):
+    """The scalar block encoder of oracle/bc_oracle.c over row bands on several host threads (full-size pictures)."""
+    h, w = img.shape[:2]
+    out = np.zeros((h // 4) * (w // 4) * D.BLOCK_BYTES[fmt], dtype=np.uint8)
+    fn = L.oracle_lib().oraclebase_bc_encode
+    fn.restype = C.c_double
+    fn(img.ctypes.data_as(C.c_void_p), C.c_uint(w), C.c_uint(h), C.c_size_t(img.strides[0]), C.c_uint(fmt),
+       out.ctypes.data_as(C.c_void_p), C.c_uint(threads), C.c_uint(1))
+    return out
+
+
 FULL_SIZE = {"C2": (3840, 2160, [L.FMT_DXT1], [1], 1),
              "C3": (3840, 2160, [L.FMT_DXT5], [8], 1),
              "C4": (7680, 4320, [L.FMT_YCOCG], [24], 3),
@@ -781,6 +796,14 @@ def test_full_size_configs_round_trip(ctx, hap, cfg):
     for t in range(count):
         for i in range(nf):
             assert ctx.compress_rgba(rgba[i], w, h, w * 4, fmts[t], tex[t][i]) == (0, sizes[t])
+    # G4 at full size: the block encoder's texture of frame 0 is the scalar oracle's, bit for bit (at 16384 wide this
+    # is the batch kernel with 64 KiB row pitch; the batch kernels' output is compared with these textures below)
+    host_rgba = rgba[0].cpu().numpy()
+    for t in range(count):
+        want = _oracle_bc_encode_threaded(host_rgba, fmts[t])
+        assert np.array_equal(tex[t][0].cpu().numpy(), want), (cfg, t)
+        del want
+    del host_rgba
     for flags in (0, hap.ENCODE_FRAGMENT_INDEX):
         r, used, results = ctx.encode_frames_rgba(rgba, w, h, w * 4, fmts, [1] * count, chunks, outs, flags=flags)
         assert r == 0 and results == [0] * nf
@@ -805,7 +828,7 @@ def test_full_size_configs_round_trip(ctx, hap, cfg):
                 assert np.array_equal(oo, tex[t][0].cpu().numpy()), (name, t)
 
 
-@pytest.mark.parametrize("cfg", ["C4", "C5"])
+@pytest.mark.parametrize("cfg", ["C2", "C3", "C4", "C5"])
 def test_full_size_frames_from_the_reference_encoder_decode_bit_exactly(ctx, hap, cfg):
     """G1 at full size: frames written by the CPU checker's HapEncode (the unmodified reference + libsnappy where
     built: one libsnappy stream per chunk, no private table) decode on the GPU to the bytes the checker itself
@@ -824,7 +847,7 @@ def test_full_size_frames_from_the_reference_encoder_decode_bit_exactly(ctx, hap
     host_tex = [t.cpu().numpy() for t in tex]
     name, api = CHECKERS[-1]                                   # the reference when it exists
     r, frame = api.encode_np(host_tex, fmts, [1] * count, chunks)
-    assert r == 0 and frame[3] == (0x0D if count == 2 else 0xCF)
+    assert r == 0 and frame[3] == {"C2": 0xCB, "C3": 0xCE, "C4": 0xCF, "C5": 0x0D}[cfg]
     dframe = torch.from_numpy(frame).cuda()
     for t in range(count):
         out = torch.zeros(sizes[t], dtype=torch.uint8, device="cuda")
@@ -1197,6 +1220,23 @@ def test_field_stream_promises_are_checked_on_hand_made_streams(ctx, hap):
     v[10] = halves[10][:-1] + [copy2(48, 48)]
     v[11] = [copy2(48, 128)] + halves[11][1:]
     lies["element across a half-tile"] = frame_of(v)
+    # a valid field stream whose parked input ends far above the first kilobyte rows of the buffer: nine half-tiles of
+    # 6 bytes, then half-tiles of 144 bytes (every field its own literal: 128 + 16 headers) -- the input's last row
+    # of 16-byte stores must not run past the LDS buffer into the tables behind it (the decode would still say OK)
+    def busy_half(seed):
+        r2 = np.random.default_rng(seed)                                 # 16 literals: 128 + 16 = 144 bytes
+        els = []
+        for _b in range(4):
+            els += [lit(r2.integers(0, 256, 2, dtype=np.uint8).tobytes()), lit(r2.integers(0, 256, 6, dtype=np.uint8).tobytes()),
+                    lit(r2.integers(0, 256, 4, dtype=np.uint8).tobytes()), lit(r2.integers(0, 256, 20, dtype=np.uint8).tobytes())]
+        return els
+    tight = [[lit(rng.integers(0, 256, 16, dtype=np.uint8).tobytes()), copy2(64, 16), copy2(48, 16)]] + \
+            [[copy2(64, 128), copy2(64, 128)] for _ in range(8)] + [busy_half(100 + h) for h in range(55)]
+    assert [len(b"".join(h)) for h in tight[:10]] == [23, 6, 6, 6, 6, 6, 6, 6, 6, 144]
+    data = frame_of(tight)
+    rc, expect, _f = ORA.decode(data, 0, 8192)
+    assert rc == 0 and hap.HapDecode(data, 0, outputBufferBytes=8192) == (0, expect, L.FMT_DXT5)
+    assert through_context(data) == (0, 0, expect, 0)
     for name, data in lies.items():
         rc, expect, _f = ORA.decode(data, 0, 8192)
         got = hap.HapDecode(data, 0, outputBufferBytes=8192)
