@@ -18,14 +18,6 @@ namespace {
 constexpr int kFmtDXT1 = 0, kFmtDXT5 = 1, kFmtYCoCg = 2, kFmtRGTC1 = 3;
 constexpr int kFmtYCoCgAlpha = 4;      // Hap Q Alpha: scaled YCoCg-DXT5 + RGTC1 alpha plane from one read of the RGBA
 
-// clamp(t, lo, hi) with lo <= hi: one v_med3_i32
-__device__ __forceinline__ int imed3(int t, int lo, int hi)
-{
-    int r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(t), "v"(lo), "v"(hi));
-    return r;
-}
-
 // Inline-asm helpers below must never consume the result of a v_dot4 directly: gfx950 needs wait states between
 // a dot product and a different VALU reader, and the compiler does not see through the asm to insert them.
 // a * b + c on the 24-bit multiplier (full rate; the 32-bit one is quarter rate); |a|, |b| < 2^23
@@ -72,16 +64,15 @@ __device__ __forceinline__ uint2 alpha_block(const int (&a)[16])
         const int rem = 524288 - (int)__umul24(q, (unsigned)d);
         q += (rem >= d ? 1u : 0u) - (rem < 0 ? 1u : 0u);
         const unsigned m = q + 1u;
-        const unsigned m14 = 14u * m;                                   // < 2^23
-        const unsigned bias = __umul24((unsigned)max(d - 6, 0), m);     // < 2^20
+        // x = (14 (a0 - a) + bias) m as one multiply-add in a; positions of pixels beyond the endpoints (the inset)
+        // come out below 0 / above 7 and are clamped afterwards, which is what clamping u to 0..d first gives
+        const int neg_m14 = -(int)(14u * m);                             // |.| < 2^23
+        const int start = mad24(a0, (int)(14u * m), (int)__umul24((unsigned)max(d - 6, 0), m));
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const int u = imed3(a0 - a[i], 0, d);
-            unsigned x;
-            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(x) : "v"(u), "v"(m14), "v"(bias));     // <= 255 * 14 m + bias < 2^31
-            const unsigned r = x >> 20;
+            const int r = min(max(mad24(a[i], neg_m14, start) >> 20, 0), 7);
             // ramp position -> S3TC code: 0->0, 7->1, r->r+1 (byte table 00 02 03 04 | 05 06 07 01, one v_perm)
-            const unsigned code = __builtin_amdgcn_perm(0x01070605u, 0x04030200u, r);
+            const unsigned code = __builtin_amdgcn_perm(0x01070605u, 0x04030200u, (unsigned)r);
             // three bits in from the top: after 8 pixels the codes occupy bits 31:8, pixel 0 lowest
             if (i < 8)
                 lo24 = __builtin_amdgcn_alignbit(code, lo24, 3);
@@ -145,17 +136,21 @@ __device__ __forceinline__ projection make_projection(unsigned p0, unsigned p1)
 template <bool FLIPPED = false>
 __device__ __forceinline__ unsigned project4(const unsigned (&px)[16], const projection &pr)
 {
-    unsigned idx = 0;
+    unsigned pos2 = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const unsigned q = FLIPPED ? px[i] : px[i] ^ pr.flip;
-        // (clamped by the compiler's own v_med3: an inline-asm reader right behind the dot product would miss its wait states)
-        const int t = min(max((int)__builtin_amdgcn_udot4(q, pr.adir, (unsigned)pr.start, false), 0), pr.top);
-        const unsigned pos = __umul24((unsigned)t, pr.m24) >> 24;        // t < 2^18, m24 < 2^22, product <= 3.5 * 2^24
-        const unsigned code = __builtin_amdgcn_perm(0u, 0x00020301u, pos);  // {1, 3, 2, 0}[pos]
-        // shift the two index bits in from the top: after 16 pixels pixel 0 sits in bits 1:0
-        idx = __builtin_amdgcn_alignbit(code, idx, 2);
+        // (t is not clamped first: the product stays far inside 32 bits -- pixels lie within a few segment lengths of
+        // p1 -- and clamping the position to 0..3 afterwards gives what the definition's clamp of t gives; the clamp is
+        // left to the compiler's v_med3: an inline-asm reader right behind the dot product would miss its wait states)
+        const int t = (int)__builtin_amdgcn_udot4(q, pr.adir, (unsigned)pr.start, false);
+        const int pos = min(max(__mul24(t, (int)pr.m24) >> 24, 0), 3);
+        // shift the two position bits in from the top: after 16 pixels pixel 0 sits in bits 1:0
+        pos2 = __builtin_amdgcn_alignbit((unsigned)pos, pos2, 2);
     }
+    // positions -> indices {1, 3, 2, 0}, all 16 at once: index high bit = pos.hi ^ pos.lo, low bit = ~pos.hi
+    const unsigned hi = pos2 & 0xAAAAAAAAu;
+    const unsigned idx = (hi ^ ((pos2 << 1) & 0xAAAAAAAAu)) | ((~hi >> 1) & 0x55555555u);
     return idx;
 }
 
@@ -225,15 +220,19 @@ __device__ __forceinline__ uint2 ycocg_colour_block(const unsigned (&cc)[16])
     int lo_o = lo.x, hi_o = hi.x, lo_g = lo.y, hi_g = hi.y;
     const int m = max(max(128 - lo_o, hi_o - 128), max(128 - lo_g, hi_g - 128));
     const int s = m <= 31 ? 4 : (m <= 63 ? 2 : 1);
-    int cov = 0;
-    const pk_i16 mid = __builtin_bit_cast(pk_i16, lo + hi);            // (lo + hi per half: at most 510)
+    // covariance sign: sum (2 Co - mo)(2 Cg - mg) = 4 sum Co Cg - 2 mg sum Co - 2 mo sum Cg + 16 mo mg with mo = lo + hi
+    // of Co, mg of Cg: per pixel one product-accumulate and one packed add
+    int prod = 0;
+    pk_u16 sums = {0, 0};
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        const pk_i16 d = __builtin_bit_cast(pk_i16, cc[i]) * (short)2 - mid;  // 2 Co - (lo + hi) | 2 Cg - (lo + hi), |.| <= 255
         int r;
-        asm("v_mad_i32_i16 %0, %1, %1, %2 op_sel:[0,1,0,0]" : "=v"(r) : "v"(d), "v"(cov));   // low half x high half + cov
-        cov = r;
+        asm("v_mad_i32_i16 %0, %1, %1, %2 op_sel:[0,1,0,0]" : "=v"(r) : "v"(cc[i]), "v"(prod));   // low half x high half + prod
+        prod = r;
+        sums += __builtin_bit_cast(pk_u16, cc[i]);
     }
+    const int mo = lo_o + hi_o, mg = lo_g + hi_g;
+    const int cov = 4 * prod - 2 * mg * (int)sums.x - 2 * mo * (int)sums.y + 16 * mo * mg;
     lo_o = (lo_o - 128) * s + 128; hi_o = (hi_o - 128) * s + 128;
     lo_g = (lo_g - 128) * s + 128; hi_g = (hi_g - 128) * s + 128;
     int ins = (hi_o - lo_o) >> 4; lo_o += ins; hi_o -= ins;
@@ -244,21 +243,27 @@ __device__ __forceinline__ uint2 ycocg_colour_block(const unsigned (&cc)[16])
     const unsigned c0 = max(qa, qb), c1 = min(qa, qb);
     unsigned idx = 0;
     if (c0 != c1) {
-        unsigned px[16];
         const projection pr = make_projection(expand_565(c0, false), expand_565(c1, false));
-        // the scaled pixel (c - 128) s + 128 of each half -- or its complement 255 - that, where the segment's direction
-        // is negative in that channel (16-bit arithmetic wraps to the right value) --, then the two bytes side by side
-        const unsigned short s_o = (unsigned short)((pr.flip & 0x00FFu) ? 0u - (unsigned)s : (unsigned)s);
-        const unsigned short s_g = (unsigned short)((pr.flip & 0xFF00u) ? 0u - (unsigned)s : (unsigned)s);
-        const unsigned short b_o = (unsigned short)((pr.flip & 0x00FFu) ? 127 + 128 * s : 128 - 128 * s);
-        const unsigned short b_g = (unsigned short)((pr.flip & 0xFF00u) ? 127 + 128 * s : 128 - 128 * s);
-        const pk_u16 scale = {s_o, s_g}, off = {b_o, b_g};
+        // project4 on the scaled pixels v = (c - 128) s + 128 without forming them: with c' = c, or 255 - c where the
+        // segment's direction is negative (one XOR on the packed pair), the (possibly complemented) scaled pixel is
+        // s c' + k, k = 128 - 128 s or 127 - 127 s, so t = s (c' . |dir|) + K and the position is
+        // (t m24) >> 24 = ((c' . |dir|) (s m24) + K m24) >> 24 -- 32-bit wrap-around arithmetic, t m24 itself fits
+        const unsigned adir2 = __builtin_amdgcn_perm(pr.adir, pr.adir, 0x0C010C00u);        // |dir| of Co', Cg' under the two halves
+        const unsigned flip2 = __builtin_amdgcn_perm(pr.flip, pr.flip, 0x0C010C00u);
+        const int k_o = (pr.flip & 0x00FFu) ? 127 - 127 * s : 128 - 128 * s;
+        const int k_g = (pr.flip & 0xFF00u) ? 127 - 127 * s : 128 - 128 * s;
+        const int K = pr.start + (int)(pr.adir & 255u) * k_o + (int)((pr.adir >> 8) & 255u) * k_g;
+        const unsigned sm = (unsigned)s * pr.m24;                                            // < 2^24
+        const unsigned Km = (unsigned)K * pr.m24;                                            // mod 2^32
+        unsigned pos2 = 0;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const unsigned t = __builtin_bit_cast(unsigned, (pk_u16)(__builtin_bit_cast(pk_u16, cc[i]) * scale + off));
-            px[i] = __builtin_amdgcn_perm(t, t, 0x0C0C0200u);            // bytes: t.0, t.2, zero, zero
+            const unsigned dot = __builtin_amdgcn_udot4(cc[i] ^ flip2, adir2, 0u, false);    // < 2^18
+            const int pos = min(max((int)(__umul24(dot, sm) + Km) >> 24, 0), 3);
+            pos2 = __builtin_amdgcn_alignbit((unsigned)pos, pos2, 2);
         }
-        idx = project4<true>(px, pr);
+        const unsigned hi = pos2 & 0xAAAAAAAAu;
+        idx = (hi ^ ((pos2 << 1) & 0xAAAAAAAAu)) | ((~hi >> 1) & 0x55555555u);
     }
     return make_uint2(c0 | (c1 << 16), idx);
 }
@@ -315,10 +320,10 @@ __device__ __forceinline__ void encode_block(const uint8_t *__restrict__ rgba, s
             // ((255-R)+2G+(255-B)+4)>>2 -- three byte dot products (alpha weight 0), upper clamp only
             const unsigned q = p[i];
             y[i] = (int)(__builtin_amdgcn_udot4(q, 0x00010201u, 2u, false) >> 2);
-            const unsigned co = __builtin_amdgcn_udot4(q ^ 0x00FF0000u, 0x00010001u, 2u, false) >> 1;      // 1..256
-            const unsigned cg = __builtin_amdgcn_udot4(q ^ 0x00FF00FFu, 0x00010201u, 4u, false) >> 2;      // 1..256
-            const pk_u16 both = __builtin_bit_cast(pk_u16, co | (cg << 16)), top = {255, 255};
-            cc[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_min(both, top));                      // upper clamp, both at once
+            const unsigned co2 = __builtin_amdgcn_udot4(q ^ 0x00FF0000u, 0x00010001u, 2u, false);           // 2 Co: 2..512
+            const unsigned cg4 = __builtin_amdgcn_udot4(q ^ 0x00FF00FFu, 0x00010201u, 4u, false);           // 4 Cg: 4..1024
+            const pk_u16 raw = __builtin_bit_cast(pk_u16, co2 | (cg4 << 16)), sh = {1, 2}, top = {255, 255};
+            cc[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_min((pk_u16)(raw >> sh), top));       // halve / quarter, upper clamp, both at once
         }
         const uint2 ab = alpha_block(y), cb = ycocg_colour_block(cc);
         *reinterpret_cast<uint4 *>(out + id * 16u) = make_uint4(ab.x, ab.y, cb.x, cb.y);
