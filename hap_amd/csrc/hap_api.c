@@ -41,8 +41,11 @@ unsigned int HapGpuCreate(int device, HapGpuContext **context)
         /* RGTC1 planes of large textures go through the [2, 6] field kernel (block-per-lane decodable: 2.9x the decode
            rate at the same size); HAP_AMD_RGTC1_LAYOUT overrides: 0 = position-per-lane compressor, 44 = [4, 4] */
         c->rgtc1_fields = 26u;
-        if (getenv("HAP_AMD_RGTC1_LAYOUT"))
-            c->rgtc1_fields = (unsigned)atoi(getenv("HAP_AMD_RGTC1_LAYOUT"));
+        if (getenv("HAP_AMD_RGTC1_LAYOUT")) {
+            const int v = atoi(getenv("HAP_AMD_RGTC1_LAYOUT"));
+            if (v == 0 || v == 26 || v == 44)
+                c->rgtc1_fields = (unsigned)v;
+        }
     }
     *context = c;
     return HapResult_No_Error;
@@ -97,6 +100,8 @@ static HapGpuContext *acquire_default_context(void)
     for (i = 0; i < g_pool_count && !c; i++)
         if (hapgpu_rt_trylock(g_pool[i]->rt) == 0)
             c = g_pool[i];
+    if (c)
+        c->frag_log2 = first->frag_log2;       /* (HapGpuSetFragmentLog2 on the default context reaches every member) */
     if (!c && g_pool_count < HAP_DEFAULT_POOL &&
         HapGpuCreate(hapgpu_rt_device(first->rt), &c) == HapResult_No_Error) {
         c->frag_log2 = first->frag_log2;
@@ -127,6 +132,14 @@ unsigned long HapGpuTableFallbackCount(HapGpuContext *context)
     hapgpu_rt_lock(context->rt);
     n = context->table_fallbacks;
     hapgpu_rt_unlock(context->rt);
+    if (context == g_default) {                /* the hap.h entry points may have run on any member of the pool */
+        unsigned i;
+        pthread_mutex_lock(&g_pool_lock);
+        for (i = 0; i < g_pool_count; i++)
+            if (g_pool[i] != context)
+                n += g_pool[i]->table_fallbacks;
+        pthread_mutex_unlock(&g_pool_lock);
+    }
     return n;
 }
 
@@ -162,7 +175,10 @@ unsigned long HapMaxEncodedLength(unsigned int count, unsigned long *lengths,
 static unsigned env_encode_flags(void)
 {
     const char *e = getenv("HAP_AMD_FRAGMENT_INDEX"), *c = getenv("HAP_AMD_COARSE_MATCHES"), *s = getenv("HAP_AMD_SMALLER_FILES");
-    return ((e && atoi(e) != 0) ? HAPGPU_ENCODE_FRAGMENT_INDEX : 0u) |
+    /* the private fragment table is written by default (the reference skips unknown sections, hap.c:701-703, and a
+       section that would not shrink with it is stored raw): frames from plain hap.h HapEncode then decode through
+       the block-per-lane kernel; HAP_AMD_FRAGMENT_INDEX=0 leaves it out */
+    return ((!e || atoi(e) != 0) ? HAPGPU_ENCODE_FRAGMENT_INDEX : 0u) |
            ((c && atoi(c) != 0) ? HAPGPU_ENCODE_COARSE_MATCHES : 0u) |
            ((s && atoi(s) != 0) ? HAPGPU_ENCODE_SMALLER_FILES : 0u);
 }
@@ -174,17 +190,26 @@ unsigned int HapEncode(unsigned int count, const void **inputBuffers, unsigned l
                        unsigned long *outputBufferBytesUsed)
 {
     HapGpuContext *ctx;
-    unsigned result = HapResult_Internal_Error, rc;
+    unsigned result = HapResult_Internal_Error, rc, flags, i;
     unsigned long used = 0;
     void *out = outputBuffer;
     if (count == 0 || count > 2 || !inputBuffers || !inputBuffersBytes || !textureFormats || !compressors ||
         !chunkCounts || !outputBuffer || outputBufferBytes == 0 || !outputBufferBytesUsed)
         return HapResult_Bad_Arguments;
+    flags = env_encode_flags();
+    /* A texture whose bytes do not divide by its chunk count is no real block texture; the reference's chunked form
+       then drops the remainder (hap.c:433), and whether a frame takes that form or the raw one must not depend on
+       the private table's few bytes: such textures are written without it, exactly as the reference decides. */
+    for (i = 0; i < count; i++) {
+        const unsigned n = chunkCounts[i] ? hapf_limit_chunk_count(inputBuffersBytes[i], textureFormats[i], chunkCounts[i]) : 0u;
+        if (n == 0u || inputBuffersBytes[i] % n != 0u)
+            flags &= ~HAPGPU_ENCODE_FRAGMENT_INDEX;
+    }
     ctx = acquire_default_context();
     if (!ctx)
         return HapResult_Internal_Error;
     rc = hapb_encode(ctx, 1, count, (const void *const *)inputBuffers, inputBuffersBytes, textureFormats,
-                     compressors, chunkCounts, &out, &outputBufferBytes, &used, &result, env_encode_flags(), 0);
+                     compressors, chunkCounts, &out, &outputBufferBytes, &used, &result, flags, 0);
     hapgpu_rt_unlock(ctx->rt);
     if (rc == HapResult_No_Error)
         *outputBufferBytesUsed = used;

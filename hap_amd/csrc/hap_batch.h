@@ -14,7 +14,7 @@ struct HapGpuContext {
     unsigned frag_log2;
     unsigned byte_granular;   /* HAP_AMD_BYTE_GRANULAR=1: never emit 16-bit granular element streams */
     unsigned position_lanes;  /* HAP_AMD_POSITION_LANES: never use the field-per-lane compressor */
-    unsigned rgtc1_fields;    /* RGTC1 planes through the [4, 4] field kernel (default; HAP_AMD_RGTC1_POSITIONS=1: position lanes) */
+    unsigned rgtc1_fields;    /* layout of RGTC1 planes for the block compressor: 26 = [2, 6] (default), 44 = [4, 4], 0 = position lanes (HAP_AMD_RGTC1_LAYOUT) */
     unsigned no_block_scan;   /* HAP_AMD_NO_BLOCK_SCAN: whole-stream units stay whole (A/B runs) */
     unsigned no_half_tiles;   /* HAP_AMD_NO_HALF_TILES: fragment table version 1 even for field streams (A/B runs) */
     /* chunk marks collected from the client's HapDecodeCallback, handed to the retry of a frame whose fragment

@@ -274,3 +274,16 @@ def test_product_does_not_reference_the_oracle():
             if name.endswith((".c", ".h", ".hip", ".py", "Makefile", ".map")):
                 text = open(os.path.join(base, name), errors="ignore").read()
                 assert not forbidden.search(text), (base, name, forbidden.search(text).group(0))
+
+
+def test_only_the_public_surface_is_exported():
+    """nm -D of the product library: the six hap.h functions, the two link-compatibility symbols the reference object
+    also exposes, and the HapGpu* / HapSequence* additions -- not the internal launch ABI (hapgpu_rt_* / hapgpu_k_*)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "hap_amd", "libhap_amd.so")], check=True, capture_output=True, text=True).stdout
+    names = [line.split()[-1] for line in out.splitlines() if line.strip()]
+    stray = [n for n in names if not (n.startswith("HapGpu") or n.startswith("HapSequence") or n in (
+        "HapMaxEncodedLength", "HapEncode", "HapDecode", "HapGetFrameTextureCount", "HapGetFrameTextureFormat",
+        "HapGetFrameTextureChunkCount", "hap_get_section_at_index", "hap_decode_single_texture"))]
+    assert stray == [], stray
+    assert "HapEncode" in names and "HapGpuEncodeFrames" in names
