@@ -326,14 +326,58 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
                 }
             }
         }
-        rc |= (unsigned)hapgpu_rt_h2d(rt, dframes, hframes, sizeof(HapGpuFrameEnc) * live);
-        if (any_snappy)
-            rc |= (unsigned)hapgpu_k_snappy_compress(rt, dframes, live, max_frags_per_tex, frag_log2, dslots, slot_stride, dfragsizes,
-                                                     dtilesizes, gran_mask | (count << 8));   /* bits 8..: textures per frame */
-        rc |= (unsigned)hapgpu_k_frame_pack(rt, dframes, live, frag_log2, dslots, slot_stride, dfragsizes, dtilesizes, dcopies,
-                                            frags_per_frame * live, chunks_per_frame, max_chunks_per_tex, count, dpack);
-        rc |= (unsigned)hapgpu_k_frame_gather(rt, dcopies, (frags_per_frame + chunks_per_frame) * live);
-        rc |= (unsigned)hapgpu_rt_d2h(rt, hframes, dframes, sizeof(HapGpuFrameEnc) * live);
+        {
+            /* The launches of this call as one sequence.  With every buffer in device memory (nothing staged) nothing
+               in it depends on the buffers themselves -- their addresses are in the tables copied from pinned memory --
+               so the sequence is recorded once per geometry as a HIP graph and replayed with one launch. */
+            const HapbBlockEncodeJob *job = ctx->block_encode_job;
+            uint64_t key = 0xCBF29CE484222325ull;
+            int graph = 2;
+            unsigned launch_rc = 0;
+#define HAPB_MIX(v) (key = (key ^ (uint64_t)(v)) * 0x100000001B3ull)
+            if (stage_in_bytes == 0 && stage_out_bytes == 0 && inputs_are_device != 2 && !smaller && frag_log2 == 13u) {
+                HAPB_MIX(live); HAPB_MIX(count); HAPB_MIX(flags); HAPB_MIX(frag_log2); HAPB_MIX(ctx->byte_granular);
+                HAPB_MIX(ctx->position_lanes); HAPB_MIX(ctx->rgtc1_fields); HAPB_MIX(ctx->no_half_tiles);
+                for (i = 0; i < count; i++) {
+                    HAPB_MIX(g[i].format); HAPB_MIX(g[i].compressor); HAPB_MIX(g[i].chunk_count); HAPB_MIX(g[i].bytes);
+                }
+                if (job) {
+                    HAPB_MIX(job->frame_count); HAPB_MIX(job->width); HAPB_MIX(job->height); HAPB_MIX(job->row_bytes);
+                    HAPB_MIX(job->wide + 2);
+                }
+                graph = hapgpu_rt_graph_begin(rt, key);
+            }
+#undef HAPB_MIX
+            if (graph != 1) {
+                if (job) {
+                    launch_rc |= (unsigned)hapgpu_rt_h2d(rt, job->device_table, job->host_table,
+                                                         sizeof(uint64_t) * (size_t)(1u + job->count) * job->frame_count);
+                    /* Hap Q Alpha: both textures from one pass over the RGBA (64 + 16 + 8 bytes per block) */
+                    if (job->count == 2 && job->formats[0] == HapTextureFormat_YCoCg_DXT5 && job->formats[1] == HapTextureFormat_A_RGTC1)
+                        launch_rc |= (unsigned)hapgpu_k_block_encode_batch_ycocg_alpha(rt, job->device_table, job->device_table + job->frame_count,
+                                                                                     job->device_table + 2u * (size_t)job->frame_count,
+                                                                                     job->frame_count, job->width, job->height,
+                                                                                     job->row_bytes, job->wide);
+                    else
+                        for (i = 0; i < job->count; i++)
+                            launch_rc |= (unsigned)hapgpu_k_block_encode_batch(rt, job->device_table,
+                                                                             job->device_table + (size_t)(1u + i) * job->frame_count,
+                                                                             job->frame_count, job->width, job->height, job->row_bytes,
+                                                                             job->formats[i], job->wide);
+                }
+                launch_rc |= (unsigned)hapgpu_rt_h2d(rt, dframes, hframes, sizeof(HapGpuFrameEnc) * live);
+                if (any_snappy)
+                    launch_rc |= (unsigned)hapgpu_k_snappy_compress(rt, dframes, live, max_frags_per_tex, frag_log2, dslots, slot_stride,
+                                                                    dfragsizes, dtilesizes, gran_mask | (count << 8));   /* bits 8..: textures per frame */
+                launch_rc |= (unsigned)hapgpu_k_frame_pack(rt, dframes, live, frag_log2, dslots, slot_stride, dfragsizes, dtilesizes,
+                                                           dcopies, frags_per_frame * live, chunks_per_frame, max_chunks_per_tex, count, dpack);
+                launch_rc |= (unsigned)hapgpu_k_frame_gather(rt, dcopies, (frags_per_frame + chunks_per_frame) * live);
+                launch_rc |= (unsigned)hapgpu_rt_d2h(rt, hframes, dframes, sizeof(HapGpuFrameEnc) * live);
+                if (graph == 0)
+                    launch_rc |= (unsigned)hapgpu_rt_graph_end(rt, key, launch_rc != 0);
+            }
+            rc |= launch_rc;
+        }
         rc |= (unsigned)hapgpu_rt_sync(rt);
         if (rc) {
             for (k = 0; k < live; k++)
@@ -539,26 +583,26 @@ unsigned hapb_encode_rgba(HapGpuContext *ctx, unsigned frame_count, const void *
             tex_ptrs[(size_t)f * count + i] = t;
         }
     }
-    /* one launch per texture format over the whole batch (addresses travel as a small device table) */
-    if (hapgpu_rt_h2d(rt, dsrc, hsrc, sizeof(uint64_t) * (size_t)(1u + count) * frame_count) == 0) {
-        /* Hap Q Alpha: both textures from one pass over the RGBA (64 + 16 + 8 bytes per block) */
-        if (count == 2 && formats[0] == HapTextureFormat_YCoCg_DXT5 && formats[1] == HapTextureFormat_A_RGTC1) {
-            if (hapgpu_k_block_encode_batch_ycocg_alpha(rt, dsrc, dsrc + frame_count, dsrc + 2u * (size_t)frame_count, frame_count,
-                                                        width, height, row_bytes, wide) != 0)
-                for (f = 0; f < (unsigned)frame_count * count; f++)
-                    tex_ptrs[f] = NULL;
-        } else
+    /* the block encode (one launch per texture format over the whole batch, addresses in a small device table) is
+       issued by hapb_encode at the head of its own launches: one sequence per call */
+    {
+        HapbBlockEncodeJob job;
+        memset(&job, 0, sizeof(job));
+        job.host_table = hsrc;
+        job.device_table = dsrc;
+        job.frame_count = frame_count;
+        job.count = count;
+        job.width = width;
+        job.height = height;
+        job.row_bytes = row_bytes;
+        job.wide = wide;
         for (i = 0; i < count; i++)
-            if (hapgpu_k_block_encode_batch(rt, dsrc, dsrc + (size_t)(1u + i) * frame_count, frame_count, width, height,
-                                            row_bytes, formats[i], wide) != 0)
-                for (f = 0; f < frame_count; f++)
-                    tex_ptrs[(size_t)f * count + i] = NULL;
-    } else {
-        for (f = 0; f < (unsigned)frame_count * count; f++)
-            tex_ptrs[f] = NULL;
+            job.formats[i] = formats[i];
+        ctx->block_encode_job = &job;
+        rc = hapb_encode(ctx, frame_count, count, tex_ptrs, tex_bytes, formats, compressors, chunk_counts, outputs,
+                         output_bytes, output_used, results, flags, rgba_stage ? 2 : 1);
+        ctx->block_encode_job = NULL;
     }
-    rc = hapb_encode(ctx, frame_count, count, tex_ptrs, tex_bytes, formats, compressors, chunk_counts, outputs,
-                     output_bytes, output_used, results, flags, 1);
     free(tex_ptrs);
     return rc;
 }

@@ -22,7 +22,18 @@ struct HapGpuContext {
     unsigned long table_fallbacks;   /* frames decoded again without their fragment table (it did not match) */
     const unsigned char *preset_marks;
     unsigned preset_count;
+    /* block encode of a batch, handed from hapb_encode_rgba to hapb_encode so that the whole call is one launch
+       sequence (recorded and replayed as one HIP graph) */
+    const struct HapbBlockEncodeJob *block_encode_job;
 };
+
+typedef struct HapbBlockEncodeJob {
+    const uint64_t *host_table;    /* pinned: [sources][outputs of texture 0][of texture 1], frame_count each */
+    uint64_t *device_table;
+    unsigned frame_count, count, width, height, formats[2];
+    unsigned long row_bytes;
+    int wide;
+} HapbBlockEncodeJob;
 
 /* inputs_are_device != 0: every input pointer is known to be device memory (skips classification) */
 unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,

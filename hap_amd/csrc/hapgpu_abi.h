@@ -210,6 +210,11 @@ void hapgpu_rt_unlock(hapgpu_rt *rt);
 /* 0: the lock was free and is now held by the caller */
 int hapgpu_rt_trylock(hapgpu_rt *rt);
 int hapgpu_rt_device(hapgpu_rt *rt);
+/* Launch sequences recorded as HIP graphs (hapgpu_runtime.hip).  key: everything the sequence's kernel arguments and
+ * copy sizes depend on.  _begin: 1 = a recorded sequence was launched (skip the launches), 0 = recording (issue the
+ * launches, then _end), 2 = launch as usual.  _end(failed): 0 = instantiated, remembered and launched. */
+int hapgpu_rt_graph_begin(hapgpu_rt *rt, uint64_t key);
+int hapgpu_rt_graph_end(hapgpu_rt *rt, uint64_t key, int failed);
 
 /* kernels: all asynchronous on the runtime's stream; 0 = launched */
 int hapgpu_k_block_encode(hapgpu_rt *rt, const void *rgba, unsigned width, unsigned height,

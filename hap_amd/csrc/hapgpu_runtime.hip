@@ -45,6 +45,11 @@ struct timed_launch {
     int cls;
     hipEvent_t start, stop;
 };
+struct recorded_graph {
+    uint64_t key;
+    hipGraphExec_t exec;
+};
+constexpr size_t kMaxGraphs = 24;
 }
 
 struct hapgpu_rt {
@@ -59,6 +64,12 @@ struct hapgpu_rt {
     std::vector<timed_launch> pending;
     std::vector<hipEvent_t> free_events;
     hipEvent_t t0, t1;
+    // launch sequences recorded as HIP graphs, by the caller's key (geometry of the call) mixed with `generation`,
+    // which moves whenever a scratch arena is reallocated (a recorded graph holds the arenas' addresses)
+    std::vector<recorded_graph> graphs;
+    uint64_t generation;
+    int graphs_off;      // HAP_AMD_NO_GRAPHS
+    int recording;
 };
 
 #define HIP_OK(expr) ((expr) == hipSuccess)
@@ -94,6 +105,9 @@ extern "C" int hapgpu_rt_create(int device, hapgpu_rt **out)
     memset(rt->pin, 0, sizeof(rt->pin));
     memset(rt->pin_cap, 0, sizeof(rt->pin_cap));
     rt->profiling = 0;
+    rt->generation = 1;
+    rt->graphs_off = getenv("HAP_AMD_NO_GRAPHS") != NULL;
+    rt->recording = 0;
     pthread_mutex_init(&rt->lock, NULL);
     if ((e = hipStreamCreateWithFlags(&rt->stream, hipStreamNonBlocking)) != hipSuccess) {
         complain("hipStreamCreate", e);
@@ -124,6 +138,8 @@ extern "C" void hapgpu_rt_destroy(hapgpu_rt *rt)
     }
     for (auto &ev : rt->free_events)
         (void)hipEventDestroy(ev);
+    for (auto &g : rt->graphs)
+        (void)hipGraphExecDestroy(g.exec);
     (void)hipEventDestroy(rt->t0);
     (void)hipEventDestroy(rt->t1);
     (void)hipStreamDestroy(rt->stream);
@@ -170,6 +186,7 @@ extern "C" void *hapgpu_rt_device_scratch(hapgpu_rt *rt, int slot, size_t bytes)
     if (rt->dev_cap[slot] < bytes) {
         // contents are not preserved; wait for work that may still use the old block
         (void)hipStreamSynchronize(rt->stream);
+        rt->generation++;
         if (rt->dev[slot])
             (void)hipFree(rt->dev[slot]);
         rt->dev[slot] = NULL;
@@ -193,6 +210,7 @@ extern "C" void *hapgpu_rt_pinned_scratch(hapgpu_rt *rt, int slot, size_t bytes)
         bytes = 256;
     if (rt->pin_cap[slot] < bytes) {
         (void)hipStreamSynchronize(rt->stream);
+        rt->generation++;
         if (rt->pin[slot])
             (void)hipHostFree(rt->pin[slot]);
         rt->pin[slot] = NULL;
@@ -244,6 +262,74 @@ extern "C" int hapgpu_rt_sync(hapgpu_rt *rt)
 {
     hipError_t e = hipStreamSynchronize(rt->stream);
     if (e != hipSuccess) { complain("hipStreamSynchronize", e); return 4; }
+    return 0;
+}
+
+// ---- recorded launch sequences ---------------------------------------------------------------
+// A batched call issues the same copies and kernels with the same arguments whenever its geometry is the same: what
+// changes from call to call (buffer addresses, sizes, per-frame results) travels through descriptor tables in pinned
+// memory, not through kernel arguments.  Such a sequence is recorded once as a HIP graph (stream capture) and
+// replayed with one launch: the fixed host cost of a call is one graph launch instead of 5-9 kernel launches and
+// 2-3 copies.  Not used while per-kernel timing is on (bench.py's HIP events bracket individual launches).
+static uint64_t mix_key(uint64_t key, uint64_t generation)
+{
+    uint64_t h = key ^ (generation * 0x9E3779B97F4A7C15ull);
+    h ^= h >> 31;
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 29;
+    return h ? h : 1;
+}
+
+// 1: a recorded sequence was launched, the caller skips its launches; 0: recording started, the caller issues its
+// launches and then calls hapgpu_rt_graph_end; 2: no graph for this call, launch as usual (and do not call _end)
+extern "C" int hapgpu_rt_graph_begin(hapgpu_rt *rt, uint64_t key)
+{
+    if (rt->graphs_off || rt->profiling || rt->recording)
+        return 2;
+    const uint64_t k = mix_key(key, rt->generation);
+    for (auto &g : rt->graphs)
+        if (g.key == k)
+            return hipGraphLaunch(g.exec, rt->stream) == hipSuccess ? 1 : 2;
+    if (hipStreamBeginCapture(rt->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        return 2;
+    }
+    rt->recording = 1;
+    return 0;
+}
+
+// ends the recording; failed != 0: something in the sequence did not launch (the recording is dropped and nothing
+// runs).  0: the sequence was instantiated, remembered and launched
+extern "C" int hapgpu_rt_graph_end(hapgpu_rt *rt, uint64_t key, int failed)
+{
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (!rt->recording)
+        return 4;
+    rt->recording = 0;
+    if (hipStreamEndCapture(rt->stream, &graph) != hipSuccess || !graph) {
+        (void)hipGetLastError();
+        return 4;
+    }
+    if (failed) {
+        (void)hipGraphDestroy(graph);
+        return 4;
+    }
+    const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess || !exec) {
+        complain("hipGraphInstantiate", e);
+        return 4;
+    }
+    if (rt->graphs.size() >= kMaxGraphs) {
+        (void)hipGraphExecDestroy(rt->graphs.front().exec);
+        rt->graphs.erase(rt->graphs.begin());
+    }
+    rt->graphs.push_back({mix_key(key, rt->generation), exec});
+    if (hipGraphLaunch(exec, rt->stream) != hipSuccess) {
+        complain("hipGraphLaunch", hipGetLastError());
+        return 4;
+    }
     return 0;
 }
 
