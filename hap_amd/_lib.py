@@ -59,6 +59,7 @@ def _load():
         "HapSequenceReaderFrameBytes": (ul, [vp, u]),
         "HapSequenceReaderRead": (u, [vp, u, u, vp, ul, P(ul)]),
         "HapGpuDecodeSequence": (u, [vp, vp, u, u, u, u, P(vp), P(ul), P(ul), P(u), P(u)]),
+        "HapGpuEncodeSequence": (u, [vp, vp, u, P(vp), u, u, ul, u, P(u), P(u), P(u), u, u, P(ul), P(u)]),
         "HapGpuSetProfiling": (u, [vp, u]),
         "HapGpuCollectProfile": (u, [vp, P(ul), P(C.c_double)]),
         "HapGpuTimerStart": (u, [vp]),

@@ -363,6 +363,18 @@ class Context:
         r = lib.HapGpuDecodeSequence(self.handle, reader.handle, first, count, index, batch, optrs, olens, used, fmts, results)
         return r, list(used), list(fmts), list(results)
 
+    def encode_sequence(self, writer, rgba_frames, width, height, row_bytes, formats, compressors, chunk_counts,
+                        flags=0, batch=0):
+        """RGBA pictures -> GPU -> pinned double buffer -> file (HapGpuEncodeSequence). Returns (result, frame bytes[], results[])."""
+        nf, count = len(rgba_frames), len(formats)
+        ptrs, _infos = self._ptr_array(rgba_frames)
+        sizes = (C.c_ulong * nf)()
+        results = (C.c_uint * nf)()
+        r = lib.HapGpuEncodeSequence(self.handle, writer.handle, nf, ptrs, width, height, row_bytes, count,
+                                     (C.c_uint * count)(*formats), (C.c_uint * count)(*compressors),
+                                     (C.c_uint * count)(*chunk_counts), flags, batch, sizes, results)
+        return r, list(sizes), list(results)
+
     def set_profiling(self, on):
         return lib.HapGpuSetProfiling(self.handle, 1 if on else 0)
 

@@ -387,3 +387,130 @@ unsigned int HapGpuDecodeSequence(HapGpuContext *ctx, HapSequenceReader *r, unsi
     free(lens);
     return first_error;
 }
+
+/* ------------------------------------------------------- encode pipeline -- */
+typedef struct write_job {
+    HapSequenceWriter *writer;
+    unsigned count;
+    const uint8_t *base;
+    size_t stride;
+    const unsigned long *used;
+    unsigned result;
+} write_job;
+
+static void *write_main(void *arg)
+{
+    write_job *j = (write_job *)arg;
+    unsigned i;
+    j->result = HapResult_No_Error;
+    for (i = 0; i < j->count && j->result == HapResult_No_Error; i++)
+        j->result = HapSequenceWriterAppend(j->writer, j->base + j->stride * i, j->used[i]);
+    return NULL;
+}
+
+unsigned int HapGpuEncodeSequence(HapGpuContext *ctx, HapSequenceWriter *w, unsigned int count,
+                                  const void *const *rgba_frames, unsigned int width, unsigned int height,
+                                  unsigned long row_bytes, unsigned int texture_count, const unsigned int *formats,
+                                  const unsigned int *compressors, const unsigned int *chunk_counts,
+                                  unsigned int flags, unsigned int batch, unsigned long *frame_bytes,
+                                  unsigned int *results)
+{
+    unsigned first_error = HapResult_No_Error, done = 0, b, batches, i;
+    unsigned long lengths[2] = {0, 0}, cap;
+    size_t stride;
+    uint8_t *pinned[2] = {NULL, NULL};
+    void **outs = NULL;
+    unsigned long *caps = NULL, *used[2] = {NULL, NULL};
+    unsigned *res = NULL;
+    write_job job;
+    pthread_t thread;
+    int thread_live = 0;
+
+    if (!ctx || !w || !rgba_frames || count == 0 || texture_count == 0 || texture_count > 2 || !formats || !compressors ||
+        !chunk_counts || width == 0 || height == 0 || (width & 3u) || (height & 3u))
+        return HapResult_Bad_Arguments;
+    for (i = 0; i < texture_count; i++) {
+        const unsigned long block = (formats[i] == HapTextureFormat_RGB_DXT1 || formats[i] == HapTextureFormat_A_RGTC1) ? 8ul : 16ul;
+        lengths[i] = (unsigned long)(width / 4u) * (height / 4u) * block;
+    }
+    cap = HapMaxEncodedLength(texture_count, lengths, (unsigned int *)formats, (unsigned int *)chunk_counts);
+    if (cap == 0)
+        return HapResult_Bad_Arguments;
+    if (batch == 0)
+        batch = 16;
+    if (batch > count)
+        batch = count;
+    batches = (count + batch - 1u) / batch;
+    stride = ((size_t)cap + 255u) & ~(size_t)255u;
+    outs = (void **)malloc(sizeof(void *) * batch);
+    caps = (unsigned long *)malloc(sizeof(unsigned long) * batch);
+    used[0] = (unsigned long *)calloc(batch, sizeof(unsigned long));
+    used[1] = (unsigned long *)calloc(batch, sizeof(unsigned long));
+    res = (unsigned *)malloc(sizeof(unsigned) * batch);
+    if (!outs || !caps || !used[0] || !used[1] || !res) {
+        free(outs); free(caps); free(used[0]); free(used[1]); free(res);
+        return HapResult_Internal_Error;
+    }
+    /* (the context stays locked for the whole call: the two frame buffers are its scratch, see HapGpuDecodeSequence) */
+    hapgpu_rt_lock(ctx->rt);
+    pinned[0] = (uint8_t *)hapgpu_rt_pinned_scratch(ctx->rt, P_SEQ0, stride * batch);
+    pinned[1] = batches > 1 ? (uint8_t *)hapgpu_rt_pinned_scratch(ctx->rt, P_SEQ1, stride * batch) : pinned[0];
+    if (!pinned[0] || !pinned[1]) {
+        hapgpu_rt_unlock(ctx->rt);
+        free(outs); free(caps); free(used[0]); free(used[1]); free(res);
+        return HapResult_Internal_Error;
+    }
+    memset(&job, 0, sizeof(job));
+    for (i = 0; results && i < count; i++)
+        results[i] = HapResult_Internal_Error;          /* (what a frame keeps when the call ends before its batch) */
+    for (i = 0; frame_bytes && i < count; i++)
+        frame_bytes[i] = 0ul;
+    for (b = 0; b < batches && first_error == HapResult_No_Error; b++) {
+        const unsigned n = (count - b * batch) < batch ? (count - b * batch) : batch;
+        uint8_t *base = pinned[b & 1u];
+        unsigned rc;
+        for (i = 0; i < n; i++) {
+            outs[i] = base + stride * i;
+            caps[i] = cap;
+        }
+        /* (the helper may still be writing batch b - 1 from the OTHER buffer: the GPU fills this one meanwhile) */
+        rc = hapb_encode_rgba(ctx, n, rgba_frames + done, width, height, row_bytes, texture_count, formats, compressors,
+                              chunk_counts, outs, caps, used[b & 1u], res, flags);
+        if (thread_live) {
+            pthread_join(thread, NULL);
+            thread_live = 0;
+            if (job.result != HapResult_No_Error)
+                first_error = job.result;
+        }
+        for (i = 0; i < n; i++) {
+            if (results)
+                results[done + i] = res[i];
+            if (frame_bytes)
+                frame_bytes[done + i] = res[i] == HapResult_No_Error ? used[b & 1u][i] : 0ul;
+            if (res[i] != HapResult_No_Error && rc == HapResult_No_Error)
+                rc = res[i];
+        }
+        if (rc != HapResult_No_Error && first_error == HapResult_No_Error)
+            first_error = rc;
+        if (first_error != HapResult_No_Error)
+            break;
+        job.writer = w; job.count = n; job.base = base; job.stride = stride; job.used = used[b & 1u];
+        job.result = HapResult_Internal_Error;
+        if (b + 1u < batches && pthread_create(&thread, NULL, write_main, &job) == 0) {
+            thread_live = 1;
+        } else {
+            write_main(&job);
+            if (job.result != HapResult_No_Error)
+                first_error = job.result;
+        }
+        done += n;
+    }
+    if (thread_live) {
+        pthread_join(thread, NULL);
+        if (job.result != HapResult_No_Error && first_error == HapResult_No_Error)
+            first_error = job.result;
+    }
+    hapgpu_rt_unlock(ctx->rt);
+    free(outs); free(caps); free(used[0]); free(used[1]); free(res);
+    return first_error;
+}

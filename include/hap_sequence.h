@@ -70,6 +70,20 @@ unsigned int HapGpuDecodeSequence(HapGpuContext *context, HapSequenceReader *rea
                                   unsigned long *outputBuffersBytesUsed, unsigned int *outputTextureFormats,
                                   unsigned int *results);
 
+/* --- GPU -> disk pipeline ---
+ * Encodes `count` RGBA pictures (host or device memory, as for HapGpuEncodeFramesRGBA: same geometry, formats,
+ * compressors and chunk counts for all) and appends the frames to the writer's file, `batch` pictures per GPU
+ * submission (0: 16).  The GPU writes each batch's frames into one of two pinned host buffers; while it encodes the
+ * next batch into the other, a helper thread appends the finished one to the file: block encode, Snappy stage, PCIe
+ * download and storage overlap.  Per-frame results as for HapGpuEncodeFramesRGBA (NULL allowed); frames that fail
+ * are not written and end the call.  frameBytes (NULL allowed): the size of every written frame. */
+unsigned int HapGpuEncodeSequence(HapGpuContext *context, HapSequenceWriter *writer, unsigned int count,
+                                  const void *const *rgbaFrames, unsigned int width, unsigned int height,
+                                  unsigned long rowBytes, unsigned int textureCount, const unsigned int *textureFormats,
+                                  const unsigned int *compressors, const unsigned int *chunkCounts,
+                                  unsigned int flags, unsigned int batch, unsigned long *frameBytes,
+                                  unsigned int *results);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1621,3 +1621,48 @@ def test_plain_hap_h_encode_takes_the_fast_path_by_default(ctx, hap):
     assert ctx.decode_frames([frame], [len(frame)], 0, [dec])[3] == [0] and dec.tobytes() == tex
     assert ctx.table_fallbacks() == n0
     assert before is None or hap.Context.default_table_fallbacks() == before
+
+
+@pytest.mark.parametrize("batch", [0, 1, 4])
+@pytest.mark.parametrize("where", ["device", "host"])
+def test_encode_sequence_to_file_matches_frame_by_frame(ctx, hap, tmp_path, batch, where):
+    """hap_sequence.h, the other direction: RGBA pictures through the double-buffered GPU -> pinned memory -> file
+    pipeline give a sequence file whose frames are byte for byte what HapGpuEncodeFramesRGBA writes one call at a time,
+    decode (checker and GPU pipeline) to the oracle's textures, and a failure ends the call without a torn file."""
+    w, h, n = 256, 128, 10
+    fmts, chunks = [L.FMT_YCOCG, L.FMT_RGTC1], [4, 2]
+    imgs = [D.rgba(w, h, frame=20 + i) for i in range(n)]
+    src = [torch.from_numpy(im).cuda() for im in imgs] if where == "device" else imgs
+    if where == "device":
+        torch.cuda.synchronize()
+    sizes = [(w // 4) * (h // 4) * D.BLOCK_BYTES[f] for f in fmts]
+    cap = hap.HapMaxEncodedLength(sizes, fmts, chunks)
+    want = []
+    for im in src:
+        out = np.zeros(cap, dtype=np.uint8)
+        r, used, res = ctx.encode_frames_rgba([im], w, h, w * 4, fmts, [1, 1], chunks, [out], flags=hap.ENCODE_FRAGMENT_INDEX)
+        assert r == 0 and res == [0]
+        want.append(out[: used[0]].tobytes())
+    path = str(tmp_path / "enc.hapseq")
+    with hap.SequenceWriter(path, w, h) as writer:
+        r, nbytes, res = ctx.encode_sequence(writer, src, w, h, w * 4, fmts, [1, 1], chunks,
+                                             flags=hap.ENCODE_FRAGMENT_INDEX, batch=batch)
+        assert (r, res) == (0, [0] * n) and nbytes == [len(f) for f in want]
+    reader = hap.SequenceReader(path)
+    assert reader.frame_count == n and reader.read(0, n) == (0, want)
+    for t, fmt in enumerate(fmts):
+        texs = [D.oracle_bc_encode(im, fmt) for im in imgs]
+        assert ORA.decode(want[3], t, sizes[t]) == (0, texs[3], fmt)
+        outs = [np.zeros(sizes[t], dtype=np.uint8) for _ in range(n)]
+        r, used, dfmts, dres = ctx.decode_sequence(reader, 0, n, t, outs, batch=3)
+        assert (r, dres, dfmts) == (0, [0] * n, [fmt] * n) and [o.tobytes() for o in outs] == texs
+    reader.close()
+    # a picture that cannot be encoded (no buffer) ends the call: earlier batches are in the file, nothing after
+    path2 = str(tmp_path / "short.hapseq")
+    with hap.SequenceWriter(path2, w, h) as writer:
+        broken = list(src[:6]) + [None] + list(src[7:])
+        r, nbytes, res = ctx.encode_sequence(writer, broken, w, h, w * 4, fmts, [1, 1], chunks, batch=2)
+        assert r == hap.HapResult.Bad_Arguments and res[:6] == [0] * 6 and res[6] == hap.HapResult.Bad_Arguments
+    reader = hap.SequenceReader(path2)
+    assert reader.frame_count == 6
+    reader.close()
