@@ -20,6 +20,22 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     (void)output_used; (void)output_formats; (void)results; (void)flags; (void)callback; (void)callback_info;
     abort();
 }
+unsigned hapb_encode_rgba(HapGpuContext *ctx, unsigned frame_count, const void *const *rgba_frames,
+                          unsigned width, unsigned height, unsigned long row_bytes, unsigned count,
+                          const unsigned *formats, const unsigned *compressors, const unsigned *chunk_counts,
+                          void *const *outputs, const unsigned long *output_bytes,
+                          unsigned long *output_used, unsigned *results, unsigned flags)
+{
+    (void)ctx; (void)frame_count; (void)rgba_frames; (void)width; (void)height; (void)row_bytes; (void)count;
+    (void)formats; (void)compressors; (void)chunk_counts; (void)outputs; (void)output_bytes; (void)output_used;
+    (void)results; (void)flags;
+    abort();
+}
+unsigned long HapMaxEncodedLength(unsigned int count, unsigned long *lengths, unsigned int *formats, unsigned int *chunks)
+{
+    (void)count; (void)lengths; (void)formats; (void)chunks;
+    abort();
+}
 void hapgpu_rt_lock(hapgpu_rt *rt) { (void)rt; abort(); }
 void hapgpu_rt_unlock(hapgpu_rt *rt) { (void)rt; abort(); }
 void *hapgpu_rt_pinned_scratch(hapgpu_rt *rt, int slot, size_t bytes) { (void)rt; (void)slot; (void)bytes; abort(); }
