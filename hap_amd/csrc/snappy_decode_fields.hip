@@ -115,15 +115,38 @@ __device__ __forceinline__ void fail_unit(HapGpuDecodeJob *job, unsigned lane)
         atomicCAS(&job->status, 0u, HAPGPU_STATUS_INDEX_MISMATCH);
 }
 
+// Everything in memory is reached through global-address-space pointers: the addresses come out of the unit as
+// integers, and a pointer of unknown address space would be accessed with FLAT instructions -- 64-bit address
+// arithmetic per access, and waits that count against the LDS counter as well.
+typedef const uint8_t __attribute__((address_space(1))) *gin_t;
+typedef uint8_t __attribute__((address_space(1))) *gout_t;
+struct alignas(16) quad16 { uint32_t a, b, c, d; };
+struct alignas(8) pair8 { uint32_t a, b; };
+__device__ __forceinline__ uint4 gload16(gin_t p)
+{
+    const quad16 __attribute__((address_space(1))) *q = reinterpret_cast<const quad16 __attribute__((address_space(1))) *>(p);
+    return make_uint4(q->a, q->b, q->c, q->d);
+}
+__device__ __forceinline__ void gstore16(gout_t p, const uint4 v)
+{
+    quad16 __attribute__((address_space(1))) *q = reinterpret_cast<quad16 __attribute__((address_space(1))) *>(p);
+    q->a = v.x; q->b = v.y; q->c = v.z; q->d = v.w;
+}
+__device__ __forceinline__ void gstore8(gout_t p, const uint2 v)
+{
+    pair8 __attribute__((address_space(1))) *q = reinterpret_cast<pair8 __attribute__((address_space(1))) *>(p);
+    q->a = v.x; q->b = v.y;
+}
+
 // 16 bytes of the unit's input at aligned coordinate x (coordinates are relative to src - shift); bytes outside
 // [shift, in_end) read as zero and are never touched in memory
 // (bytes below `shift` belong to the same frame -- its headers precede every chunk -- and are fetched with the piece;
 // `readable_end` = in_end + the bytes known to follow the fragment inside the texture section)
-__device__ __forceinline__ uint4 load_input16(const uint8_t *src_al, unsigned x, unsigned shift, unsigned in_end, unsigned readable_end)
+__device__ __forceinline__ uint4 load_input16(gin_t src_al, unsigned x, unsigned shift, unsigned in_end, unsigned readable_end)
 {
     uint4 v = make_uint4(0, 0, 0, 0);
     if (x < in_end && x + 16u <= readable_end) {
-        v = *reinterpret_cast<const uint4 *>(src_al + x);
+        v = gload16(src_al + x);
     } else if (x < in_end) {
         unsigned w[4] = {0, 0, 0, 0};
 #pragma unroll 1
@@ -160,9 +183,9 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
     if (u.kind != layout_of<LAYOUT>::unit_kind)
         return;
     HapGpuDecodeJob *job = &jobs[u.job];
-    const uint8_t *src = (const uint8_t *)u.src;
-    uint8_t *dst = (uint8_t *)u.dst;
-    const uint8_t *tile_sizes = (const uint8_t *)u.aux;
+    const gin_t src = (gin_t)u.src;
+    const gout_t dst = (gout_t)u.dst;
+    const gin_t tile_sizes = (gin_t)u.aux;
     const unsigned total = u.src_len, out_len = u.dst_len;
     if (out_len == 0u || out_len > kFragBytes || (out_len % kBlock) != 0u || total > kMaxFragCompressed || !tile_sizes) {
         fail_unit(job, lane);
@@ -173,7 +196,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
     // everything the unit needs from memory is requested at once: the job's status word, the half-tile table and
     // the first 4 KiB of input (what comes later is fetched by the loop below)
     const unsigned shift = (unsigned)((uintptr_t)src & 15u);
-    const uint8_t *src_al = src - shift;
+    const gin_t src_al = src - shift;
     const unsigned in_end = shift + total;
     const unsigned readable_end = in_end + (unsigned)(u.reserved & 15u);
     const unsigned job_status = __builtin_nontemporal_load(&job->status);
@@ -210,7 +233,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
     }
     // records below the parked input when they fit, else in the unit's own output range (2-byte aligned) in memory
     const bool rec_in_lds = rbytes <= S - shift;
-    uint8_t *const rec_mem = (uint8_t *)(((uintptr_t)dst + 1u) & ~(uintptr_t)1u);
+    const gout_t rec_mem = (gout_t)(((uintptr_t)dst + 1u) & ~(uintptr_t)1u);
     {
         // (every lane stores only granules that hold input: the last 1 KiB row of stores would otherwise run up to
         // 1008 bytes past S + total, beyond the buffer for fragments that begin with well-compressed half-tiles)
@@ -249,7 +272,8 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
         unsigned min_off = 0xFFFFFu, max_up = 0;           // smallest copy offset, largest literal length code
         // (two typed pointers and a uniform branch at the store: one pointer chosen between LDS and memory would make
         // every record a flat store)
-        uint8_t *const rec_lds = buf + 2u * rbase, *const rec_glb = rec_mem + 2u * rbase;
+        uint8_t *const rec_lds = buf + 2u * rbase;
+        const gout_t rec_glb = rec_mem + 2u * rbase;
         const unsigned reccap = 2u * nrec;                 // (a stream with more elements than that has left its bytes)
         // (every element advances p by at least one byte, so the walk is bounded; elements that start off a field
         // boundary -- the only way to have more than 32 of them -- are caught below, and the record index is masked)
@@ -281,7 +305,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
                     if (rec_in_lds)
                         *reinterpret_cast<uint16_t *>(rec_lds + recp) = record;
                     else
-                        *reinterpret_cast<uint16_t *>(rec_glb + recp) = record;
+                        *reinterpret_cast<uint16_t __attribute__((address_space(1))) *>(rec_glb + recp) = record;
                 }
                 recp += 2u;
                 const unsigned long long bit = 1ull << (p >> kPosShift);
@@ -366,7 +390,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
             lds_wait();
         } else {
             // (the wave's own stores, read back past the CU's L1, which may hold these lines as they were before)
-            const int16_t *rb = reinterpret_cast<const int16_t *>(rec_mem);
+            const int16_t __attribute__((address_space(1))) *rb = reinterpret_cast<const int16_t __attribute__((address_space(1))) *>(rec_mem);
 #pragma unroll
             for (unsigned s = 0; s < kMaxSteps; s++) {
                 const unsigned msel = upper ? my[s] : mx[s];
@@ -470,7 +494,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
                 const uint4 v = make_uint4(out[0], out[1], out[2 % (kBlock / 4u)], out[3 % (kBlock / 4u)]);
                 *reinterpret_cast<uint4 *>(buf + opos) = v;
                 if (dst_wide) {
-                    *reinterpret_cast<uint4 *>(dst + opos) = v;
+                    gstore16(dst + opos, v);
                 } else {
 #pragma unroll 1
                     for (unsigned k = 0; k < 16u; k++)
@@ -480,7 +504,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
                 const uint2 v = make_uint2(out[0], out[1]);
                 *reinterpret_cast<uint2 *>(buf + opos) = v;
                 if (dst_wide) {
-                    *reinterpret_cast<uint2 *>(dst + opos) = v;
+                    gstore8(dst + opos, v);
                 } else {
 #pragma unroll 1
                     for (unsigned k = 0; k < 8u; k++)
