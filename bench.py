@@ -42,6 +42,7 @@ CONFIGS = {
     "C5": (16384, 16384, [0x01, 0x8DBB], [64, 64], 4),
 }
 BLOCK_BYTES = {0x83F0: 8, 0x8DBB: 8, 0x83F3: 16, 0x01: 16}
+ROUND_TAG = "r03"        # profiles/<round>_traffic_<cfg>.json is what roofline.traffic quotes
 
 
 def parse_args():
@@ -667,7 +668,7 @@ def measured_traffic(config, kernel, frames):
     profiles/).  Counters cannot be read from inside the timed process, so the bench line carries the profile's
     figure scaled to the frames per launch of this run, and names its source.  (None, None) when the round has no
     profile for the config."""
-    name = "r02_traffic_%s.json" % config.lower()
+    name = "%s_traffic_%s.json" % (ROUND_TAG, config.lower())
     path = os.path.join(ROOT, "profiles", name)
     try:
         with open(path) as f:
