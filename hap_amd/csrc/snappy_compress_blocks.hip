@@ -269,6 +269,7 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
                 ok &= lane == 0u ? 0x000Cu : lane == 1u ? 0x0CFFu : 0xFFFFu;
         }
         unsigned P = ~differ & ok;
+        const unsigned eq_fixed = P;
         // table candidates of the index fields
         unsigned slot[2], klo[2], khi[2], valid[2];
         unsigned long long e[2];
@@ -294,8 +295,10 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
             const bool hit = (miss == 0u) & (dist * B <= window);
             hd2[i] = hit ? dist : 0u;
             P |= hit ? (dist * B >= 2048u ? 0x220000u : 0x020000u) << (2u * i) : 0u;
-            // (units beyond the data insert a zero, which changes nothing)
-            atomicMax(&table[slot[i]], ((unsigned long long)((khi[i] | (blk << 18)) & valid[i]) << 32) | (klo[i] & valid[i]));
+            // (units beyond the data insert a zero, which changes nothing; so do fields that repeat the same field one block
+            // back: the first block of a run stays the candidate, and the lanes of a flat area do not queue up on one entry)
+            const unsigned enter = valid[i] & ~(0u - ((eq_fixed >> (2u * i + 1u)) & 1u));
+            atomicMax(&table[slot[i]], ((unsigned long long)((khi[i] | (blk << 18)) & enter) << 32) | (klo[i] & enter));
         }
         HD[s] = hd2[0] | (hd2[1] << 16);
         // nibbles of 8 lanes -> one 32-bit mask per kind: lane j of the group ends up with kind j of its half-tile

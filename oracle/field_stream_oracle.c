@@ -16,7 +16,8 @@
  *   a. field i matches at distance d (1..4 blocks) when its bytes equal the same field d blocks back;
  *      a 2-byte field only counts together with the field behind it;
  *   b. index fields (6-byte / 4-byte index words) look up the most recent earlier block with the same value in a
- *      direct-mapped table that is updated after every 64 units ("step"), most recent block wins;
+ *      direct-mapped table that is updated after every 64 units ("step") with the fields that differ from the same
+ *      field one block back, most recent block wins;
  *   c. per half-tile: copies are chosen left to right -- at the first uncovered matching position the NEAREST
  *      matching distance starts a copy that runs to the end of its match ("sticky"), the next one starts where it
  *      ends; copies are cut at field 16 (64 bytes); fields no distance covers are single-field copies from their
@@ -99,7 +100,9 @@ unsigned ofs_compress_fragment(const uint8_t *src, unsigned n, unsigned layout, 
                             if (!window_bytes || dist * L->block <= window_bytes)
                                 hd[4u * u + k] = (uint16_t)dist;
                         }
-                    } else {
+                    } else if (!eq[0][4u * u + k]) {
+                        /* (a field that repeats the one a block earlier is not entered again: the run's first block
+                           stays the candidate, and flat areas do not hammer one table entry) */
                         const uint64_t e = (blk << 50) | key;
                         if (e > table[slot])
                             table[slot] = e;
