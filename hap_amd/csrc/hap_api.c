@@ -83,6 +83,7 @@ HapGpuContext *HapGpuDefaultContext(void)
  * outer call is still waiting for it.  A context serves one call at a time, so the hap.h entry points take
  * whichever default context is free and add one (same device, own stream and scratch) when all are busy. */
 #define HAP_DEFAULT_POOL 8
+#define HAP_BATCH_SLICE 32768u      /* frames per launch sequence: grid dimensions y / z hold at most 65535 */
 static HapGpuContext *g_pool[HAP_DEFAULT_POOL];
 static unsigned g_pool_count;
 static pthread_mutex_t g_pool_lock = PTHREAD_MUTEX_INITIALIZER;
@@ -402,12 +403,25 @@ unsigned int HapGpuEncodeFrames(HapGpuContext *context, unsigned int frameCount,
                                 const unsigned long *outputBuffersBytes, unsigned long *outputBuffersBytesUsed,
                                 unsigned int *results, unsigned int flags)
 {
-    unsigned r;
+    unsigned r = HapResult_No_Error, done;
     if (!context)
         return HapResult_Bad_Arguments;
     hapgpu_rt_lock(context->rt);
-    r = hapb_encode(context, frameCount, count, inputBuffers, inputBuffersBytes, textureFormats, compressors,
-                    chunkCounts, outputBuffers, outputBuffersBytes, outputBuffersBytesUsed, results, flags, 0);
+    /* (the kernels index frames with a grid dimension that holds 65535: larger batches go in slices) */
+    if (frameCount <= HAP_BATCH_SLICE || !inputBuffers || !outputBuffers || !outputBuffersBytes || !outputBuffersBytesUsed || !results ||
+        count == 0 || count > 2) {
+        r = hapb_encode(context, frameCount, count, inputBuffers, inputBuffersBytes, textureFormats, compressors,
+                        chunkCounts, outputBuffers, outputBuffersBytes, outputBuffersBytesUsed, results, flags, 0);
+    } else {
+        for (done = 0; done < frameCount; done += HAP_BATCH_SLICE) {
+            const unsigned n = frameCount - done < HAP_BATCH_SLICE ? frameCount - done : HAP_BATCH_SLICE;
+            const unsigned rc = hapb_encode(context, n, count, inputBuffers + (size_t)done * count, inputBuffersBytes, textureFormats,
+                                            compressors, chunkCounts, outputBuffers + done, outputBuffersBytes + done,
+                                            outputBuffersBytesUsed + done, results + done, flags, 0);
+            if (r == HapResult_No_Error)
+                r = rc;
+        }
+    }
     hapgpu_rt_unlock(context->rt);
     return r;
 }
@@ -421,13 +435,24 @@ unsigned int HapGpuEncodeFramesRGBA(HapGpuContext *context, unsigned int frameCo
                                     unsigned long *outputBuffersBytesUsed, unsigned int *results,
                                     unsigned int flags)
 {
-    unsigned r;
+    unsigned r = HapResult_No_Error, done;
     if (!context)
         return HapResult_Bad_Arguments;
     hapgpu_rt_lock(context->rt);
-    r = hapb_encode_rgba(context, frameCount, rgbaFrames, width, height, rowBytes, count, textureFormats,
-                         compressors, chunkCounts, outputBuffers, outputBuffersBytes, outputBuffersBytesUsed,
-                         results, flags);
+    if (frameCount <= HAP_BATCH_SLICE || !rgbaFrames || !outputBuffers || !outputBuffersBytes || !outputBuffersBytesUsed || !results) {
+        r = hapb_encode_rgba(context, frameCount, rgbaFrames, width, height, rowBytes, count, textureFormats,
+                             compressors, chunkCounts, outputBuffers, outputBuffersBytes, outputBuffersBytesUsed,
+                             results, flags);
+    } else {
+        for (done = 0; done < frameCount; done += HAP_BATCH_SLICE) {
+            const unsigned n = frameCount - done < HAP_BATCH_SLICE ? frameCount - done : HAP_BATCH_SLICE;
+            const unsigned rc = hapb_encode_rgba(context, n, rgbaFrames + done, width, height, rowBytes, count, textureFormats,
+                                                 compressors, chunkCounts, outputBuffers + done, outputBuffersBytes + done,
+                                                 outputBuffersBytesUsed + done, results + done, flags);
+            if (r == HapResult_No_Error)
+                r = rc;
+        }
+    }
     hapgpu_rt_unlock(context->rt);
     return r;
 }
@@ -438,12 +463,23 @@ unsigned int HapGpuDecodeFrames(HapGpuContext *context, unsigned int frameCount,
                                 const unsigned long *outputBuffersBytes, unsigned long *outputBuffersBytesUsed,
                                 unsigned int *outputTextureFormats, unsigned int *results, unsigned int flags)
 {
-    unsigned r;
+    unsigned r = HapResult_No_Error, done;
     if (!context)
         return HapResult_Bad_Arguments;
     hapgpu_rt_lock(context->rt);
-    r = hapb_decode(context, frameCount, inputBuffers, inputBuffersBytes, index, outputBuffers,
-                    outputBuffersBytes, outputBuffersBytesUsed, outputTextureFormats, results, flags, NULL, NULL);
+    if (frameCount <= HAP_BATCH_SLICE || !inputBuffers || !inputBuffersBytes || !outputBuffers || !outputBuffersBytes || !results) {
+        r = hapb_decode(context, frameCount, inputBuffers, inputBuffersBytes, index, outputBuffers,
+                        outputBuffersBytes, outputBuffersBytesUsed, outputTextureFormats, results, flags, NULL, NULL);
+    } else {
+        for (done = 0; done < frameCount; done += HAP_BATCH_SLICE) {
+            const unsigned n = frameCount - done < HAP_BATCH_SLICE ? frameCount - done : HAP_BATCH_SLICE;
+            const unsigned rc = hapb_decode(context, n, inputBuffers + done, inputBuffersBytes + done, index, outputBuffers + done,
+                                            outputBuffersBytes + done, outputBuffersBytesUsed ? outputBuffersBytesUsed + done : NULL,
+                                            outputTextureFormats ? outputTextureFormats + done : NULL, results + done, flags, NULL, NULL);
+            if (r == HapResult_No_Error)
+                r = rc;
+        }
+    }
     hapgpu_rt_unlock(context->rt);
     return r;
 }

@@ -504,8 +504,15 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
         if (split) {
             const uint32_t *bpos = (const uint32_t *)scan->bpos;
             const unsigned from = bpos[u.reserved], to = bpos[u.reserved + 1u];
+            // (the block positions live in scratch the scan fills: whatever it left there, a block never reaches
+            // outside its stream -- the frame is decoded again without the scan instead)
+            if (from > to || to > bpos[scan->expected]) {          // (the last word is the stream's end, written with `ok`)
+                if (lane == 0)
+                    atomicCAS(&jobs[u.job].status, 0u, HAPGPU_STATUS_INDEX_MISMATCH);
+                return;
+            }
             src += from;
-            src_len = to >= from ? to - from : 0u;
+            src_len = to - from;
         }
     }
     constexpr bool kFlushEarly = STREAM || SLIDE;
