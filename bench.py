@@ -504,20 +504,24 @@ def c5_chunk_groups(hap_amd, ctx, dist, dev, rank, world, fence, reps=3):
     fence(); t0 = time.perf_counter()
     parts = shard.gather_variable(piece, root=0)
     fence(); t["gather_band_frames_ms"] = (time.perf_counter() - t0) * 1e3
-    t0 = time.perf_counter()
-    frame = None
+    # join on the device: the band frames arrived over xGMI and stay in HBM (tables through the host, payloads D2D)
+    fence(); t0 = time.perf_counter()
+    joined_bytes = 0
+    dframe = None
     if parts is not None:
-        r, frame = hap_amd.HapGpuJoinChunkGroups([p.cpu().numpy() for p in parts])
+        dframe = torch.empty(sum(int(p.numel()) for p in parts) + 64, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        r, joined_bytes = ctx.join_chunk_groups(parts, [int(p.numel()) for p in parts], dframe)
         if r != 0:
             raise RuntimeError("join failed %r" % r)
-    t["join_on_host_ms"] = (time.perf_counter() - t0) * 1e3
-    n = torch.tensor([len(frame) if frame is not None else 0], dtype=torch.int64, device=dev)
+        dframe = dframe[:joined_bytes]
+    fence(); t["join_on_device_ms"] = (time.perf_counter() - t0) * 1e3
+    n = torch.tensor([joined_bytes], dtype=torch.int64, device=dev)
     dist.broadcast(n, src=0)
-    dframe = torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
-    if rank == 0:
-        dframe.copy_(torch.frombuffer(bytearray(frame), dtype=torch.uint8))
+    if dframe is None:
+        dframe = torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
     dist.broadcast(dframe, src=0)
-    frame = dframe.cpu().numpy()
+    frame = dframe
     ok = True
     for idx in (0, 1):
         r, layout = hap_amd.HapGpuGetFrameTextureChunkLayout(frame, idx)
@@ -555,7 +559,7 @@ def c5_chunk_groups(hap_amd, ctx, dist, dev, rank, world, fence, reps=3):
     rgba_gb = w * h * 4 / 1e9
     enc = t["encode_bands_ms"]
     dec = t["decode_groups_tex0_ms"] + t["decode_groups_tex1_ms"]
-    enc_g = enc + t["gather_band_frames_ms"] + t["join_on_host_ms"]
+    enc_g = enc + t["gather_band_frames_ms"] + t["join_on_device_ms"]
     dec_g = dec + t["gather_slices_tex0_ms"] + t["gather_slices_tex1_ms"]
     return {"workload": "one 16384x16384 Hap Q Alpha frame, 64+64 chunks, split by chunk groups over %d GPUs" % world,
             "bit_exact": bool(flag.item()), "frame_bytes": int(n.item()),

@@ -50,6 +50,7 @@ def _load():
         "HapGpuDecodeChunkGroup": (u, [vp, vp, ul, u, u, u, vp, ul, P(ul), P(u)]),
         "HapGpuGetFrameTextureChunkLayout": (u, [vp, ul, u, u, P(ul), P(u)]),
         "HapGpuJoinChunkGroups": (u, [u, P(vp), P(ul), vp, ul, P(ul)]),
+        "HapGpuJoinChunkGroupsDevice": (u, [vp, u, P(vp), P(ul), vp, ul, P(ul)]),
         "HapSequenceWriterOpen": (u, [C.c_char_p, u, u, u, u, P(vp)]),
         "HapSequenceWriterAppend": (u, [vp, vp, ul]),
         "HapSequenceWriterClose": (u, [vp]),

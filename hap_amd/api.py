@@ -363,6 +363,15 @@ class Context:
         r = lib.HapGpuDecodeSequence(self.handle, reader.handle, first, count, index, batch, optrs, olens, used, fmts, results)
         return r, list(used), list(fmts), list(results)
 
+    def join_chunk_groups(self, group_frames, group_bytes, output):
+        """HapGpuJoinChunkGroupsDevice: group frames and output in device memory. Returns (result, used)."""
+        n = len(group_frames)
+        ptrs, _infos = self._ptr_array(group_frames)
+        oaddr, olen, _keep = _addr_len(output)
+        used = C.c_ulong(0)
+        r = lib.HapGpuJoinChunkGroupsDevice(self.handle, n, ptrs, (C.c_ulong * max(1, n))(*group_bytes), oaddr, olen, C.byref(used))
+        return r, used.value
+
     def encode_sequence(self, writer, rgba_frames, width, height, row_bytes, formats, compressors, chunk_counts,
                         flags=0, batch=0):
         """RGBA pictures -> GPU -> pinned double buffer -> file (HapGpuEncodeSequence). Returns (result, frame bytes[], results[])."""

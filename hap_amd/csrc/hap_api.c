@@ -484,6 +484,21 @@ unsigned int HapGpuDecodeFrames(HapGpuContext *context, unsigned int frameCount,
     return r;
 }
 
+unsigned int HapGpuJoinChunkGroupsDevice(HapGpuContext *context, unsigned int groupCount,
+                                         const void *const *groupFrames, const unsigned long *groupFramesBytes,
+                                         void *outputBuffer, unsigned long outputBufferBytes,
+                                         unsigned long *outputBufferBytesUsed)
+{
+    unsigned r;
+    if (!context)
+        return HapResult_Bad_Arguments;
+    hapgpu_rt_lock(context->rt);
+    r = hapb_join_device(context, groupCount, groupFrames, groupFramesBytes, outputBuffer, outputBufferBytes,
+                         outputBufferBytesUsed);
+    hapgpu_rt_unlock(context->rt);
+    return r;
+}
+
 /* callback that "runs" one contiguous group of chunks (hap.h:113-130 lets a client run any subset) */
 typedef struct chunk_group {
     unsigned first, count;

@@ -1161,3 +1161,165 @@ fail_alloc:
     free(in_dev); free(out_dev); free(client_marks);
     return HapResult_Internal_Error;
 }
+
+/* ============================================================= join on the device */
+/* Sink of hapj_join for frames in device memory: header bytes are collected on the host and uploaded in one copy, the
+   groups' tables and payloads become device-to-device moves of the gather kernel (pieces of at most 64 KiB, one
+   wavefront each).  Two launches: what the host made first, then the moves (table contents land on top of the zeros
+   of their header region). */
+#define JOIN_PIECE 65536u
+typedef struct move_list {
+    HapGpuCopyEntry *e;
+    size_t count, cap;
+} move_list;
+
+typedef struct device_sink {
+    uint8_t *bytes;               /* host-made bytes, 16-byte aligned pieces */
+    size_t bytes_used, bytes_cap;
+    move_list puts, moves;        /* puts: src = offset into `bytes` until the upload address is known */
+    const void *const *frames;
+    uint8_t *out;
+} device_sink;
+
+static int move_append(move_list *l, uint64_t src, uint64_t dst, size_t len)
+{
+    while (len) {
+        const size_t n = len < JOIN_PIECE ? len : JOIN_PIECE;
+        if (l->count == l->cap) {
+            const size_t cap = l->cap ? 2u * l->cap : 256u;
+            HapGpuCopyEntry *e = (HapGpuCopyEntry *)realloc(l->e, cap * sizeof(*e));
+            if (!e)
+                return 1;
+            l->e = e;
+            l->cap = cap;
+        }
+        l->e[l->count].src = src;
+        l->e[l->count].dst = dst;
+        l->e[l->count].len = (uint32_t)n;
+        l->e[l->count].reserved = 0;
+        l->count++;
+        src += n; dst += n; len -= n;
+    }
+    return 0;
+}
+
+static int device_put(void *user, uint64_t dst_off, const void *src, size_t len)
+{
+    device_sink *d = (device_sink *)user;
+    const size_t padded = (len + 15u) & ~(size_t)15u;
+    if (len == 0)
+        return 0;
+    if (d->bytes_used + padded > d->bytes_cap) {
+        const size_t cap = 2u * (d->bytes_used + padded) + 4096u;
+        uint8_t *b = (uint8_t *)realloc(d->bytes, cap);
+        if (!b)
+            return 1;
+        d->bytes = b;
+        d->bytes_cap = cap;
+    }
+    memcpy(d->bytes + d->bytes_used, src, len);
+    memset(d->bytes + d->bytes_used + len, 0, padded - len);
+    if (move_append(&d->puts, (uint64_t)d->bytes_used, (uint64_t)(uintptr_t)(d->out + dst_off), len))
+        return 1;
+    d->bytes_used += padded;
+    return 0;
+}
+
+static int device_move(void *user, unsigned group, uint64_t src_off, uint64_t dst_off, size_t len)
+{
+    device_sink *d = (device_sink *)user;
+    return move_append(&d->moves, (uint64_t)(uintptr_t)((const uint8_t *)d->frames[group] + src_off),
+                       (uint64_t)(uintptr_t)(d->out + dst_off), len);
+}
+
+unsigned hapb_join_device(HapGpuContext *ctx, unsigned group_count, const void *const *frames,
+                          const unsigned long *frame_bytes, void *output, unsigned long output_bytes,
+                          unsigned long *output_used)
+{
+    hapgpu_rt *rt = ctx->rt;
+    hapf_reader *readers;
+    fetch_ctx *fetchers;
+    uint8_t *prefix, *dprefix;
+    uint64_t *hptr, *dptr;
+    device_sink ds;
+    hapj_sink sink;
+    unsigned g, result, rc = 0;
+
+    if (group_count == 0 || !frames || !frame_bytes || !output || !output_used)
+        return HapResult_Bad_Arguments;
+    for (g = 0; g < group_count; g++)
+        if (!frames[g] || frame_bytes[g] > 0xFFFFFFFFul || !is_dev(ctx, frames[g]))
+            return HapResult_Bad_Arguments;
+    if (!is_dev(ctx, output))
+        return HapResult_Bad_Arguments;
+    readers = (hapf_reader *)calloc(group_count, sizeof(*readers));
+    fetchers = (fetch_ctx *)calloc(group_count, sizeof(*fetchers));
+    hptr = (uint64_t *)hapgpu_rt_pinned_scratch(rt, P_PTRS, sizeof(uint64_t) * 2u * group_count);
+    dptr = (uint64_t *)hapgpu_rt_device_scratch(rt, D_PTRS, sizeof(uint64_t) * 2u * group_count);
+    dprefix = (uint8_t *)hapgpu_rt_device_scratch(rt, D_PREFIX, (size_t)PREFIX_BYTES * group_count);
+    prefix = (uint8_t *)hapgpu_rt_pinned_scratch(rt, P_PREFIX, (size_t)PREFIX_BYTES * group_count);
+    if (!readers || !fetchers || !hptr || !dptr || !dprefix || !prefix) {
+        free(readers); free(fetchers);
+        return HapResult_Internal_Error;
+    }
+    /* the groups' headers come to the host (one gather + one copy); what the planner needs beyond the prefix -- the
+       tables of frames with many chunks -- it fetches on demand */
+    for (g = 0; g < group_count; g++) {
+        hptr[g] = (uint64_t)(uintptr_t)frames[g];
+        hptr[group_count + g] = frame_bytes[g];
+    }
+    rc |= (unsigned)hapgpu_rt_h2d(rt, dptr, hptr, sizeof(uint64_t) * 2u * group_count);
+    rc |= (unsigned)hapgpu_k_gather_prefixes(rt, dptr, dptr + group_count, group_count, PREFIX_BYTES, dprefix);
+    rc |= (unsigned)hapgpu_rt_d2h(rt, prefix, dprefix, (size_t)PREFIX_BYTES * group_count);
+    rc |= (unsigned)hapgpu_rt_sync(rt);
+    if (rc) {
+        free(readers); free(fetchers);
+        return HapResult_Internal_Error;
+    }
+    for (g = 0; g < group_count; g++) {
+        const size_t n = frame_bytes[g] < PREFIX_BYTES ? frame_bytes[g] : PREFIX_BYTES;
+        hapf_reader_init_host(&readers[g], prefix + (size_t)PREFIX_BYTES * g, n);
+        fetchers[g].ctx = ctx;
+        fetchers[g].device_frame = (const uint8_t *)frames[g];
+        readers[g].fetch = fetch_from_device;
+        readers[g].user = &fetchers[g];
+        readers[g].total_len = frame_bytes[g];
+    }
+    memset(&ds, 0, sizeof(ds));
+    ds.frames = frames;
+    ds.out = (uint8_t *)output;
+    sink.user = &ds;
+    sink.put = device_put;
+    sink.move = device_move;
+    result = hapj_join(group_count, readers, frame_bytes, &sink, output_bytes, output_used);
+    if (result == HapResult_No_Error) {
+        const size_t entries = ds.puts.count + ds.moves.count;
+        uint8_t *dbytes = (uint8_t *)hapgpu_rt_device_scratch(rt, D_JOBS, ds.bytes_used + 16u);
+        HapGpuCopyEntry *dmoves = (HapGpuCopyEntry *)hapgpu_rt_device_scratch(rt, D_COPIES, sizeof(HapGpuCopyEntry) * (entries + 1u));
+        size_t i;
+        if (!dbytes || !dmoves) {
+            result = HapResult_Internal_Error;
+        } else {
+            for (i = 0; i < ds.puts.count; i++)
+                ds.puts.e[i].src += (uint64_t)(uintptr_t)dbytes;
+            if (ds.bytes_used)
+                rc |= (unsigned)hapgpu_rt_h2d(rt, dbytes, ds.bytes, ds.bytes_used);
+            if (ds.puts.count)
+                rc |= (unsigned)hapgpu_rt_h2d(rt, dmoves, ds.puts.e, sizeof(HapGpuCopyEntry) * ds.puts.count);
+            if (ds.moves.count)
+                rc |= (unsigned)hapgpu_rt_h2d(rt, dmoves + ds.puts.count, ds.moves.e, sizeof(HapGpuCopyEntry) * ds.moves.count);
+            if (ds.puts.count)
+                rc |= (unsigned)hapgpu_k_frame_gather(rt, dmoves, (unsigned)ds.puts.count);
+            if (ds.moves.count)
+                rc |= (unsigned)hapgpu_k_frame_gather(rt, dmoves + ds.puts.count, (unsigned)ds.moves.count);
+            rc |= (unsigned)hapgpu_rt_sync(rt);     /* (the lists live in pageable memory: nothing may still read them) */
+            if (rc)
+                result = HapResult_Internal_Error;
+        }
+    }
+    free(ds.bytes); free(ds.puts.e); free(ds.moves.e);
+    for (g = 0; g < group_count; g++)
+        hapf_reader_free(&readers[g]);
+    free(readers); free(fetchers);
+    return result;
+}

@@ -60,4 +60,20 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                      unsigned *output_formats, unsigned *results, unsigned flags,
                      HapDecodeCallback callback, void *callback_info);
 
+/* groups and output in device memory: tables through the host, payloads device to device */
+unsigned hapb_join_device(HapGpuContext *ctx, unsigned group_count, const void *const *frames,
+                          const unsigned long *frame_bytes, void *output, unsigned long output_bytes,
+                          unsigned long *output_used);
+
+/* hap_join.c: the join proper, reading the groups' headers through `readers` (host views, or device frames with a
+ * fetch callback) and writing through a sink: `put` = bytes made here to output offset, `move` = bytes of group g's
+ * frame to output offset.  Non-zero from a sink callback ends the join with Internal_Error. */
+typedef struct hapj_sink {
+    void *user;
+    int (*put)(void *user, uint64_t dst_off, const void *src, size_t len);
+    int (*move)(void *user, unsigned group, uint64_t src_off, uint64_t dst_off, size_t len);
+} hapj_sink;
+unsigned hapj_join(unsigned groupCount, hapf_reader *readers, const unsigned long *groupFramesBytes,
+                   const hapj_sink *sink, unsigned long outputBufferBytes, unsigned long *outputBufferBytesUsed);
+
 #endif

@@ -2,8 +2,11 @@
  * hap_join.c -- joins frames that each carry one contiguous group of a
  * texture's chunks into one Hap frame (one huge frame split
  * over GPUs by chunk groups; every GPU encodes its band of block rows as a
- * frame of its own, the root joins them).  Host-only scalar work on the
- * tables; payload bytes are copied once.
+ * frame of its own, the root joins them).  Scalar work on the tables; payload
+ * bytes move once, through a sink: memcpy for frames in host memory
+ * (HapGpuJoinChunkGroups), device-to-device moves for frames in HBM
+ * (HapGpuJoinChunkGroupsDevice in hap_batch.c: the band frames of a node's
+ * GPUs arrive over xGMI and never touch host memory).
  *
  * The joined frame is an ordinary Hap frame (layout as written by reference
  * hap.c:430-442 for one texture, hap.c:562-598 for two): its chunk list is
@@ -23,7 +26,8 @@ typedef struct joined_texture {
     unsigned chunk_count;
     int all_raw;
     int keep_index;           /* every group brought a compatible fragment table */
-    unsigned frag_log2, frag_gran_log2, frag_window256, frags_per_chunk;
+    int keep_tiles;           /* ... of version 2 with the same block layout: the half-tile sizes are carried over */
+    unsigned frag_log2, frag_gran_log2, frag_window256, frags_per_chunk, frag_fields;
     uint64_t payload;         /* stored bytes of all chunks */
     uint64_t body;            /* section length, header excluded */
     unsigned header_len;
@@ -33,36 +37,24 @@ static uint64_t instructions_bytes(const joined_texture *t)
 {
     uint64_t n = hapf_instructions_length(t->chunk_count);
     if (t->keep_index)
-        n += 8u + 4u * (uint64_t)t->chunk_count * t->frags_per_chunk;
+        n += 8u + (t->keep_tiles ? 4u + HAP_HALF_TILES_PER_FRAGMENT : 4u) * (uint64_t)t->chunk_count * t->frags_per_chunk;
     return n;
 }
 
-unsigned int HapGpuJoinChunkGroups(unsigned int groupCount, const void *const *groupFrames,
-                                   const unsigned long *groupFramesBytes, void *outputBuffer,
-                                   unsigned long outputBufferBytes, unsigned long *outputBufferBytesUsed)
+unsigned hapj_join(unsigned groupCount, hapf_reader *readers, const unsigned long *groupFramesBytes,
+                   const hapj_sink *sink, unsigned long outputBufferBytes, unsigned long *outputBufferBytesUsed)
 {
-    hapf_reader *readers = NULL;
     hapf_texture_plan *plans = NULL;   /* [texture][group] */
     joined_texture tex[2];
     unsigned count = 0, g, t, result = HapResult_No_Error;
-    uint64_t total = 0, outer_header = 0;
-    uint8_t *out = (uint8_t *)outputBuffer, *cursor;
+    uint64_t total = 0, outer_header = 0, cursor;
+    uint8_t *hdr = NULL;
 
-    if (groupCount == 0 || !groupFrames || !groupFramesBytes || !outputBuffer || !outputBufferBytesUsed)
-        return HapResult_Bad_Arguments;
-    for (g = 0; g < groupCount; g++)
-        if (!groupFrames[g] || groupFramesBytes[g] > 0xFFFFFFFFul)
-            return HapResult_Bad_Arguments;
-
-    readers = (hapf_reader *)calloc(groupCount, sizeof(*readers));
     plans = (hapf_texture_plan *)calloc((size_t)groupCount * 2u, sizeof(*plans));
-    if (!readers || !plans) {
-        free(readers); free(plans);
+    if (!plans)
         return HapResult_Internal_Error;
-    }
     for (g = 0; g < groupCount; g++) {
         unsigned n = 0, r;
-        hapf_reader_init_host(&readers[g], groupFrames[g], groupFramesBytes[g]);
         r = hapf_texture_count(&readers[g], groupFramesBytes[g], &n);
         if (r != HapResult_No_Error || n == 0 || n > 2 || (g && n != count)) {
             result = r != HapResult_No_Error ? r : HapResult_Bad_Frame;
@@ -76,6 +68,7 @@ unsigned int HapGpuJoinChunkGroups(unsigned int groupCount, const void *const *g
         joined_texture *j = &tex[t];
         j->all_raw = 1;
         j->keep_index = 1;
+        j->keep_tiles = 1;
         for (g = 0; g < groupCount; g++) {
             hapf_texture_plan *p = &plans[t * groupCount + g];
             unsigned nibble;
@@ -119,9 +112,12 @@ unsigned int HapGpuJoinChunkGroups(unsigned int groupCount, const void *const *g
                     j->frag_log2 = p->frag_log2;
                     j->frag_gran_log2 = p->frag_gran_log2;
                     j->frag_window256 = p->frag_window256;
+                    j->frag_fields = p->frag_fields;
                 } else if (per_chunk != j->frags_per_chunk || p->frag_log2 != j->frag_log2) {
                     j->keep_index = 0;
                 }
+                if (!p->frag_tiles_offset || !p->frag_fields || p->frag_fields != j->frag_fields)
+                    j->keep_tiles = 0;
                 if (p->frag_gran_log2 < j->frag_gran_log2)
                     j->frag_gran_log2 = p->frag_gran_log2;   /* the weakest promise holds for all */
                 if (p->frag_window256 == 0 || j->frag_window256 == 0)
@@ -132,6 +128,8 @@ unsigned int HapGpuJoinChunkGroups(unsigned int groupCount, const void *const *g
         }
         if (j->frags_per_chunk == 0)
             j->keep_index = 0;
+        if (!j->keep_index)
+            j->keep_tiles = 0;
         if (j->all_raw) {
             j->body = j->payload;
         } else {
@@ -161,82 +159,163 @@ unsigned int HapGpuJoinChunkGroups(unsigned int groupCount, const void *const *g
         goto done;
     }
 
-    cursor = out + outer_header;
-    for (t = 0; t < count; t++) {
+    /* per texture: the header region (section headers, codec and size tables, fragment-table header) is built here
+       and put first; the groups' table contents and payloads are then moved on top of / behind it */
+    cursor = outer_header;
+    for (t = 0; t < count && result == HapResult_No_Error; t++) {
         const joined_texture *j = &tex[t];
-        uint8_t *sec = cursor, *ctab = NULL, *stab = NULL, *ftab = NULL, *payload;
+        uint64_t payload, ftab = 0, ttab = 0;
         unsigned chunk = 0;
+        size_t hdr_len;
+        uint8_t *ctab = NULL, *stab = NULL;
+        int bad = 0;
         if (j->all_raw) {
-            hapf_write_section(sec, j->header_len, (uint32_t)j->body, (HAP_NIBBLE_NONE << 4) | j->format_nibble);
-            payload = sec + j->header_len;
+            hdr_len = j->header_len;
+            hdr = (uint8_t *)calloc(1, hdr_len);
+            if (!hdr) { result = HapResult_Internal_Error; break; }
+            hapf_write_section(hdr, j->header_len, (uint32_t)j->body, (HAP_NIBBLE_NONE << 4) | j->format_nibble);
+            payload = cursor + j->header_len;
         } else {
             const uint32_t ilen = (uint32_t)instructions_bytes(j);
             const unsigned n = j->chunk_count;
-            hapf_write_section(sec, j->header_len, (uint32_t)j->body, (HAP_NIBBLE_COMPLEX << 4) | j->format_nibble);
-            hapf_write_section(sec + j->header_len, 4u, ilen, HAP_SECTION_INSTRUCTIONS);       /* hap.c:436 */
-            hapf_write_section(sec + j->header_len + 4u, 4u, n, HAP_SECTION_COMPRESSORS);      /* hap.c:438 */
-            ctab = sec + j->header_len + 8u;
+            hdr_len = (size_t)j->header_len + 4u + ilen;
+            hdr = (uint8_t *)calloc(1, hdr_len);
+            if (!hdr) { result = HapResult_Internal_Error; break; }
+            hapf_write_section(hdr, j->header_len, (uint32_t)j->body, (HAP_NIBBLE_COMPLEX << 4) | j->format_nibble);
+            hapf_write_section(hdr + j->header_len, 4u, ilen, HAP_SECTION_INSTRUCTIONS);       /* hap.c:436 */
+            hapf_write_section(hdr + j->header_len + 4u, 4u, n, HAP_SECTION_COMPRESSORS);      /* hap.c:438 */
+            ctab = hdr + j->header_len + 8u;
             hapf_write_section(ctab + n, 4u, 4u * n, HAP_SECTION_SIZES);                       /* hap.c:440 */
             stab = ctab + n + 4u;
             if (j->keep_index) {
                 uint8_t *isec = stab + 4u * (size_t)n;
-                hapf_write_section(isec, 4u, 4u + 4u * n * j->frags_per_chunk, HAP_SECTION_FRAGMENTS);
-                isec[4] = (uint8_t)HAP_FRAGMENT_TABLE_VERSION;
+                const uint32_t entries = n * j->frags_per_chunk;
+                hapf_write_section(isec, 4u, 4u + (j->keep_tiles ? 4u + HAP_HALF_TILES_PER_FRAGMENT : 4u) * entries, HAP_SECTION_FRAGMENTS);
+                isec[4] = (uint8_t)(j->keep_tiles ? HAP_FRAGMENT_TABLE_VERSION_FIELDS : HAP_FRAGMENT_TABLE_VERSION);
                 isec[5] = (uint8_t)j->frag_log2;
-                isec[6] = (uint8_t)j->frag_gran_log2;
+                isec[6] = (uint8_t)(j->frag_gran_log2 | (j->keep_tiles ? j->frag_fields << 4 : 0u));
                 isec[7] = (uint8_t)j->frag_window256;
-                ftab = isec + 8u;
+                ftab = cursor + (uint64_t)(isec + 8u - hdr);
+                ttab = ftab + 4u * (uint64_t)entries;
             }
-            payload = sec + j->header_len + 4u + ilen;
+            payload = cursor + j->header_len + 4u + ilen;
         }
-        for (g = 0; g < groupCount; g++) {
+        /* chunk tables first (host bytes), then the moves */
+        for (g = 0; g < groupCount && !j->all_raw; g++) {
             const hapf_texture_plan *p = &plans[t * groupCount + g];
-            const uint8_t *frame = (const uint8_t *)groupFrames[g];
             int c;
             if (p->mode != HAPGPU_JOB_COMPLEX) {
-                memcpy(payload, frame + p->section_offset, p->section_length);
-                if (!j->all_raw) {
-                    ctab[chunk] = p->mode == HAPGPU_JOB_RAW ? (uint8_t)HAP_NIBBLE_NONE : (uint8_t)HAP_NIBBLE_SNAPPY;
-                    stab[4u * chunk + 0] = (uint8_t)(p->section_length);
-                    stab[4u * chunk + 1] = (uint8_t)(p->section_length >> 8);
-                    stab[4u * chunk + 2] = (uint8_t)(p->section_length >> 16);
-                    stab[4u * chunk + 3] = (uint8_t)(p->section_length >> 24);
-                }
-                payload += p->section_length;
+                ctab[chunk] = p->mode == HAPGPU_JOB_RAW ? (uint8_t)HAP_NIBBLE_NONE : (uint8_t)HAP_NIBBLE_SNAPPY;
+                stab[4u * chunk + 0] = (uint8_t)(p->section_length);
+                stab[4u * chunk + 1] = (uint8_t)(p->section_length >> 8);
+                stab[4u * chunk + 2] = (uint8_t)(p->section_length >> 16);
+                stab[4u * chunk + 3] = (uint8_t)(p->section_length >> 24);
                 chunk++;
                 continue;
             }
             for (c = 0; c < p->chunk_count; c++) {
                 const uint32_t len = p->chunks[c].src_len;
-                memcpy(payload, frame + p->payload_offset + p->chunks[c].src_off, len);
-                payload += len;
-                if (!j->all_raw) {
-                    ctab[chunk] = (uint8_t)(p->chunks[c].codec & 0xFFu);
-                    stab[4u * chunk + 0] = (uint8_t)(len);
-                    stab[4u * chunk + 1] = (uint8_t)(len >> 8);
-                    stab[4u * chunk + 2] = (uint8_t)(len >> 16);
-                    stab[4u * chunk + 3] = (uint8_t)(len >> 24);
-                }
+                ctab[chunk] = (uint8_t)(p->chunks[c].codec & 0xFFu);
+                stab[4u * chunk + 0] = (uint8_t)(len);
+                stab[4u * chunk + 1] = (uint8_t)(len >> 8);
+                stab[4u * chunk + 2] = (uint8_t)(len >> 16);
+                stab[4u * chunk + 3] = (uint8_t)(len >> 24);
                 chunk++;
             }
+        }
+        bad |= sink->put(sink->user, cursor, hdr, hdr_len);
+        free(hdr);
+        hdr = NULL;
+        for (g = 0; g < groupCount && !bad; g++) {
+            const hapf_texture_plan *p = &plans[t * groupCount + g];
+            int c;
+            if (p->mode != HAPGPU_JOB_COMPLEX) {
+                bad |= sink->move(sink->user, g, p->section_offset, payload, p->section_length);
+                payload += p->section_length;
+                continue;
+            }
+            /* (the chunks of a group lie back to back in its frame: one move for all of them when they do) */
+            for (c = 0; c < p->chunk_count && !bad; c++) {
+                const uint32_t len = p->chunks[c].src_len;
+                bad |= sink->move(sink->user, g, p->payload_offset + p->chunks[c].src_off, payload, len);
+                payload += len;
+            }
             if (ftab) {
-                memcpy(ftab, frame + p->frag_table_offset, 4u * (size_t)p->frag_entries);
-                ftab += 4u * (size_t)p->frag_entries;
+                bad |= sink->move(sink->user, g, p->frag_table_offset, ftab, 4u * (size_t)p->frag_entries);
+                ftab += 4u * (uint64_t)p->frag_entries;
+                if (j->keep_tiles) {
+                    bad |= sink->move(sink->user, g, p->frag_tiles_offset, ttab, (size_t)HAP_HALF_TILES_PER_FRAGMENT * p->frag_entries);
+                    ttab += (uint64_t)HAP_HALF_TILES_PER_FRAGMENT * p->frag_entries;
+                }
             }
         }
+        if (bad)
+            result = HapResult_Internal_Error;
         cursor += j->header_len + j->body;
     }
-    if (outer_header)
-        hapf_write_section(out, (unsigned)outer_header, (uint32_t)total, HAP_SECTION_MULTI);   /* hap.c:598 */
-    *outputBufferBytesUsed = (unsigned long)(outer_header + total);
+    if (outer_header && result == HapResult_No_Error) {
+        uint8_t top[8];
+        hapf_write_section(top, (unsigned)outer_header, (uint32_t)total, HAP_SECTION_MULTI);   /* hap.c:598 */
+        if (sink->put(sink->user, 0, top, (size_t)outer_header))
+            result = HapResult_Internal_Error;
+    }
+    if (result == HapResult_No_Error)
+        *outputBufferBytesUsed = (unsigned long)(outer_header + total);
 
 done:
-    for (g = 0; g < groupCount; g++) {
+    for (g = 0; g < groupCount; g++)
         for (t = 0; t < 2; t++)
             hapf_plan_free(&plans[t * groupCount + g]);
-        hapf_reader_free(&readers[g]);
-    }
-    free(readers);
     free(plans);
+    free(hdr);
+    return result;
+}
+
+/* ---- frames in host memory ---- */
+typedef struct host_sink {
+    uint8_t *out;
+    const void *const *frames;
+} host_sink;
+
+static int host_put(void *user, uint64_t dst_off, const void *src, size_t len)
+{
+    memcpy(((host_sink *)user)->out + dst_off, src, len);
+    return 0;
+}
+
+static int host_move(void *user, unsigned group, uint64_t src_off, uint64_t dst_off, size_t len)
+{
+    host_sink *h = (host_sink *)user;
+    memcpy(h->out + dst_off, (const uint8_t *)h->frames[group] + src_off, len);
+    return 0;
+}
+
+unsigned int HapGpuJoinChunkGroups(unsigned int groupCount, const void *const *groupFrames,
+                                   const unsigned long *groupFramesBytes, void *outputBuffer,
+                                   unsigned long outputBufferBytes, unsigned long *outputBufferBytesUsed)
+{
+    hapf_reader *readers;
+    host_sink hs;
+    hapj_sink sink;
+    unsigned g, result;
+    if (groupCount == 0 || !groupFrames || !groupFramesBytes || !outputBuffer || !outputBufferBytesUsed)
+        return HapResult_Bad_Arguments;
+    for (g = 0; g < groupCount; g++)
+        if (!groupFrames[g] || groupFramesBytes[g] > 0xFFFFFFFFul)
+            return HapResult_Bad_Arguments;
+    readers = (hapf_reader *)calloc(groupCount, sizeof(*readers));
+    if (!readers)
+        return HapResult_Internal_Error;
+    for (g = 0; g < groupCount; g++)
+        hapf_reader_init_host(&readers[g], groupFrames[g], groupFramesBytes[g]);
+    hs.out = (uint8_t *)outputBuffer;
+    hs.frames = groupFrames;
+    sink.user = &hs;
+    sink.put = host_put;
+    sink.move = host_move;
+    result = hapj_join(groupCount, readers, groupFramesBytes, &sink, outputBufferBytes, outputBufferBytesUsed);
+    for (g = 0; g < groupCount; g++)
+        hapf_reader_free(&readers[g]);
+    free(readers);
     return result;
 }

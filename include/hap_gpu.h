@@ -204,6 +204,17 @@ unsigned int HapGpuJoinChunkGroups(unsigned int groupCount,
                                    void *outputBuffer, unsigned long outputBufferBytes,
                                    unsigned long *outputBufferBytesUsed);
 
+/* The same join for group frames AND output in HIP device memory of `context`'s device (band frames that arrived
+ * over xGMI): the groups' headers and tables are read through the host, the joined frame's headers are made there and
+ * uploaded, every table and payload byte moves device to device.  Version-2 fragment tables (half-tile sizes) are
+ * carried over by both joins when every group has one with the same block layout, so a joined frame decodes through
+ * the block-per-lane kernel like its parts.  Bad_Arguments for host pointers. */
+unsigned int HapGpuJoinChunkGroupsDevice(HapGpuContext *context, unsigned int groupCount,
+                                         const void *const *groupFrames,
+                                         const unsigned long *groupFramesBytes,
+                                         void *outputBuffer, unsigned long outputBufferBytes,
+                                         unsigned long *outputBufferBytesUsed);
+
 /* --- measurement hooks (used by bench.py; see DESIGN.md "Measurement") --- */
 
 /* Kernel classes whose launches are bracketed with HIP events on the

@@ -941,6 +941,21 @@ def test_row_bands_encoded_separately_join_into_the_whole_frame(ctx, hap, format
             r, used, fmts, res = ctx.decode_frames([joined], [len(joined)], idx, [dec], flags=flags)
             assert (r, used, fmts, res) == (0, [len(want)], [fmt], [0]) and dec.tobytes() == want
     assert b"\x46" in joined[:4096]      # the private fragment-size section survived the join
+    # the join on the device (band frames and output in HBM: what arrives over xGMI never touches the host) writes the
+    # same bytes; and the half-tile tables are carried over, so the joined frame takes the block-per-lane decoder
+    dparts = [torch.from_numpy(np.frombuffer(f, dtype=np.uint8).copy()).cuda() for f in frames]
+    dout = torch.full((sum(len(f) for f in frames) + 64,), 0x5A, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    r, used = ctx.join_chunk_groups(dparts, [len(f) for f in frames], dout)
+    assert (r, used) == (0, len(joined)) and dout[:used].cpu().numpy().tobytes() == joined
+    assert dout[used:].cpu().tolist() == [0x5A] * (dout.numel() - used)
+    assert ctx.join_chunk_groups([frames[0]] + dparts[1:], [len(f) for f in frames], dout)[0] == hap.HapResult.Bad_Arguments
+    if all(f in (L.FMT_DXT1, L.FMT_DXT5, L.FMT_YCOCG) for f in formats):
+        at, ver, _hdr = find_fragment_table(joined, 0, 4000)
+        assert at > 0 and ver == 2
+        n0 = ctx.table_fallbacks()
+        dec = np.zeros(len(D.oracle_bc_encode(img, formats[0])), dtype=np.uint8)
+        assert ctx.decode_frames([joined], [len(joined)], 0, [dec])[3] == [0] and ctx.table_fallbacks() == n0
 
 
 @pytest.mark.parametrize("fmt", [L.FMT_DXT5, L.FMT_YCOCG, L.FMT_RGTC1, L.FMT_BC7])
