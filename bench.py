@@ -111,6 +111,8 @@ class Stream:
         self.frames = hap_amd.BufferList([torch.empty(self.cap, dtype=torch.uint8, device=dev) for _ in frame_ids])
         self.dec = [hap_amd.BufferList([torch.empty(tb, dtype=torch.uint8, device=dev) for _ in frame_ids])
                     for tb in self.tex_bytes]
+        # entry f * T + t = texture t of frame f: the order HapGpuDecodeFrameTextures takes
+        self.dec_all = hap_amd.BufferList([self.dec[t][f] for f in range(self.nf) for t in range(len(self.fmts))])
         self.used = None
         torch.cuda.synchronize()
 
@@ -122,10 +124,16 @@ class Stream:
         return used
 
     def decode(self, used):
-        for idx in range(len(self.fmts)):
-            r, dused, _dfmts, dres = self.ctx.decode_frames(self.frames, used, idx, self.dec[idx])
-            if r != 0 or dused[0] != self.tex_bytes[idx]:
+        if len(self.fmts) > 1:
+            # every texture of every frame in one batch (HapGpuDecodeFrameTextures)
+            nt = len(self.fmts)
+            r, dused, _dfmts, dres = self.ctx.decode_frame_textures(self.frames, used, nt, self.dec_all)
+            if r != 0 or dused[:nt] != [self.tex_bytes[t] for t in range(nt)]:
                 raise RuntimeError("decode failed: %r %r" % (r, dres[:4]))
+            return
+        r, dused, _dfmts, dres = self.ctx.decode_frames(self.frames, used, 0, self.dec[0])
+        if r != 0 or dused[0] != self.tex_bytes[0]:
+            raise RuntimeError("decode failed: %r %r" % (r, dres[:4]))
 
     def step(self):
         if self.nf == 0:

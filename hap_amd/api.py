@@ -353,6 +353,23 @@ class Context:
         r = lib.HapGpuDecodeFrames(self.handle, nf, ptrs, lens, index, optrs, olens, used, fmts, results, flags)
         return r, list(used), list(fmts), list(results)
 
+    def decode_frame_textures(self, frames, frame_bytes, texture_count, outputs, flags=0):
+        """All textures of every frame in one batch (HapGpuDecodeFrameTextures).  outputs[f * texture_count + t].
+        Returns (result, used[], formats[], results[]), one entry per frame and texture."""
+        nf = len(frames)
+        n = nf * texture_count
+        if len(outputs) != n:
+            raise ValueError("outputs must hold frames x textures buffers")
+        ptrs, infos = self._ptr_array(frames)
+        lens = (C.c_ulong * nf)(*[fb if fb is not None else infos[i][1] for i, fb in enumerate(frame_bytes)])
+        optrs, oinfos = self._ptr_array(outputs)
+        olens = (C.c_ulong * n)(*[i[1] for i in oinfos])
+        used = (C.c_ulong * n)()
+        fmts = (C.c_uint * n)()
+        results = (C.c_uint * n)()
+        r = lib.HapGpuDecodeFrameTextures(self.handle, nf, ptrs, lens, texture_count, optrs, olens, used, fmts, results, flags)
+        return r, list(used), list(fmts), list(results)
+
     def decode_sequence(self, reader, first, count, index, outputs, batch=0):
         """Disk -> pinned double buffer -> GPU (HapGpuDecodeSequence). Returns (result, used[], formats[], results[])."""
         optrs, oinfos = self._ptr_array(outputs)

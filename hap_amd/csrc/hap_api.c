@@ -484,6 +484,60 @@ unsigned int HapGpuDecodeFrames(HapGpuContext *context, unsigned int frameCount,
     return r;
 }
 
+unsigned int HapGpuDecodeFrameTextures(HapGpuContext *context, unsigned int frameCount,
+                                       const void *const *inputBuffers, const unsigned long *inputBuffersBytes,
+                                       unsigned int textureCount, void *const *outputBuffers,
+                                       const unsigned long *outputBuffersBytes, unsigned long *outputBuffersBytesUsed,
+                                       unsigned int *outputTextureFormats, unsigned int *results, unsigned int flags)
+{
+    unsigned r = HapResult_No_Error, f, t;
+    const void **inputs;
+    unsigned long *bytes;
+    unsigned *indices;
+    size_t entries, done;
+    if (!context || !results || textureCount == 0 || textureCount > 2)
+        return HapResult_Bad_Arguments;
+    if (frameCount == 0)
+        return HapResult_No_Error;
+    entries = (size_t)frameCount * textureCount;
+    if (!inputBuffers || !inputBuffersBytes || !outputBuffers || !outputBuffersBytes) {
+        for (done = 0; done < entries; done++)
+            results[done] = HapResult_Bad_Arguments;
+        return HapResult_Bad_Arguments;
+    }
+    /* entry f * textureCount + t = texture t of frame f: one batch, so the frames' headers come to the host once
+       and every texture's units go out in the same launches */
+    inputs = (const void **)malloc(sizeof(*inputs) * entries);
+    bytes = (unsigned long *)malloc(sizeof(*bytes) * entries);
+    indices = (unsigned *)malloc(sizeof(*indices) * entries);
+    if (!inputs || !bytes || !indices) {
+        free(inputs); free(bytes); free(indices);
+        for (done = 0; done < entries; done++)
+            results[done] = HapResult_Internal_Error;
+        return HapResult_Internal_Error;
+    }
+    for (f = 0; f < frameCount; f++)
+        for (t = 0; t < textureCount; t++) {
+            inputs[(size_t)f * textureCount + t] = inputBuffers[f];
+            bytes[(size_t)f * textureCount + t] = inputBuffersBytes[f];
+            indices[(size_t)f * textureCount + t] = t;
+        }
+    hapgpu_rt_lock(context->rt);
+    for (done = 0; done < entries; done += HAP_BATCH_SLICE) {
+        const unsigned n = (unsigned)(entries - done < HAP_BATCH_SLICE ? entries - done : HAP_BATCH_SLICE);
+        unsigned rc;
+        context->decode_indices = indices + done;
+        rc = hapb_decode(context, n, inputs + done, bytes + done, 0, outputBuffers + done, outputBuffersBytes + done,
+                         outputBuffersBytesUsed ? outputBuffersBytesUsed + done : NULL,
+                         outputTextureFormats ? outputTextureFormats + done : NULL, results + done, flags, NULL, NULL);
+        if (r == HapResult_No_Error)
+            r = rc;
+    }
+    hapgpu_rt_unlock(context->rt);
+    free(inputs); free(bytes); free(indices);
+    return r;
+}
+
 unsigned int HapGpuJoinChunkGroupsDevice(HapGpuContext *context, unsigned int groupCount,
                                          const void *const *groupFrames, const unsigned long *groupFramesBytes,
                                          void *outputBuffer, unsigned long outputBufferBytes,

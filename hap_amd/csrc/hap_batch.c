@@ -684,6 +684,10 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     unsigned frag_log2_seen = 0, frag_kinds = 0, max_chunks = 0;
     int any_stream = 0, need_retry = 0;
     unsigned scan_chunks = 0, scan_segs = 0, scan_words = 0;   /* streams with BLOCK slots; their segments; bpos words */
+    unsigned far_seen = 0;
+    /* (a call for several textures of the same frames: HapGpuDecodeFrameTextures hands the per-entry indices over) */
+    const unsigned *const entry_index = ctx->decode_indices;
+#define TEXTURE_INDEX(f) (entry_index ? entry_index[f] : index)
     const int block_scan = !(flags & HAPGPU_DECODE_NO_BLOCK_SCAN) && !ctx->no_block_scan;
     uint8_t *prefix = NULL, *in_stage = NULL, *out_stage = NULL;
     size_t in_stage_bytes = 0, out_stage_bytes = 0;
@@ -701,6 +705,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     unsigned client_marks_count = 0;
     int rc = 0;
 
+    ctx->decode_indices = NULL;
     if (frame_count == 0)
         return HapResult_No_Error;
     if (!results)
@@ -738,11 +743,17 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                 device_frames++;
         }
         if (device_frames) {
-            /* one gather kernel + one copy bring every device frame's header prefix to the host */
-            uint64_t *hptr = (uint64_t *)hapgpu_rt_pinned_scratch(rt, P_PTRS, sizeof(uint64_t) * 2u * frame_count);
-            uint64_t *dptr = (uint64_t *)hapgpu_rt_device_scratch(rt, D_PTRS, sizeof(uint64_t) * 2u * frame_count);
-            uint8_t *dprefix = (uint8_t *)hapgpu_rt_device_scratch(rt, D_PREFIX, (size_t)PREFIX_BYTES * frame_count);
-            prefix = (uint8_t *)hapgpu_rt_pinned_scratch(rt, P_PREFIX, (size_t)PREFIX_BYTES * frame_count);
+            /* one gather kernel + one copy bring every device frame's header prefix to the host -- and, for a later
+               texture of a multi-texture frame (which begins where the first one ends, far beyond the prefix), the
+               bytes at its section too: the kernel reads the two section headers in front of it itself.
+               Device block: prefixes | second prefixes | their offsets;  upload: pointers | lengths | wanted flags */
+            const size_t up_bytes = sizeof(uint64_t) * 2u * frame_count + frame_count;
+            const size_t block = (size_t)PREFIX_BYTES * frame_count;
+            uint64_t *hptr = (uint64_t *)hapgpu_rt_pinned_scratch(rt, P_PTRS, up_bytes);
+            uint64_t *dptr = (uint64_t *)hapgpu_rt_device_scratch(rt, D_PTRS, up_bytes);
+            uint8_t *dprefix = (uint8_t *)hapgpu_rt_device_scratch(rt, D_PREFIX, 2u * block + sizeof(uint64_t) * frame_count);
+            unsigned far = 0;
+            prefix = (uint8_t *)hapgpu_rt_pinned_scratch(rt, P_PREFIX, 2u * block + sizeof(uint64_t) * frame_count);
             if (!prefix || !hptr || !dptr || !dprefix) {
                 rc = 1;
                 goto fail_alloc;
@@ -751,10 +762,20 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                 const int dev_frame = results[f] == HapResult_No_Error && in_dev[f];
                 hptr[f] = dev_frame ? (uint64_t)(uintptr_t)inputs[f] : 0u;
                 hptr[frame_count + f] = input_bytes[f];
+                ((uint8_t *)(hptr + 2u * frame_count))[f] = (uint8_t)(dev_frame && TEXTURE_INDEX(f) > 0);
+                far += dev_frame && TEXTURE_INDEX(f) > 0;
             }
-            rc |= hapgpu_rt_h2d(rt, dptr, hptr, sizeof(uint64_t) * 2u * frame_count);
-            rc |= hapgpu_k_gather_prefixes(rt, dptr, dptr + frame_count, frame_count, PREFIX_BYTES, dprefix);
-            rc |= hapgpu_rt_d2h(rt, prefix, dprefix, (size_t)PREFIX_BYTES * frame_count);
+            rc |= hapgpu_rt_h2d(rt, dptr, hptr, up_bytes);
+            if (far) {
+                rc |= hapgpu_k_gather_prefixes_far(rt, dptr, dptr + frame_count, frame_count, PREFIX_BYTES, dprefix,
+                                                   (const uint8_t *)(dptr + 2u * frame_count), dprefix + block,
+                                                   (uint64_t *)(dprefix + 2u * block));
+                rc |= hapgpu_rt_d2h(rt, prefix, dprefix, 2u * block + sizeof(uint64_t) * frame_count);
+            } else {
+                rc |= hapgpu_k_gather_prefixes(rt, dptr, dptr + frame_count, frame_count, PREFIX_BYTES, dprefix);
+                rc |= hapgpu_rt_d2h(rt, prefix, dprefix, block);
+            }
+            far_seen = far;
         }
         for (f = 0; f < frame_count; f++) {
             if (results[f] != HapResult_No_Error)
@@ -777,47 +798,26 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
             rc |= hapgpu_rt_sync(rt);
         if (rc)
             goto fail_alloc;
-        /* a later texture of a multi-texture frame begins where the first one ends, far beyond the prefix: the start
-           of its section comes over in a second gather for the whole call instead of one round trip per frame and table */
-        if (device_frames && index > 0) {
-            uint64_t *hptr = (uint64_t *)hapgpu_rt_pinned_scratch(rt, P_PTRS, sizeof(uint64_t) * 2u * frame_count);
-            uint64_t *dptr = (uint64_t *)hapgpu_rt_device_scratch(rt, D_PTRS, sizeof(uint64_t) * 2u * frame_count);
-            uint8_t *dprefix = (uint8_t *)hapgpu_rt_device_scratch(rt, D_PREFIX, (size_t)PREFIX_BYTES * frame_count);
-            uint8_t *prefix2 = (uint8_t *)hapgpu_rt_pinned_scratch(rt, P_PREFIX2, (size_t)PREFIX_BYTES * frame_count);
-            unsigned far = 0;
-            if (hptr && dptr && dprefix && prefix2) {
-                for (f = 0; f < frame_count; f++) {
-                    hapf_section top, first;
-                    uint64_t at;
-                    hptr[f] = 0u;
-                    hptr[frame_count + f] = 0u;
-                    if (results[f] != HapResult_No_Error || !in_dev[f] || readers[f].view_len < 16u)
-                        continue;
-                    if (hapf_read_section(readers[f].view, (uint32_t)input_bytes[f], &top) != HapResult_No_Error ||
-                        top.type != 0x0Du || top.header_len + 8u > readers[f].view_len ||
-                        hapf_read_section(readers[f].view + top.header_len, top.length, &first) != HapResult_No_Error)
-                        continue;                                  /* (the planner reports what is wrong with it) */
-                    at = (uint64_t)top.header_len + first.header_len + first.length;
-                    if (at + 16u <= readers[f].view_len || at >= input_bytes[f])
-                        continue;
-                    hptr[f] = (uint64_t)(uintptr_t)inputs[f] + at;
-                    hptr[frame_count + f] = input_bytes[f] - at;
-                    readers[f].view2_off = at;
-                    far++;
-                }
-                if (far) {
-                    rc |= hapgpu_rt_h2d(rt, dptr, hptr, sizeof(uint64_t) * 2u * frame_count);
-                    rc |= hapgpu_k_gather_prefixes(rt, dptr, dptr + frame_count, frame_count, PREFIX_BYTES, dprefix);
-                    rc |= hapgpu_rt_d2h(rt, prefix2, dprefix, (size_t)PREFIX_BYTES * frame_count);
-                    rc |= hapgpu_rt_sync(rt);
-                    if (rc)
-                        goto fail_alloc;
-                    for (f = 0; f < frame_count; f++)
-                        if (hptr[f]) {
-                            readers[f].view2 = prefix2 + (size_t)PREFIX_BYTES * f;
-                            readers[f].view2_len = hptr[frame_count + f] < PREFIX_BYTES ? hptr[frame_count + f] : PREFIX_BYTES;
-                        }
-                }
+        if (far_seen) {
+            /* the second prefix is a second window of the reader -- taken only where the host, reading the same two
+               section headers, arrives at the offset the kernel reported (anything else: the reader fetches on demand) */
+            const size_t block = (size_t)PREFIX_BYTES * frame_count;
+            const uint64_t *far_at = (const uint64_t *)(prefix + 2u * block);
+            for (f = 0; f < frame_count; f++) {
+                hapf_section top, first;
+                uint64_t at;
+                if (results[f] != HapResult_No_Error || !in_dev[f] || TEXTURE_INDEX(f) == 0 || readers[f].view_len < 16u)
+                    continue;
+                if (hapf_read_section(readers[f].view, (uint32_t)input_bytes[f], &top) != HapResult_No_Error ||
+                    top.type != 0x0Du || top.header_len + 8u > readers[f].view_len ||
+                    hapf_read_section(readers[f].view + top.header_len, top.length, &first) != HapResult_No_Error)
+                    continue;                                  /* (the planner reports what is wrong with it) */
+                at = (uint64_t)top.header_len + first.header_len + first.length;
+                if (at + 16u <= readers[f].view_len || at >= input_bytes[f] || far_at[f] != at)
+                    continue;
+                readers[f].view2_off = at;
+                readers[f].view2 = prefix + block + (size_t)PREFIX_BYTES * f;
+                readers[f].view2_len = input_bytes[f] - at < PREFIX_BYTES ? input_bytes[f] - at : PREFIX_BYTES;
             }
         }
     }
@@ -829,7 +829,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
         int c;
         if (results[f] != HapResult_No_Error)
             continue;
-        hapf_plan_texture(&readers[f], (uint32_t)input_bytes[f], index, 1, p);
+        hapf_plan_texture(&readers[f], (uint32_t)input_bytes[f], TEXTURE_INDEX(f), 1, p);
         if (output_formats && p->format)
             output_formats[f] = p->format;
         if (p->result != HapResult_No_Error) {
@@ -1130,7 +1130,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                 ctx->preset_marks = client_marks;
                 ctx->preset_count = client_marks_count;
             }
-            hapb_decode(ctx, 1, &inputs[f], &input_bytes[f], index, &outputs[f], &output_bytes[f],
+            hapb_decode(ctx, 1, &inputs[f], &input_bytes[f], TEXTURE_INDEX(f), &outputs[f], &output_bytes[f],
                         output_used ? &output_used[f] : NULL, output_formats ? &output_formats[f] : NULL,
                         &results[f], flags | HAPGPU_DECODE_IGNORE_FRAGMENT_INDEX | HAPGPU_DECODE_NO_BLOCK_SCAN,
                         frame_count == 1 ? callback : NULL, callback_info);

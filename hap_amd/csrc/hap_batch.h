@@ -25,6 +25,8 @@ struct HapGpuContext {
     /* block encode of a batch, handed from hapb_encode_rgba to hapb_encode so that the whole call is one launch
        sequence (recorded and replayed as one HIP graph) */
     const struct HapbBlockEncodeJob *block_encode_job;
+    /* texture index of every entry of the next hapb_decode call (NULL: its `index` argument for all) */
+    const unsigned *decode_indices;
 };
 
 typedef struct HapbBlockEncodeJob {

@@ -246,6 +246,11 @@ int hapgpu_k_frame_gather(hapgpu_rt *rt, const HapGpuCopyEntry *copies, unsigned
 /* first `prefix` bytes of every device-resident frame (0 pointer = skip) -> out_dev + i * prefix */
 int hapgpu_k_gather_prefixes(hapgpu_rt *rt, const uint64_t *frames_dev, const uint64_t *lengths_dev,
                              unsigned count, unsigned prefix, void *out_dev);
+/* ... and, for entries with far_dev[f] != 0, the bytes at the second texture's section when it starts beyond the first
+   prefix (far_at_dev[f] = its offset, 0 = none / inside the first prefix) */
+int hapgpu_k_gather_prefixes_far(hapgpu_rt *rt, const uint64_t *frames_dev, const uint64_t *lengths_dev,
+                                 unsigned count, unsigned prefix, void *out_dev, const uint8_t *far_dev,
+                                 void *out2_dev, uint64_t *far_at_dev);
 /* clears `units` (all SKIP) then plans every job; max_chunks: largest chunk_count among the jobs */
 int hapgpu_k_decode_plan(hapgpu_rt *rt, HapGpuDecodeJob *jobs, unsigned job_count,
                          HapGpuDecodeUnit *units, unsigned unit_count, unsigned max_chunks);

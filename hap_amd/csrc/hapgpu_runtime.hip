@@ -403,15 +403,8 @@ extern "C" int hapgpu_rt_timer_stop(hapgpu_rt *rt, double *ms)
 // ---- header prefixes of device-resident frames ------------------------------------------------
 // The host parses section headers and tables (hap_frame.c); for frames that live in HBM their first
 // `prefix` bytes are gathered into one contiguous block so that a single copy brings them back.
-__global__ __launch_bounds__(256) void gather_prefix_kernel(const uint64_t *__restrict__ frames,
-                                                            const uint64_t *__restrict__ lengths, unsigned prefix,
-                                                            uint8_t *__restrict__ out)
+__device__ void copy_prefix(const uint8_t *src, uint64_t n, uint8_t *dst)
 {
-    const uint8_t *src = (const uint8_t *)frames[blockIdx.x];
-    if (!src)
-        return;
-    const uint64_t n = lengths[blockIdx.x] < prefix ? lengths[blockIdx.x] : prefix;
-    uint8_t *dst = out + (size_t)blockIdx.x * prefix;
     if ((((uintptr_t)src) & 15u) == 0) {
         const unsigned wide = (unsigned)(n >> 4);
         for (unsigned i = threadIdx.x; i < wide; i += 256u)
@@ -424,13 +417,76 @@ __global__ __launch_bounds__(256) void gather_prefix_kernel(const uint64_t *__re
     }
 }
 
+// section header at p (3-byte length + type, or 0 + type + 4-byte length: the container of hap.c:160-181): header
+// bytes, or 0 when it does not fit `available`
+__device__ unsigned section_header(const uint8_t *p, uint64_t available, uint64_t *length, unsigned *type)
+{
+    if (available < 4u)
+        return 0u;
+    uint64_t len = (uint64_t)p[0] | ((uint64_t)p[1] << 8) | ((uint64_t)p[2] << 16);
+    unsigned header = 4u;
+    if (len == 0u) {
+        if (available < 8u)
+            return 0u;
+        len = (uint64_t)p[4] | ((uint64_t)p[5] << 8) | ((uint64_t)p[6] << 16) | ((uint64_t)p[7] << 24);
+        header = 8u;
+    }
+    *length = len;
+    *type = p[3];
+    return header + len > available ? 0u : header;
+}
+
+// `far` (optional): entries with far[f] != 0 also want the bytes where the SECOND texture's section of a
+// multi-texture frame begins, when that lies beyond the first prefix.  The two section headers in front of it are
+// read here, so that both prefixes come back in one copy (the host parses the same headers again and takes the second
+// prefix only when it finds the same offset).
+__global__ __launch_bounds__(256) void gather_prefix_kernel(const uint64_t *__restrict__ frames,
+                                                            const uint64_t *__restrict__ lengths, unsigned prefix,
+                                                            uint8_t *__restrict__ out, const uint8_t *__restrict__ far,
+                                                            uint8_t *__restrict__ out2, uint64_t *__restrict__ far_at)
+{
+    const uint8_t *src = (const uint8_t *)frames[blockIdx.x];
+    if (!src)
+        return;
+    const uint64_t total = lengths[blockIdx.x];
+    copy_prefix(src, total < prefix ? total : prefix, out + (size_t)blockIdx.x * prefix);
+    if (!far || !far[blockIdx.x])
+        return;
+    uint64_t at = 0, top_len = 0, first_len = 0;
+    unsigned top_type = 0, first_type = 0;
+    const unsigned top_header = section_header(src, total, &top_len, &top_type);
+    if (top_header && top_type == 0x0Du) {
+        const unsigned first_header = section_header(src + top_header, top_len, &first_len, &first_type);
+        if (first_header) {
+            at = (uint64_t)top_header + first_header + first_len;
+            if (at + 16u <= prefix || at >= total)
+                at = 0;                                              // inside the first prefix, or nothing there
+        }
+    }
+    if (threadIdx.x == 0)
+        far_at[blockIdx.x] = at;
+    if (at)
+        copy_prefix(src + at, total - at < prefix ? total - at : prefix, out2 + (size_t)blockIdx.x * prefix);
+}
+
 extern "C" int hapgpu_k_gather_prefixes(hapgpu_rt *rt, const uint64_t *frames_dev, const uint64_t *lengths_dev,
                                         unsigned count, unsigned prefix, void *out_dev)
 {
     if (count == 0)
         return 0;
     hipLaunchKernelGGL(gather_prefix_kernel, dim3(count), dim3(256), 0, rt->stream, frames_dev, lengths_dev, prefix,
-                       (uint8_t *)out_dev);
+                       (uint8_t *)out_dev, (const uint8_t *)nullptr, (uint8_t *)nullptr, (uint64_t *)nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}
+
+extern "C" int hapgpu_k_gather_prefixes_far(hapgpu_rt *rt, const uint64_t *frames_dev, const uint64_t *lengths_dev,
+                                            unsigned count, unsigned prefix, void *out_dev, const uint8_t *far_dev,
+                                            void *out2_dev, uint64_t *far_at_dev)
+{
+    if (count == 0)
+        return 0;
+    hipLaunchKernelGGL(gather_prefix_kernel, dim3(count), dim3(256), 0, rt->stream, frames_dev, lengths_dev, prefix,
+                       (uint8_t *)out_dev, far_dev, (uint8_t *)out2_dev, far_at_dev);
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 

@@ -165,6 +165,22 @@ unsigned int HapGpuDecodeFrames(HapGpuContext *context, unsigned int frameCount,
                                 unsigned int *results,
                                 unsigned int flags);
 
+/* The same for textures 0 .. textureCount-1 (1 or 2) of every frame in ONE batch: the arrays outputBuffers,
+ * outputBuffersBytes, outputBuffersBytesUsed, outputTextureFormats and results have frameCount * textureCount
+ * entries, entry f * textureCount + t belonging to texture t of frame f (what HapDecode(..., index = t, ...) would
+ * be handed for that frame, reference hap.h:132-140).  A Hap Q Alpha stream decoded this way pays the per-call
+ * costs (header read-back, launches, completion) once instead of once per texture. */
+unsigned int HapGpuDecodeFrameTextures(HapGpuContext *context, unsigned int frameCount,
+                                       const void *const *inputBuffers,
+                                       const unsigned long *inputBuffersBytes,
+                                       unsigned int textureCount,
+                                       void *const *outputBuffers,
+                                       const unsigned long *outputBuffersBytes,
+                                       unsigned long *outputBuffersBytesUsed,
+                                       unsigned int *outputTextureFormats,
+                                       unsigned int *results,
+                                       unsigned int flags);
+
 /* --- one frame split over several GPUs by chunk groups ------------------------ */
 
 /* HapDecode restricted to the chunks [firstChunk, firstChunk + chunkCount) of texture `index`:

@@ -650,6 +650,59 @@ def test_device_resident_batch_round_trip(ctx, hap):
             assert r == 0 and all(torch.equal(x, y) for x, y in zip(dec, dec2))
 
 
+def test_both_textures_of_a_batch_decode_in_one_call(ctx, hap):
+    """HapGpuDecodeFrameTextures: entry f * T + t is what HapDecode(frame f, index t) gives -- frames in HBM (second
+    section located by the prefix gather itself), on the host, from a checker's encoder, and a single-texture frame
+    whose entry for index 1 fails the way the reference's HapDecode does."""
+    w, h, nf = 512, 256, 4
+    fmts = [L.FMT_YCOCG, L.FMT_RGTC1]
+    sizes = [(w // 4) * (h // 4) * 16, (w // 4) * (h // 4) * 8]
+    cap = hap.HapMaxEncodedLength(sizes, fmts, [8, 8])
+    from hap_amd import synth
+    frames_rgba = [synth.rgba_frame(w, h, i, device="cuda") for i in range(nf)]
+    outs = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(nf)]
+    torch.cuda.synchronize()
+    r, used, results = ctx.encode_frames_rgba(frames_rgba, w, h, w * 4, fmts, [1, 1], [8, 8], outs)
+    assert r == 0 and results == [0] * nf
+    want = [[D.oracle_bc_encode(frames_rgba[i].cpu().numpy(), fmts[t]) for t in range(2)] for i in range(nf)]
+    assert min(used) > 16384          # (the alpha plane's section starts beyond the 8 KiB header prefix)
+    # frame 1 goes through the host, frame 2 is replaced by the reference encoder's frame of the same textures
+    host1 = outs[1][: used[1]].cpu().numpy().tobytes()
+    r, ref2 = REF.encode([want[2][0], want[2][1]], fmts, [1, 1], [8, 8])
+    assert r == 0
+    frames = [outs[0], host1, ref2, outs[3]]
+    lens = [used[0], len(host1), len(ref2), used[3]]
+    dec = [torch.zeros(sizes[t], dtype=torch.uint8, device="cuda") for _ in range(nf) for t in range(2)]
+    torch.cuda.synchronize()
+    n0 = ctx.table_fallbacks()
+    r, dused, dfmts, dres = ctx.decode_frame_textures(frames, lens, 2, dec)
+    assert r == 0 and dres == [0] * (2 * nf) and ctx.table_fallbacks() == n0
+    assert dused == sizes * nf and dfmts == fmts * nf
+    for i in range(nf):
+        for t in range(2):
+            assert dec[2 * i + t].cpu().numpy().tobytes() == want[i][t], (i, t)
+    # one texture asked for: the same as HapGpuDecodeFrames(index 0)
+    dec0 = [torch.zeros(sizes[0], dtype=torch.uint8, device="cuda") for _ in range(nf)]
+    torch.cuda.synchronize()
+    r, dused, dfmts, dres = ctx.decode_frame_textures(frames, lens, 1, dec0)
+    assert r == 0 and dres == [0] * nf and all(torch.equal(dec0[i], dec[2 * i]) for i in range(nf))
+    # a single-texture frame in the batch: its index-1 entry reports what HapDecode reports, the others decode
+    r, single = hap.HapEncode([want[0][0]], [fmts[0]], [1], [4])
+    assert r == 0
+    code = REF.decode(single, 1, sizes[1])[0]
+    assert code != 0 and hap.HapDecode(single, 1, outputBufferBytes=sizes[1])[0] == code
+    dec = [torch.zeros(sizes[t], dtype=torch.uint8, device="cuda") for _ in range(2) for t in range(2)]
+    torch.cuda.synchronize()
+    r, dused, dfmts, dres = ctx.decode_frame_textures([single, outs[3]], [len(single), used[3]], 2, dec)
+    assert r == code and dres == [0, code, 0, 0]
+    assert dec[0].cpu().numpy().tobytes() == want[0][0]
+    assert dec[2].cpu().numpy().tobytes() == want[3][0] and dec[3].cpu().numpy().tobytes() == want[3][1]
+    # argument errors
+    assert ctx.decode_frame_textures([], [], 2, [])[0] == 0
+    with pytest.raises(ValueError):
+        ctx.decode_frame_textures(frames, lens, 2, dec0)
+
+
 def test_encode_is_deterministic_and_batch_independent(ctx, hap):
     """G5 stand-in on one GPU: a frame's bytes do not depend on run, batch size or position in the batch
     (round-synchronous hash inserts with LDS atomicMax make the compressor timing-independent), so
