@@ -85,36 +85,70 @@ HapGpuContext *HapGpuDefaultContext(void)
 #define HAP_DEFAULT_POOL 8
 #define HAP_BATCH_SLICE 32768u      /* frames per launch sequence: grid dimensions y / z hold at most 65535 */
 static HapGpuContext *g_pool[HAP_DEFAULT_POOL];
+static pthread_t g_pool_owner[HAP_DEFAULT_POOL];     /* the thread inside a hap.h call on that member, if g_pool_busy */
+static unsigned char g_pool_busy[HAP_DEFAULT_POOL];
 static unsigned g_pool_count;
 static pthread_mutex_t g_pool_lock = PTHREAD_MUTEX_INITIALIZER;
 
-/* returns a default context with its lock HELD, or NULL when there is no GPU */
+/* returns a default context with its lock HELD, or NULL when there is no GPU -- or when every member of the pool is
+   in use by calls of THIS thread (HapDecode nested HAP_DEFAULT_POOL deep through callbacks): waiting would never end */
 static HapGpuContext *acquire_default_context(void)
 {
     HapGpuContext *first = HapGpuDefaultContext(), *c = NULL;
+    const pthread_t self = pthread_self();
     unsigned i;
+    int wait_for = -1;
     if (!first)
         return NULL;
     pthread_mutex_lock(&g_pool_lock);
     if (g_pool_count == 0)
         g_pool[g_pool_count++] = first;
     for (i = 0; i < g_pool_count && !c; i++)
-        if (hapgpu_rt_trylock(g_pool[i]->rt) == 0)
+        if (hapgpu_rt_trylock(g_pool[i]->rt) == 0) {
             c = g_pool[i];
+            g_pool_owner[i] = self;
+            g_pool_busy[i] = 1;
+        }
     if (c)
         c->frag_log2 = first->frag_log2;       /* (HapGpuSetFragmentLog2 on the default context reaches every member) */
     if (!c && g_pool_count < HAP_DEFAULT_POOL &&
         HapGpuCreate(hapgpu_rt_device(first->rt), &c) == HapResult_No_Error) {
         c->frag_log2 = first->frag_log2;
+        g_pool_owner[g_pool_count] = self;
+        g_pool_busy[g_pool_count] = 1;
         g_pool[g_pool_count++] = c;
         hapgpu_rt_lock(c->rt);
     }
-    pthread_mutex_unlock(&g_pool_lock);
     if (!c) {
-        c = first;                 /* pool exhausted: wait for the first one */
+        /* pool exhausted: wait for a member that some other thread (or a client holding the default context's handle)
+           is using */
+        for (i = 0; i < g_pool_count; i++) {
+            if (!(g_pool_busy[i] && pthread_equal(g_pool_owner[i], self)) && wait_for < 0)
+                wait_for = (int)i;
+        }
+    }
+    pthread_mutex_unlock(&g_pool_lock);
+    if (!c && wait_for >= 0) {
+        c = g_pool[wait_for];
         hapgpu_rt_lock(c->rt);
+        pthread_mutex_lock(&g_pool_lock);
+        g_pool_owner[wait_for] = self;
+        g_pool_busy[wait_for] = 1;
+        c->frag_log2 = first->frag_log2;
+        pthread_mutex_unlock(&g_pool_lock);
     }
     return c;
+}
+
+static void release_default_context(HapGpuContext *c)
+{
+    unsigned i;
+    pthread_mutex_lock(&g_pool_lock);
+    for (i = 0; i < g_pool_count; i++)
+        if (g_pool[i] == c)
+            g_pool_busy[i] = 0;
+    pthread_mutex_unlock(&g_pool_lock);
+    hapgpu_rt_unlock(c->rt);
 }
 
 unsigned int HapGpuSetFragmentLog2(HapGpuContext *context, unsigned int log2_bytes)
@@ -211,7 +245,7 @@ unsigned int HapEncode(unsigned int count, const void **inputBuffers, unsigned l
         return HapResult_Internal_Error;
     rc = hapb_encode(ctx, 1, count, (const void *const *)inputBuffers, inputBuffersBytes, textureFormats,
                      compressors, chunkCounts, &out, &outputBufferBytes, &used, &result, flags, 0);
-    hapgpu_rt_unlock(ctx->rt);
+    release_default_context(ctx);
     if (rc == HapResult_No_Error)
         *outputBufferBytesUsed = used;
     return rc;
@@ -233,7 +267,7 @@ unsigned int HapDecode(const void *inputBuffer, unsigned long inputBufferBytes, 
         return HapResult_Internal_Error;
     rc = hapb_decode(ctx, 1, &inputBuffer, &inputBufferBytes, index, &outputBuffer, &outputBufferBytes, &used,
                      &fmt, &result, 0, callback, info);
-    hapgpu_rt_unlock(ctx->rt);
+    release_default_context(ctx);
     /* the reference stores the format as soon as the section type has been read (hap.c:754) */
     *outputBufferTextureFormat = fmt;
     if (rc == HapResult_No_Error && outputBufferBytesUsed)

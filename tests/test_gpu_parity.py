@@ -520,6 +520,34 @@ def test_decode_partial_callback(hap):
     assert got[:q] == b"\xEE" * q and got[2 * q:3 * q] == b"\xEE" * q
 
 
+def test_decode_nested_deeper_than_the_context_pool_fails_instead_of_hanging(hap):
+    """hap.h has no context argument; HapDecode called again from inside its callback takes another default context
+    (the reference is re-entrant).  Nine calls deep on one thread every member of the pool is busy with a call that
+    cannot finish before this one does: Internal_Error, and the eight outer calls complete."""
+    from hap_amd._lib import CALLBACK
+    tex = D.stream_bytes(16 * 4 * 64, "runs")
+    _, frame = ORA.encode([tex], [L.FMT_DXT5], [1], [2])
+    seen = []
+    keep = []
+
+    def make(depth):
+        def cb(fn, p, count, info):
+            if depth < 9:
+                inner = make(depth + 1)
+                keep.append(inner)
+                r, out, _fmt = hap.HapDecode(frame, 0, callback=inner, outputBufferBytes=len(tex))
+                seen.append((depth + 1, r, out == tex if r == 0 else None))
+            for i in range(count):
+                fn(p, i)
+        return CALLBACK(cb)
+    outer = make(1)
+    r, out, fmt = hap.HapDecode(frame, 0, callback=outer, outputBufferBytes=len(tex))
+    assert (r, out, fmt) == (0, tex, L.FMT_DXT5)
+    assert sorted(seen) == [(d, 0, True) for d in range(2, 9)] + [(9, hap.HapResult.Internal_Error, None)]
+    # and the pool is free again afterwards
+    assert hap.HapDecode(frame, 0, outputBufferBytes=len(tex)) == (0, tex, L.FMT_DXT5)
+
+
 # ------------------------------------------------------------------ encode --
 def _check_frame_structure(frame, tex, fmt, chunks_expected):
     """Header/table layout rules of hap.c:425-501 on a frame we produced."""
