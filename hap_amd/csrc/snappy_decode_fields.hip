@@ -351,8 +351,9 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
 #pragma unroll
     for (unsigned k = 0; k < PERIOD; k++)
         ring_k[k] = lane * kBlock + field_pos<LAYOUT>(k);
-    // 2a. every step's fields -> source descriptors ("state"): >= 0 an address in buf (literal bytes, or the ring for a
-    //     copy whose source block lies in an earlier step), < 0 pending: sign bit | 4 x (source lane in the same step).
+    // 2a. every step's fields -> source descriptors ("state"): >= 0 resolved: (an address in buf) << 8 -- literal bytes, or
+    //     the ring for a copy whose source block lies in an earlier step -- | 4 x the own lane; < 0 pending: sign bit |
+    //     4 x (source lane in the same step).
     //     All steps are looked up before anything is produced: the LDS round trips of the 8 steps overlap.
     //     (Lanes beyond the end of a short fragment compute garbage that nothing reads: sources are always lower lanes.)
     constexpr unsigned kMaxSteps = kFragBytes / kStepBytes;               // 8 or 16
@@ -403,29 +404,62 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
                 }
             }
         }
+        // Descriptors keep the address in bits 31..8 and a lane number (x 4) in bits 7..0: a pending field names the lane it
+        // copies from, a resolved one ITSELF -- so that one ds_bpermute addressed by the descriptor fetches the next
+        // descriptor of the chain for pending fields and the same descriptor again for resolved ones (directly, or
+        // from the lane at the root of their chain, which holds the same value): no select after the fetch.
 #pragma unroll
         for (unsigned s = 0; s < kMaxSteps; s++)
-            cof[s] &= 0xFFFF;
+            cof[s] = ((cof[s] & 0xFFFF) << 8) + (int)(lane * 4u);
 #pragma unroll
         for (unsigned s = 0; s < kMaxSteps; s++) {
 #pragma unroll
             for (unsigned k = 0; k < PERIOD; k++) {
                 const int rr = r[s][k];
-                const int lit_addr = cof[s] + (int)fbias[k] + rr;          // (rr = record - 0x10000 for literals)
+                const int lit_res = cof[s] + (int)(fbias[k] << 8) + rr * 256;    // (rr = record - 0x10000 for literals)
                 // copy: source = same field, rr / 4 blocks back.  Inside this step (rr / 4 <= lane): pending = sign bit
                 // | 4 x source lane (negative); else lane4s - rr wraps to a huge positive number and the minimum is
                 // the ring address (the walk above made sure it does not lie before the fragment)
                 const int pend = (int)(lane4s - (unsigned)rr);
-                const int ring_addr = (int)(ring_k[k] + s * kStepBytes) - rr * (int)(kBlock / 4u);
-                const int cpy = min(pend, ring_addr);
+                const int ring_res = (int)(((ring_k[k] + s * kStepBytes) << 8) + lane * 4u) - rr * (int)(kBlock * 64u);
+                const int cpy = min(pend, ring_res);
                 const int lit_mask = rr >> 31;                              // all ones: literal
-                state[s][k] = bit_select(lit_mask, lit_addr, cpy);
+                state[s][k] = bit_select(lit_mask, lit_res, cpy);
             }
         }
     }
-    // 2b. sources produced in the same step: follow the chains to a literal or to an earlier step by pointer doubling
-    //     (a chain is at most 63 links long: 6 rounds); the columns of all steps advance together, so a round is 32
-    //     independent ds_bpermutes in flight instead of one dependent LDS round trip per step and round
+    // 2b. sources produced in the same step: follow the chains to a literal or to an earlier step.
+    //     First the hops to a lane 1, 2, 4, 8 below in the same row of 16, taken with DPP moves (the vector unit has
+    //     slack, the LDS pipe does not): runs of copies at distance 1, 2 or 4 blocks -- the common ones -- collapse to
+    //     the lane in front of their row.
+    {
+        const unsigned row_lane = lane & 15u;
+        // the descriptor "pending, copies from the lane m below" -- or a value no descriptor has, where that lane lies in another row
+        const int want1 = row_lane >= 1u ? (int)(0x80000000u + (lane - 1u) * 4u) : 0x40000000;
+        const int want2 = row_lane >= 2u ? (int)(0x80000000u + (lane - 2u) * 4u) : 0x40000000;
+        const int want4 = row_lane >= 4u ? (int)(0x80000000u + (lane - 4u) * 4u) : 0x40000000;
+        const int want8 = row_lane >= 8u ? (int)(0x80000000u + (lane - 8u) * 4u) : 0x40000000;
+#pragma unroll
+        for (unsigned s = 0; s < kMaxSteps; s++)
+#pragma unroll
+            for (unsigned k = 0; k < PERIOD; k++) {
+                int v = state[s][k];
+                int t = __builtin_amdgcn_update_dpp(v, v, 0x111, 0xF, 0xF, false);     // row_shr:1
+                v = v == want1 ? t : v;
+                t = __builtin_amdgcn_update_dpp(v, v, 0x112, 0xF, 0xF, false);         // row_shr:2
+                v = v == want2 ? t : v;
+                t = __builtin_amdgcn_update_dpp(v, v, 0x114, 0xF, 0xF, false);         // row_shr:4
+                v = v == want4 ? t : v;
+                t = __builtin_amdgcn_update_dpp(v, v, 0x118, 0xF, 0xF, false);         // row_shr:8
+                v = v == want8 ? t : v;
+                state[s][k] = v;
+            }
+    }
+    //     Then pointer doubling (a chain is at most 63 links long: 6 rounds); the columns of all steps advance together,
+    //     so a round is 32 independent ds_bpermutes in flight instead of one dependent LDS round trip per step and
+    //     round.  Descriptors are self-addressed (see above): the fetched value IS the new descriptor.  (The rounds are
+    //     bound by the LDS pipe; skipping columns with nothing pending under wave-uniform branches was measured slower
+    //     -- every branch target waits for all LDS results -- and checks only every second or third round no faster.)
 #pragma unroll 1
     for (unsigned round = 0; round < 6u; round++) {
         int any = state[0][0];
@@ -437,22 +471,10 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
         if (__builtin_amdgcn_ballot_w64(any < 0 && lane * kBlock < out_len) == 0ull)
             break;
 #pragma unroll
-        for (unsigned s0 = 0; s0 < kMaxSteps; s0 += 4u) {
-            int g[4][PERIOD];
+        for (unsigned s = 0; s < kMaxSteps; s++)
 #pragma unroll
-            for (unsigned s = 0; s < 4u; s++)
-#pragma unroll
-                for (unsigned k = 0; k < PERIOD; k++)
-                    g[s][k] = __builtin_amdgcn_ds_bpermute(state[s0 + s][k], state[s0 + s][k]);   // (lane = address bits 7..2)
-            lds_wait();
-#pragma unroll
-            for (unsigned s = 0; s < 4u; s++)
-#pragma unroll
-                for (unsigned k = 0; k < PERIOD; k++) {
-                    const int pm = state[s0 + s][k] >> 31;                  // all ones: still pending
-                    state[s0 + s][k] = bit_select(pm, g[s][k], state[s0 + s][k]);
-                }
-        }
+            for (unsigned k = 0; k < PERIOD; k++)
+                state[s][k] = __builtin_amdgcn_ds_bpermute(state[s][k], state[s][k]);   // (lane = address bits 7..2)
     }
     // 2c. field bytes -> 16-byte block -> ring (later steps copy from it) and memory, step after step
     const unsigned nsteps = (out_len + kStepBytes - 1u) / kStepBytes;
@@ -468,7 +490,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
             unsigned lo[PERIOD], hi1 = 0;
 #pragma unroll
             for (unsigned k = 0; k < PERIOD; k++) {
-                const unsigned a = (unsigned)state[s][k], aw = a >> 2, sh = a & 3u;
+                const unsigned a = (unsigned)state[s][k] >> 8, aw = a >> 2, sh = a & 3u;
                 const unsigned d0 = bufw[aw], d1 = bufw[aw + 1u];
                 lo[k] = __builtin_amdgcn_alignbyte(d1, d0, sh);
                 if (k == 1) {
@@ -485,7 +507,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
         } else {
 #pragma unroll
             for (unsigned k = 0; k < 2; k++) {
-                const unsigned a = (unsigned)state[s][k], aw = a >> 2, sh = a & 3u;
+                const unsigned a = (unsigned)state[s][k] >> 8, aw = a >> 2, sh = a & 3u;
                 out[k] = __builtin_amdgcn_alignbyte(bufw[aw + 1u], bufw[aw], sh);
             }
         }
