@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
             const unsigned vlen = varint_len(cb);
             // fragment table version 2 (field streams): + 64 half-tile size bytes per fragment
             const bool with_tiles = tex.emit_index && ((tex.reserved >> 20) & 1u) != 0u && tile_sizes != nullptr;
-            const unsigned index_len = tex.emit_index ? 8u + (with_tiles ? 68u : 4u) * n * fpc : 0u;
+            const unsigned index_len = tex.emit_index ? 8u + (with_tiles ? 4u + HAP_GROUP_TABLE_BYTES : 4u) * n * fpc : 0u;
             const unsigned ilen = 5u * n + 8u + index_len;
             // pass 1: total stored payload
             unsigned long long total = 0;
@@ -203,9 +203,9 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
                         // the half-tile size bytes follow the fragment sizes: one move per chunk (consecutive fragments)
                         HapGpuCopyEntry e;
                         e.reserved = 0;
-                        e.src = (uint64_t)(tile_sizes + (size_t)(tex.frag_first + i * fpc) * HAP_HALF_TILES_PER_FRAGMENT);
-                        e.dst = (uint64_t)(itab + 8u + 4u * n * fpc + (size_t)i * fpc * HAP_HALF_TILES_PER_FRAGMENT);
-                        e.len = with_tiles ? fpc * HAP_HALF_TILES_PER_FRAGMENT : 0u;
+                        e.src = (uint64_t)(tile_sizes + (size_t)(tex.frag_first + i * fpc) * HAP_GROUP_TABLE_BYTES);
+                        e.dst = (uint64_t)(itab + 8u + 4u * n * fpc + (size_t)i * fpc * HAP_GROUP_TABLE_BYTES);
+                        e.len = with_tiles ? fpc * HAP_GROUP_TABLE_BYTES : 0u;
                         copies[extra_at + i] = e;
                     }
                 }

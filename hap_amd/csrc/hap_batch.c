@@ -175,7 +175,7 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
             /* header choice uses the layout that will actually be written (hap.c:425-428) */
             size_t ilen = hapf_instructions_length(t->chunk_count);
             if (flags & HAPGPU_ENCODE_FRAGMENT_INDEX)
-                ilen += 8u + (t->half_tiles ? 68u : 4u) * (size_t)t->chunk_count * t->fpc;
+                ilen += 8u + (t->half_tiles ? 4u + HAP_GROUP_TABLE_BYTES : 4u) * (size_t)t->chunk_count * t->fpc;
             if (ilen + 4u > 0xFFFFFFu) {          /* instruction container must fit a 24-bit length */
                 for (f = 0; f < frame_count; f++) {
                     results[f] = HapResult_Bad_Arguments;
@@ -268,7 +268,7 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
     dcopies = (HapGpuCopyEntry *)hapgpu_rt_device_scratch(rt, D_COPIES, sizeof(HapGpuCopyEntry) * ((size_t)frags_per_frame + chunks_per_frame) * live);
     dpack = hapgpu_rt_device_scratch(rt, D_PACK, (size_t)hapgpu_pack_scratch_bytes_per_chunk() * chunks_per_frame * live);
     if (any_half_tiles)
-        dtilesizes = (uint8_t *)hapgpu_rt_device_scratch(rt, D_TILESIZES, (size_t)HAP_HALF_TILES_PER_FRAGMENT * frags_per_frame * live);
+        dtilesizes = (uint8_t *)hapgpu_rt_device_scratch(rt, D_TILESIZES, (size_t)HAP_GROUP_TABLE_BYTES * frags_per_frame * live);
     if (stage_in_bytes)
         tex_stage = (uint8_t *)hapgpu_rt_device_scratch(rt, D_TEX_STAGE, stage_in_bytes);
     if (stage_out_bytes)

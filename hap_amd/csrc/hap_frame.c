@@ -290,14 +290,14 @@ static void plan_complex(hapf_reader *r, hapf_texture_plan *plan, int want_chunk
             plan->frag_window256 = fh[3];
             plan->frag_entries = (frag_bytes - 4u) / 4u;
             plan->frag_table_offset = base + (uint64_t)frags + 4u;
-        } else if (fh[0] == HAP_FRAGMENT_TABLE_VERSION_FIELDS && fh[1] == 13u && (frag_bytes - 4u) % 68u == 0u &&
+        } else if (fh[0] == HAP_FRAGMENT_TABLE_VERSION_FIELDS && fh[1] == 13u && (frag_bytes - 4u) % (4u + HAP_GROUP_TABLE_BYTES) == 0u &&
                    ((fh[2] >> 4) == 4u || (fh[2] >> 4) == 2u || (fh[2] >> 4) == 6u)) {
             /* version 2: [2][13][granularity log2 | fields per block << 4][window] + u32 x N + 64 bytes x N */
             plan->frag_log2 = 13u;
             plan->frag_gran_log2 = (fh[2] & 15u) <= 2u ? (fh[2] & 15u) : 0u;
             plan->frag_fields = fh[2] >> 4;
             plan->frag_window256 = fh[3];
-            plan->frag_entries = (frag_bytes - 4u) / 68u;
+            plan->frag_entries = (frag_bytes - 4u) / (4u + HAP_GROUP_TABLE_BYTES);
             plan->frag_table_offset = base + (uint64_t)frags + 4u;
             plan->frag_tiles_offset = plan->frag_table_offset + 4u * (uint64_t)plan->frag_entries;
         }

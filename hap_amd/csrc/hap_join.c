@@ -37,7 +37,7 @@ static uint64_t instructions_bytes(const joined_texture *t)
 {
     uint64_t n = hapf_instructions_length(t->chunk_count);
     if (t->keep_index)
-        n += 8u + (t->keep_tiles ? 4u + HAP_HALF_TILES_PER_FRAGMENT : 4u) * (uint64_t)t->chunk_count * t->frags_per_chunk;
+        n += 8u + (t->keep_tiles ? 4u + HAP_GROUP_TABLE_BYTES : 4u) * (uint64_t)t->chunk_count * t->frags_per_chunk;
     return n;
 }
 
@@ -190,7 +190,7 @@ unsigned hapj_join(unsigned groupCount, hapf_reader *readers, const unsigned lon
             if (j->keep_index) {
                 uint8_t *isec = stab + 4u * (size_t)n;
                 const uint32_t entries = n * j->frags_per_chunk;
-                hapf_write_section(isec, 4u, 4u + (j->keep_tiles ? 4u + HAP_HALF_TILES_PER_FRAGMENT : 4u) * entries, HAP_SECTION_FRAGMENTS);
+                hapf_write_section(isec, 4u, 4u + (j->keep_tiles ? 4u + HAP_GROUP_TABLE_BYTES : 4u) * entries, HAP_SECTION_FRAGMENTS);
                 isec[4] = (uint8_t)(j->keep_tiles ? HAP_FRAGMENT_TABLE_VERSION_FIELDS : HAP_FRAGMENT_TABLE_VERSION);
                 isec[5] = (uint8_t)j->frag_log2;
                 isec[6] = (uint8_t)(j->frag_gran_log2 | (j->keep_tiles ? j->frag_fields << 4 : 0u));
@@ -244,8 +244,8 @@ unsigned hapj_join(unsigned groupCount, hapf_reader *readers, const unsigned lon
                 bad |= sink->move(sink->user, g, p->frag_table_offset, ftab, 4u * (size_t)p->frag_entries);
                 ftab += 4u * (uint64_t)p->frag_entries;
                 if (j->keep_tiles) {
-                    bad |= sink->move(sink->user, g, p->frag_tiles_offset, ttab, (size_t)HAP_HALF_TILES_PER_FRAGMENT * p->frag_entries);
-                    ttab += (uint64_t)HAP_HALF_TILES_PER_FRAGMENT * p->frag_entries;
+                    bad |= sink->move(sink->user, g, p->frag_tiles_offset, ttab, (size_t)HAP_GROUP_TABLE_BYTES * p->frag_entries);
+                    ttab += (uint64_t)HAP_GROUP_TABLE_BYTES * p->frag_entries;
                 }
             }
         }

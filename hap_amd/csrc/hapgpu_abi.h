@@ -26,7 +26,9 @@ extern "C" {
 #define HAP_SECTION_OFFSETS 0x04u
 #define HAP_SECTION_FRAGMENTS 0x46u   /* private: hap_gpu.h */
 #define HAP_FRAGMENT_TABLE_VERSION 1u       /* fragment sizes only */
-#define HAP_FRAGMENT_TABLE_VERSION_FIELDS 2u /* + one byte per 128-byte half-tile of every fragment: "field streams" */
+#define HAP_FRAGMENT_TABLE_VERSION_FIELDS 3u /* + a group table per fragment: "field streams" (version 2, one byte per
+                                                half-tile, was written by earlier builds: such tables are ignored) */
+#define HAP_GROUP_TABLE_BYTES 96u            /* 64 groups of equally many elements, 12 bits each: the bytes of the group */
 #define HAP_HALF_TILE_BYTES 128u
 #define HAP_HALF_TILES_PER_FRAGMENT 64u      /* 8 KiB fragments */
 

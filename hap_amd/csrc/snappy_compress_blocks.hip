@@ -310,6 +310,7 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
     __syncthreads();
 
     // ---- 2. choose: lane = half-tile ----
+    unsigned counts_and_bytes = 0;          // inclusive scan over the half-tiles: elements << 16 | bytes (for the group table)
     {
         const uint4 ma = *reinterpret_cast<const uint4 *>(&masks[lane * 8u]);
         const uint4 mb = *reinterpret_cast<const uint4 *>(&masks[lane * 8u + 4u]);
@@ -363,14 +364,16 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
         const unsigned D0 = A[1] | A[3], D1 = A[2] | A[3];       // (distance - 1) of a copy's fields: the A[] are disjoint
         const unsigned lit_bytes = 4u * popc(L) - 2u * popc(L & UL::small32) + 2u * popc(L & UL::big32);
         const unsigned total = lit_bytes + popc(S) + popc(CS) + popc(X3);
-        const unsigned incl = (unsigned)scan_add((int)total);
+        // one scan for the bytes (low half: at most 64 x 144) and the elements (high half: at most 2048) before the half-tile
+        const unsigned count = popc(S);
+        const unsigned both = (unsigned)scan_add((int)(total | (count << 16)));
+        const unsigned incl = both & 0xFFFFu;
         const unsigned base = incl - total;
         *reinterpret_cast<uint4 *>(&masks[lane * 8u]) = make_uint4(S, L, X3, D0);
         *reinterpret_cast<uint4 *>(&masks[lane * 8u + 4u]) = make_uint4(D1, Hm, Sx1, base);
-        if (want_sizes)
-            tile_sizes[(size_t)f * HAP_HALF_TILES_PER_FRAGMENT + lane] = (uint8_t)total;
         if (lane == 63u)
             frag_sizes[f] = incl;
+        counts_and_bytes = both;
     }
     __syncthreads();
 
@@ -436,6 +439,59 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
                 }
             }
             off += is_l & UL::fs(k);
+        }
+    }
+
+    // ---- 4. the group table (fragment table version 3) ----
+    // The elements in stream order in 64 groups of G = ceil(N / 64); entry g = the bytes of group g -- where the
+    // decoder's lane g starts reading.  Lane = half-tile first: it tells every group that begins inside it where to
+    // look; then lane = group: the stream offset of its first element from that half-tile's masks (the bytes of the
+    // elements below it, as in phase 3).  (Done last: nothing of phases 1 and 3 is live any more.)
+    if (want_sizes) {
+        uint32_t *owner = reinterpret_cast<uint32_t *>(table);                 // (the table is not used after phase 1)
+        const unsigned both = counts_and_bytes;
+        const unsigned stream_bytes = (unsigned)__builtin_amdgcn_readlane((int)both, 63) & 0xFFFFu;
+        const unsigned elements = (unsigned)__builtin_amdgcn_readlane((int)both, 63) >> 16;        // >= 1
+        const unsigned G = (elements + 63u) >> 6;
+        {
+            const unsigned count = popc(masks[lane * 8u]);
+            const unsigned first = (both >> 16) - count;                       // ordinal of the half-tile's first element
+            const unsigned inv = (1u << 20) / G + 1u;                          // x / G = (x inv) >> 20 for x < 2^11 + 32
+            unsigned m = ((first + G - 1u) * inv) >> 20;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+            for (unsigned b = m * G; b < first + count; b += G, m++)
+                owner[m] = lane | (first << 8);
+        }
+        __syncthreads();
+        unsigned bound = stream_bytes;                                         // (groups beyond the last element: empty)
+        if (lane * G < elements) {
+            const unsigned o = owner[lane], h = o & 63u;
+            const uint4 ma = *reinterpret_cast<const uint4 *>(&masks[h * 8u]);
+            const unsigned S = ma.x, L = ma.y, X3 = ma.z, CS = S & ~L, base = masks[h * 8u + 7u];
+            // position of set bit number (ordinal - the half-tile's first ordinal) of S
+            unsigned r = lane * G - (o >> 8), q = 0, c = popc(S & 0xFFFFu);
+            if (r >= c) { q = 16u; r -= c; }
+            c = popc((S >> q) & 0xFFu);
+            if (r >= c) { q += 8u; r -= c; }
+            c = popc((S >> q) & 0xFu);
+            if (r >= c) { q += 4u; r -= c; }
+            c = popc((S >> q) & 0x3u);
+            if (r >= c) { q += 2u; r -= c; }
+            if (r >= ((S >> q) & 1u))
+                q += 1u;
+            const unsigned under = (1u << q) - 1u;
+            bound = base + 4u * popc(L & under) + 2u * popc(L & UL::big32 & under) - 2u * popc(L & UL::small32 & under) +
+                    popc(S & under) + popc(CS & under) + popc(X3 & under);
+        }
+        // 12 bits per group, two groups in three bytes
+        // (the shuffle on its own line: inside the conditional it would run without lane 63, whose value lane 62 reads)
+        const unsigned above = (unsigned)__shfl_down((int)bound, 1);
+        const unsigned size = (lane == 63u ? stream_bytes : above) - bound;
+        const unsigned pair = size | ((unsigned)__shfl_down((int)size, 1) << 12);
+        if ((lane & 1u) == 0u) {
+            const gdst_t at = (gdst_t)((uintptr_t)tile_sizes + (size_t)f * HAP_GROUP_TABLE_BYTES + (lane >> 1) * 3u);
+            put16(at, pair);
+            put8(at + 2, pair >> 16);
         }
     }
 }

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(64) void decode_expand_kernel(HapGpuDecodeJob *jobs
             w.dst_len = min(frag_bytes, c.plan_out_len - k * frag_bytes);
             w.kind = kind;
             w.job = j;
-            w.aux = fields ? job->tile_sizes + (uint64_t)(c.frag_first + k) * HAP_HALF_TILES_PER_FRAGMENT : 0u;
+            w.aux = fields ? job->tile_sizes + (uint64_t)(c.frag_first + k) * HAP_GROUP_TABLE_BYTES : 0u;
             // bytes of the texture section that follow the fragment (up to 15): the decoder may fetch its last
             // 16-byte piece whole when they exist
             const uint64_t end = (uint64_t)c.src_off + at + sz;

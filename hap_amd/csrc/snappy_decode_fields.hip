@@ -43,11 +43,9 @@ namespace {
 constexpr unsigned kFragBytes = 8192u;
 constexpr unsigned kHalf = 128u;                       // bytes of output per half-tile
 constexpr unsigned kHalves = kFragBytes / kHalf;       // 64: one parse lane each
-constexpr unsigned kMaxHalfCompressed = 144u;          // an honest encoder stays <= 130 (all literal + 2 header bytes)
 constexpr unsigned kMaxFragCompressed = kFragBytes + 320u;
-// ring + parked input: worst case max_h(128 h + 144 (64 - h)) + alignment slack (see the S computation below)
+// ring + parked input (at the end of the buffer: see the S computation below) + alignment slack
 constexpr unsigned kBufBytes = 9344u + 32u;
-constexpr unsigned kRecPerHalf = 32u;
 
 __device__ __forceinline__ int fdpp_shr(int v, int n)
 {
@@ -68,17 +66,6 @@ __device__ __forceinline__ int fwave_scan_add(int v)       // inclusive
     v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1,3
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2,3
     return v;
-}
-
-__device__ __forceinline__ int fwave_max(int v)            // values >= 0; result in lane 63, returned uniform
-{
-    v = max(v, fdpp_shr(v, 1));
-    v = max(v, fdpp_shr(v, 2));
-    v = max(v, fdpp_shr(v, 4));
-    v = max(v, fdpp_shr(v, 8));
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false));
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false));
-    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // Block layouts ("fields per block" nibble of the fragment table, include/hap_gpu.h):
@@ -185,22 +172,24 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
     HapGpuDecodeJob *job = &jobs[u.job];
     const gin_t src = (gin_t)u.src;
     const gout_t dst = (gout_t)u.dst;
-    const gin_t tile_sizes = (gin_t)u.aux;
+    const gin_t group_table = (gin_t)u.aux;
     const unsigned total = u.src_len, out_len = u.dst_len;
-    if (out_len == 0u || out_len > kFragBytes || (out_len % kBlock) != 0u || total > kMaxFragCompressed || !tile_sizes) {
+    if (out_len == 0u || out_len > kFragBytes || (out_len % kBlock) != 0u || total > kMaxFragCompressed || !group_table) {
         fail_unit(job, lane);
         return;
     }
     const unsigned nhalf = (out_len + kHalf - 1u) / kHalf;
 
-    // everything the unit needs from memory is requested at once: the job's status word, the half-tile table and
+    // everything the unit needs from memory is requested at once: the job's status word, the group table and
     // the first 4 KiB of input (what comes later is fetched by the loop below)
     const unsigned shift = (unsigned)((uintptr_t)src & 15u);
     const gin_t src_al = src - shift;
     const unsigned in_end = shift + total;
     const unsigned readable_end = in_end + (unsigned)(u.reserved & 15u);
     const unsigned job_status = __builtin_nontemporal_load(&job->status);
-    const unsigned tsz = lane < nhalf ? (unsigned)tile_sizes[lane] : 0u;
+    // 64 groups x 12 bits, packed little endian: group g sits in bits 12 g .. 12 g + 11
+    const unsigned gat = lane + (lane >> 1);
+    const unsigned gpair = (unsigned)group_table[gat] | ((unsigned)group_table[gat + 1u] << 8);
     uint4 early[4];
 #pragma unroll
     for (unsigned i = 0; i < 4u; i++)
@@ -208,35 +197,21 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
     if (job_status != 0u)
         return;
 
-    // ---- half-tile table -> compressed offsets, and where to park the input ----
-    // (one scan for both prefix sums: sizes in the low half -- at most 64 x 144 -- and record counts in the high half)
-    const unsigned hfields = lane < nhalf ? min(kHalf, out_len - kHalf * lane) / kBlock * PERIOD : 0u;
-    const unsigned nrec = min(min(kRecPerHalf, tsz >> 1), hfields);   // a half-tile of tsz bytes holds at most tsz / 2 elements
-    const unsigned both = (unsigned)fwave_scan_add((int)(tsz | (nrec << 16)));
-    const unsigned incl = both & 0xFFFFu;
-    const unsigned coff = incl - tsz;
-    const bool table_bad = ((unsigned)__builtin_amdgcn_readlane((int)both, 63) & 0xFFFFu) != total ||
-                           __builtin_amdgcn_ballot_w64(tsz > kMaxHalfCompressed) != 0ull;
-    if (table_bad) {
+    // ---- group table -> where every lane starts reading ----
+    const unsigned gsz = (lane & 1u) ? gpair >> 4 : gpair & 0xFFFu;
+    const unsigned gincl = (unsigned)fwave_scan_add((int)gsz);
+    const unsigned coff = gincl - gsz;
+    if ((unsigned)__builtin_amdgcn_readlane((int)gincl, 63) != total) {
         fail_unit(job, lane);
         return;
     }
-    const unsigned rbase = (both >> 16) - nrec;
-    const unsigned rbytes = 2u * ((unsigned)__builtin_amdgcn_readlane((int)both, 63) >> 16);
-    coffs[lane] = coff | (rbase << 16);
-    // Output of half-tiles < h may overwrite buffer bytes below 128 h; the input of half-tile h sits at S + coff[h].
-    const int lead = lane < nhalf ? (int)(kHalf * lane) - (int)coff : 0;
-    const unsigned S = (((unsigned)fwave_max(max(lead, 0)) + kHalf + 15u - shift) & ~15u) + shift;   // S = shift (mod 16)
-    if (S + total + 16u > kBufBytes) {          // cannot happen within the limits checked above
-        fail_unit(job, lane);
-        return;
-    }
-    // records below the parked input when they fit, else in the unit's own output range (2-byte aligned) in memory
-    const bool rec_in_lds = rbytes <= S - shift;
-    const gout_t rec_mem = (gout_t)(((uintptr_t)dst + 1u) & ~(uintptr_t)1u);
+    // The input is parked at the END of the buffer: output written by step s then never reaches compressed bytes that
+    // later steps still read as literals, as long as what is left of the input at any point fits between the output
+    // produced so far and the end of the buffer -- true for every honest stream (<= 130 bytes per half-tile), and
+    // verified per group below.
+    const unsigned S = ((kBufBytes - 16u - total - shift) & ~15u) + shift;                 // S = shift (mod 16)
     {
-        // (every lane stores only granules that hold input: the last 1 KiB row of stores would otherwise run up to
-        // 1008 bytes past S + total, beyond the buffer for fragments that begin with well-compressed half-tiles)
+        // (every lane stores only granules that hold input)
         uint8_t *park = buf + (S - shift) + lane * 16u;
 #pragma unroll
         for (unsigned i = 0; i < 4u; i++)
@@ -246,39 +221,72 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
             if (x + lane * 16u < in_end)
                 *reinterpret_cast<uint4 *>(park + x) = load_input16(src_al, x + lane * 16u, shift, in_end, readable_end);
     }
+    masks[lane] = make_uint2(0u, 0u);
     __syncthreads();
 
-    // ---- 1. parse: lane h walks the elements of half-tile h ----
-    // Straight-line code under the loop's exec mask: the three element kinds are decoded side by side and selected.
-    // Per element one signed 16-bit record,
-    //     literal:  0x8000 | (offset of its bytes in the half-tile's input - its output position + 128)   (negative)
-    //     copy:     4 x distance in blocks                                                                (positive)
-    // and one bit of the start mask (bit = output position in 2- or 4-byte units).  Promise checks are accumulated
-    // and looked at once at the end.
+    // ---- 1. parse: lane g walks the elements of group g -- every group holds the same number of them ----
+    // 1a. measure: bytes produced and elements of the group (tags only), so that the lane knows where its group's
+    //     output begins and where its records go
+    const unsigned cbegin = S + coff, cend = cbegin + gsz;
+    unsigned out_g = 0, count_g = 0;
+    {
+        unsigned cp = cbegin;
+        do {
+            if (cp < cend) {
+                const unsigned aw = cp >> 2;
+                const unsigned w = __builtin_amdgcn_alignbyte(bufw[aw + 1u], bufw[aw], cp);
+                const unsigned kind = w & 3u, up = __builtin_amdgcn_ubfe(w, 2u, 6u);
+                const bool is_lit = kind == 0u, lng = is_lit && up == 60u;
+                unsigned lm1 = lng ? __builtin_amdgcn_ubfe(w, 8u, 8u) : up;
+                lm1 = kind == 1u ? __builtin_amdgcn_ubfe(w, 2u, 3u) + 3u : lm1;
+                cp += is_lit ? lm1 + (lng ? 3u : 2u) : kind + 1u;
+                out_g += lm1 + 1u;
+                count_g += 1u;
+            }
+        } while (__builtin_amdgcn_ballot_w64(cp < cend) != 0ull);
+        // (a group that ends inside an element: the next pass stops at the same place and reports it)
+    }
+    const unsigned oincl = (unsigned)fwave_scan_add((int)min(out_g, 0xFFFFu));
+    const unsigned nincl = (unsigned)fwave_scan_add((int)count_g);
+    const unsigned obegin = oincl - min(out_g, 0xFFFFu);           // output position of the group's first element
+    const unsigned rbase = nincl - count_g;                        // ordinal of the group's first element
+    const unsigned elements = (unsigned)__builtin_amdgcn_readlane((int)nincl, 63);
+    {
+        // the output adds up; every element is at least two bytes (a field), so the records (2 bytes each) fit the
+        // unit's own output range if they have to go to memory; the parked input stays ahead of the output (see S)
+        const bool unsafe = (total - coff) + (oincl < kFragBytes ? oincl : kFragBytes) > kBufBytes - 16u;
+        if ((unsigned)__builtin_amdgcn_readlane((int)oincl, 63) != out_len || 2u * elements > out_len ||
+            __builtin_amdgcn_ballot_w64(out_g > kFragBytes || (gsz != 0u && unsafe)) != 0ull) {
+            fail_unit(job, lane);
+            return;
+        }
+    }
+    // records below the parked input when they fit, else in the unit's own output range (2-byte aligned) in memory
+    const unsigned rbytes = 2u * elements;
+    const bool rec_in_lds = rbytes <= S - shift;
+    const gout_t rec_mem = (gout_t)(((uintptr_t)dst + 1u) & ~(uintptr_t)1u);
+
+    // 1b. the walk proper.  Straight-line code under the loop's exec mask: the three element kinds are decoded side by
+    // side and selected.  Per element one signed 16-bit record,
+    //     literal:  0x8000 | (offset of its bytes in the parked input - its position in the half-tile + 128)   (negative)
+    //     copy:     4 x distance in blocks                                                                     (positive)
+    // and one bit of its half-tile's start mask (bit = position in 2- or 4-byte units).  Promise checks are
+    // accumulated and looked at once at the end.
     constexpr unsigned kRecShift = kBlock == 16u ? 2u : 1u;       // byte offset -> 4 x blocks
     {
-        const unsigned h = lane;
-        const unsigned hbytes = h < nhalf ? min(kHalf, out_len - kHalf * h) : 0u;
-        const unsigned cbase = S + coff;
-        unsigned cp = cbase;
-        const unsigned cend = cbase + tsz;
-        const unsigned obase = kHalf * h;                 // output position of the half-tile inside the fragment
-        const unsigned litk = 1u + kLitBias + 0x8000u - cbase;
-        unsigned p = 0, mlo = 0, mhi = 0;
-        unsigned recp = 0;                                 // byte offset into this half-tile's records
+        unsigned cp = cbegin;
+        unsigned p = obegin;                               // output position inside the fragment
+        unsigned recp = 2u * rbase;
         unsigned acc_or = 0;                               // OR of copy offsets (low bits) and start positions << 17
         unsigned max_kind = 0;                             // 3 = a copy-4 element
         int max_reach = 0;                                 // how far before the fragment the farthest copy reaches
         unsigned min_off = 0xFFFFFu, max_up = 0;           // smallest copy offset, largest literal length code
+        unsigned crossed = 0;                              // an element that leaves its half-tile
+        uint32_t *const mask_words = reinterpret_cast<uint32_t *>(masks);
         // (two typed pointers and a uniform branch at the store: one pointer chosen between LDS and memory would make
         // every record a flat store)
-        uint8_t *const rec_lds = buf + 2u * rbase;
-        const gout_t rec_glb = rec_mem + 2u * rbase;
-        const unsigned reccap = 2u * nrec;                 // (a stream with more elements than that has left its bytes)
-        // (every element advances p by at least one byte, so the walk is bounded; elements that start off a field
-        // boundary -- the only way to have more than 32 of them -- are caught below, and the record index is masked)
         do {
-            if (p < hbytes) {
+            if (cp < cend) {
                 const unsigned aw = cp >> 2;
                 const unsigned w = __builtin_amdgcn_alignbyte(bufw[aw + 1u], bufw[aw], cp);     // bytes cp .. cp+3 (shift = cp & 3)
                 const unsigned kind = w & 3u, up = __builtin_amdgcn_ubfe(w, 2u, 6u);
@@ -291,36 +299,37 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
                 lm1 = is_c1 ? __builtin_amdgcn_ubfe(w, 2u, 3u) + 3u : lm1;
                 const unsigned adv = is_lit ? lm1 + lngv + 2u : kind + 1u;
                 const unsigned off = is_c1 ? (((w << 3) & 0x700u) | b1) : __builtin_amdgcn_ubfe(w, 8u, 16u);
-                const unsigned litrec = (cp - p) + lngv + litk;                 // 0x8000 | 1 .. 128 + 146
+                const unsigned hp = p & (kHalf - 1u);                           // position inside the half-tile
+                const unsigned litrec = (cp - S) + lngv + (1u + kLitBias + 0x8000u) - hp;   // 0x8000 | 1 .. 128 + input bytes
                 // promises: whole blocks back (low offset bits 0), at least one, not before the fragment; no copy-4
-                // (kind 3); no literal with 2..4 length bytes (tag >> 2 in 61..63); starts on 2- / 4-byte positions
+                // (kind 3); no literal with 2..4 length bytes (tag >> 2 in 61..63); starts on 2- / 4-byte positions;
+                // the element ends inside its half-tile
                 const unsigned offx = is_lit ? 0x10000u : off;                  // (a literal counts as offset 64 Ki: neutral below)
                 acc_or |= offx | (p << 17);
                 min_off = min(min_off, offx);
                 max_up = max(max_up, is_lit ? up : 0u);
                 max_kind = max(max_kind, kind);
-                max_reach = max(max_reach, (int)(offx & 0xFFFFu) - (int)(obase + p));   // > 0: a copy from before the fragment
-                if (recp < reccap) {
+                max_reach = max(max_reach, (int)(offx & 0xFFFFu) - (int)p);     // > 0: a copy from before the fragment
+                crossed |= (hp + lm1) >> 7;
+                {
                     const uint16_t record = (uint16_t)(is_lit ? litrec : off >> kRecShift);
                     if (rec_in_lds)
-                        *reinterpret_cast<uint16_t *>(rec_lds + recp) = record;
+                        *reinterpret_cast<uint16_t *>(buf + recp) = record;
                     else
-                        *reinterpret_cast<uint16_t __attribute__((address_space(1))) *>(rec_glb + recp) = record;
+                        *reinterpret_cast<uint16_t __attribute__((address_space(1))) *>(rec_mem + recp) = record;
                 }
                 recp += 2u;
-                const unsigned long long bit = 1ull << (p >> kPosShift);
-                mlo |= (unsigned)bit;
-                mhi |= (unsigned)(bit >> 32);
+                const unsigned bit = hp >> kPosShift;                           // 0 .. 63 (2-byte positions) or 0 .. 31
+                atomicOr(&mask_words[2u * (p >> 7) + (bit >> 5)], 1u << (bit & 31u));
                 p += lm1 + 1u;
                 cp += adv;
             }
-        } while (__builtin_amdgcn_ballot_w64(p < hbytes) != 0ull);
-        // an element that overshoots its half-tile or the table's byte count ends up with p / cp off the mark;
-        // starts off a field boundary show in the mask (16-byte blocks: fields begin at bytes 0, 2, 8, 12)
-        bool bad = max_kind == 3u || max_reach > 0 || (acc_or & (kBlock - 1u)) != 0u ||
-                   ((acc_or >> 17) & ((1u << kPosShift) - 1u)) != 0u || min_off < kBlock || max_up > 60u || (h < nhalf && (cp != cend || p != hbytes)) || recp > reccap;
-        bad = bad || ((mlo | mhi) & ~start_positions<LAYOUT>()) != 0u;
-        masks[h] = make_uint2(mlo, mhi);
+        } while (__builtin_amdgcn_ballot_w64(cp < cend) != 0ull);
+        // an element that overshoots its group's bytes leaves cp off the mark; starts off a field boundary show in the
+        // masks (checked below, per half-tile)
+        const bool bad = max_kind == 3u || max_reach > 0 || (acc_or & (kBlock - 1u)) != 0u ||
+                         ((acc_or >> 17) & ((1u << kPosShift) - 1u)) != 0u || min_off < kBlock || max_up > 60u ||
+                         crossed != 0u || cp != cend || p != obegin + out_g;
         if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
             fail_unit(job, lane);
             return;
@@ -328,6 +337,21 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
     }
     if (!rec_in_lds)
         __threadfence();
+    __syncthreads();
+    // per half-tile: the start mask may only have bits where fields begin (16-byte blocks: bytes 0, 2, 8, 12), the
+    // half-tile begins with an element, and the ordinal of its first element follows from the counts
+    {
+        const uint2 m = masks[lane];
+        const bool live = lane < nhalf;
+        const unsigned starts = live ? __builtin_popcount(m.x) + __builtin_popcount(m.y) : 0u;
+        const unsigned sincl = (unsigned)fwave_scan_add((int)starts);
+        const bool bad = live && (((m.x | m.y) & ~start_positions<LAYOUT>()) != 0u || (m.x & 1u) == 0u);
+        if (__builtin_amdgcn_ballot_w64(bad) != 0ull || (unsigned)__builtin_amdgcn_readlane((int)sincl, 63) != elements) {
+            fail_unit(job, lane);
+            return;
+        }
+        coffs[lane] = (sincl - starts) << 16;               // (low half: the literal records are relative to S already)
+    }
     __syncthreads();
 
     // ---- 2. produce: lane = block, 64 blocks per step ----

@@ -9,8 +9,9 @@
  *   2. the kernel's bytes are exactly the bytes of this scalar definition (same tests), which makes every
  *      matching rule below a checked statement instead of a comment.
  * The stream this writes is ordinary Snappy (literal / copy-1 / copy-2 elements) obeying the extra promises of the
- * private fragment table version 2 (include/hap_gpu.h, snappy_decode_fields.hip): no element crosses a 128-byte
- * half-tile, every element starts and ends on a block-field boundary, copy offsets are whole blocks.
+ * private fragment table version 3 (include/hap_gpu.h, snappy_decode_fields.hip): no element crosses a 128-byte
+ * half-tile, every element starts and ends on a block-field boundary, copy offsets are whole blocks; the table lists
+ * the bytes of 64 groups of equally many elements, one group per decoder lane.
  *
  * Algorithm, per fragment of <= 8 KiB (units of 16 bytes = 4 fields; 32 fields = one half-tile):
  *   a. field i matches at distance d (1..4 blocks) when its bytes equal the same field d blocks back;
@@ -41,6 +42,7 @@ static const ofs_layout k_layout6 = {{0, 2, 8, 10}, {2, 6, 2, 6}, 8, {0, 1, 0, 1
 #define OFS_TABLE_BITS 9u
 #define OFS_STEP_UNITS 64u
 #define OFS_DISTANCES 4u
+#define OFS_GROUP_TABLE_BYTES 96u
 
 static uint64_t field_value(const uint8_t *p, unsigned size)
 {
@@ -60,7 +62,7 @@ static unsigned table_slot(uint64_t value, unsigned cls)
 static unsigned fpos(const ofs_layout *L, unsigned i) { return (i >> 2) * 16u + (i < 32u ? L->fo[i & 3u] : 0u); }
 
 unsigned ofs_compress_fragment(const uint8_t *src, unsigned n, unsigned layout, unsigned window_bytes, uint8_t *out,
-                               uint8_t *half_sizes)
+                               uint8_t *group_table)
 {
     const ofs_layout *L = layout == 4u ? &k_layout4 : layout == 2u ? &k_layout2 : &k_layout6;
     static uint8_t eq[OFS_DISTANCES][2048];
@@ -68,8 +70,10 @@ unsigned ofs_compress_fragment(const uint8_t *src, unsigned n, unsigned layout, 
     uint64_t table[1u << OFS_TABLE_BITS];
     const unsigned units = (n + 15u) / 16u, fields = units * 4u;
     unsigned produced = 0;
+    static uint16_t element_at[2048 + 1];          /* stream offset of every element, in order */
+    unsigned elements = 0;
 
-    memset(half_sizes, 0, 64);
+    memset(group_table, 0, OFS_GROUP_TABLE_BYTES);
     if (n == 0 || n > 8192u || (n % L->block) != 0u)
         return 0;
     /* a. fixed distances */
@@ -166,6 +170,7 @@ unsigned ofs_compress_fragment(const uint8_t *src, unsigned n, unsigned layout, 
             unsigned q = p + 1u;
             while (q < nv && !((S >> q) & 1u))
                 q++;
+            element_at[elements++] = (uint16_t)(o - out);
             const unsigned at = (f0 >> 2) * 16u + fpos(L, p);
             const unsigned len = (q < 32u ? fpos(L, q) : 128u) - fpos(L, p);
             if ((lit >> p) & 1u) {
@@ -194,8 +199,20 @@ unsigned ofs_compress_fragment(const uint8_t *src, unsigned n, unsigned layout, 
             }
             p = q;
         }
-        half_sizes[h] = (uint8_t)(o - start);
         produced += (unsigned)(o - start);
+    }
+    /* e. the group table the decoder's lanes start from: the elements in order, in 64 groups of G = ceil(elements / 64)
+          (the last ones shorter or empty); entry g = the bytes of group g, 12 bits each, packed little endian */
+    {
+        const unsigned G = (elements + 63u) / 64u;
+        element_at[elements] = (uint16_t)produced;
+        for (unsigned g = 0; g < 64u; g++) {
+            const unsigned a = g * G < elements ? g * G : elements, b = (g + 1u) * G < elements ? (g + 1u) * G : elements;
+            const unsigned size = (unsigned)element_at[b] - element_at[a];
+            const unsigned bit = 12u * g;
+            group_table[bit >> 3] |= (uint8_t)(size << (bit & 7u));
+            group_table[(bit >> 3) + 1u] |= (uint8_t)(size >> (8u - (bit & 7u)));
+        }
     }
     return produced;
 }
@@ -203,7 +220,7 @@ unsigned ofs_compress_fragment(const uint8_t *src, unsigned n, unsigned layout, 
 /* whole texture, chunk by chunk and fragment by fragment: total element bytes (for ratio studies) */
 unsigned long ofs_texture_bytes(const uint8_t *tex, unsigned long bytes, unsigned chunks, unsigned layout)
 {
-    static uint8_t out[8192 + 512], hs[64];
+    static uint8_t out[8192 + 512], hs[OFS_GROUP_TABLE_BYTES];
     unsigned long total = 0;
     const unsigned long cb = bytes / chunks;
     for (unsigned c = 0; c < chunks; c++)

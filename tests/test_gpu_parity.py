@@ -30,8 +30,8 @@ def ctx(hap):
 
 def find_fragment_table(frame, start=0, stop=400):
     """(offset of the 0x46 type byte, version, header bytes) of the private fragment table; version 1:
-    [ver][log2 F][granularity log2][window], version 2 (field streams): [2][13][granularity | fields << 4][window]."""
-    for ver in (1, 2):
+    [ver][log2 F][granularity log2][window], version 3 (field streams): [3][13][granularity | fields << 4][window]."""
+    for ver in (1, 3):
         at = bytes(frame).find(bytes([0x46, ver, 13]), start, stop)
         if at > 0:
             return at, ver, bytes(frame[at + 1: at + 5])
@@ -952,7 +952,7 @@ def test_full_size_frames_from_the_reference_encoder_decode_bit_exactly(ctx, hap
 @pytest.mark.parametrize("maker", ["checker", "ours+index"])
 def test_chunk_group_decode_fills_exactly_its_slice(ctx, hap, world, maker):
     from hap_amd import shard
-    tex = D.stream_bytes(16 * 64 * 48, "mixed", seed=21)
+    tex = D.stream_bytes(16 * 64 * 48, "runs", seed=21)
     if maker == "checker":
         frame = ORA.encode([tex], [L.FMT_YCOCG], [1], [8])[1]
     else:
@@ -993,7 +993,7 @@ def test_row_bands_encoded_separately_join_into_the_whole_frame(ctx, hap, format
     """C5-style encode: every 'GPU' block-compresses and packs its band of rows, HapGpuJoinChunkGroups makes one
     frame; the checker decodes it to exactly the textures of the undivided picture."""
     from hap_amd import shard
-    w, h, chunks = 256, 64 * world, 4 * world
+    w, h, chunks = 512, 128 * world, 4 * world          # (bands of 128 rows: DXT1 chunks of a whole 8 KiB fragment)
     img = D.rgba(w, h, frame=6)
     band_rows = h // world
     frames = []
@@ -1023,7 +1023,7 @@ def test_row_bands_encoded_separately_join_into_the_whole_frame(ctx, hap, format
             assert (r, used, fmts, res) == (0, [len(want)], [fmt], [0]) and dec.tobytes() == want
     assert b"\x46" in joined[:4096]      # the private fragment-size section survived the join
     # the join on the device (band frames and output in HBM: what arrives over xGMI never touches the host) writes the
-    # same bytes; and the half-tile tables are carried over, so the joined frame takes the block-per-lane decoder
+    # same bytes; and the group tables are carried over, so the joined frame takes the block-per-lane decoder
     dparts = [torch.from_numpy(np.frombuffer(f, dtype=np.uint8).copy()).cuda() for f in frames]
     dout = torch.full((sum(len(f) for f in frames) + 64,), 0x5A, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
@@ -1033,7 +1033,7 @@ def test_row_bands_encoded_separately_join_into_the_whole_frame(ctx, hap, format
     assert ctx.join_chunk_groups([frames[0]] + dparts[1:], [len(f) for f in frames], dout)[0] == hap.HapResult.Bad_Arguments
     if all(f in (L.FMT_DXT1, L.FMT_DXT5, L.FMT_YCOCG) for f in formats):
         at, ver, _hdr = find_fragment_table(joined, 0, 4000)
-        assert at > 0 and ver == 2
+        assert at > 0 and ver == 3
         n0 = ctx.table_fallbacks()
         dec = np.zeros(len(D.oracle_bc_encode(img, formats[0])), dtype=np.uint8)
         assert ctx.decode_frames([joined], [len(joined)], 0, [dec])[3] == [0] and ctx.table_fallbacks() == n0
@@ -1122,13 +1122,13 @@ def test_match_window_promise_is_checked_and_optional(ctx, hap):
     import os
     if os.environ.get("HAP_AMD_BYTE_GRANULAR"):
         pytest.skip("byte-granular streams keep no match window")
-    tex = D.stream_bytes(16 * 64 * 1024, "mixed", seed=41)          # 1 MiB: large enough for the window to be used
+    tex = D.stream_bytes(16 * 64 * 1024, "runs", seed=41)           # 1 MiB: large enough for the window to be used
     out = np.zeros(hap.HapMaxEncodedLength([len(tex)], [L.FMT_YCOCG], [2]) + 4096, dtype=np.uint8)
     r, used, res = ctx.encode_frames([[tex]], [L.FMT_YCOCG], [1], [2], [out], flags=hap.ENCODE_FRAGMENT_INDEX)
     assert r == 0
     frame = bytearray(out[: used[0]].tobytes())
     at, ver, hdr = find_fragment_table(frame)
-    assert at > 0 and ver == 2 and hdr == bytes([2, 13, 0x41, 12])     # field stream, 16-bit granular, 3 KiB window
+    assert at > 0 and ver == 3 and hdr == bytes([3, 13, 0x41, 12])     # field stream, 16-bit granular, 3 KiB window
     assert hap.HapDecode(bytes(frame), 0, outputBufferBytes=len(tex)) == (0, tex, L.FMT_YCOCG)
     for name, api in CHECKERS:
         assert api.decode(bytes(frame), 0, len(tex)) == (0, tex, L.FMT_YCOCG), name
@@ -1143,7 +1143,7 @@ def test_match_window_promise_is_checked_and_optional(ctx, hap):
     # small textures keep the whole fragment as their window (their block rows are short enough to matter)
     small = tex[: 16 * 64 * 96]
     r, used, res = ctx.encode_frames([[small]], [L.FMT_YCOCG], [1], [2], [out], flags=hap.ENCODE_FRAGMENT_INDEX)
-    assert r == 0 and find_fragment_table(out[: used[0]].tobytes())[2] == bytes([2, 13, 0x41, 0])
+    assert r == 0 and find_fragment_table(out[: used[0]].tobytes())[2] == bytes([3, 13, 0x41, 0])
     assert hap.HapDecode(out[: used[0]].tobytes(), 0, outputBufferBytes=len(small)) == (0, small, L.FMT_YCOCG)
     # a hand-made fragment whose copy reaches 6 KiB back, filed under a table that promises 3 KiB
     lit = bytes(range(256)) * 24                                     # 6144 literal bytes
@@ -1165,21 +1165,38 @@ def test_match_window_promise_is_checked_and_optional(ctx, hap):
     assert hap.HapDecode(bytes(honest), 0, outputBufferBytes=8192) == (0, want, L.FMT_DXT5)
 
 
-# ------------------------------------------------ field streams: fragment table version 2 --
-def _half_tile_table(frame):
-    """(offset of the LE32 fragment sizes, number of entries, offset of the half-tile bytes) of a version-2 table."""
+# ------------------------------------------------ field streams: fragment table version 3 --
+def _group_table(frame):
+    """(offset of the LE32 fragment sizes, number of entries, offset of the group tables) of a version-3 table."""
     at, ver, _hdr = find_fragment_table(frame, 0, 4000)
-    assert ver == 2
+    assert ver == 3
     ln = int.from_bytes(frame[at - 3: at], "little")
-    n = (ln - 4) // 68
+    n = (ln - 4) // 100
     return at + 5, n, at + 5 + 4 * n
 
 
+def _unpack_groups(table96):
+    bits = int.from_bytes(bytes(table96), "little")
+    return [(bits >> (12 * g)) & 0xFFF for g in range(64)]
+
+
+def _pack_groups(sizes):
+    assert len(sizes) == 64 and all(0 <= v < 4096 for v in sizes)
+    return sum(v << (12 * g) for g, v in enumerate(sizes)).to_bytes(96, "little")
+
+
+def _groups_of(element_sizes):
+    """The group table of a fragment whose elements have these byte sizes: 64 groups of ceil(N / 64) elements."""
+    n = len(element_sizes)
+    per = (n + 63) // 64
+    return _pack_groups([sum(element_sizes[g * per: (g + 1) * per]) for g in range(64)])
+
+
 def test_field_stream_table_is_described_exactly_and_every_lie_falls_back(ctx, hap):
-    """Frames of DXT5 / YCoCg-DXT5 textures written with the fragment table carry version 2 of it: the compressed
-    size of every 128-byte half-tile of every 8 KiB fragment, with the promise that no element crosses a half-tile,
-    elements start and end on field boundaries and copy offsets are whole blocks (include/hap_gpu.h).  The table is
-    checked against the streams by parsing them on the CPU; then every promise is broken in turn -- the block-per-
+    """Frames of DXT5 / YCoCg-DXT5 textures written with the fragment table carry version 3 of it: for every 8 KiB
+    fragment the bytes of 64 groups of equally many elements, with the promise that no element crosses a 128-byte
+    half-tile, elements start and end on field boundaries and copy offsets are whole blocks (include/hap_gpu.h).  The
+    table is checked against the streams by parsing them on the CPU; then promises are broken in turn -- the block-per-
     lane decoder must notice and the frame must still decode to the right bytes through the generic kernels."""
     tex = D.oracle_bc_encode(D.rgba(1024, 256, frame=6), L.FMT_YCOCG)          # 256 KiB of real blocks
     out = np.zeros(hap.HapMaxEncodedLength([len(tex)], [L.FMT_YCOCG], [4]) + 65536, dtype=np.uint8)
@@ -1188,21 +1205,23 @@ def test_field_stream_table_is_described_exactly_and_every_lie_falls_back(ctx, h
     frame = out[: used[0]].tobytes()
     for name, api in CHECKERS:
         assert api.decode(frame, 0, len(tex)) == (0, tex, L.FMT_YCOCG), name
-    fs_at, n, ht_at = _half_tile_table(frame)
+    fs_at, n, gt_at = _group_table(frame)
     assert n == 4 * 8                                                            # 4 chunks x 64 KiB / 8 KiB
     frag_sizes = [int.from_bytes(frame[fs_at + 4 * i: fs_at + 4 * i + 4], "little") for i in range(n)]
-    half = np.frombuffer(frame, dtype=np.uint8, count=64 * n, offset=ht_at).reshape(n, 64)
-    assert [int(x) for x in half.sum(axis=1)] == frag_sizes
-    # walk the element streams with the table: every half-tile boundary is an element boundary, offsets are whole blocks
-    payload = ht_at + 64 * n
+    groups = [_unpack_groups(frame[gt_at + 96 * i: gt_at + 96 * (i + 1)]) for i in range(n)]
+    assert [sum(g) for g in groups] == frag_sizes
+    # walk the element streams with the table: every group boundary is an element boundary, every group of a fragment
+    # holds the same number of elements (the last ones fewer), offsets are whole blocks, nothing crosses a half-tile
+    payload = gt_at + 96 * n
     sizes_at = frame.find(bytes([16, 0, 0, 3]), 0, 64) + 4
     chunk_sizes = [int.from_bytes(frame[sizes_at + 4 * i: sizes_at + 4 * i + 4], "little") for i in range(4)]
     at = payload
     for c in range(4):
         q = at + 3                                                               # varint(65536) is 3 bytes
         for f in range(8):
-            for h in range(64):
-                end, produced = q + int(half[c * 8 + f][h]), 0
+            produced, counts = 0, []
+            for g in range(64):
+                end, count = q + groups[c * 8 + f][g], 0
                 while q < end:
                     tag = frame[q]
                     kind = tag & 3
@@ -1219,9 +1238,14 @@ def test_field_stream_table_is_described_exactly_and_every_lie_falls_back(ctx, h
                         off = ((tag >> 5) << 8) | frame[q + 1] if kind == 1 else frame[q + 1] | (frame[q + 2] << 8)
                         assert off % 16 == 0 and 16 <= off <= 8192 - 16        # (a small texture: no match window)
                         q += 1 + kind
-                    assert produced % 16 in (0, 2, 8, 12)
+                    assert produced % 16 in (0, 2, 8, 12) and produced // 128 == (produced + ln - 1) // 128
                     produced += ln
-                assert q == end and produced == 128
+                    count += 1
+                assert q == end
+                counts.append(count)
+            per = (sum(counts) + 63) // 64
+            full = sum(counts) // per
+            assert produced == 8192 and counts[:full] == [per] * full and sum(counts[full + 1:]) == 0
         at += chunk_sizes[c]
     # decoding: the field-stream path, the generic fragment path on the same table, and no table at all agree
     before = ctx.table_fallbacks()
@@ -1230,29 +1254,36 @@ def test_field_stream_table_is_described_exactly_and_every_lie_falls_back(ctx, h
         r, du, df, dr = ctx.decode_frames([frame], [len(frame)], 0, [dec], flags=flags)
         assert (r, du, df, dr) == (0, [len(tex)], [L.FMT_YCOCG], [0]) and dec.tobytes() == tex
     assert ctx.table_fallbacks() == before                                       # the table was believed every time
-    # lies: half-tile sizes that move a boundary, that no longer add up, that exceed the limit; a wrong field count
+    # lies: group sizes that move a boundary, that no longer add up; a wrong field count; an empty table
     def decodes(data):
         canary = np.full(len(tex), 0x5A, dtype=np.uint8)
         n0 = ctx.table_fallbacks()
         r, u2, f2, res = ctx.decode_frames([bytes(data)], [len(data)], 0, [canary])
         return (r, u2, f2, res) == (0, [len(tex)], [L.FMT_YCOCG], [0]) and canary.tobytes() == tex and \
             ctx.table_fallbacks() == n0 + 1                                      # noticed, and decoded the generic way
-    k = int(np.argmax(half[3] > 8))                                              # a half-tile with a few elements
+    k = 5
     for delta_a, delta_b in ((1, -1), (-2, 2), (3, 0), (0, 200)):
         bad = bytearray(frame)
-        bad[ht_at + 3 * 64 + k] = (bad[ht_at + 3 * 64 + k] + delta_a) & 0xFF
-        bad[ht_at + 3 * 64 + k + 1] = (bad[ht_at + 3 * 64 + k + 1] + delta_b) & 0xFF
+        g3 = list(groups[3])
+        g3[k] += delta_a
+        g3[k + 1] += delta_b
+        bad[gt_at + 3 * 96: gt_at + 4 * 96] = _pack_groups(g3)
         assert decodes(bad), (delta_a, delta_b)
     bad = bytearray(frame)
-    bad[ht_at - 4 * n - 2] = (bad[ht_at - 4 * n - 2] & 15) | 0x20                    # [4, 4] fields claimed for 16-byte blocks
+    bad[gt_at - 4 * n - 2] = (bad[gt_at - 4 * n - 2] & 15) | 0x20                    # [4, 4] fields claimed for 16-byte blocks
     assert decodes(bad)
     bad = bytearray(frame)
-    bad[ht_at: ht_at + 64] = bytes(64)                                           # a fragment with an all-zero table
+    bad[gt_at: gt_at + 96] = bytes(96)                                           # a fragment with an all-zero table
     assert decodes(bad)
+    bad = bytearray(frame)                                                       # everything in the first group
+    bad[gt_at: gt_at + 96] = _pack_groups([min(frag_sizes[0], 4095)] + [frag_sizes[0] - min(frag_sizes[0], 4095)] + [0] * 62)
+    canary = np.full(len(tex), 0x5A, dtype=np.uint8)
+    r, u2, f2, res = ctx.decode_frames([bytes(bad)], [len(bad)], 0, [canary])
+    assert (r, res) == (0, [0]) and canary.tobytes() == tex                      # (right whether or not it counts as a lie)
 
 
 def test_field_stream_promises_are_checked_on_hand_made_streams(ctx, hap):
-    """One 8 KiB fragment written by hand under a version-2 table: the honest stream decodes; then streams that are
+    """One 8 KiB fragment written by hand under a version-3 table: the honest stream decodes; then streams that are
     valid Snappy (the checker decodes them) but break one promise each -- a copy offset that is not a whole block,
     an element that starts off a field boundary, an element that crosses a half-tile, a copy-4 element, a literal
     with a 2-byte length -- must come out right all the same (generic path) and never take the process down."""
@@ -1268,10 +1299,10 @@ def test_field_stream_promises_are_checked_on_hand_made_streams(ctx, hap):
     def frame_of(halves):
         """halves: 64 lists of element byte strings, each producing 128 bytes."""
         stream = b"".join(b"".join(h) for h in halves)
-        table = bytes(len(b"".join(h)) for h in halves)
+        table = _groups_of([len(e) for h in halves for e in h])
         chunk = bytes([0x80, 0x40]) + stream
         tables = bytes([1, 0, 0, 2, 0x0B]) + bytes([4, 0, 0, 3]) + len(chunk).to_bytes(4, "little") + \
-            bytes([72, 0, 0, 0x46, 2, 13, 0x41, 0]) + len(stream).to_bytes(4, "little") + table
+            bytes([104, 0, 0, 0x46, 3, 13, 0x41, 0]) + len(stream).to_bytes(4, "little") + table
         body = len(tables).to_bytes(3, "little") + bytes([1]) + tables + chunk
         return len(body).to_bytes(3, "little") + bytes([0xCE]) + body
 
@@ -1619,7 +1650,7 @@ def test_field_streams_that_compress_poorly_keep_their_records_in_memory(ctx, ha
     assert r == 0 and res == [0]
     frame = out[: used[0]].tobytes()
     at, ver, _hdr = find_fragment_table(frame)
-    assert at > 0 and ver == 2 and 0.45 < len(frame) / len(tex) < 1.0, (ver, len(frame) / len(tex))
+    assert at > 0 and ver == 3 and 0.45 < len(frame) / len(tex) < 1.0, (ver, len(frame) / len(tex))
     for name, api in CHECKERS:
         assert api.decode(frame, 0, len(tex)) == (0, tex, fmt), name
     dframe = torch.from_numpy(np.frombuffer(frame, dtype=np.uint8).copy()).cuda()
@@ -1639,15 +1670,15 @@ def _ofs_fragment(data, layout, window=0):
     o = L.oracle_lib()
     o.ofs_compress_fragment.restype = C.c_uint
     out = (C.c_ubyte * (8192 + 512))()
-    halves = (C.c_ubyte * 64)()
-    n = o.ofs_compress_fragment(bytes(data), C.c_uint(len(data)), C.c_uint(layout), C.c_uint(window), out, halves)
-    return bytes(out[:n]), bytes(halves)
+    table = (C.c_ubyte * 96)()
+    n = o.ofs_compress_fragment(bytes(data), C.c_uint(len(data)), C.c_uint(layout), C.c_uint(window), out, table)
+    return bytes(out[:n]), bytes(table)
 
 
 def _own_frame_sections(frame, chunks):
-    """(chunk codec bytes, chunk sizes, fragment sizes, half-tile bytes [n, 64], payload offset) of a one-texture frame
-    written with the version-2 fragment table."""
-    fs_at, n, ht_at = _half_tile_table(frame)
+    """(chunk codec bytes, chunk sizes, fragment sizes, group tables [n, 96], payload offset) of a one-texture frame
+    written with the version-3 fragment table."""
+    fs_at, n, ht_at = _group_table(frame)
     hdr = 4 if int.from_bytes(frame[0:3], "little") else 8
     p = hdr + 4
     assert frame[p + 3] == 0x02
@@ -1656,8 +1687,8 @@ def _own_frame_sections(frame, chunks):
     assert frame[p + 3] == 0x03
     sizes = [int.from_bytes(frame[p + 4 + 4 * i: p + 8 + 4 * i], "little") for i in range(chunks)]
     frag_sizes = [int.from_bytes(frame[fs_at + 4 * i: fs_at + 4 * i + 4], "little") for i in range(n)]
-    half = np.frombuffer(frame, dtype=np.uint8, count=64 * n, offset=ht_at).reshape(n, 64)
-    return codecs, sizes, frag_sizes, half, ht_at + 64 * n
+    half = np.frombuffer(frame, dtype=np.uint8, count=96 * n, offset=ht_at).reshape(n, 96)
+    return codecs, sizes, frag_sizes, half, ht_at + 96 * n
 
 
 @pytest.mark.parametrize("fmt,layout,shape,chunks", [
@@ -1665,7 +1696,7 @@ def _own_frame_sections(frame, chunks):
     (L.FMT_DXT1, 2, (1024, 256), 2), (L.FMT_DXT1, 2, (1028, 252), 3), (L.FMT_RGTC1, 6, (4096, 1028), 2)])
 def test_block_compressor_writes_exactly_the_bytes_of_its_scalar_definition(ctx, hap, fmt, layout, shape, chunks):
     """The Snappy stage for block textures (snappy_compress_blocks.hip, in place of hap.c:453) is defined by
-    oracle/field_stream_oracle.c: every chunk's stream, every fragment size and every half-tile byte of the frame are
+    oracle/field_stream_oracle.c: every chunk's stream, every fragment size and every group table of the frame are
     the scalar code's, for the three unit layouts, short last fragments and 8-byte tails included -- and both checkers
     decode the frame to the texture."""
     w, h = shape
@@ -1687,7 +1718,7 @@ def test_block_compressor_writes_exactly_the_bytes_of_its_scalar_definition(ctx,
         for o in range(0, cb, 8192):
             piece, halves = _ofs_fragment(tex[c * cb + o: c * cb + min(cb, o + 8192)], layout, window)
             assert frag_sizes[fi] == len(piece), (c, o)
-            assert half[fi].tobytes() == halves, (c, o)
+            assert _unpack_groups(half[fi].tobytes()) == _unpack_groups(halves), (c, o)
             want += piece
             fi += 1
         assert sizes[c] == len(want)
@@ -1701,13 +1732,13 @@ def test_block_compressor_writes_exactly_the_bytes_of_its_scalar_definition(ctx,
 
 def test_plain_hap_h_encode_takes_the_fast_path_by_default(ctx, hap):
     """HapEncode through hap.h writes the private fragment table unless HAP_AMD_FRAGMENT_INDEX=0 says otherwise: its
-    frames carry the version-2 table, both checkers decode them (unknown sections are skipped, hap.c:701-703), and this
+    frames carry the version-3 table, both checkers decode them (unknown sections are skipped, hap.c:701-703), and this
     library decodes them with the block-per-lane kernel -- no fallback to the generic path."""
     tex = D.oracle_bc_encode(D.rgba(1024, 512, frame=11), L.FMT_YCOCG)
     r, frame = hap.HapEncode([tex], [L.FMT_YCOCG], [1], [8])
     assert r == 0
     at, ver, _hdr = find_fragment_table(frame, 0, 4000)
-    assert at > 0 and ver == 2
+    assert at > 0 and ver == 3
     for name, api in CHECKERS:
         assert api.decode(frame, 0, len(tex)) == (0, tex, L.FMT_YCOCG), name
     before = hap.Context.default_table_fallbacks() if hasattr(hap.Context, "default_table_fallbacks") else None

@@ -237,9 +237,9 @@ def test_ycocg_blocks_are_dxt5_blocks_a_hap_q_shader_reconstructs():
 @pytest.mark.parametrize("fmt,layout,block", [(L.FMT_YCOCG, 4, 16), (L.FMT_DXT5, 4, 16), (L.FMT_DXT1, 2, 8), (L.FMT_RGTC1, 6, 8)])
 def test_field_stream_definition_is_snappy_and_keeps_its_promises(fmt, layout, block):
     """What ofs_compress_fragment writes is an ordinary Snappy stream (libsnappy and the restatement decode it to the
-    input) that keeps the promises of the fragment table version 2: the half-tile bytes add up, no element crosses a
-    128-byte half-tile, elements start on field boundaries, copies reach back whole blocks inside the fragment,
-    literal runs use at most one length byte."""
+    input) that keeps the promises of the fragment table version 3: the group bytes add up, every group holds the same
+    number of elements (the last ones fewer), no element crosses a 128-byte half-tile, elements start on field
+    boundaries, copies reach back whole blocks inside the fragment, literal runs use at most one length byte."""
     import ctypes as C
     o = L.oracle_lib()
     o.ofs_compress_fragment.restype = C.c_uint
@@ -252,10 +252,12 @@ def test_field_stream_definition_is_snappy_and_keeps_its_promises(fmt, layout, b
         at = int(rng.integers(0, (len(tex) - n) // block)) * block
         data = tex[at: at + n]
         out = (C.c_ubyte * (8192 + 512))()
-        halves = (C.c_ubyte * 64)()
-        m = o.ofs_compress_fragment(data, C.c_uint(n), C.c_uint(layout), C.c_uint(0 if trial % 2 else 3072), out, halves)
+        table = (C.c_ubyte * 96)()
+        m = o.ofs_compress_fragment(data, C.c_uint(n), C.c_uint(layout), C.c_uint(0 if trial % 2 else 3072), out, table)
         stream = bytes(out[:m])
-        assert sum(halves) == m and m <= n + n // 32 + 64
+        bits = int.from_bytes(bytes(table), "little")
+        groups = [(bits >> (12 * g)) & 0xFFF for g in range(64)]
+        assert sum(groups) == m and m <= n + n // 32 + 64
         head = bytearray()
         v = n
         while v >= 128:
@@ -265,13 +267,14 @@ def test_field_stream_definition_is_snappy_and_keeps_its_promises(fmt, layout, b
         assert D.osnappy_uncompress(bytes(head) + stream, n) == (0, data)
         if L.snappy_lib() is not None:
             assert D.ref_snappy_uncompress(bytes(head) + stream, n) == (0, data)
-        q = produced_total = 0
-        for h in range((n + 127) // 128):
-            end, produced = q + halves[h], 0
+        q = produced = 0
+        counts = []
+        for g in range(64):
+            end, count = q + groups[g], 0
             while q < end:
                 tag = stream[q]
                 kind = tag & 3
-                assert produced % block in starts
+                assert (produced % 128) % block in starts
                 if kind == 0:
                     ln, hd = (tag >> 2) + 1, 1
                     assert ln <= 61
@@ -283,14 +286,19 @@ def test_field_stream_definition_is_snappy_and_keeps_its_promises(fmt, layout, b
                     assert kind in (1, 2)
                     ln = 4 + ((tag >> 2) & 7) if kind == 1 else (tag >> 2) + 1
                     off = ((tag >> 5) << 8) | stream[q + 1] if kind == 1 else stream[q + 1] | (stream[q + 2] << 8)
-                    assert off % block == 0 and block <= off <= produced_total + produced
+                    assert off % block == 0 and block <= off <= produced
                     if trial % 2 == 0:
                         assert off <= 3072
                     q += 1 + kind
+                assert produced // 128 == (produced + ln - 1) // 128          # inside one half-tile
                 produced += ln
-            assert q == end and produced == min(128, n - 128 * h)
-            produced_total += produced
-        assert q == m
+                count += 1
+            assert q == end
+            counts.append(count)
+        assert q == m and produced == n
+        per_group = (sum(counts) + 63) // 64
+        full = sum(counts) // per_group
+        assert counts[:full] == [per_group] * full and sum(counts[full + 1:]) == 0
         total_in += n
         total_out += m
     assert total_out < total_in
