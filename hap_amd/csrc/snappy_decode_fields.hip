@@ -468,13 +468,13 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
 #pragma unroll
             for (unsigned k = 0; k < PERIOD; k++) {
                 int v = state[s][k];
-                int t = __builtin_amdgcn_update_dpp(v, v, 0x111, 0xF, 0xF, false);     // row_shr:1
+                int t = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);      // row_shr:1
                 v = v == want1 ? t : v;
-                t = __builtin_amdgcn_update_dpp(v, v, 0x112, 0xF, 0xF, false);         // row_shr:2
+                t = __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);          // row_shr:2
                 v = v == want2 ? t : v;
-                t = __builtin_amdgcn_update_dpp(v, v, 0x114, 0xF, 0xF, false);         // row_shr:4
+                t = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);          // row_shr:4
                 v = v == want4 ? t : v;
-                t = __builtin_amdgcn_update_dpp(v, v, 0x118, 0xF, 0xF, false);         // row_shr:8
+                t = __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);          // row_shr:8
                 v = v == want8 ? t : v;
                 state[s][k] = v;
             }
