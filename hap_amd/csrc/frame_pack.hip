@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
     const unsigned tid = threadIdx.x;
     uint8_t *cursor = (uint8_t *)frame.dst + frame.outer_header_len;
     unsigned long long sections_total = 0;
-    unsigned extra_at = extra_first + blockIdx.x * chunks_per_frame;      // this frame's half-tile table moves
+    unsigned extra_at = extra_first + blockIdx.x * chunks_per_frame;      // this frame's group table moves
     ChunkPack *pk = packs + (size_t)blockIdx.x * chunks_per_frame;
 
     for (unsigned t = 0; t < frame.tex_count; t++) {
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
 
         if (tex.compressor == 1u) {
             const unsigned vlen = varint_len(cb);
-            // fragment table version 2 (field streams): + 64 half-tile size bytes per fragment
+            // fragment table version 3 (field streams): + a 96-byte group table per fragment
             const bool with_tiles = tex.emit_index && ((tex.reserved >> 20) & 1u) != 0u && tile_sizes != nullptr;
             const unsigned index_len = tex.emit_index ? 8u + (with_tiles ? 4u + HAP_GROUP_TABLE_BYTES : 4u) * n * fpc : 0u;
             const unsigned ilen = 5u * n + 8u + index_len;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
                         write_section(itab, 4u, index_len - 4u, HAP_SECTION_FRAGMENTS);
                         itab[4] = (uint8_t)(with_tiles ? HAP_FRAGMENT_TABLE_VERSION_FIELDS : HAP_FRAGMENT_TABLE_VERSION);
                         itab[5] = (uint8_t)frag_log2;
-                        // granularity_log2 of the element streams (version 2: | block layout << 4;
+                        // granularity_log2 of the element streams (version 3: | block layout << 4;
                         // compressor code 4 -> 4 = [2,6,4,4], 10 -> 2 = [4,4], 2 -> 6 = [2,6])
                         const unsigned code = (tex.reserved >> 16) & 0xFu;
                         itab[6] = (uint8_t)((tex.reserved & 0xFu) | (with_tiles ? (code == 4u ? 4u : code == 10u ? 2u : 6u) << 4 : 0u));
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
                         pk[i].dst = (uint64_t)at;
                         pk[i].itab = tex.emit_index ? (uint64_t)(itab + 8u + 4u * (size_t)i * fpc) : 0u;
                         pk[i].how = raw ? 1u : 0u;
-                        // the half-tile size bytes follow the fragment sizes: one move per chunk (consecutive fragments)
+                        // the group tables follow the fragment sizes: one move per chunk (consecutive fragments)
                         HapGpuCopyEntry e;
                         e.reserved = 0;
                         e.src = (uint64_t)(tile_sizes + (size_t)(tex.frag_first + i * fpc) * HAP_GROUP_TABLE_BYTES);

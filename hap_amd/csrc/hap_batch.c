@@ -163,8 +163,8 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
                ones stay with positions per lane: their matches start inside the index bytes of the row above, which
                lies inside the fragment -- 0.25 against 0.45 of a 2048 x 512 plane) */
         }
-        /* field streams (fragment table version 2): with the table requested, the [2,6,4,4] compressor also keeps
-           elements inside 128-byte half-tiles and records their sizes for the block-per-lane decoder */
+        /* field streams (fragment table version 3): with the table requested, the block compressor's streams come with
+           a group table per fragment (96 bytes: where each of the decoder's 64 lanes starts reading) */
         t->half_tiles = ((t->field_period == 4u || t->field_period == 10u || t->field_period == 2u) && (flags & HAPGPU_ENCODE_FRAGMENT_INDEX) &&
                          !ctx->no_half_tiles) ? 1u : 0u;
         if (t->half_tiles)
@@ -986,7 +986,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                     job->frag_entries = p->frag_entries;
                     job->reserved = p->frag_gran_log2 | (p->frag_window256 << 8);
                     /* bits 0..2: plain fragment kernels needed, bits 4..6: windowed ones (8 KiB fragments whose
-                       table promises offsets of at most 3 KiB), bits 8 / 9: field streams (table version 2) */
+                       table promises offsets of at most 3 KiB), bits 8 / 9: field streams (table version 3) */
                     if (p->frag_tiles_offset && p->frag_fields && !(flags & HAPGPU_DECODE_IGNORE_HALF_TILES)) {
                         job->fields_period = p->frag_fields;
                         job->tile_sizes = (uint64_t)(uintptr_t)(frame_dev + p->frag_tiles_offset);

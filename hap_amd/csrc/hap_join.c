@@ -26,7 +26,7 @@ typedef struct joined_texture {
     unsigned chunk_count;
     int all_raw;
     int keep_index;           /* every group brought a compatible fragment table */
-    int keep_tiles;           /* ... of version 2 with the same block layout: the half-tile sizes are carried over */
+    int keep_tiles;           /* ... of version 3 with the same block layout: the group tables are carried over */
     unsigned frag_log2, frag_gran_log2, frag_window256, frags_per_chunk, frag_fields;
     uint64_t payload;         /* stored bytes of all chunks */
     uint64_t body;            /* section length, header excluded */

@@ -57,7 +57,7 @@ typedef struct HapGpuTexEnc {
     uint32_t frag_first;     /* global index of this texture's first fragment */
     uint32_t emit_index;     /* write the fragment-size section */
     uint32_t reserved;       /* bit 20: "field stream": no element crosses a 128-byte half-tile and the compressor
-                                records every half-tile's compressed size (fragment table version 2);
+                                writes every fragment's group table (fragment table version 3);
                                 bits 16..19: fields per block for the field-per-lane compressor (0: position per lane,
                                 2: RGTC1 layout, 4: DXT5 / YCoCg-DXT5, 10: DXT1); bits 8..15: match window in 256-byte units (0 = whole fragment); bits 0..7:
                                 granularity_log2 of the element stream: 0 = bytes, 1 = every position, offset
@@ -129,8 +129,8 @@ typedef struct HapGpuDecodeJob {
     /* results */
     uint64_t bytes_used;
     uint32_t status;         /* HapResult or HAPGPU_STATUS_* */
-    uint32_t fields_period;  /* 4 / 2 / 6: the table is version 2 and promises [2,6,4,4] / [4,4] / [2,6] field streams; 0 otherwise */
-    uint64_t tile_sizes;     /* device address of the half-tile size bytes inside the frame (64 per fragment entry), or 0 */
+    uint32_t fields_period;  /* 4 / 2 / 6: the table is version 3 and promises [2,6,4,4] / [4,4] / [2,6] field streams; 0 otherwise */
+    uint64_t tile_sizes;     /* device address of the group tables inside the frame (96 bytes per fragment entry), or 0 */
 } HapGpuDecodeJob;
 
 #define HAPGPU_UNIT_SKIP 0u
@@ -139,7 +139,7 @@ typedef struct HapGpuDecodeJob {
 #define HAPGPU_UNIT_COPY 3u
 #define HAPGPU_UNIT_SNAPPY_FRAGMENT16 4u /* fragment whose elements are all 16-bit granular */
 #define HAPGPU_UNIT_SNAPPY_FRAGMENT32 5u /* ... all 32-bit granular */
-#define HAPGPU_UNIT_SNAPPY_FIELDS4 6u   /* fragment of a field stream, 16-byte blocks of 2 + 6 + 4 + 4 bytes; aux = its half-tile sizes */
+#define HAPGPU_UNIT_SNAPPY_FIELDS4 6u   /* fragment of a field stream, 16-byte blocks of 2 + 6 + 4 + 4 bytes; aux = its group table */
 #define HAPGPU_UNIT_SNAPPY_FIELDS2 7u   /* ... 8-byte blocks of 4 + 4 bytes */
 #define HAPGPU_UNIT_SNAPPY_FIELDS26 8u  /* ... 8-byte blocks of 2 + 6 bytes */
 #define HAPGPU_UNIT_SNAPPY_BLOCK 9u     /* one 64 KiB block of another encoder's stream, found by the block scan: bare
@@ -183,7 +183,7 @@ typedef struct HapGpuDecodeUnit {
     uint32_t dst_len;
     uint32_t kind;           /* HAPGPU_UNIT_* */
     uint32_t job;            /* index of the owning job (status word) */
-    uint64_t aux;            /* FIELDS units: device address of the fragment's 64 half-tile size bytes;
+    uint64_t aux;            /* FIELDS units: device address of the fragment's group table (96 bytes);
                                 STREAM units: number of SKIP slots that follow for the block scan's BLOCK units */
     /* reserved: fragment units: readable bytes after the fragment (<= 15); STREAM units: 0 or the HapGpuScanChunk
        that decides whether the stream unit or its BLOCK units run */
@@ -236,7 +236,7 @@ int hapgpu_k_snappy_compress(hapgpu_rt *rt, const HapGpuFrameEnc *frames, unsign
                              void *slots, unsigned slot_stride, uint32_t *frag_sizes, uint8_t *tile_sizes,
                              unsigned granularity_mask /* bit g (0..2) set: some position-per-lane texture has granularity_log2 == g; bit 4 / 5 / 6: some texture uses the field-per-lane kernel ([2,6] / [2,6,4,4] / [4,4] fields per block); bits 8..: textures per frame */);
 /* copies: one entry per fragment, then (from index extra_first) chunks_per_frame entries per frame for the
- * half-tile tables of field streams */
+ * group tables of field streams */
 int hapgpu_k_frame_pack(hapgpu_rt *rt, HapGpuFrameEnc *frames, unsigned frame_count,
                         unsigned frag_log2, const void *slots, unsigned slot_stride,
                         const uint32_t *frag_sizes, const uint8_t *tile_sizes, HapGpuCopyEntry *copies,

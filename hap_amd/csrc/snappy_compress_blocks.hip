@@ -2,9 +2,10 @@
 //
 // Replaces the snappy_compress call-out of the reference's chunk loop (hap.c:448-476, call at hap.c:453) for DXT5 /
 // YCoCg-DXT5 / DXT1 / RGTC1 textures.  The output is ordinary Snappy (literal / copy-1 / copy-2 elements: the
-// reference decodes it unchanged) that keeps the promises of the private fragment table version 2
+// reference decodes it unchanged) that keeps the promises of the private fragment table version 3
 // (include/hap_gpu.h, snappy_decode_fields.hip): 8 KiB fragments, no element crosses a 128-byte half-tile, every
-// element starts and ends on a block-field boundary, copy offsets are whole blocks.  Its bytes are DEFINED by the
+// element starts and ends on a block-field boundary, copy offsets are whole blocks; and a table of the bytes of 64
+// groups of equally many elements per fragment, the decoder's starting points.  Its bytes are DEFINED by the
 // scalar restatement oracle/field_stream_oracle.c; the tests compare the two byte for byte.
 //
 // One wavefront per fragment, a lane owns a 16-byte UNIT (one DXT5 block or two 8-byte blocks = 4 fields), so one
@@ -22,10 +23,13 @@
 //      stretch starts one copy and an integer ADD carries it through its run of ones, so the loop runs as often as
 //      the longest chain of touching copies (1.2 on average), not once per element.  Start, literal, "one more
 //      byte" and distance masks, the half-tile's compressed size (popcounts) and -- one DPP scan -- its offset in
-//      the fragment go back to LDS; the sizes are the fragment table's half-tile bytes.
+//      the fragment go back to LDS.
 //   3. EMIT, lane = unit, 8 steps: popcounts of the masks below the unit give its output offset; each of its 4
 //      fields forms its element bytes (header / copy tag from the distance to the next start bit) and stores
 //      them and its literal bytes at their final place.
+//   4. GROUP TABLE, lane = group: the N elements of the fragment in 64 groups of ceil(N / 64); a group's first element
+//      lies in one half-tile, whose masks give its stream offset (popcounts again); differences of neighbours are
+//      the 12-bit entries.
 //
 // HBM traffic: texture read once (the neighbour loads hit L1 / L2), compressed bytes written once.
 #include <hip/hip_runtime.h>

@@ -26,7 +26,7 @@
 //                         found in parallel over 4 KiB segments of compressed bytes without producing
 //                         output -- see the comment in front of them.
 //
-// Frames written by this library with the version-2 table ("field streams": DXT5, YCoCg-DXT5, DXT1,
+// Frames written by this library with the version-3 table ("field streams": DXT5, YCoCg-DXT5, DXT1,
 // large RGTC1 planes) are decoded by the block-per-lane kernel of snappy_decode_fields.hip instead.
 // HBM traffic: compressed bytes read once + output written once.
 #include <hip/hip_runtime.h>
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64) void decode_expand_kernel(HapGpuDecodeJob *jobs
     if (job->frag_log2 == 13u && window256 != 0 && window256 <= HAP_FRAGMENT_WINDOW_256)
         kind |= HAPGPU_UNIT_WINDOWED;
     const bool fields = job->fields_period != 0u && job->tile_sizes != 0u;
-    if (fields)       // field stream (table version 2): block-per-lane decoder, with the fragment's half-tile sizes
+    if (fields)       // field stream (table version 3): block-per-lane decoder, with the fragment's group table
         kind = job->fields_period == 4u ? HAPGPU_UNIT_SNAPPY_FIELDS4
              : job->fields_period == 2u ? HAPGPU_UNIT_SNAPPY_FIELDS2 : HAPGPU_UNIT_SNAPPY_FIELDS26;
     unsigned long long run = c.plan_hdr;
@@ -1347,7 +1347,7 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
 {
     if (unit_count == 0)
         return 0;
-    // field streams (fragment table version 2): the block-per-lane decoder of snappy_decode_fields.hip
+    // field streams (fragment table version 3): the block-per-lane decoder of snappy_decode_fields.hip
     if ((fragment_kinds >> 8) & 7u) {
         if (hapgpu_launch_snappy_decode_fields(units, unit_count, jobs, (fragment_kinds >> 8) & 7u, stream) != 0)
             return 4;

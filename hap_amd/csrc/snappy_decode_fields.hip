@@ -1,38 +1,41 @@
 // snappy_decode_fields.hip -- block-per-lane Snappy decoder for "field streams" (gfx950).
 //
 // Replaces hap_decode_chunk's snappy_uncompress (reference hap.c:606-642, call at hap.c:612) for the frames this
-// library writes itself with the fragment table version 2 (private section 0x46, include/hap_gpu.h).  Such a chunk
+// library writes itself with the fragment table version 3 (private section 0x46, include/hap_gpu.h).  Such a chunk
 // is an ordinary Snappy stream -- the reference decodes it unchanged -- whose elements obey extra rules that the
 // table announces and this kernel VERIFIES while it parses (any violation fails the unit with
 // HAPGPU_STATUS_INDEX_MISMATCH and the host decodes the frame again through the generic kernels):
 //
 //   * the stream is cut into independent 8 KiB fragments (compressed size of each in the table);
-//   * inside a fragment no element crosses a 128-byte "half-tile" of output, and the table holds the compressed size
-//     of every half-tile (one byte each);
+//   * the table holds, per fragment, the bytes of 64 GROUPS of its elements: the elements in stream order,
+//     ceil(N / 64) to a group (12 bits per group);
+//   * inside a fragment no element crosses a 128-byte "half-tile" of output;
 //   * every element starts and ends on a block FIELD boundary -- DXT5 / YCoCg-DXT5 blocks are 2 + 6 + 4 + 4 bytes
-//     (alpha endpoints, alpha indices, colour endpoints, colour indices), DXT1 blocks 4 + 4 -- and every copy offset
-//     is a whole number of blocks.  So each field of each block is produced by exactly one element, either from
-//     literal bytes or from the SAME field of an earlier block.
+//     (alpha endpoints, alpha indices, colour endpoints, colour indices), DXT1 blocks 4 + 4, RGTC1 blocks 2 + 6 -- and
+//     every copy offset is a whole number of blocks.  So each field of each block is produced by exactly one element,
+//     either from literal bytes or from the SAME field of an earlier block.
 //
 // One wavefront decodes one fragment in two phases:
 //
-//   1. PARSE, one lane per half-tile (64 half-tiles = the whole fragment at once): the lane walks its half-tile's
-//      elements serially -- the only serial dependency of Snappy, the element chain, is now 64 independent short
-//      chains -- and leaves per element a 16-bit record {first field, literal?, literal position | block distance}
-//      plus a 32-bit mask of the fields at which an element starts.
+//   1. PARSE, one lane per group: the only serial dependency of Snappy, the element chain, is 64 independent chains of
+//      EQUAL length (r03's first table gave a lane to every half-tile: the busiest of 64 set the trip count, 21
+//      elements against a mean of 6).  A first walk over the tags measures the group (bytes produced, elements); a
+//      scan gives every group its output position and its record slots; the second walk leaves per element a
+//      16-bit record {literal?, literal position | block distance} and ORs one bit into the start mask of the
+//      element's half-tile.
 //   2. PRODUCE, one lane per BLOCK, 64 blocks (1 KiB of DXT5) per step: for each of its 4 fields the lane finds the
-//      owning element with one popcount of the start mask, reads the record, and turns it into a source address:
+//      owning element with one popcount of the start mask, reads the record, and turns it into a source descriptor:
 //      literal bytes in the staged input, or the same field of block (b - distance) in the output ring.  Sources
-//      inside the current step are resolved by pointer doubling on lane indices (ds_bpermute, <= 6 rounds, usually
-//      0-2); then 4 field reads, one 16-byte LDS store (later steps copy from it) and one 16-byte global store.
+//      inside the current step are resolved first by DPP hops (lanes 1, 2, 4, 8 below), then by pointer doubling on
+//      lane indices (ds_bpermute, <= 6 rounds); then 4 field reads, one 16-byte LDS store (later steps copy from
+//      it) and one 16-byte global store.
 //
-// LDS: the output ring (8 KiB) and the staged compressed bytes share one buffer -- the input is parked high enough
-// that output written by step s never reaches the compressed bytes of later steps (positions follow from the
-// half-tile table).  The element records live in the same buffer too, BELOW the parked input, where output only
-// arrives after every record has been read (a half-tile of c compressed bytes has at most c / 2 elements, so their
-// places follow from the table as well); fragments whose records do not fit there -- compressed to more than about
-// half -- keep them in the first bytes of their own output range in memory until production overwrites them.
-// 9.9 KiB per wave, 16 waves per CU (r02 first version: records in 4 KiB of their own, 11 waves).
+// LDS: the output ring (8 KiB) and the staged compressed bytes share one buffer -- the input is parked at its END,
+// where output written by step s never reaches the compressed bytes that later steps still read (checked per group).
+// The element records live in the same buffer too, BELOW the parked input, where output only arrives after every
+// record has been read; fragments whose records do not fit there -- hardly compressible ones -- keep them in the
+// first bytes of their own output range in memory until production overwrites them.
+// 9.9 KiB per wave, 16 waves per CU.
 // HBM traffic: compressed bytes read once, output written once (algorithmic bytes b(1 + c)).
 #include <hip/hip_runtime.h>
 #include <stdint.h>

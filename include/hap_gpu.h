@@ -29,13 +29,16 @@
  * granularity (1, 2 or 4 bytes) that every element of the streams honours.
  *
  * Section 0x46, version 1:  [1][log2 F][granularity log2][match window / 256 B][LE32 compressed size x fragments]
- *               version 2:  [2][13][granularity log2 | fields per block << 4][window][LE32 size x fragments]
- *                           [u8 compressed size x 64 half-tiles x fragments]
- * Version 2 ("field streams": DXT5 / YCoCg-DXT5 textures, 8 KiB fragments) adds the compressed size of every
- * 128-byte half-tile of output and promises that no element crosses a half-tile, that every element starts and
- * ends on a block field boundary (2 + 6 + 4 + 4 bytes) and that every copy offset is a whole number of blocks:
- * the decoder then parses 64 half-tiles at once and produces one block per lane.  Every promise is checked while
- * decoding; a frame whose table lies is decoded again without it.
+ *               version 3:  [3][13][granularity log2 | fields per block << 4][window][LE32 size x fragments]
+ *                           [96-byte group table x fragments]
+ * Version 3 ("field streams": block textures, 8 KiB fragments) adds, per fragment, the compressed bytes of 64
+ * groups of its elements -- the elements in stream order, ceil(N / 64) to a group, the last groups shorter or empty;
+ * 12 bits per group, packed little endian -- and promises that no element crosses a 128-byte half-tile of output,
+ * that every element starts and ends on a block field boundary (2 + 6 + 4 + 4, 4 + 4 or 2 + 6 bytes) and that every
+ * copy offset is a whole number of blocks: the decoder's 64 lanes then each walk one group -- the same number of
+ * elements -- and produce one block per lane.  Every promise is checked while decoding; a frame whose table lies is
+ * decoded again without it.  (Version 2, written by earlier builds, listed one size byte per half-tile; such tables
+ * are ignored, the frames decode like any other encoder's.)
  */
 #ifndef HAP_AMD_HAP_GPU_H
 #define HAP_AMD_HAP_GPU_H
@@ -63,8 +66,8 @@ typedef struct HapGpuContext HapGpuContext;
 
 /* Decode flags */
 #define HAPGPU_DECODE_IGNORE_FRAGMENT_INDEX 0x1u /* decode as a decoder unaware of section 0x46 would */
-#define HAPGPU_DECODE_IGNORE_HALF_TILES 0x2u     /* use a version-2 table's fragment sizes only (the generic
-                                                    fragment decoder), not its half-tile sizes: for A/B measurements */
+#define HAPGPU_DECODE_IGNORE_HALF_TILES 0x2u     /* use a version-3 table's fragment sizes only (the generic
+                                                    fragment decoder), not its group tables: for A/B measurements */
 #define HAPGPU_DECODE_NO_BLOCK_SCAN 0x4u         /* decode other encoders' Snappy streams with one wavefront per
                                                     stream instead of looking for their 64 KiB blocks first: for A/B
                                                     measurements (environment HAP_AMD_NO_BLOCK_SCAN does the same) */
@@ -222,7 +225,7 @@ unsigned int HapGpuJoinChunkGroups(unsigned int groupCount,
 
 /* The same join for group frames AND output in HIP device memory of `context`'s device (band frames that arrived
  * over xGMI): the groups' headers and tables are read through the host, the joined frame's headers are made there and
- * uploaded, every table and payload byte moves device to device.  Version-2 fragment tables (half-tile sizes) are
+ * uploaded, every table and payload byte moves device to device.  Version-3 fragment tables (group tables) are
  * carried over by both joins when every group has one with the same block layout, so a joined frame decodes through
  * the block-per-lane kernel like its parts.  Bad_Arguments for host pointers. */
 unsigned int HapGpuJoinChunkGroupsDevice(HapGpuContext *context, unsigned int groupCount,

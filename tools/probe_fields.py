@@ -1,4 +1,4 @@
-"""GPU probe for the field-stream path (fragment table version 2): parity of the new decoder against the block
+"""GPU probe for the field-stream path (fragment table version 3): parity of the new decoder against the block
 encoder's output and the CPU checker, sizes with / without half-tile splitting, kernel times of both decoders.
     python tools/probe_fields.py [C4|C3|C5] [frames]"""
 import os
@@ -58,7 +58,7 @@ for flags, name in ((0, "fields"), (hap_amd.DECODE_IGNORE_HALF_TILES, "generic-f
                 p = int(bad[0]) & ~15
                 print("   got ", a[p:p + 32].tobytes().hex())
                 print("   want", b[p:p + 32].tobytes().hex())
-# the CPU checker decodes the frame with the version-2 table unchanged
+# the CPU checker decodes the frame with the version-3 table unchanged
 frame = frames[0][: used[0]].cpu().numpy()
 api = L.ref_api() or L.oracle_api()
 for t in range(len(fmts)):
