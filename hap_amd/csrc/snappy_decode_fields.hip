@@ -208,10 +208,10 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
         fail_unit(job, lane);
         return;
     }
-    // The input is parked at the END of the buffer: output written by step s then never reaches compressed bytes that
-    // later steps still read as literals, as long as what is left of the input at any point fits between the output
-    // produced so far and the end of the buffer -- true for every honest stream (<= 130 bytes per half-tile), and
-    // verified per group below.
+    // The input is parked at the END of the buffer: output written by the steps before step s then never reaches the
+    // compressed bytes that step s reads as literals, as long as what is left of the input at any point fits between the
+    // output produced so far and the end of the buffer -- true for every honest stream (<= 130 bytes per half-tile),
+    // and verified element by element in the walk below.
     const unsigned S = ((kBufBytes - 16u - total - shift) & ~15u) + shift;                 // S = shift (mod 16)
     {
         // (every lane stores only granules that hold input)
@@ -256,10 +256,9 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
     const unsigned elements = (unsigned)__builtin_amdgcn_readlane((int)nincl, 63);
     {
         // the output adds up; every element is at least two bytes (a field), so the records (2 bytes each) fit the
-        // unit's own output range if they have to go to memory; the parked input stays ahead of the output (see S)
-        const bool unsafe = (total - coff) + (oincl < kFragBytes ? oincl : kFragBytes) > kBufBytes - 16u;
+        // unit's own output range if they have to go to memory
         if ((unsigned)__builtin_amdgcn_readlane((int)oincl, 63) != out_len || 2u * elements > out_len ||
-            __builtin_amdgcn_ballot_w64(out_g > kFragBytes || (gsz != 0u && unsafe)) != 0ull) {
+            __builtin_amdgcn_ballot_w64(out_g > kFragBytes) != 0ull) {
             fail_unit(job, lane);
             return;
         }
@@ -285,6 +284,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
         int max_reach = 0;                                 // how far before the fragment the farthest copy reaches
         unsigned min_off = 0xFFFFFu, max_up = 0;           // smallest copy offset, largest literal length code
         unsigned crossed = 0;                              // an element that leaves its half-tile
+        unsigned overrun = 0;                              // an element whose bytes the output of earlier steps would reach
         uint32_t *const mask_words = reinterpret_cast<uint32_t *>(masks);
         // (two typed pointers and a uniform branch at the store: one pointer chosen between LDS and memory would make
         // every record a flat store)
@@ -314,6 +314,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
                 max_kind = max(max_kind, kind);
                 max_reach = max(max_reach, (int)(offx & 0xFFFFu) - (int)p);     // > 0: a copy from before the fragment
                 crossed |= (hp + lm1) >> 7;
+                overrun |= (p & ~(kStepBytes - 1u)) > cp ? 1u : 0u;            // the steps before this one write up to there
                 {
                     const uint16_t record = (uint16_t)(is_lit ? litrec : off >> kRecShift);
                     if (rec_in_lds)
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
         // masks (checked below, per half-tile)
         const bool bad = max_kind == 3u || max_reach > 0 || (acc_or & (kBlock - 1u)) != 0u ||
                          ((acc_or >> 17) & ((1u << kPosShift) - 1u)) != 0u || min_off < kBlock || max_up > 60u ||
-                         crossed != 0u || cp != cend || p != obegin + out_g;
+                         crossed != 0u || overrun != 0u || cp != cend || p != obegin + out_g;
         if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
             fail_unit(job, lane);
             return;

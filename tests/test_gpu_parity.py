@@ -1364,6 +1364,15 @@ def test_field_stream_promises_are_checked_on_hand_made_streams(ctx, hap):
     rc, expect, _f = ORA.decode(data, 0, 8192)
     assert rc == 0 and hap.HapDecode(data, 0, outputBufferBytes=8192) == (0, expect, L.FMT_DXT5)
     assert through_context(data) == (0, 0, expect, 0)
+    # ... and a stream that is too much for that buffer: 2 KiB of output from a few bytes, then every field its own
+    # literal (160 bytes per half-tile, more than any honest encoder writes): the output of the first steps would reach
+    # literal bytes before they are read.  Noticed per element; the generic kernels decode it.
+    def field_literals(seed):
+        r2 = np.random.default_rng(seed)
+        return [lit(r2.integers(0, 256, n, dtype=np.uint8).tobytes()) for _b in range(8) for n in (2, 6, 4, 4)]
+    lies["input the output would overrun"] = frame_of(
+        [[lit(rng.integers(0, 256, 16, dtype=np.uint8).tobytes()), copy2(64, 16), copy2(48, 16)]] +
+        [[copy2(64, 128), copy2(64, 128)] for _ in range(15)] + [field_literals(300 + h) for h in range(48)])
     for name, data in lies.items():
         rc, expect, _f = ORA.decode(data, 0, 8192)
         got = hap.HapDecode(data, 0, outputBufferBytes=8192)
