@@ -26,4 +26,4 @@ for _ in range(n):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 prof = {k: round(v[1] / max(v[0], 1), 3) for k, v in ctx.collect_profile().items() if v[0]}
-print(os.environ.get("HAP_AMD_LIBRARY", "default").split("/")[-1], cfg, "encode call ms %.3f" % (dt * 1e3), prof, "slot encodes", ctx.slot_encodes())
+print(os.environ.get("HAP_AMD_LIBRARY", "default").split("/")[-1], cfg, "encode call ms %.3f" % (dt * 1e3), prof)
