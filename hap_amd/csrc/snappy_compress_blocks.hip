@@ -186,6 +186,7 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
     constexpr unsigned B = UL::block;
     __shared__ unsigned long long table[1u << kTableBits];
     __shared__ __attribute__((aligned(16))) uint32_t masks[64u * 8u];
+    __shared__ uint16_t bounds[66];                      // stream offset of every group's first element (+ the end)
 
     const unsigned lane = threadIdx.x;
     const HapGpuTexEnc tex = frames[blockIdx.z].tex[blockIdx.y < 2u ? blockIdx.y : 0u];
@@ -313,6 +314,17 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
     }
     __syncthreads();
 
+    // (the table has served: its first half now holds the candidates of every unit, for the lanes that will write the
+    // elements; its second half, cleared here, one byte per element: which half-tile it belongs to)
+    {
+        uint32_t *hd_tab = reinterpret_cast<uint32_t *>(table);
+#pragma unroll
+        for (unsigned s = 0; s < kSteps; s++)
+            hd_tab[64u * s + lane] = HD[s];
+        uint4 *marker16 = reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(table) + 2048u);
+        marker16[2u * lane] = make_uint4(0, 0, 0, 0);
+        marker16[2u * lane + 1u] = make_uint4(0, 0, 0, 0);
+    }
     // ---- 2. choose: lane = half-tile ----
     unsigned counts_and_bytes = 0;          // inclusive scan over the half-tiles: elements << 16 | bytes (for the group table)
     {
@@ -374,15 +386,16 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
         const unsigned incl = both & 0xFFFFu;
         const unsigned base = incl - total;
         *reinterpret_cast<uint4 *>(&masks[lane * 8u]) = make_uint4(S, L, X3, D0);
-        *reinterpret_cast<uint4 *>(&masks[lane * 8u + 4u]) = make_uint4(D1, Hm, Sx1, base);
+        *reinterpret_cast<uint4 *>(&masks[lane * 8u + 4u]) = make_uint4(D1, Hm, Sx1, base | (((both >> 16) - count) << 16));
         if (lane == 63u)
             frag_sizes[f] = incl;
         counts_and_bytes = both;
     }
     __syncthreads();
 
-    // ---- 3. emit: lane = unit ----
-    // (values are formed without lane-varying branches; only the stores themselves are predicated)
+    // ---- 3a. emit the literal bytes: lane = unit ----
+    // popcounts of the masks below the unit give its output offset; a field that is part of a literal run stores its
+    // bytes behind the headers and bytes of what comes before it (only the stores are predicated)
     const unsigned j4 = 4u * (lane & 7u);
     const unsigned below = (1u << j4) - 1u;
 #pragma unroll
@@ -391,46 +404,16 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
             continue;
         const unsigned hh = 8u * s + (lane >> 3);
         const uint4 ma = *reinterpret_cast<const uint4 *>(&masks[hh * 8u]);
-        const uint4 mb = *reinterpret_cast<const uint4 *>(&masks[hh * 8u + 4u]);
-        const unsigned S = ma.x, L = ma.y, X3 = ma.z, D0 = ma.w, D1 = mb.x, Hm = mb.y, Sx1 = mb.z;
-        const unsigned CS = S & ~L;
-        unsigned off = mb.w + 4u * popc(L & below) + 2u * popc(L & UL::big32 & below) - 2u * popc(L & UL::small32 & below) +
-                       popc(S & below) + popc(CS & below) + popc(X3 & below);
-        const unsigned sj = S >> j4, lj = L >> j4, xj = X3 >> j4, d0j = D0 >> j4, d1j = D1 >> j4, hj = Hm >> j4, nj = Sx1 >> j4;
-        const unsigned third = sj & ~lj & xj;              // copy-2 elements: a third byte
+        const unsigned S = ma.x, L = ma.y, X3 = ma.z, CS = S & ~L;
+        unsigned off = (masks[hh * 8u + 7u] & 0xFFFFu) + 4u * popc(L & below) + 2u * popc(L & UL::big32 & below) -
+                       2u * popc(L & UL::small32 & below) + popc(S & below) + popc(CS & below) + popc(X3 & below);
+        const unsigned sj = S >> j4, lj = L >> j4, xj = X3 >> j4;
         const uint4 xs = X[s];
         const unsigned fw[4] = {xs.x, LAYOUT == 2u ? xs.y : xs.x >> 16, xs.z, LAYOUT == 4u ? xs.w : LAYOUT == 2u ? xs.w : xs.z >> 16};
 #pragma unroll
         for (unsigned k = 0; k < 4u; k++) {
             const unsigned is_s = bit_mask(sj, k), is_l = bit_mask(lj, k), x3 = bit_mask(xj, k);
-            // bytes from this field to the next start: 4 per field, corrected by where the two fields sit in their units
-            const unsigned c = (unsigned)__builtin_ctz(nj >> k);              // fields in between (the mask ends with a set bit)
-            unsigned len4 = 4u * (4u * c + 4u + (4u * k - UL::fo(k)));        // ... times 4, for the tags
-            if (LAYOUT == 4u)
-                len4 -= 8u - 8u * nonzero((c + k) & 3u);                      // the next start is a field 1
-            else if (LAYOUT == 6u)
-                len4 -= 8u * ((c + k + 1u) & 1u);                             // ... an odd field
-            // literal run: tag = len - 1 (60 = one length byte follows); the first data byte rides along, so that every
-            // start stores 16 bits
-            const unsigned lit = bfi(x3, (len4 << 6) - 0x10u, (len4 - 4u) | ((fw[k] & 0xFFu) << 8));
-            // copy: copy-2 tag 2 | (len - 1) << 2, offset in the next two bytes; copy-1 (len 4..11, offset < 2048):
-            // tag 1 | (len - 4) << 2 | (offset >> 8) << 5, then the offset's low byte
-            unsigned dist = 1u + ((d0j >> k) & 1u) + 2u * ((d1j >> k) & 1u);
-            unsigned near_high = 0;
-            if (k & 1u) {
-                const unsigned h = bit_mask(hj, k);
-                const unsigned hd = (HD[s] >> (8u * (k - 1u))) & 0xFFFFu;
-                dist = bfi(h, hd, dist);
-                near_high = (((hd * B) >> 8) << 5) & h;
-            }
-            const unsigned c2 = len4 + (dist * B << 8) - 2u;
-            const unsigned cpy = c2 - (13u & ~x3) + (near_high & ~x3);
-            const unsigned v = bfi(is_l, lit, cpy);
-            if (is_s)
-                put16(out + off, v);
-            if (bit_mask(third, k))
-                put8(out + off + 2, v >> 16);
-            // element bytes: literal header 1 (+1), copy 2 (+1)
+            // element bytes in front of the field's own: literal header 1 (+1), copy 2 (+1)
             off += is_s & ((is_l & 1u) + (~is_l & 2u) + (x3 & 1u));
             if (is_l) {
                 if (UL::fs(k) == 2u) {
@@ -446,56 +429,100 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
         }
     }
 
-    // ---- 4. the group table (fragment table version 3) ----
-    // The elements in stream order in 64 groups of G = ceil(N / 64); entry g = the bytes of group g -- where the
-    // decoder's lane g starts reading.  Lane = half-tile first: it tells every group that begins inside it where to
-    // look; then lane = group: the stream offset of its first element from that half-tile's masks (the bytes of the
-    // elements below it, as in phase 3).  (Done last: nothing of phases 1 and 3 is live any more.)
-    if (want_sizes) {
-        uint32_t *owner = reinterpret_cast<uint32_t *>(table);                 // (the table is not used after phase 1)
+    // ---- 3b. emit the elements' tags: lane = element, 64 at a time in stream order ----
+    // The half-tile of element e: every half-tile marked the place of its first element; a running maximum over the
+    // markers is the half-tile.  Its masks then give the element's field (set bit number e - first of S), its stream
+    // offset (the bytes of what lies below), its length (fields up to the next start) and its kind.  The elements whose
+    // ordinal is a multiple of G = ceil(N / 64) begin the groups of the fragment table (version 3): their offsets go to
+    // bounds[].
+    {
         const unsigned both = counts_and_bytes;
         const unsigned stream_bytes = (unsigned)__builtin_amdgcn_readlane((int)both, 63) & 0xFFFFu;
         const unsigned elements = (unsigned)__builtin_amdgcn_readlane((int)both, 63) >> 16;        // >= 1
         const unsigned G = (elements + 63u) >> 6;
+        const unsigned inv = (1u << 20) / G + 1u;                              // x / G = (x inv) >> 20 for x < 2^11 + 32
+        uint8_t *marker = reinterpret_cast<uint8_t *>(table) + 2048u;
+        const uint32_t *hd_tab = reinterpret_cast<const uint32_t *>(table);
         {
-            const unsigned count = popc(masks[lane * 8u]);
-            const unsigned first = (both >> 16) - count;                       // ordinal of the half-tile's first element
-            const unsigned inv = (1u << 20) / G + 1u;                          // x / G = (x inv) >> 20 for x < 2^11 + 32
-            unsigned m = ((first + G - 1u) * inv) >> 20;
-#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-            for (unsigned b = m * G; b < first + count; b += G, m++)
-                owner[m] = lane | (first << 8);
+            const unsigned word7 = masks[lane * 8u + 7u];
+            if (masks[lane * 8u] != 0u)                                        // (a half-tile with elements)
+                marker[word7 >> 16] = (uint8_t)(lane + 1u);
+            bounds[lane] = (uint16_t)stream_bytes;                             // (groups beyond the last element: empty)
+            if (lane < 2u)
+                bounds[64u + lane] = (uint16_t)stream_bytes;
         }
         __syncthreads();
-        unsigned bound = stream_bytes;                                         // (groups beyond the last element: empty)
-        if (lane * G < elements) {
-            const unsigned o = owner[lane], h = o & 63u;
-            const uint4 ma = *reinterpret_cast<const uint4 *>(&masks[h * 8u]);
-            const unsigned S = ma.x, L = ma.y, X3 = ma.z, CS = S & ~L, base = masks[h * 8u + 7u];
-            // position of set bit number (ordinal - the half-tile's first ordinal) of S
-            unsigned r = lane * G - (o >> 8), q = 0, c = popc(S & 0xFFFFu);
-            if (r >= c) { q = 16u; r -= c; }
-            c = popc((S >> q) & 0xFFu);
-            if (r >= c) { q += 8u; r -= c; }
-            c = popc((S >> q) & 0xFu);
-            if (r >= c) { q += 4u; r -= c; }
-            c = popc((S >> q) & 0x3u);
-            if (r >= c) { q += 2u; r -= c; }
-            if (r >= ((S >> q) & 1u))
-                q += 1u;
-            const unsigned under = (1u << q) - 1u;
-            bound = base + 4u * popc(L & under) + 2u * popc(L & UL::big32 & under) - 2u * popc(L & UL::small32 & under) +
-                    popc(S & under) + popc(CS & under) + popc(X3 & under);
+        constexpr unsigned FO = LAYOUT == 4u ? 0x0C080200u : LAYOUT == 2u ? 0x0C080400u : 0x0A080200u;   // fo(k), a byte each
+        unsigned carry = 0;                                                    // half-tile (+ 1) of the element before the pass
+#pragma unroll 1
+        for (unsigned e0 = 0; e0 < elements; e0 += 64u) {
+            const unsigned e = e0 + lane;
+            int own = e < elements ? (int)marker[e] : 0;
+            own = max(own, __builtin_amdgcn_update_dpp(own, own, 0x111, 0xF, 0xF, false));     // running maximum over the lanes
+            own = max(own, __builtin_amdgcn_update_dpp(own, own, 0x112, 0xF, 0xF, false));
+            own = max(own, __builtin_amdgcn_update_dpp(own, own, 0x114, 0xF, 0xF, false));
+            own = max(own, __builtin_amdgcn_update_dpp(own, own, 0x118, 0xF, 0xF, false));
+            own = max(own, __builtin_amdgcn_update_dpp(own, own, 0x142, 0xA, 0xF, false));     // row_bcast:15 -> rows 1, 3
+            own = max(own, __builtin_amdgcn_update_dpp(own, own, 0x143, 0xC, 0xF, false));     // row_bcast:31 -> rows 2, 3
+            own = max(own, (int)carry);
+            carry = (unsigned)__builtin_amdgcn_readlane(own, 63);
+            if (e < elements) {
+                const unsigned h = (unsigned)own - 1u;
+                const uint4 ma = *reinterpret_cast<const uint4 *>(&masks[h * 8u]);
+                const uint4 mb = *reinterpret_cast<const uint4 *>(&masks[h * 8u + 4u]);
+                const unsigned S = ma.x, L = ma.y, X3 = ma.z, D0 = ma.w, D1 = mb.x, Hm = mb.y, Sx1 = mb.z, CS = S & ~L;
+                // position of set bit number (e - the half-tile's first ordinal) of S
+                unsigned r = e - (mb.w >> 16), q = 0, c = popc(S & 0xFFFFu);
+                if (r >= c) { q = 16u; r -= c; }
+                c = popc((S >> q) & 0xFFu);
+                if (r >= c) { q += 8u; r -= c; }
+                c = popc((S >> q) & 0xFu);
+                if (r >= c) { q += 4u; r -= c; }
+                c = popc((S >> q) & 0x3u);
+                if (r >= c) { q += 2u; r -= c; }
+                if (r >= ((S >> q) & 1u))
+                    q += 1u;
+                const unsigned under = (1u << q) - 1u;
+                const unsigned off = (mb.w & 0xFFFFu) + 4u * popc(L & under) + 2u * popc(L & UL::big32 & under) -
+                                     2u * popc(L & UL::small32 & under) + popc(S & under) + popc(CS & under) + popc(X3 & under);
+                // bytes from this field to the next start (the mask ends with a set bit)
+                const unsigned qn = q + 1u + (unsigned)__builtin_ctz(Sx1 >> q);
+                const unsigned len = (qn >> 2) * 16u + ((FO >> (8u * (qn & 3u))) & 0xFFu) - (q >> 2) * 16u - ((FO >> (8u * (q & 3u))) & 0xFFu);
+                const bool is_l = ((L >> q) & 1u) != 0u, x3 = ((X3 >> q) & 1u) != 0u;
+                // literal run: tag = len - 1 (60 = one length byte follows)
+                // copy: copy-2 tag 2 | (len - 1) << 2, offset in the next two bytes; copy-1 (len 4..11, offset < 2048):
+                // tag 1 | (len - 4) << 2 | (offset >> 8) << 5, then the offset's low byte
+                unsigned dist = 1u + ((D0 >> q) & 1u) + 2u * ((D1 >> q) & 1u);
+                if ((Hm >> q) & 1u)
+                    dist = (hd_tab[h * 8u + (q >> 2)] >> (8u * (q & 2u))) & 0xFFFFu;        // (index fields are k = 1, 3)
+                const unsigned offset = dist * B;
+                const unsigned lit = x3 ? 0xF0u | ((len - 1u) << 8) : (len - 1u) << 2;
+                const unsigned cpy = x3 ? 2u | ((len - 1u) << 2) | (offset << 8)
+                                        : 1u | ((len - 4u) << 2) | ((offset >> 8) << 5) | ((offset & 0xFFu) << 8);
+                const unsigned v = is_l ? lit : cpy;
+                if (is_l && !x3)
+                    put8(out + off, v);
+                else
+                    put16(out + off, v);
+                if (!is_l && x3)
+                    put8(out + off + 2, v >> 16);
+                const unsigned m = (e * inv) >> 20;
+                if (m * G == e)
+                    bounds[m] = (uint16_t)off;
+            }
         }
-        // 12 bits per group, two groups in three bytes
-        // (the shuffle on its own line: inside the conditional it would run without lane 63, whose value lane 62 reads)
-        const unsigned above = (unsigned)__shfl_down((int)bound, 1);
-        const unsigned size = (lane == 63u ? stream_bytes : above) - bound;
-        const unsigned pair = size | ((unsigned)__shfl_down((int)size, 1) << 12);
-        if ((lane & 1u) == 0u) {
-            const gdst_t at = (gdst_t)((uintptr_t)tile_sizes + (size_t)f * HAP_GROUP_TABLE_BYTES + (lane >> 1) * 3u);
-            put16(at, pair);
-            put8(at + 2, pair >> 16);
+        __syncthreads();
+        if (want_sizes) {
+            // 12 bits per group, two groups in three bytes
+            const unsigned size = (unsigned)bounds[lane + 1u] - (unsigned)bounds[lane];
+            // (the shuffle on its own line: inside a conditional it would run without the lanes the others read)
+            const unsigned above = (unsigned)__shfl_down((int)size, 1);
+            const unsigned pair = size | (above << 12);
+            if ((lane & 1u) == 0u) {
+                const gdst_t at = (gdst_t)((uintptr_t)tile_sizes + (size_t)f * HAP_GROUP_TABLE_BYTES + (lane >> 1) * 3u);
+                put16(at, pair);
+                put8(at + 2, pair >> 16);
+            }
         }
     }
 }
