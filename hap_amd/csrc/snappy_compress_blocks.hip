@@ -24,12 +24,13 @@
 //      the longest chain of touching copies (1.2 on average), not once per element.  Start, literal, "one more
 //      byte" and distance masks, the half-tile's compressed size (popcounts) and -- one DPP scan -- its offset in
 //      the fragment go back to LDS.
-//   3. EMIT, lane = unit, 8 steps: popcounts of the masks below the unit give its output offset; each of its 4
-//      fields forms its element bytes (header / copy tag from the distance to the next start bit) and stores
-//      them and its literal bytes at their final place.
-//   4. GROUP TABLE, lane = group: the N elements of the fragment in 64 groups of ceil(N / 64); a group's first element
-//      lies in one half-tile, whose masks give its stream offset (popcounts again); differences of neighbours are
-//      the 12-bit entries.
+//   3. EMIT.  a: lane = unit, 8 steps: popcounts of the masks below the unit give its output offset; fields of
+//      literal runs store their bytes at their final place.  b: lane = ELEMENT, 64 at a time in stream order (a fifth
+//      of the fields start an element: a tag per field, predicated away, was half the kernel): a running maximum over
+//      one marker per half-tile finds the element's half-tile, whose masks give field, stream offset, length and kind;
+//      one to three tag bytes per element.
+//   4. GROUP TABLE: the N elements of the fragment in 64 groups of ceil(N / 64); the first element of every group
+//      leaves its stream offset behind during 3b; differences of neighbours are the 12-bit entries.
 //
 // HBM traffic: texture read once (the neighbour loads hit L1 / L2), compressed bytes written once.
 #include <hip/hip_runtime.h>
