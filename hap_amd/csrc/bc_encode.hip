@@ -50,29 +50,27 @@ __device__ __forceinline__ uint2 alpha_block(const int (&a)[16])
         lo = min(lo, a[i]);
         hi = max(hi, a[i]);
     }
-    const int inset = (hi - lo) >> 5;
-    const int a0 = hi - inset, a1 = lo + inset;
+    const int a0 = hi, a1 = lo;            // (the exact range: every pixel lies on the ramp, no position needs clamping)
     unsigned lo24 = 0, hi24 = 0;       // 3-bit codes of pixels 0..7 and 8..15
     if (a0 != a1) {
-        // oracle/bc_oracle.c: with d = a0 - a1 and u = a0 - a clamped to 0..d, the ramp position is
+        // oracle/bc_oracle.c: with d = a0 - a1 and u = a0 - a (0..d), the ramp position is
         // r = ((14 u + max(d - 6, 0)) * m) >> 20, m = floor(2^19 / d) + 1 -- the pixel's place on the ramp rounded to
         // the nearest of its 8 steps (x * m >> 20 = x / 2d), thresholds moved by the 3/7 the decoder's steps are
-        // rounded down on average.  Per pixel: subtract, clamp, one multiply-add, shift, code, insert.
+        // rounded down on average; 0..7 by construction.  Per pixel: one multiply-add, shift, code, insert.
         const int d = a0 - a1;
         // floor(2^19 / d): the reciprocal from v_rcp_f32, made exact
         unsigned q = (unsigned)(524288.0f * __builtin_amdgcn_rcpf((float)d));
         const int rem = 524288 - (int)__umul24(q, (unsigned)d);
         q += (rem >= d ? 1u : 0u) - (rem < 0 ? 1u : 0u);
         const unsigned m = q + 1u;
-        // x = (14 (a0 - a) + bias) m as one multiply-add in a; positions of pixels beyond the endpoints (the inset)
-        // come out below 0 / above 7 and are clamped afterwards, which is what clamping u to 0..d first gives
+        // x = (14 (a0 - a) + bias) m as one multiply-add in a
         const int neg_m14 = -(int)(14u * m);                             // |.| < 2^23
         const int start = mad24(a0, (int)(14u * m), (int)__umul24((unsigned)max(d - 6, 0), m));
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const int r = min(max(mad24(a[i], neg_m14, start) >> 20, 0), 7);
+            const unsigned r = (unsigned)mad24(a[i], neg_m14, start) >> 20;
             // ramp position -> S3TC code: 0->0, 7->1, r->r+1 (byte table 00 02 03 04 | 05 06 07 01, one v_perm)
-            const unsigned code = __builtin_amdgcn_perm(0x01070605u, 0x04030200u, (unsigned)r);
+            const unsigned code = __builtin_amdgcn_perm(0x01070605u, 0x04030200u, r);
             // three bits in from the top: after 8 pixels the codes occupy bits 31:8, pixel 0 lowest
             if (i < 8)
                 lo24 = __builtin_amdgcn_alignbit(code, lo24, 3);

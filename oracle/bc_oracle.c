@@ -31,8 +31,8 @@
  *     c0==c1  -> all indices 0
  *
  *   alpha block (DXT5 alpha half, RGTC1, Y of YCoCg)
- *     inset = (hi-lo)>>5 ; a0 = hi-inset ; a1 = lo+inset
- *     a0==a1 -> indices 0, else d = a0-a1, u = clamp(a0-a, 0, d),
+ *     a0 = hi ; a1 = lo   (the exact range, as stb_dxt / DirectXTex do for ramps: every pixel lies on the ramp)
+ *     a0==a1 -> indices 0, else d = a0-a1, u = a0-a,
  *     ramp position r = (14u + max(d-6,0)) / 2d (floor), code = r==0?0 : r==7?1 : r+1
  *
  *   YCoCg: Y=(R+2G+B+2)>>2, Co=clamp(((R-B+1)>>1)+128), Cg=clamp(((-R+2G-B+2)>>2)+128)
@@ -58,15 +58,14 @@ static void store32(uint8_t *p, uint32_t v) { store16(p, v & 0xFFFF); store16(p 
 /* alpha-style block: 2 endpoint bytes + 48 bits of 3-bit codes */
 static void alpha_block(const int a[16], uint8_t out[8])
 {
-    int lo = 255, hi = 0, i, inset, a0, a1;
+    int lo = 255, hi = 0, i, a0, a1;
     uint64_t bits = 0;
     for (i = 0; i < 16; i++) {
         lo = imin(lo, a[i]);
         hi = imax(hi, a[i]);
     }
-    inset = (hi - lo) >> 5;
-    a0 = hi - inset;
-    a1 = lo + inset;
+    a0 = hi;
+    a1 = lo;
     if (a0 != a1) {
 #ifdef OBC_EXACT_NEAREST
         int q[8], j;
@@ -85,7 +84,7 @@ static void alpha_block(const int a[16], uint8_t out[8])
         const int d = a0 - a1, bias = d > 6 ? d - 6 : 0;
         const uint32_t m = (1u << 19) / (uint32_t)d + 1u;      /* (x * m) >> 20 = x / 2d, the kernel's fixed point */
         for (i = 0; i < 16; i++) {
-            const int u = a0 - a[i] < 0 ? 0 : a0 - a[i] > d ? d : a0 - a[i];
+            const int u = a0 - a[i];                             /* 0 .. d: r comes out in 0 .. 7 */
             const int r = (int)(((uint32_t)(14 * u + bias) * m) >> 20);
             bits |= (uint64_t)(r == 0 ? 0 : r == 7 ? 1 : r + 1) << (3 * i);
         }
