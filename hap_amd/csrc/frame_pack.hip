@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64) void frame_chunk_sums_kernel(const HapGpuFrameE
 // 2. one workgroup per frame: store-raw decisions, chunk positions (prefix sums over the chunk sizes of kernel 1),
 //    every header and table except the per-fragment entries
 __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames, unsigned frag_log2,
-                                                         const uint8_t *__restrict__ tile_sizes,
+                                                         const uint8_t *__restrict__ group_tables,
                                                          HapGpuCopyEntry *__restrict__ copies, unsigned extra_first,
                                                          ChunkPack *__restrict__ packs, unsigned chunks_per_frame)
 {
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
         if (tex.compressor == 1u) {
             const unsigned vlen = varint_len(cb);
             // fragment table version 3 (field streams): + a 96-byte group table per fragment
-            const bool with_tiles = tex.emit_index && ((tex.reserved >> 20) & 1u) != 0u && tile_sizes != nullptr;
+            const bool with_tiles = tex.emit_index && ((tex.reserved >> 20) & 1u) != 0u && group_tables != nullptr;
             const unsigned index_len = tex.emit_index ? 8u + (with_tiles ? 4u + HAP_GROUP_TABLE_BYTES : 4u) * n * fpc : 0u;
             const unsigned ilen = 5u * n + 8u + index_len;
             // pass 1: total stored payload
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
                         // the group tables follow the fragment sizes: one move per chunk (consecutive fragments)
                         HapGpuCopyEntry e;
                         e.reserved = 0;
-                        e.src = (uint64_t)(tile_sizes + (size_t)(tex.frag_first + i * fpc) * HAP_GROUP_TABLE_BYTES);
+                        e.src = (uint64_t)(group_tables + (size_t)(tex.frag_first + i * fpc) * HAP_GROUP_TABLE_BYTES);
                         e.dst = (uint64_t)(itab + 8u + 4u * n * fpc + (size_t)i * fpc * HAP_GROUP_TABLE_BYTES);
                         e.len = with_tiles ? fpc * HAP_GROUP_TABLE_BYTES : 0u;
                         copies[extra_at + i] = e;
@@ -348,7 +348,7 @@ extern "C" unsigned hapgpu_pack_scratch_bytes_per_chunk(void) { return (unsigned
 
 extern "C" int hapgpu_launch_frame_pack(HapGpuFrameEnc *frames, unsigned frame_count, unsigned frag_log2,
                                         const void *slots, unsigned slot_stride, const uint32_t *frag_sizes,
-                                        const uint8_t *tile_sizes, HapGpuCopyEntry *copies, unsigned extra_first,
+                                        const uint8_t *group_tables, HapGpuCopyEntry *copies, unsigned extra_first,
                                         unsigned chunks_per_frame, unsigned max_chunks_per_texture, unsigned textures,
                                         void *pack_scratch, hipStream_t stream)
 {
@@ -359,7 +359,7 @@ extern "C" int hapgpu_launch_frame_pack(HapGpuFrameEnc *frames, unsigned frame_c
     ChunkPack *packs = (ChunkPack *)pack_scratch;
     const dim3 per_chunk(max_chunks_per_texture, textures, frame_count);
     hipLaunchKernelGGL(frame_chunk_sums_kernel, per_chunk, dim3(64), 0, stream, frames, frag_sizes, packs, chunks_per_frame);
-    hipLaunchKernelGGL(frame_pack_kernel, dim3(frame_count), dim3(256), 0, stream, frames, frag_log2, tile_sizes, copies,
+    hipLaunchKernelGGL(frame_pack_kernel, dim3(frame_count), dim3(256), 0, stream, frames, frag_log2, group_tables, copies,
                        extra_first, packs, chunks_per_frame);
     hipLaunchKernelGGL(frame_moves_kernel, per_chunk, dim3(64), 0, stream, frames, frag_log2, (const uint8_t *)slots,
                        slot_stride, frag_sizes, copies, packs, chunks_per_frame);

@@ -21,7 +21,7 @@ enum {
     D_FRAMES = 0, D_SLOTS, D_FRAGSIZES, D_COPIES, D_TEX_STAGE, D_FRAME_STAGE, D_BC_TEX, D_RGBA_STAGE,
     D_JOBS, D_CHUNKS, D_UNITS, D_IN_STAGE, D_OUT_STAGE, D_PTRS, D_PREFIX, D_BC_PTRS
 };
-#define D_TILESIZES D_PTRS   /* encode-only arenas in decode-only slots: one call never needs both */
+#define D_GROUPTABLES D_PTRS   /* encode-only arenas in decode-only slots: one call never needs both */
 #define D_PACK D_PREFIX
 #define D_SCAN D_SLOTS       /* ... and the decoder's block-scan arena in an encode-only one */
 #define P_SCAN P_FRAMES
@@ -53,7 +53,7 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
     unsigned i, f, first_error = HapResult_No_Error;
     unsigned outer_header = 0, frags_per_frame = 0, max_frags_per_tex = 0, live = 0, chunks_per_frame = 0;
     int any_half_tiles = 0;
-    uint8_t *dtilesizes = NULL;
+    uint8_t *dgrouptables = NULL;
     void *dpack = NULL;
     unsigned max_chunks_per_tex = 0;
     /* HAPGPU_ENCODE_SMALLER_FILES: 64 KiB fragments (a match may lie 64 KiB back, like libsnappy's), elements on
@@ -268,12 +268,12 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
     dcopies = (HapGpuCopyEntry *)hapgpu_rt_device_scratch(rt, D_COPIES, sizeof(HapGpuCopyEntry) * ((size_t)frags_per_frame + chunks_per_frame) * live);
     dpack = hapgpu_rt_device_scratch(rt, D_PACK, (size_t)hapgpu_pack_scratch_bytes_per_chunk() * chunks_per_frame * live);
     if (any_half_tiles)
-        dtilesizes = (uint8_t *)hapgpu_rt_device_scratch(rt, D_TILESIZES, (size_t)HAP_GROUP_TABLE_BYTES * frags_per_frame * live);
+        dgrouptables = (uint8_t *)hapgpu_rt_device_scratch(rt, D_GROUPTABLES, (size_t)HAP_GROUP_TABLE_BYTES * frags_per_frame * live);
     if (stage_in_bytes)
         tex_stage = (uint8_t *)hapgpu_rt_device_scratch(rt, D_TEX_STAGE, stage_in_bytes);
     if (stage_out_bytes)
         out_stage = (uint8_t *)hapgpu_rt_device_scratch(rt, D_FRAME_STAGE, stage_out_bytes);
-    if (!hframes || !dframes || (any_snappy && !dslots) || !dfragsizes || !dcopies || !dpack || (any_half_tiles && !dtilesizes) ||
+    if (!hframes || !dframes || (any_snappy && !dslots) || !dfragsizes || !dcopies || !dpack || (any_half_tiles && !dgrouptables) ||
         (stage_in_bytes && !tex_stage) || (stage_out_bytes && !out_stage)) {
         free(live_index); free(stage_off_in); free(stage_off_out);
         for (f = 0; f < frame_count; f++)
@@ -368,8 +368,8 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
                 launch_rc |= (unsigned)hapgpu_rt_h2d(rt, dframes, hframes, sizeof(HapGpuFrameEnc) * live);
                 if (any_snappy)
                     launch_rc |= (unsigned)hapgpu_k_snappy_compress(rt, dframes, live, max_frags_per_tex, frag_log2, dslots, slot_stride,
-                                                                    dfragsizes, dtilesizes, gran_mask | (count << 8));   /* bits 8..: textures per frame */
-                launch_rc |= (unsigned)hapgpu_k_frame_pack(rt, dframes, live, frag_log2, dslots, slot_stride, dfragsizes, dtilesizes,
+                                                                    dfragsizes, dgrouptables, gran_mask | (count << 8));   /* bits 8..: textures per frame */
+                launch_rc |= (unsigned)hapgpu_k_frame_pack(rt, dframes, live, frag_log2, dslots, slot_stride, dfragsizes, dgrouptables,
                                                            dcopies, frags_per_frame * live, chunks_per_frame, max_chunks_per_tex, count, dpack);
                 launch_rc |= (unsigned)hapgpu_k_frame_gather(rt, dcopies, (frags_per_frame + chunks_per_frame) * live);
                 launch_rc |= (unsigned)hapgpu_rt_d2h(rt, hframes, dframes, sizeof(HapGpuFrameEnc) * live);
@@ -989,7 +989,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                        table promises offsets of at most 3 KiB), bits 8 / 9: field streams (table version 3) */
                     if (p->frag_tiles_offset && p->frag_fields && !(flags & HAPGPU_DECODE_IGNORE_HALF_TILES)) {
                         job->fields_period = p->frag_fields;
-                        job->tile_sizes = (uint64_t)(uintptr_t)(frame_dev + p->frag_tiles_offset);
+                        job->group_tables = (uint64_t)(uintptr_t)(frame_dev + p->frag_tiles_offset);
                         frag_kinds |= p->frag_fields == 4u ? 0x100u : p->frag_fields == 2u ? 0x200u : 0x400u;
                     } else if (p->frag_log2 == 13u && p->frag_window256 != 0 && p->frag_window256 <= HAP_FRAGMENT_WINDOW_256)
                         frag_kinds |= 16u << p->frag_gran_log2;

@@ -130,7 +130,7 @@ typedef struct HapGpuDecodeJob {
     uint64_t bytes_used;
     uint32_t status;         /* HapResult or HAPGPU_STATUS_* */
     uint32_t fields_period;  /* 4 / 2 / 6: the table is version 3 and promises [2,6,4,4] / [4,4] / [2,6] field streams; 0 otherwise */
-    uint64_t tile_sizes;     /* device address of the group tables inside the frame (96 bytes per fragment entry), or 0 */
+    uint64_t group_tables;     /* device address of the group tables inside the frame (96 bytes per fragment entry), or 0 */
 } HapGpuDecodeJob;
 
 #define HAPGPU_UNIT_SKIP 0u
@@ -230,16 +230,16 @@ int hapgpu_k_block_encode_batch_ycocg_alpha(hapgpu_rt *rt, const uint64_t *sourc
                                             unsigned height, size_t row_bytes, int wide);
 int hapgpu_k_block_decode(hapgpu_rt *rt, const void *blocks, const void *alpha, unsigned width, unsigned height,
                           unsigned hap_texture_format, void *rgba, size_t row_bytes);
-/* tile_sizes: 64 bytes per fragment (same indexing as frag_sizes), written for textures whose reserved bit 20 is set */
+/* group_tables: 64 bytes per fragment (same indexing as frag_sizes), written for textures whose reserved bit 20 is set */
 int hapgpu_k_snappy_compress(hapgpu_rt *rt, const HapGpuFrameEnc *frames, unsigned frame_count,
                              unsigned max_frags_per_texture, unsigned frag_log2,
-                             void *slots, unsigned slot_stride, uint32_t *frag_sizes, uint8_t *tile_sizes,
+                             void *slots, unsigned slot_stride, uint32_t *frag_sizes, uint8_t *group_tables,
                              unsigned granularity_mask /* bit g (0..2) set: some position-per-lane texture has granularity_log2 == g; bit 4 / 5 / 6: some texture uses the field-per-lane kernel ([2,6] / [2,6,4,4] / [4,4] fields per block); bits 8..: textures per frame */);
 /* copies: one entry per fragment, then (from index extra_first) chunks_per_frame entries per frame for the
  * group tables of field streams */
 int hapgpu_k_frame_pack(hapgpu_rt *rt, HapGpuFrameEnc *frames, unsigned frame_count,
                         unsigned frag_log2, const void *slots, unsigned slot_stride,
-                        const uint32_t *frag_sizes, const uint8_t *tile_sizes, HapGpuCopyEntry *copies,
+                        const uint32_t *frag_sizes, const uint8_t *group_tables, HapGpuCopyEntry *copies,
                         unsigned extra_first, unsigned chunks_per_frame, unsigned max_chunks_per_texture,
                         unsigned textures, void *pack_scratch);
 /* bytes of pack_scratch needed per chunk (frame_count * chunks_per_frame of them) */

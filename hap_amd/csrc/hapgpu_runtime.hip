@@ -24,9 +24,9 @@ int hapgpu_launch_block_decode(const void *blocks, const void *alpha, unsigned w
                                unsigned format, void *rgba, size_t row_bytes, hipStream_t stream);
 int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsigned frame_count, unsigned max_frags_per_texture,
                                   unsigned frag_log2, void *slots, unsigned slot_stride, uint32_t *frag_sizes,
-                                  uint8_t *tile_sizes, unsigned granularity_mask, hipStream_t stream);
+                                  uint8_t *group_tables, unsigned granularity_mask, hipStream_t stream);
 int hapgpu_launch_frame_pack(HapGpuFrameEnc *frames, unsigned frame_count, unsigned frag_log2, const void *slots,
-                             unsigned slot_stride, const uint32_t *frag_sizes, const uint8_t *tile_sizes,
+                             unsigned slot_stride, const uint32_t *frag_sizes, const uint8_t *group_tables,
                              HapGpuCopyEntry *copies, unsigned extra_first, unsigned chunks_per_frame,
                              unsigned max_chunks_per_texture, unsigned textures, void *pack_scratch, hipStream_t stream);
 int hapgpu_launch_frame_gather(const HapGpuCopyEntry *copies, unsigned count, hipStream_t stream);
@@ -526,22 +526,22 @@ extern "C" int hapgpu_k_block_decode(hapgpu_rt *rt, const void *blocks, const vo
 
 extern "C" int hapgpu_k_snappy_compress(hapgpu_rt *rt, const HapGpuFrameEnc *frames, unsigned frame_count,
                                         unsigned max_frags_per_texture, unsigned frag_log2, void *slots,
-                                        unsigned slot_stride, uint32_t *frag_sizes, uint8_t *tile_sizes,
+                                        unsigned slot_stride, uint32_t *frag_sizes, uint8_t *group_tables,
                                         unsigned granularity_mask)
 {
     scoped_timing st(rt, 1);
     return hapgpu_launch_snappy_compress(frames, frame_count, max_frags_per_texture, frag_log2, slots, slot_stride,
-                                         frag_sizes, tile_sizes, granularity_mask, rt->stream);
+                                         frag_sizes, group_tables, granularity_mask, rt->stream);
 }
 
 extern "C" int hapgpu_k_frame_pack(hapgpu_rt *rt, HapGpuFrameEnc *frames, unsigned frame_count, unsigned frag_log2,
                                    const void *slots, unsigned slot_stride, const uint32_t *frag_sizes,
-                                   const uint8_t *tile_sizes, HapGpuCopyEntry *copies, unsigned extra_first,
+                                   const uint8_t *group_tables, HapGpuCopyEntry *copies, unsigned extra_first,
                                    unsigned chunks_per_frame, unsigned max_chunks_per_texture, unsigned textures,
                                    void *pack_scratch)
 {
     scoped_timing st(rt, 2);
-    return hapgpu_launch_frame_pack(frames, frame_count, frag_log2, slots, slot_stride, frag_sizes, tile_sizes, copies,
+    return hapgpu_launch_frame_pack(frames, frame_count, frag_log2, slots, slot_stride, frag_sizes, group_tables, copies,
                                     extra_first, chunks_per_frame, max_chunks_per_texture, textures, pack_scratch, rt->stream);
 }
 

@@ -9,12 +9,11 @@
 // differ from libsnappy's (Snappy encoding is not unique); parity is defined as: the reference
 // decoder reproduces the input exactly.
 //
-// Kernels (one 256-thread workgroup per fragment, fragment + hash table in LDS, synchronous rounds):
-//   snappy_compress_field_kernel  block textures: a lane owns one block FIELD (DXT5 / YCoCg-DXT5 [2,6,4,4],
-//                                 DXT1 [4,4], large RGTC1 planes [2,6]); with the fragment table requested it
-//                                 writes "field streams" (half-tile sizes, see snappy_decode_fields.hip);
-//   snappy_compress_wg_kernel     everything else: a lane owns a 1 / 2 / 4-byte position.
-// Per tile: (a) candidates, all lanes at once: the most recent earlier position / field with the same hash
+// Block textures (DXT1 / DXT5 / YCoCg-DXT5, large RGTC1 planes) go to the block-per-lane kernels of
+// snappy_compress_blocks.hip; this file holds the compressor for everything else:
+//   snappy_compress_wg_kernel     one 256-thread workgroup per fragment (fragment + hash table in LDS, synchronous
+//                                 rounds), a lane owns a 1 / 2 / 4-byte position.
+// Per tile: (a) candidates, all lanes at once: the most recent earlier position with the same hash
 // (LDS table, updated between rounds), and fixed block-pitch distances through wave ballots (equality bit per
 // lane, run length = count-trailing-ones of the shifted mask); (b) greedy left-to-right selection on the
 // scalar unit; (c) emission, all lanes at once: every lane knows the bytes it emits, offsets come from a DPP
@@ -483,365 +482,16 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
 }
 
 
-// ------------------------------------------------------------------------------------------
-// field-per-lane compressor for block textures
-// ------------------------------------------------------------------------------------------
-//
-// DXT5 / YCoCg-DXT5 blocks are four fields -- 2 endpoint bytes and 6 index bytes of the alpha-style half, 4
-// endpoint bytes and 4 index bytes of the colour half -- and RGTC1 blocks the first two.  Matches in such data
-// start and end at field boundaries (a CPU model of this kernel on the 8K test stream: same compressed size as the
-// position-per-lane kernel), so here a lane owns one FIELD instead of one 16-bit position: a tile of 64 lanes is
-// 256 bytes (16 or 32 blocks), equality at a distance is one 8-byte LDS read and a masked compare, and a
-// fragment takes 4 rounds instead of 8.  Candidates: the same field 1..4 blocks back (runs through ballots, as
-// above) and the most recent field with the same hash (type + value); neighbouring lanes whose hash candidates
-// lie at the same distance join into one copy.  Everything else -- synchronous rounds, table inserts between
-// rounds (every field is inserted), greedy selection on the scalar unit, direct final-position stores, 16-bit
-// granular elements, match window -- is as in the kernel above.
-__device__ __forceinline__ int cwave_scan_add(int v)   // inclusive
-{
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
-    return v;
-}
-
-#ifndef HAP_FIELD_SUBS
-#define HAP_FIELD_SUBS 1
-#endif
-constexpr unsigned kFieldSubs = HAP_FIELD_SUBS;   // tiles (256 bytes each) per wave per round
-
-// Field layouts: PERIOD 4 = [2, 6, 4, 4] bytes (DXT5 / YCoCg-DXT5, 16-byte blocks); PERIOD 2 = [2, 6] (RGTC1 layout,
-// not used: see hap_batch.c) or, with COLOUR, [4, 4] (DXT1: endpoints, indices).
-template <unsigned PERIOD, bool COLOUR>
-__device__ __forceinline__ unsigned field_offset(unsigned j)      // byte position of field j, fields counted from a block boundary
-{
-    if (PERIOD == 4)
-        return (j >> 2) * 16u + __builtin_amdgcn_ubfe(0x0C080200u, (j & 3u) * 8u, 8u);
-    return (j >> 1) * 8u + (COLOUR ? 4u : 2u) * (j & 1u);
-}
-
-// Fixed candidate distances of the field kernel, in blocks, nearest first ("farther wins ties").  The near ones catch
-// neighbouring blocks that share a field; 64 blocks = 1 KiB of 16-byte blocks = one production step of the
-// block-per-lane decoder back: in long runs of equal fields (flat picture areas) every copy then takes its bytes from
-// output that is already complete, instead of forming a chain the decoder has to chase inside its step.
-#ifndef HAP_FIELD_DISTANCES
-#define HAP_FIELD_DISTANCES 1, 2, 3, 4
-#endif
-__device__ constexpr unsigned kFieldDist[] = {HAP_FIELD_DISTANCES};
-constexpr int kFieldFixed = (int)(sizeof(kFieldDist) / sizeof(kFieldDist[0]));
-static_assert(kFieldFixed >= 1 && kFieldFixed <= 7, "priorities are kept in 3 bits");
-constexpr bool field_distances_consecutive()
-{
-    for (int d = 0; d < kFieldFixed; d++)
-        if (kFieldDist[d] != (unsigned)(d + 1))
-            return false;
-    return true;
-}
-constexpr bool kFieldConsecutive = field_distances_consecutive();
-
-// bits lane .. lane + 31 of a wave-wide mask (continued by the next tile's mask), as this lane sees them: with one tile
-// per round a single 64-bit shift of the scalar pair; picking halves per lane and funnel-shifting costs twice as much
-__device__ __forceinline__ unsigned mask_window(unsigned long long cur, unsigned long long next, unsigned lane)
-{
-    if (kFieldSubs == 1u)
-        return (unsigned)(cur >> lane);
-    const bool upper = lane >= 32u;
-    const unsigned lo = upper ? (unsigned)(cur >> 32) : (unsigned)cur;
-    const unsigned hi = upper ? (unsigned)next : (unsigned)(cur >> 32);
-    return __builtin_amdgcn_alignbit(hi, lo, lane & 31u);
-}
-
-template <unsigned PERIOD, bool COLOUR = false>
-__global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_field_kernel(const HapGpuFrameEnc *__restrict__ frames,
-                                                                   uint8_t *__restrict__ slots, unsigned slot_stride,
-                                                                   uint32_t *__restrict__ frag_sizes,
-                                                                   uint8_t *__restrict__ tile_sizes)
-{
-    constexpr unsigned FL = 13u, kFragBytes = 1u << FL;
-    constexpr unsigned kBlock = PERIOD == 4 ? 16u : 8u;
-    constexpr unsigned TB = 64u / PERIOD * kBlock;                // 256 bytes per tile
-    // (kLead zero bytes in front of the fragment: the candidate 1..4 blocks back is read at a constant offset from the
-    // lane's own position, without a clamp for the first blocks -- whose lanes are masked out of the match anyway)
-    constexpr unsigned kLead = (kFieldDist[kFieldFixed - 1] * 16u + 15u) & ~15u;
-    static_assert(kLead <= 1024u, "candidate distances are ascending and short");
-    __shared__ __attribute__((aligned(16))) uint8_t smem_all[kLead + kFragBytes + 32u + kWgHashEntries * 4u + kWgWaves * 4u];
-    uint8_t *const smem = smem_all + kLead;
-    uint32_t *table = reinterpret_cast<uint32_t *>(smem + kFragBytes + 32);
-    uint32_t *roundsz = table + kWgHashEntries;
-
-    const unsigned tid = threadIdx.x, lane = tid & 63u;
-    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const HapGpuTexEnc tex = frames[blockIdx.z].tex[blockIdx.y < 2u ? blockIdx.y : 0u];
-    const unsigned tex_count = frames[blockIdx.z].tex_count;
-    const unsigned x = blockIdx.x;
-    if ((blockIdx.y >= tex_count) | (tex.compressor != 1u) | (((tex.reserved >> 16) & 0xFu) != (PERIOD | (COLOUR ? 8u : 0u))) |
-        (x >= tex.chunk_count * tex.frags_per_chunk) | (tex.src == 0) | (tex.chunk_bytes == 0))
-        return;
-    const unsigned chunk = x / tex.frags_per_chunk, j = x - chunk * tex.frags_per_chunk;
-    const unsigned begin = j << FL;
-    const unsigned n = min(kFragBytes, tex.chunk_bytes - begin);          // a whole number of blocks (host-checked)
-    const uint8_t *src = (const uint8_t *)tex.src + (size_t)chunk * tex.chunk_bytes + begin;
-    const unsigned f = tex.frag_first + x;
-    uint8_t *out = slots + (size_t)f * slot_stride;
-    const unsigned window = ((tex.reserved >> 8) & 0xFFu) ? ((tex.reserved >> 8) & 0xFFu) * 256u : 0xFFFFFFFFu;
-    // "field stream" (fragment table version 2): no element crosses a 128-byte half-tile (32 lanes), and the
-    // compressed size of every half-tile is recorded for the block-per-lane decoder (snappy_decode_fields.hip)
-    const bool halves = ((tex.reserved >> 20) & 1u) != 0u && tile_sizes != nullptr;
-    uint8_t *const my_tiles = tile_sizes + (size_t)f * HAP_HALF_TILES_PER_FRAGMENT;
-    if (halves && tid < HAP_HALF_TILES_PER_FRAGMENT / 4u)
-        reinterpret_cast<uint32_t *>(my_tiles)[tid] = 0u;          // half-tiles beyond a short fragment read as 0
-
-    if (((uintptr_t)src & 15u) == 0) {
-        uint4 v[3];
-#pragma unroll
-        for (unsigned u = 0; u < 3; u++) {
-            const unsigned i = tid * 16u + u * 4096u;
-            v[u] = make_uint4(0, 0, 0, 0);
-            if (i + 16u <= n)
-                v[u] = *reinterpret_cast<const uint4 *>(src + i);
-        }
-#pragma unroll
-        for (unsigned u = 0; u < 3; u++) {
-            const unsigned i = tid * 16u + u * 4096u;
-            if (i < n && i + 16u > n) {                 // (n is a multiple of 8: an 8-byte tail is possible)
-                unsigned w[4] = {0, 0, 0, 0};
-                for (unsigned k = 0; i + k < n; k++)
-                    w[k >> 2] |= (unsigned)src[i + k] << (8 * (k & 3));
-                v[u] = make_uint4(w[0], w[1], w[2], w[3]);
-            }
-            if (i < kFragBytes + 32u)
-                *reinterpret_cast<uint4 *>(smem + i) = v[u];
-        }
-    } else {
-        for (unsigned i = tid; i < n + 32u; i += 64u * kWgWaves)
-            smem[i] = i < n ? src[i] : (uint8_t)0;
-    }
-    for (unsigned i = tid; i < kWgHashEntries; i += 64u * kWgWaves)
-        table[i] = 0u;
-    if (tid * 16u < kLead)
-        *reinterpret_cast<uint4 *>(smem_all + tid * 16u) = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-
-    // per-lane constants: field type, position of the 8-byte half block that holds the field, compare masks
-    const unsigned t = lane & (PERIOD - 1u);
-    const unsigned half = (lane / PERIOD) * kBlock + ((PERIOD == 4 && (t & 2u)) ? 8u : 0u);
-    const unsigned m1 = PERIOD == 4 ? (t == 0 ? 0x0000FFFFu : t == 1 ? 0xFFFF0000u : t == 2 ? 0xFFFFFFFFu : 0u)
-                      : COLOUR ? (t == 0 ? 0xFFFFFFFFu : 0u) : (t == 0 ? 0x0000FFFFu : 0xFFFF0000u);
-    const unsigned m2 = PERIOD == 4 ? ((t & 1u) ? 0xFFFFFFFFu : 0u) : (t == 1 ? 0xFFFFFFFFu : 0u);
-    const unsigned size = PERIOD == 4 ? (t == 0 ? 2u : t == 1 ? 6u : 4u) : COLOUR ? 4u : (t == 0 ? 2u : 6u);
-    // how the field's bytes come out of the 8 bytes (ux, vx) read at `half`: [2,6]: field 0 = ux & 0xFFFF, field 1 = the
-    // six bytes from byte 2; the 4-byte fields are ux (field 2 of [2,6,4,4], field 0 of [4,4]) or vx
-    const bool f_from_v = PERIOD == 4 ? t == 3u : (COLOUR && t == 1u);
-    const unsigned f_shift = (!COLOUR && t == 1u) ? 16u : 0u;
-    const unsigned f_mask_lo = (!COLOUR && t == 0u) ? 0xFFFFu : 0xFFFFFFFFu;
-    const unsigned f_mask_hi = (!COLOUR && t == 1u) ? 0xFFFFu : 0u;
-
-    const unsigned lane31 = lane & 31u;
-    const unsigned my_off = field_offset<PERIOD, COLOUR>(lane);
-
-    const unsigned tiles = (n + TB - 1u) / TB, supers = (tiles + kFieldSubs - 1u) / kFieldSubs;
-    unsigned round_base = 0;
-    for (unsigned base = 0; base < supers; base += kWgWaves) {
-        const unsigned k = base + wave;
-        const bool have = k < supers;
-        unsigned p_at[kFieldSubs] = {}, p_lo[kFieldSubs] = {}, p_hi[kFieldSubs] = {}, p_cnt[kFieldSubs] = {}, p_hash[kFieldSubs] = {};
-        unsigned long long m_in[kFieldSubs] = {};
-        unsigned total = 0;
-        if (have) {
-            const unsigned super_base = kFieldSubs * k * TB;
-            const unsigned lanes_in_super = min(64u * kFieldSubs, (n - super_base) / kBlock * PERIOD);
-            unsigned long long eq[kFieldFixed][kFieldSubs], in_mask[kFieldSubs];
-            unsigned ux[kFieldSubs], vx[kFieldSubs];
-#pragma unroll
-            for (int sub = 0; sub < (int)kFieldSubs; sub++) {
-                const unsigned tile_base = super_base + sub * TB;
-                const unsigned cnt = lanes_in_super > 64u * sub ? min(64u, lanes_in_super - 64u * sub) : 0u;
-                in_mask[sub] = cnt >= 64u ? ~0ull : ((1ull << cnt) - 1ull);
-                const uint2 xv = *reinterpret_cast<const uint2 *>(smem + tile_base + half);
-                ux[sub] = xv.x;
-                vx[sub] = xv.y;
-#pragma unroll
-                for (int d = 0; d < kFieldFixed; d++) {
-                    const unsigned dist = kFieldDist[d] * kBlock;
-                    const unsigned at = tile_base + half;
-                    const uint2 yv = *reinterpret_cast<const uint2 *>(smem + at - dist);     // (may lie in the lead bytes)
-                    // lanes whose source lies inside the fragment (and inside the match window)
-                    unsigned long long reachable = ~0ull;
-                    if (tile_base < dist) {
-                        const unsigned first = (dist - tile_base) / kBlock * PERIOD;
-                        reachable = first >= 64u ? 0ull : ~0ull << first;
-                    }
-                    if (dist > 256u && dist > window)       // (the window is never below one tile)
-                        reachable = 0ull;
-                    eq[d][sub] = ballot64((((xv.x ^ yv.x) & m1) | ((xv.y ^ yv.y) & m2)) == 0u) & in_mask[sub] & reachable;
-                }
-            }
-            // hash candidates: most recent field of the same type and value (inserted in earlier rounds)
-            unsigned hd[kFieldSubs], hh[kFieldSubs];
-#pragma unroll
-            for (int sub = 0; sub < (int)kFieldSubs; sub++) {
-                const unsigned tile_base = super_base + sub * TB;
-                const unsigned fi = tile_base / kBlock * PERIOD + lane;          // field index inside the fragment
-                const unsigned a = ux[sub] & m1, b = vx[sub] & m2;
-                const unsigned z = a ^ __builtin_amdgcn_alignbit(b, b, 19) ^ (t << 29);
-                hh[sub] = (z * 0x9E3779B1u) >> (32u - kWgHashBits);
-                const unsigned c = table[hh[sub]];
-                const unsigned gap = fi - c;                                     // in fields
-                const unsigned dist = gap / PERIOD * kBlock;
-                const bool valid = __builtin_amdgcn_inverse_ballot_w64(in_mask[sub]) && c < fi &&
-                                   (gap & (PERIOD - 1u)) == 0u && dist <= window;
-                const unsigned at = tile_base + half;
-                const uint2 yv = *reinterpret_cast<const uint2 *>(smem + (valid ? at - dist : 0u));
-                hd[sub] = (valid && ((((ux[sub] ^ yv.x) & m1) | ((vx[sub] ^ yv.y) & m2)) == 0u)) ? dist : 0u;
-            }
-            unsigned best_k2[kFieldSubs], best_off2[kFieldSubs];
-#pragma unroll
-            for (int sub = 0; sub < (int)kFieldSubs; sub++) {
-                // lanes a copy starting here may span: up to 16 fields, the end of the data, and (field streams) the
-                // end of this lane's half-tile
-                const unsigned seg_end = min(lanes_in_super, 64u * sub + (halves ? (lane | 31u) + 1u : 64u));
-                const unsigned room_lanes = seg_end > 64u * sub + lane ? min(16u, seg_end - 64u * sub - lane) : 0u;
-                // lanes to the right whose hash candidate lies at the same distance join this one
-                const unsigned next_hd = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hd[sub], 0x130, 0xF, 0xF, false);
-                const unsigned long long same = ballot64(next_hd == hd[sub]) & ballot64(hd[sub] != 0u);
-                unsigned best_key;
-                {
-                    const unsigned inv = ~mask_window(same, 0ull, lane);
-                    const unsigned more = inv ? (unsigned)__builtin_ctz(inv) : 32u;
-                    best_key = hd[sub] ? (min(1u + more, room_lanes) << 3) : 0u;
-                }
-                unsigned fixed_off = 0;
-#pragma unroll
-                for (int d = kFieldFixed - 1; d >= 0; d--) {
-                    const unsigned long long c = eq[d][sub], nx = sub + 1 < (int)kFieldSubs ? eq[d][sub + 1 < (int)kFieldSubs ? sub + 1 : sub] : 0ull;
-                    if (c == 0ull)
-                        continue;
-                    const unsigned inv = ~mask_window(c, nx, lane);
-                    const unsigned l = min(inv ? (unsigned)__builtin_ctz(inv) : 32u, room_lanes);
-                    best_key = max(best_key, (l << 3) | (unsigned)(d + 1));            // farther wins ties
-                }
-                const unsigned prio = best_key & 7u;
-                if (kFieldConsecutive) {
-                    fixed_off = prio * kBlock;
-                } else {
-#pragma unroll
-                    for (int d = 0; d < kFieldFixed; d++)
-                        fixed_off = prio == (unsigned)(d + 1) ? kFieldDist[d] * kBlock : fixed_off;
-                }
-                best_k2[sub] = best_key >> 3;
-                best_off2[sub] = prio ? fixed_off : hd[sub];
-            }
-            unsigned skip = 0;
-#pragma unroll
-            for (int sub = 0; sub < (int)kFieldSubs; sub++) {
-                const unsigned kk = best_k2[sub], best_off = best_off2[sub];
-                const unsigned best_len = field_offset<PERIOD, COLOUR>(lane + kk) - my_off;        // bytes of kk fields from here
-                const unsigned long long cand_mask = ballot64(best_len >= 4u);
-                unsigned long long sel = 0;
-                unsigned cursor = (unsigned)__builtin_amdgcn_readfirstlane((int)skip);
-                const unsigned next_free = lane + kk;
-                greedy_select(cand_mask, next_free, cursor, sel);
-                const unsigned carry = cursor > 64u ? cursor - 64u : 0u;
-                const int reach = cwave_scan_max(__builtin_amdgcn_inverse_ballot_w64(sel) ? (int)next_free : 0);
-                const unsigned long long skipmask = skip >= 64u ? ~0ull : ((1ull << skip) - 1ull);
-                const unsigned long long lit = ~(ballot64((unsigned)reach > lane) | skipmask) & in_mask[sub];
-                skip = carry;
-                // (field streams: a literal run ends at the half-tile boundary, a new one starts at lane 32)
-                const unsigned long long starts = (lit & ~(lit << 1)) | (halves ? lit & (1ull << 32) : 0ull);
-                // literal run that starts at this lane, in bytes (0: none starts here).  Everything below is worked out for
-                // every lane and selected at the end: branches on lane-varying conditions cost more scalar bookkeeping
-                // than the few instructions they would skip.
-                unsigned r;
-                if (halves) {                              // (uniform) runs end with the half-tile: 32 lanes are enough
-                    const unsigned inv = ~(unsigned)(lit >> lane);
-                    r = min(inv ? (unsigned)__builtin_ctz(inv) : 32u, 32u - lane31);
-                } else {
-                    const unsigned long long a = ~(lit >> lane);
-                    r = a ? (unsigned)__builtin_ctzll(a) : 64u;
-                }
-                const unsigned run = __builtin_amdgcn_inverse_ballot_w64(starts) ? field_offset<PERIOD, COLOUR>(lane + r) - my_off : 0u;
-                // literal element: [run header] + the field's bytes, low byte first (f_* are per-lane constants)
-                const unsigned fbase = f_from_v ? vx[sub] : ux[sub];
-                const unsigned flo = __builtin_amdgcn_alignbit(vx[sub], fbase, f_shift) & f_mask_lo;
-                const unsigned fhi = (vx[sub] >> 16) & f_mask_hi;
-                const unsigned hdr_len = (run != 0u ? 1u : 0u) + (run > 60u ? 1u : 0u);
-                const unsigned hdr = run == 0u ? 0u : run > 60u ? (0xF0u | ((run - 1u) << 8)) : ((run - 1u) << 2);
-                const unsigned long long lit_bytes = ((((unsigned long long)fhi << 32) | flo) << (8u * hdr_len)) | hdr;
-                // copy element: 2 bytes (copy-1: 4..11 bytes from less than 2 KiB back) or 3
-                const bool c1 = best_len < 12u && best_off < 2048u;
-                const unsigned e1 = 1u | ((best_len - 4u) << 2) | ((best_off >> 8) << 5) | ((best_off & 0xFFu) << 8);
-                const unsigned e2 = 2u | ((best_len - 1u) << 2) | (best_off << 8);
-                const bool is_lit = __builtin_amdgcn_inverse_ballot_w64(lit), is_sel = __builtin_amdgcn_inverse_ballot_w64(sel & ~lit);
-                const unsigned cnt = is_lit ? size + hdr_len : is_sel ? (c1 ? 2u : 3u) : 0u;
-                const unsigned vlo = is_lit ? (unsigned)lit_bytes : (c1 ? e1 : e2);
-                const unsigned vhi = is_lit ? (unsigned)(lit_bytes >> 32) : 0u;
-                const int incl = cwave_scan_add((int)cnt);
-                p_at[sub] = total + (unsigned)incl - cnt;
-                if (halves) {
-                    const unsigned lower = (unsigned)__builtin_amdgcn_readlane(incl, 31);
-                    const unsigned both = (unsigned)__builtin_amdgcn_readlane(incl, 63);
-                    if (lane == 0)
-                        *reinterpret_cast<uint16_t *>(my_tiles + 2u * (kFieldSubs * k + sub)) = (uint16_t)(lower | ((both - lower) << 8));
-                }
-                total += (unsigned)__builtin_amdgcn_readlane(incl, 63);
-                p_lo[sub] = vlo;
-                p_hi[sub] = vhi;
-                p_cnt[sub] = cnt;
-                p_hash[sub] = hh[sub];
-                m_in[sub] = in_mask[sub];
-            }
-        }
-        if (lane == 0)
-            roundsz[wave] = total;
-        lds_barrier();
-        unsigned my_base = round_base, all = 0;
-#pragma unroll
-        for (unsigned w = 0; w < kWgWaves; w++) {
-            const unsigned sz = roundsz[w];
-            if (w < wave)
-                my_base += sz;
-            all += sz;
-        }
-        round_base += all;
-        if (have) {
-#pragma unroll
-            for (int sub = 0; sub < (int)kFieldSubs; sub++) {
-                uint8_t *dst = out + my_base + p_at[sub];
-                const unsigned cnt = p_cnt[sub], vlo = p_lo[sub], vhi = p_hi[sub];
-                if (cnt >= 2u)
-                    store16(dst, vlo);
-                if (cnt >= 4u)
-                    store16(dst + 2, vlo >> 16);
-                if (cnt >= 6u)
-                    store16(dst + 4, vhi);
-                if (cnt == 8u)
-                    store16(dst + 6, vhi >> 16);
-                if (cnt & 1u)                                // 3, 5 or 7 bytes: the last one on its own
-                    dst[cnt - 1u] = (uint8_t)(cnt == 3u ? vlo >> 16 : cnt == 5u ? vhi : vhi >> 16);
-                // every field is remembered (candidates are looked up by field, not by element)
-                if (__builtin_amdgcn_inverse_ballot_w64(m_in[sub]))
-                    atomicMax(&table[p_hash[sub]], (kFieldSubs * k + sub) * TB / kBlock * PERIOD + lane);
-            }
-        }
-        lds_barrier();
-    }
-    if (tid == 0)
-        frag_sizes[f] = round_base;
-}
-
 } // namespace
 
 extern "C" int hapgpu_launch_snappy_compress_blocks(const HapGpuFrameEnc *frames, unsigned frame_count,
                                                     unsigned max_frags_per_texture, unsigned textures, void *slots,
-                                                    unsigned slot_stride, uint32_t *frag_sizes, uint8_t *tile_sizes,
+                                                    unsigned slot_stride, uint32_t *frag_sizes, uint8_t *group_tables,
                                                     unsigned layouts, hipStream_t stream);
 
 extern "C" int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsigned frame_count,
                                              unsigned max_frags_per_texture, unsigned frag_log2, void *slots,
-                                             unsigned slot_stride, uint32_t *frag_sizes, uint8_t *tile_sizes,
+                                             unsigned slot_stride, uint32_t *frag_sizes, uint8_t *group_tables,
                                              unsigned granularity_mask, hipStream_t stream)
 {
     if (frame_count == 0 || max_frags_per_texture == 0)
@@ -871,25 +521,15 @@ extern "C" int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsig
                 hipLaunchKernelGGL((snappy_compress_wg_kernel<G, 0u>), grid, block, lds2, stream, frames, frag_log2,            \
                                    (uint8_t *)slots, slot_stride, frag_sizes);                                                  \
         } while (0)
-        // block textures: the block-per-lane kernels of snappy_compress_blocks.hip (HAP_AMD_FIELD_LANES=1 selects the
-        // field-per-lane kernel of this file instead, kept for comparison)
-        static const bool field_lanes = getenv("HAP_AMD_FIELD_LANES") != nullptr && atoi(getenv("HAP_AMD_FIELD_LANES")) != 0;
-        if (frag_log2 == 13u && (granularity_mask & 0x70u) && !field_lanes) {
+        // block textures: the block-per-lane kernels of snappy_compress_blocks.hip
+        if (granularity_mask & 0x70u) {
+            if (frag_log2 != 13u)
+                return 1;
             const unsigned layouts = ((granularity_mask & 32u) ? 1u : 0u) | ((granularity_mask & 64u) ? 2u : 0u) |
                                      ((granularity_mask & 16u) ? 4u : 0u);
             if (hapgpu_launch_snappy_compress_blocks(frames, frame_count, max_frags_per_texture, textures, slots, slot_stride,
-                                                     frag_sizes, tile_sizes, layouts, stream))
+                                                     frag_sizes, group_tables, layouts, stream))
                 return 4;
-        } else if (frag_log2 == 13u) {
-            if (granularity_mask & 16u)
-                hipLaunchKernelGGL((snappy_compress_field_kernel<2u>), grid, block, 0, stream, frames, (uint8_t *)slots,
-                                   slot_stride, frag_sizes, tile_sizes);
-            if (granularity_mask & 64u)
-                hipLaunchKernelGGL((snappy_compress_field_kernel<2u, true>), grid, block, 0, stream, frames, (uint8_t *)slots,
-                                   slot_stride, frag_sizes, tile_sizes);
-            if (granularity_mask & 32u)
-                hipLaunchKernelGGL((snappy_compress_field_kernel<4u>), grid, block, 0, stream, frames, (uint8_t *)slots,
-                                   slot_stride, frag_sizes, tile_sizes);
         }
         if (granularity_mask & 1u)
             HAP_LAUNCH_COMPRESS(1u);

@@ -181,7 +181,7 @@ template <unsigned LAYOUT>
 __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpuFrameEnc *__restrict__ frames,
                                                                     uint8_t *__restrict__ slots, unsigned slot_stride,
                                                                     uint32_t *__restrict__ frag_sizes,
-                                                                    uint8_t *__restrict__ tile_sizes)
+                                                                    uint8_t *__restrict__ group_tables)
 {
     using UL = unit_layout<LAYOUT>;
     constexpr unsigned B = UL::block;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
     const unsigned f = tex.frag_first + x;
     const gdst_t out = (gdst_t)((uintptr_t)slots + (size_t)f * slot_stride);
     const unsigned window = ((tex.reserved >> 8) & 0xFFu) ? ((tex.reserved >> 8) & 0xFFu) * 256u : 0xFFFFFFFFu;
-    const bool want_sizes = ((tex.reserved >> 20) & 1u) != 0u && tile_sizes != nullptr;
+    const bool want_sizes = ((tex.reserved >> 20) & 1u) != 0u && group_tables != nullptr;
 
     // table: empty
     {
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
             const unsigned above = (unsigned)__shfl_down((int)size, 1);
             const unsigned pair = size | (above << 12);
             if ((lane & 1u) == 0u) {
-                const gdst_t at = (gdst_t)((uintptr_t)tile_sizes + (size_t)f * HAP_GROUP_TABLE_BYTES + (lane >> 1) * 3u);
+                const gdst_t at = (gdst_t)((uintptr_t)group_tables + (size_t)f * HAP_GROUP_TABLE_BYTES + (lane >> 1) * 3u);
                 put16(at, pair);
                 put8(at + 2, pair >> 16);
             }
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
 // layouts: bit 0 = [2,6,4,4] textures present, bit 1 = [4,4], bit 2 = [2,6]
 extern "C" int hapgpu_launch_snappy_compress_blocks(const HapGpuFrameEnc *frames, unsigned frame_count,
                                                     unsigned max_frags_per_texture, unsigned textures, void *slots,
-                                                    unsigned slot_stride, uint32_t *frag_sizes, uint8_t *tile_sizes,
+                                                    unsigned slot_stride, uint32_t *frag_sizes, uint8_t *group_tables,
                                                     unsigned layouts, hipStream_t stream)
 {
     if (frame_count == 0 || max_frags_per_texture == 0 || layouts == 0)
@@ -541,12 +541,12 @@ extern "C" int hapgpu_launch_snappy_compress_blocks(const HapGpuFrameEnc *frames
     const dim3 grid(max_frags_per_texture, textures, frame_count), block(64);
     if (layouts & 1u)
         hipLaunchKernelGGL((snappy_compress_blocks_kernel<4u>), grid, block, 0, stream, frames, (uint8_t *)slots, slot_stride,
-                           frag_sizes, tile_sizes);
+                           frag_sizes, group_tables);
     if (layouts & 2u)
         hipLaunchKernelGGL((snappy_compress_blocks_kernel<2u>), grid, block, 0, stream, frames, (uint8_t *)slots, slot_stride,
-                           frag_sizes, tile_sizes);
+                           frag_sizes, group_tables);
     if (layouts & 4u)
         hipLaunchKernelGGL((snappy_compress_blocks_kernel<6u>), grid, block, 0, stream, frames, (uint8_t *)slots, slot_stride,
-                           frag_sizes, tile_sizes);
+                           frag_sizes, group_tables);
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }

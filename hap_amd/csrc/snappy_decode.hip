@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64) void decode_expand_kernel(HapGpuDecodeJob *jobs
     unsigned kind = gran == 2 ? HAPGPU_UNIT_SNAPPY_FRAGMENT32 : gran == 1 ? HAPGPU_UNIT_SNAPPY_FRAGMENT16 : HAPGPU_UNIT_SNAPPY_FRAGMENT;
     if (job->frag_log2 == 13u && window256 != 0 && window256 <= HAP_FRAGMENT_WINDOW_256)
         kind |= HAPGPU_UNIT_WINDOWED;
-    const bool fields = job->fields_period != 0u && job->tile_sizes != 0u;
+    const bool fields = job->fields_period != 0u && job->group_tables != 0u;
     if (fields)       // field stream (table version 3): block-per-lane decoder, with the fragment's group table
         kind = job->fields_period == 4u ? HAPGPU_UNIT_SNAPPY_FIELDS4
              : job->fields_period == 2u ? HAPGPU_UNIT_SNAPPY_FIELDS2 : HAPGPU_UNIT_SNAPPY_FIELDS26;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(64) void decode_expand_kernel(HapGpuDecodeJob *jobs
             w.dst_len = min(frag_bytes, c.plan_out_len - k * frag_bytes);
             w.kind = kind;
             w.job = j;
-            w.aux = fields ? job->tile_sizes + (uint64_t)(c.frag_first + k) * HAP_GROUP_TABLE_BYTES : 0u;
+            w.aux = fields ? job->group_tables + (uint64_t)(c.frag_first + k) * HAP_GROUP_TABLE_BYTES : 0u;
             // bytes of the texture section that follow the fragment (up to 15): the decoder may fetch its last
             // 16-byte piece whole when they exist
             const uint64_t end = (uint64_t)c.src_off + at + sz;
