@@ -271,7 +271,7 @@ def main():
     if world > 1:
         # the other scaling mode beside the headline (same kernels, same step; a second timed region)
         mode = "weak" if args.scaling == "strong" else "strong"
-        del stream.rgba, stream.frames, stream.dec
+        del stream.rgba, stream.frames, stream.dec, stream.dec_all
         torch.cuda.empty_cache()
         s2 = Stream(hap_amd, ctx, dev, args.config, frames_of_rank(nf_total, rank, world, mode), flags)
         e2, _p2 = s2.timed(args.steps, 1, fence)
