@@ -512,18 +512,24 @@ def c5_chunk_groups(hap_amd, ctx, dist, dev, rank, world, fence, reps=3):
     fence(); t0 = time.perf_counter()
     parts = shard.gather_variable(piece, root=0)
     fence(); t["gather_band_frames_ms"] = (time.perf_counter() - t0) * 1e3
-    # join on the device: the band frames arrived over xGMI and stay in HBM (tables through the host, payloads D2D)
-    fence(); t0 = time.perf_counter()
+    # join on the device: the band frames arrived over xGMI and stay in HBM (tables through the host, payloads D2D).
+    # Like the other legs: one untimed call first (scratch arenas, the output buffer), then the timed ones.
     joined_bytes = 0
     dframe = None
     if parts is not None:
         dframe = torch.empty(sum(int(p.numel()) for p in parts) + 64, dtype=torch.uint8, device=dev)
+        part_bytes = [int(p.numel()) for p in parts]
         torch.cuda.synchronize()
-        r, joined_bytes = ctx.join_chunk_groups(parts, [int(p.numel()) for p in parts], dframe)
-        if r != 0:
-            raise RuntimeError("join failed %r" % r)
+        ctx.join_chunk_groups(parts, part_bytes, dframe)
+    fence(); t0 = time.perf_counter()
+    if parts is not None:
+        for _ in range(reps):
+            r, joined_bytes = ctx.join_chunk_groups(parts, part_bytes, dframe)
+            if r != 0:
+                raise RuntimeError("join failed %r" % r)
+    fence(); t["join_on_device_ms"] = (time.perf_counter() - t0) / reps * 1e3
+    if dframe is not None:
         dframe = dframe[:joined_bytes]
-    fence(); t["join_on_device_ms"] = (time.perf_counter() - t0) * 1e3
     n = torch.tensor([joined_bytes], dtype=torch.int64, device=dev)
     dist.broadcast(n, src=0)
     if dframe is None:

@@ -160,7 +160,7 @@ unsigned hapj_join(unsigned groupCount, hapf_reader *readers, const unsigned lon
     }
 
     /* per texture: the header region (section headers, codec and size tables, fragment-table header) is built here
-       and put first; the groups' table contents and payloads are then moved on top of / behind it */
+       and put first; the groups' table contents and payloads are then moved behind it */
     cursor = outer_header;
     for (t = 0; t < count && result == HapResult_No_Error; t++) {
         const joined_texture *j = &tex[t];
@@ -178,7 +178,8 @@ unsigned hapj_join(unsigned groupCount, hapf_reader *readers, const unsigned lon
         } else {
             const uint32_t ilen = (uint32_t)instructions_bytes(j);
             const unsigned n = j->chunk_count;
-            hdr_len = (size_t)j->header_len + 4u + ilen;
+            /* (only what is made here: the fragment table's entries behind its 8 header bytes are moved from the groups) */
+            hdr_len = (size_t)j->header_len + 4u + 5u * (size_t)n + 8u + (j->keep_index ? 8u : 0u);
             hdr = (uint8_t *)calloc(1, hdr_len);
             if (!hdr) { result = HapResult_Internal_Error; break; }
             hapf_write_section(hdr, j->header_len, (uint32_t)j->body, (HAP_NIBBLE_COMPLEX << 4) | j->format_nibble);
