@@ -27,7 +27,7 @@ enum {
 #define P_SCAN P_FRAMES
 enum { P_FRAMES = 0, P_JOBS, P_CHUNKS, P_PREFIX, P_PTRS, P_BC_PTRS, P_PREFIX2 };   /* (8, 9: hap_sequence.c) */
 
-#define PREFIX_BYTES 8192u   /* headers + tables of a frame with a few hundred chunks; larger ones are fetched on demand */
+#define PREFIX_BYTES 2048u   /* headers + tables of a frame with up to ~400 chunks; larger ones are fetched on demand */
 #define COPY_PIECE 65536u
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -693,7 +693,7 @@ def test_both_textures_of_a_batch_decode_in_one_call(ctx, hap):
     r, used, results = ctx.encode_frames_rgba(frames_rgba, w, h, w * 4, fmts, [1, 1], [8, 8], outs)
     assert r == 0 and results == [0] * nf
     want = [[D.oracle_bc_encode(frames_rgba[i].cpu().numpy(), fmts[t]) for t in range(2)] for i in range(nf)]
-    assert min(used) > 16384          # (the alpha plane's section starts beyond the 8 KiB header prefix)
+    assert min(used) > 16384          # (the alpha plane's section starts beyond the header prefix)
     # frame 1 goes through the host, frame 2 is replaced by the reference encoder's frame of the same textures
     host1 = outs[1][: used[1]].cpu().numpy().tobytes()
     r, ref2 = REF.encode([want[2][0], want[2][1]], fmts, [1, 1], [8, 8])
