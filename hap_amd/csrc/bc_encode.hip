@@ -242,21 +242,24 @@ __device__ __forceinline__ uint2 ycocg_colour_block(const unsigned (&cc)[16])
     unsigned idx = 0;
     if (c0 != c1) {
         const projection pr = make_projection(expand_565(c0, false), expand_565(c1, false));
-        // project4 on the scaled pixels v = (c - 128) s + 128 without forming them: with c' = c, or 255 - c where the
-        // segment's direction is negative (one XOR on the packed pair), the (possibly complemented) scaled pixel is
-        // s c' + k, k = 128 - 128 s or 127 - 127 s, so t = s (c' . |dir|) + K and the position is
-        // (t m24) >> 24 = ((c' . |dir|) (s m24) + K m24) >> 24 -- 32-bit wrap-around arithmetic, t m24 itself fits
-        const unsigned adir2 = __builtin_amdgcn_perm(pr.adir, pr.adir, 0x0C010C00u);        // |dir| of Co', Cg' under the two halves
-        const unsigned flip2 = __builtin_amdgcn_perm(pr.flip, pr.flip, 0x0C010C00u);
-        const int k_o = (pr.flip & 0x00FFu) ? 127 - 127 * s : 128 - 128 * s;
-        const int k_g = (pr.flip & 0xFF00u) ? 127 - 127 * s : 128 - 128 * s;
-        const int K = pr.start + (int)(pr.adir & 255u) * k_o + (int)((pr.adir >> 8) & 255u) * k_g;
+        // project4 on the scaled pixels v = (c - 128) s + 128 without forming them, and without complementing: with the
+        // direction SIGNED per channel (16-bit pair, one v_dot2 on the packed Co | Cg pair) the projection is
+        // t = s (c . dir) + K, K = start + sum |dir| (128 - 128 s) over the channels that point up and
+        // |dir| (127 + 128 s) over the ones that point down (project4's complement, multiplied out).  The dot product
+        // starts from an offset that keeps it non-negative for the unsigned 24-bit multiply; the position is
+        // (t m24) >> 24 = ((c . dir + offset) (s m24) + (K - s offset) m24) >> 24 in 32-bit wrap-around arithmetic (t m24
+        // itself fits).
+        const int a_o = (int)(pr.adir & 255u), a_g = (int)((pr.adir >> 8) & 255u);
+        const bool down_o = (pr.flip & 0x00FFu) != 0u, down_g = (pr.flip & 0xFF00u) != 0u;
+        const pk_i16 dir2 = {(short)(down_o ? -a_o : a_o), (short)(down_g ? -a_g : a_g)};
+        const int K = pr.start + a_o * (down_o ? 127 + 128 * s : 128 - 128 * s) + a_g * (down_g ? 127 + 128 * s : 128 - 128 * s);
+        constexpr int kDotOffset = 1 << 17;                                                  // > 2 x 255 x 255
         const unsigned sm = (unsigned)s * pr.m24;                                            // < 2^24
-        const unsigned Km = (unsigned)K * pr.m24;                                            // mod 2^32
+        const unsigned Km = (unsigned)(K - s * kDotOffset) * pr.m24;                         // mod 2^32
         unsigned pos2 = 0;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const unsigned dot = __builtin_amdgcn_udot4(cc[i] ^ flip2, adir2, 0u, false);    // < 2^18
+            const unsigned dot = (unsigned)__builtin_amdgcn_sdot2(__builtin_bit_cast(pk_i16, cc[i]), dir2, kDotOffset, false);   // 1 .. 2^18
             const int pos = min(max((int)(__umul24(dot, sm) + Km) >> 24, 0), 3);
             pos2 = __builtin_amdgcn_alignbit((unsigned)pos, pos2, 2);
         }
