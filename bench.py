@@ -48,8 +48,8 @@ ROUND_TAG = "r03"        # profiles/<round>_traffic_<cfg>.json is what roofline.
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C4", choices=sorted(CONFIGS))
     ap.add_argument("--frames", type=int, default=0, help="frames of the stream (default: the config's)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
