@@ -95,8 +95,7 @@ __global__ __launch_bounds__(64) void decode_plan_kernel(HapGpuDecodeJob *jobs, 
             return;
         unsigned status = 0;
         unsigned long long used = 0;
-        for (unsigned k = 0; k < job->unit_count; k++)
-            units[k].kind = HAPGPU_UNIT_SKIP;
+        // (every unit slot reads SKIP already: hapgpu_k_decode_plan clears the array before this kernel)
         if (job->mode == HAPGPU_JOB_RAW) {                 // reference hap.c:905-916
             used = job->payload_len;
             if (used > job->dst_cap)
@@ -168,9 +167,7 @@ __global__ __launch_bounds__(64) void decode_plan_kernel(HapGpuDecodeJob *jobs, 
         const unsigned long long my_off = run + incl - out_len;
         run += __shfl(incl, 63);
         if (i < n) {
-            HapGpuDecodeUnit *u = units + c.unit_first;
-            for (unsigned k = 0; k < c.unit_count; k++)
-                u[k].kind = HAPGPU_UNIT_SKIP;
+            HapGpuDecodeUnit *u = units + c.unit_first;                 // (all SKIP so far: cleared before the launch)
             if (!wanted || my_off + out_len > job->dst_cap) {
                 // not requested by the client / will be rejected as Buffer_Too_Small below
             } else if (codec == HAP_NIBBLE_NONE) {
