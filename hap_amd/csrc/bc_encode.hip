@@ -318,13 +318,13 @@ __device__ __forceinline__ void encode_block(const uint8_t *__restrict__ rgba, s
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             // Y = (R+2G+B+2)>>2 ; Co = ((R-B+1)>>1)+128 = (R+(255-B)+2)>>1 ; Cg = ((-R+2G-B+2)>>2)+128 =
-            // ((255-R)+2G+(255-B)+4)>>2 -- three byte dot products (alpha weight 0), upper clamp only
+            // ((255-R)+2G+(255-B)+4)>>2 -- three byte dot products (alpha weight 0); no clamp (oracle/bc_oracle.c)
             const unsigned q = p[i];
             y[i] = (int)(__builtin_amdgcn_udot4(q, 0x00010201u, 2u, false) >> 2);
             const unsigned co2 = __builtin_amdgcn_udot4(q ^ 0x00FF0000u, 0x00010001u, 2u, false);           // 2 Co: 2..512
             const unsigned cg4 = __builtin_amdgcn_udot4(q ^ 0x00FF00FFu, 0x00010201u, 4u, false);           // 4 Cg: 4..1024
-            const pk_u16 raw = __builtin_bit_cast(pk_u16, co2 | (cg4 << 16)), sh = {1, 2}, top = {255, 255};
-            cc[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_min((pk_u16)(raw >> sh), top));       // halve / quarter, upper clamp, both at once
+            const pk_u16 raw = __builtin_bit_cast(pk_u16, co2 | (cg4 << 16)), sh = {1, 2};
+            cc[i] = __builtin_bit_cast(unsigned, (pk_u16)(raw >> sh));                                       // halve / quarter, both at once: 1 .. 256
         }
         const uint2 ab = alpha_block(y), cb = ycocg_colour_block(cc);
         *reinterpret_cast<uint4 *>(out + id * 16u) = make_uint4(ab.x, ab.y, cb.x, cb.y);

@@ -35,7 +35,8 @@
  *     a0==a1 -> indices 0, else d = a0-a1, u = a0-a,
  *     ramp position r = (14u + max(d-6,0)) / 2d (floor), code = r==0?0 : r==7?1 : r+1
  *
- *   YCoCg: Y=(R+2G+B+2)>>2, Co=clamp(((R-B+1)>>1)+128), Cg=clamp(((-R+2G-B+2)>>2)+128)
+ *   YCoCg: Y=(R+2G+B+2)>>2, Co=((R-B+1)>>1)+128, Cg=((-R+2G-B+2)>>2)+128   (1..256: no clamp per pixel -- 256 only
+ *     for saturated primaries, and the 5:6:5 endpoints quantise 256 to their top code like 255)
  *     scale s = 4 if max|C-128|<=31, 2 if <=63, else 1 ; C' = (C-128)s+128
  *     2-D (Co',Cg') bounding box with the same diagonal/inset/565 rules,
  *     blue 5-bit field = s-1 in both endpoints (decodes to 0/8/24).
@@ -196,7 +197,7 @@ static void colour_block(const int px[16][3], uint8_t out[8])
 
 static void ycocg_colour_block(const int co[16], const int cg[16], uint8_t out[8])
 {
-    int lo_o = 255, hi_o = 0, lo_g = 255, hi_g = 0, i, m, s, cov = 0, ins;
+    int lo_o = 256, hi_o = 0, lo_g = 256, hi_g = 0, i, m, s, cov = 0, ins;
     int px[16][3], ao, ag, bo, bg;
     unsigned qa, qb, c0, c1;
     uint32_t idx = 0;
@@ -298,8 +299,8 @@ void obc_encode_ycocg_dxt5(const uint8_t *rgba, unsigned w, unsigned h, size_t r
                 const uint8_t *p = pixel(rgba, row_bytes, bx * 4 + (i & 3), by * 4 + (i >> 2));
                 int r = p[0], g = p[1], b = p[2];
                 y[i] = (r + 2 * g + b + 2) >> 2;
-                co[i] = clamp255(((r - b + 1) >> 1) + 128);
-                cg[i] = clamp255(((-r + 2 * g - b + 2) >> 2) + 128);
+                co[i] = ((r - b + 1) >> 1) + 128;                  /* 1 .. 256 (256: R = 255, B = 0) */
+                cg[i] = ((-r + 2 * g - b + 2) >> 2) + 128;         /* 1 .. 256 (256: G = 255, R = B = 0) */
             }
             alpha_block(y, out);
             ycocg_colour_block(co, cg, out + 8);
