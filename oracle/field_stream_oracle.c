@@ -21,7 +21,7 @@
  *      field one block back, most recent block wins;
  *   c. per half-tile: copies are chosen left to right -- at the first uncovered matching position the NEAREST
  *      matching distance starts a copy that runs to the end of its match ("sticky"), the next one starts where it
- *      ends; copies are cut at field 16 (64 bytes); fields no distance covers are single-field copies from their
+ *      ends; a copy longer than 64 bytes is cut at field 16 (byte 64); fields no distance covers are single-field copies from their
  *      table candidate if they have one, literals otherwise;
  *   d. literal runs take a 1-byte header up to 60 bytes and (0xF0, len - 1) above; copies are copy-1 when shorter
  *      than 12 bytes and nearer than 2048 bytes, else copy-2.
@@ -161,8 +161,18 @@ unsigned ofs_compress_fragment(const uint8_t *src, unsigned n, unsigned layout, 
         uint32_t S = H | (lit & ~(lit << 1));
         for (unsigned d = 0; d < OFS_DISTANCES; d++)
             S |= A[d] & ~(A[d] << 1);
-        S |= (1u << 16) & ~lit;
         S &= valid;
+        /* a copy is at most 64 bytes: the one that runs across field 16 (byte 64 of the half-tile) is cut there if it
+           is longer -- both pieces then fit */
+        if (((valid & ~S & ~lit) >> 16) & 1u) {
+            unsigned a = 15, b = 17;
+            while (!((S >> a) & 1u))
+                a--;                                       /* (field 0 always starts an element) */
+            while (b < nv && !((S >> b) & 1u))
+                b++;
+            if ((b < 32u ? fpos(L, b) : 128u) - fpos(L, a) > 64u)
+                S |= 1u << 16;
+        }
         /* elements in order */
         uint8_t *const start = out + produced;
         uint8_t *o = start;
