@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
         unsigned U = 0;
 #pragma unroll
         for (unsigned d = 0; d < kDistances; d++) {
-            E[d] &= ~(UL::small32 & ~(E[d] >> 1));          // a 2-byte field only together with the field behind it
+            E[d] &= ~(UL::small32 & ~(E[d] >> 1) & ~(E[d] << 1));     // a 2-byte field only next to a neighbour that matches too
             U |= E[d];
         }
         unsigned front = U & ~(U << 1);
@@ -362,22 +362,35 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
         }
         const unsigned cov = A[0] | A[1] | A[2] | A[3];
         const unsigned Hm = mb.x & ~cov;
-        const unsigned L = valid & ~(cov | Hm);
-        unsigned S = Hm | (L & ~(L << 1));
+        unsigned L = valid & ~(cov | Hm);
+        unsigned S = 0;
 #pragma unroll
-        for (unsigned d = 0; d < kDistances; d++)
-            S |= A[d] & ~(A[d] << 1);
-        S &= valid;
-        {
-            // a copy is at most 64 bytes: the one that runs across field 16 (byte 64 of the half-tile) is cut there if
-            // it is longer -- both pieces then fit.  a: its first field (the last start below 16; field 0 always starts
-            // an element), b: the next start, or the end of the data
-            constexpr unsigned FO = LAYOUT == 4u ? 0x0C080200u : LAYOUT == 2u ? 0x0C080400u : 0x0A080200u;   // fo(k), a byte each
-            const unsigned a = 31u - (unsigned)__builtin_clz((S & 0xFFFFu) | 1u);
-            const unsigned b = 17u + (unsigned)__builtin_ctz(((S | ~valid) >> 17) | 0x8000u);
-            const unsigned bytes = (b >> 2) * 16u + ((FO >> (8u * (b & 3u))) & 0xFFu) - (a >> 2) * 16u - ((FO >> (8u * (a & 3u))) & 0xFFu);
-            const unsigned inside = (valid & ~S & ~L) >> 16;          // field 16 lies inside a copy
-            S |= (inside & (bytes > 64u ? 1u : 0u)) << 16;
+        for (int pass = 0; pass < 2; pass++) {
+            S = Hm | (L & ~(L << 1));
+#pragma unroll
+            for (unsigned d = 0; d < kDistances; d++)
+                S |= A[d] & ~(A[d] << 1);
+            S &= valid;
+            {
+                // a copy is at most 64 bytes: the one that runs across field 16 (byte 64 of the half-tile) is cut there
+                // if it is longer -- both pieces then fit.  a: its first field (the last start below 16; field 0 always
+                // starts an element), b: the next start, or the end of the data
+                constexpr unsigned FO = LAYOUT == 4u ? 0x0C080200u : LAYOUT == 2u ? 0x0C080400u : 0x0A080200u;   // fo(k), a byte each
+                const unsigned a = 31u - (unsigned)__builtin_clz((S & 0xFFFFu) | 1u);
+                const unsigned b = 17u + (unsigned)__builtin_ctz(((S | ~valid) >> 17) | 0x8000u);
+                const unsigned bytes = (b >> 2) * 16u + ((FO >> (8u * (b & 3u))) & 0xFFu) - (a >> 2) * 16u - ((FO >> (8u * (a & 3u))) & 0xFFu);
+                const unsigned inside = (valid & ~S & ~L) >> 16;          // field 16 lies inside a copy
+                S |= (inside & (bytes > 64u ? 1u : 0u)) << 16;
+            }
+            if (pass == 0 && UL::small32 != 0u) {
+                // a copy never consists of a 2-byte field alone (no copy element is that short): such fields -- the tail
+                // of a run that was cut, a match that nothing continues -- become literals, and the starts are found again
+                const unsigned lone = UL::small32 & S & (((S | ~valid) >> 1) | 0x80000000u) & ~L & ~Hm & valid;
+                L |= lone;
+#pragma unroll
+                for (unsigned d = 0; d < kDistances; d++)
+                    A[d] &= ~lone;
+            }
         }
         const unsigned Sx1 = ((S | ~valid) >> 1) | 0x80000000u;       // bit i: position i + 1 starts an element (or ends the data)
         const unsigned CS = S & ~L;

@@ -15,7 +15,8 @@
  *
  * Algorithm, per fragment of <= 8 KiB (units of 16 bytes = 4 fields; 32 fields = one half-tile):
  *   a. field i matches at distance d (1..4 blocks) when its bytes equal the same field d blocks back;
- *      a 2-byte field only counts together with the field behind it;
+ *      a 2-byte field only counts next to a neighbouring field that matches at the same distance, and never makes a
+ *      copy of its own;
  *   b. index fields (6-byte / 4-byte index words) look up the most recent earlier block with the same value in a
  *      direct-mapped table that is updated after every 64 units ("step") with the fields that differ from the same
  *      field one block back, most recent block wins;
@@ -133,7 +134,7 @@ unsigned ofs_compress_fragment(const uint8_t *src, unsigned n, unsigned layout, 
             uint32_t e = 0;
             for (unsigned i = 0; i < nv; i++)
                 e |= (uint32_t)eq[d][f0 + i] << i;
-            e &= ~(small32 & ~(e >> 1));
+            e &= ~(small32 & ~(e >> 1) & ~(e << 1));      /* a 2-byte field only next to a neighbour that matches too */
             E[d] = e;
             A[d] = 0;
             U |= e;
@@ -157,21 +158,32 @@ unsigned ofs_compress_fragment(const uint8_t *src, unsigned n, unsigned layout, 
         for (unsigned d = 0; d < OFS_DISTANCES; d++)
             cov |= A[d];
         H &= ~cov & cls32;
-        const uint32_t lit = valid & ~(cov | H);
-        uint32_t S = H | (lit & ~(lit << 1));
-        for (unsigned d = 0; d < OFS_DISTANCES; d++)
-            S |= A[d] & ~(A[d] << 1);
-        S &= valid;
-        /* a copy is at most 64 bytes: the one that runs across field 16 (byte 64 of the half-tile) is cut there if it
-           is longer -- both pieces then fit */
-        if (((valid & ~S & ~lit) >> 16) & 1u) {
-            unsigned a = 15, b = 17;
-            while (!((S >> a) & 1u))
-                a--;                                       /* (field 0 always starts an element) */
-            while (b < nv && !((S >> b) & 1u))
-                b++;
-            if ((b < 32u ? fpos(L, b) : 128u) - fpos(L, a) > 64u)
-                S |= 1u << 16;
+        uint32_t lit = valid & ~(cov | H), S = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            S = H | (lit & ~(lit << 1));
+            for (unsigned d = 0; d < OFS_DISTANCES; d++)
+                S |= A[d] & ~(A[d] << 1);
+            S &= valid;
+            /* a copy is at most 64 bytes: the one that runs across field 16 (byte 64 of the half-tile) is cut there if
+               it is longer -- both pieces then fit */
+            if (((valid & ~S & ~lit) >> 16) & 1u) {
+                unsigned a = 15, b = 17;
+                while (!((S >> a) & 1u))
+                    a--;                                   /* (field 0 always starts an element) */
+                while (b < nv && !((S >> b) & 1u))
+                    b++;
+                if ((b < 32u ? fpos(L, b) : 128u) - fpos(L, a) > 64u)
+                    S |= 1u << 16;
+            }
+            if (pass == 0) {
+                /* a copy never consists of a 2-byte field alone (no copy element is that short): such fields -- the tail
+                   of a run that was cut, a match that nothing continues -- become literals, and the starts are found again */
+                const uint32_t next_starts = ((S | ~valid) >> 1) | 0x80000000u;
+                const uint32_t lone = small32 & S & next_starts & ~lit & ~H & valid;
+                lit |= lone;
+                for (unsigned d = 0; d < OFS_DISTANCES; d++)
+                    A[d] &= ~lone;
+            }
         }
         /* elements in order */
         uint8_t *const start = out + produced;
