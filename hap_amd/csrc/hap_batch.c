@@ -319,7 +319,8 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
                    (rows of up to ~5 KiB: below 1080p for 16-byte blocks, below 4K for 8-byte blocks) */
                 {
                     const int small_blocks = g[i].format == HapTextureFormat_RGB_DXT1 || g[i].format == HapTextureFormat_A_RGTC1;
-                    const int windowed = frag_log2 == 13u &&
+                    /* (field streams with their group table are decoded over a whole-fragment ring: no window) */
+                    const int windowed = frag_log2 == 13u && !g[i].half_tiles &&
                                          g[i].bytes >= (small_blocks ? ((size_t)2u << 20) : ((size_t)1u << 20));
                     te->reserved = g[i].gran_log2 | (windowed ? (HAP_FRAGMENT_WINDOW_256 << 8) : 0u) | (g[i].field_period << 16) |
                                    (g[i].half_tiles << 20);

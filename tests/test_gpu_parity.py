@@ -1123,28 +1123,35 @@ def test_match_window_promise_is_checked_and_optional(ctx, hap):
     if os.environ.get("HAP_AMD_BYTE_GRANULAR"):
         pytest.skip("byte-granular streams keep no match window")
     tex = D.stream_bytes(16 * 64 * 1024, "runs", seed=41)           # 1 MiB: large enough for the window to be used
-    out = np.zeros(hap.HapMaxEncodedLength([len(tex)], [L.FMT_YCOCG], [2]) + 4096, dtype=np.uint8)
-    r, used, res = ctx.encode_frames([[tex]], [L.FMT_YCOCG], [1], [2], [out], flags=hap.ENCODE_FRAGMENT_INDEX)
+    fmt = L.FMT_BC7                                                  # (an opaque format: the position-per-lane compressor)
+    out = np.zeros(hap.HapMaxEncodedLength([len(tex)], [fmt], [2]) + 4096, dtype=np.uint8)
+    r, used, res = ctx.encode_frames([[tex]], [fmt], [1], [2], [out], flags=hap.ENCODE_FRAGMENT_INDEX)
     assert r == 0
     frame = bytearray(out[: used[0]].tobytes())
     at, ver, hdr = find_fragment_table(frame)
-    assert at > 0 and ver == 3 and hdr == bytes([3, 13, 0x41, 12])     # field stream, 16-bit granular, 3 KiB window
-    assert hap.HapDecode(bytes(frame), 0, outputBufferBytes=len(tex)) == (0, tex, L.FMT_YCOCG)
+    assert at > 0 and ver == 1 and hdr == bytes([1, 13, 1, 12])        # 16-bit granular, 3 KiB window
+    assert hap.HapDecode(bytes(frame), 0, outputBufferBytes=len(tex)) == (0, tex, fmt)
     for name, api in CHECKERS:
-        assert api.decode(bytes(frame), 0, len(tex)) == (0, tex, L.FMT_YCOCG), name
+        assert api.decode(bytes(frame), 0, len(tex)) == (0, tex, fmt), name
     # no promise: same bytes, whole-fragment ring
     plain = bytearray(frame)
     plain[at + 4] = 0
-    assert hap.HapDecode(bytes(plain), 0, outputBufferBytes=len(tex)) == (0, tex, L.FMT_YCOCG)
+    assert hap.HapDecode(bytes(plain), 0, outputBufferBytes=len(tex)) == (0, tex, fmt)
     # a tighter promise than the streams keep (1 x 256 bytes is certainly violated by hash matches or is harmless):
     tight = bytearray(frame)
     tight[at + 4] = 1
-    assert hap.HapDecode(bytes(tight), 0, outputBufferBytes=len(tex)) == (0, tex, L.FMT_YCOCG)
+    assert hap.HapDecode(bytes(tight), 0, outputBufferBytes=len(tex)) == (0, tex, fmt)
     # small textures keep the whole fragment as their window (their block rows are short enough to matter)
     small = tex[: 16 * 64 * 96]
-    r, used, res = ctx.encode_frames([[small]], [L.FMT_YCOCG], [1], [2], [out], flags=hap.ENCODE_FRAGMENT_INDEX)
-    assert r == 0 and find_fragment_table(out[: used[0]].tobytes())[2] == bytes([3, 13, 0x41, 0])
-    assert hap.HapDecode(out[: used[0]].tobytes(), 0, outputBufferBytes=len(small)) == (0, small, L.FMT_YCOCG)
+    r, used, res = ctx.encode_frames([[small]], [fmt], [1], [2], [out], flags=hap.ENCODE_FRAGMENT_INDEX)
+    assert r == 0 and find_fragment_table(out[: used[0]].tobytes())[2] == bytes([1, 13, 1, 0])
+    assert hap.HapDecode(out[: used[0]].tobytes(), 0, outputBufferBytes=len(small)) == (0, small, fmt)
+    # field streams (block textures with their group table) are decoded over a whole-fragment ring: no window at any size
+    for part in (tex, small):
+        out2 = np.zeros(hap.HapMaxEncodedLength([len(part)], [L.FMT_YCOCG], [2]) + 4096, dtype=np.uint8)
+        r, used, res = ctx.encode_frames([[part]], [L.FMT_YCOCG], [1], [2], [out2], flags=hap.ENCODE_FRAGMENT_INDEX)
+        assert r == 0 and find_fragment_table(out2[: used[0]].tobytes())[2] == bytes([3, 13, 0x41, 0])
+        assert hap.HapDecode(out2[: used[0]].tobytes(), 0, outputBufferBytes=len(part)) == (0, part, L.FMT_YCOCG)
     # a hand-made fragment whose copy reaches 6 KiB back, filed under a table that promises 3 KiB
     lit = bytes(range(256)) * 24                                     # 6144 literal bytes
     def literal(b):
@@ -1719,7 +1726,7 @@ def test_block_compressor_writes_exactly_the_bytes_of_its_scalar_definition(ctx,
     limited = ORA.chunk_count(_encode_with(ORA, tex, fmt, L.COMP_SNAPPY, chunks), 0)[1]
     codecs, sizes, frag_sizes, half, at = _own_frame_sections(frame, limited)
     cb = len(tex) // limited
-    window = 3072 if len(tex) >= ((2 << 20) if layout != 4 else (1 << 20)) else 0
+    window = 0                                   # (field streams keep no match window)
     fi = 0
     for c in range(limited):
         assert codecs[c] == 0x0B
