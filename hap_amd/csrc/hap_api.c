@@ -210,10 +210,11 @@ unsigned long HapMaxEncodedLength(unsigned int count, unsigned long *lengths,
 static unsigned env_encode_flags(void)
 {
     const char *e = getenv("HAP_AMD_FRAGMENT_INDEX"), *c = getenv("HAP_AMD_COARSE_MATCHES"), *s = getenv("HAP_AMD_SMALLER_FILES");
-    /* the private fragment table is written by default (the reference skips unknown sections, hap.c:701-703, and a
-       section that would not shrink with it is stored raw): frames from plain hap.h HapEncode then decode through
-       the block-per-lane kernel; HAP_AMD_FRAGMENT_INDEX=0 leaves it out */
-    return ((!e || atoi(e) != 0) ? HAPGPU_ENCODE_FRAGMENT_INDEX : 0u) |
+    /* Frames from plain hap.h HapEncode carry nothing the Hap specification does not name: the private fragment table
+       (section 0x46 inside the Decode Instructions Container) is written on request only, HAP_AMD_FRAGMENT_INDEX=1 --
+       the reference skips unknown sections there (hap.c:701-703), but a drop-in library cannot know that every other
+       parser of its frames does.  The batched HapGpu* calls take it as a flag. */
+    return ((e && atoi(e) != 0) ? HAPGPU_ENCODE_FRAGMENT_INDEX : 0u) |
            ((c && atoi(c) != 0) ? HAPGPU_ENCODE_COARSE_MATCHES : 0u) |
            ((s && atoi(s) != 0) ? HAPGPU_ENCODE_SMALLER_FILES : 0u);
 }

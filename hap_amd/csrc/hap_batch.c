@@ -349,7 +349,9 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
                 graph = hapgpu_rt_graph_begin(rt, key);
             }
 #undef HAPB_MIX
-            if (graph != 1) {
+            /* (a recording that cannot be ended, instantiated or launched has run nothing: graphs are switched off for
+               this context and the same launches are issued once more, plainly) */
+            while (graph != 1) {
                 if (job) {
                     launch_rc |= (unsigned)hapgpu_rt_h2d(rt, job->device_table, job->host_table,
                                                          sizeof(uint64_t) * (size_t)(1u + job->count) * job->frame_count);
@@ -374,8 +376,16 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
                                                            dcopies, frags_per_frame * live, chunks_per_frame, max_chunks_per_tex, count, dpack);
                 launch_rc |= (unsigned)hapgpu_k_frame_gather(rt, dcopies, (frags_per_frame + chunks_per_frame) * live);
                 launch_rc |= (unsigned)hapgpu_rt_d2h(rt, hframes, dframes, sizeof(HapGpuFrameEnc) * live);
-                if (graph == 0)
-                    launch_rc |= (unsigned)hapgpu_rt_graph_end(rt, key, launch_rc != 0);
+                if (graph == 0) {
+                    const int ended = hapgpu_rt_graph_end(rt, key, launch_rc != 0);
+                    if (ended != 0 && launch_rc == 0) {
+                        hapgpu_rt_graphs_disable(rt);
+                        graph = 2;
+                        continue;
+                    }
+                    launch_rc |= (unsigned)ended;
+                }
+                break;
             }
             rc |= launch_rc;
         }

@@ -315,6 +315,8 @@ unsigned int HapGpuDecodeSequence(HapGpuContext *ctx, HapSequenceReader *r, unsi
         batch = 16;
     if (batch > count)
         batch = count;
+    if (batch > 32768u)
+        batch = 32768u;                                 /* (one launch sequence: grid dimensions hold at most 65535) */
     batches = (count + batch - 1u) / batch;
     for (b = 0; b < batches; b++) {
         const unsigned f0 = first + b * batch, n = (count - b * batch) < batch ? (count - b * batch) : batch;
@@ -396,6 +398,7 @@ typedef struct write_job {
     size_t stride;
     const unsigned long *used;
     unsigned result;
+    unsigned written;           /* frames of the batch that were appended */
 } write_job;
 
 static void *write_main(void *arg)
@@ -403,9 +406,29 @@ static void *write_main(void *arg)
     write_job *j = (write_job *)arg;
     unsigned i;
     j->result = HapResult_No_Error;
-    for (i = 0; i < j->count && j->result == HapResult_No_Error; i++)
+    j->written = 0;
+    for (i = 0; i < j->count && j->result == HapResult_No_Error; i++) {
         j->result = HapSequenceWriterAppend(j->writer, j->base + j->stride * i, j->used[i]);
+        if (j->result == HapResult_No_Error)
+            j->written = i + 1u;
+    }
     return NULL;
+}
+
+/* frames [first, first + count) were encoded; the first `written` of them are in the file: only those report their
+   size, the others a failure (their own, or Internal_Error for a frame that was fine but never written) */
+static void publish_batch(unsigned int *results, unsigned long *frame_bytes, unsigned first, unsigned count, unsigned written,
+                          const unsigned *res, const unsigned long *used)
+{
+    unsigned i;
+    for (i = 0; i < count; i++) {
+        const int in_file = i < written && res[i] == HapResult_No_Error;
+        if (results)
+            results[first + i] = in_file ? (unsigned)HapResult_No_Error
+                                         : res[i] != HapResult_No_Error ? res[i] : (unsigned)HapResult_Internal_Error;
+        if (frame_bytes)
+            frame_bytes[first + i] = in_file ? used[i] : 0ul;
+    }
 }
 
 unsigned int HapGpuEncodeSequence(HapGpuContext *ctx, HapSequenceWriter *w, unsigned int count,
@@ -421,10 +444,11 @@ unsigned int HapGpuEncodeSequence(HapGpuContext *ctx, HapSequenceWriter *w, unsi
     uint8_t *pinned[2] = {NULL, NULL};
     void **outs = NULL;
     unsigned long *caps = NULL, *used[2] = {NULL, NULL};
-    unsigned *res = NULL;
+    unsigned *res[2] = {NULL, NULL};
     write_job job;
     pthread_t thread;
     int thread_live = 0;
+    unsigned pending_first = 0, pending_slot = 0;       /* the batch the helper thread is appending */
 
     if (!ctx || !w || !rgba_frames || count == 0 || texture_count == 0 || texture_count > 2 || !formats || !compressors ||
         !chunk_counts || width == 0 || height == 0 || (width & 3u) || (height & 3u))
@@ -440,15 +464,18 @@ unsigned int HapGpuEncodeSequence(HapGpuContext *ctx, HapSequenceWriter *w, unsi
         batch = 16;
     if (batch > count)
         batch = count;
+    if (batch > 32768u)
+        batch = 32768u;                                 /* (one launch sequence: grid dimensions hold at most 65535) */
     batches = (count + batch - 1u) / batch;
     stride = ((size_t)cap + 255u) & ~(size_t)255u;
     outs = (void **)malloc(sizeof(void *) * batch);
     caps = (unsigned long *)malloc(sizeof(unsigned long) * batch);
     used[0] = (unsigned long *)calloc(batch, sizeof(unsigned long));
     used[1] = (unsigned long *)calloc(batch, sizeof(unsigned long));
-    res = (unsigned *)malloc(sizeof(unsigned) * batch);
-    if (!outs || !caps || !used[0] || !used[1] || !res) {
-        free(outs); free(caps); free(used[0]); free(used[1]); free(res);
+    res[0] = (unsigned *)malloc(sizeof(unsigned) * batch);
+    res[1] = (unsigned *)malloc(sizeof(unsigned) * batch);
+    if (!outs || !caps || !used[0] || !used[1] || !res[0] || !res[1]) {
+        free(outs); free(caps); free(used[0]); free(used[1]); free(res[0]); free(res[1]);
         return HapResult_Internal_Error;
     }
     /* (the context stays locked for the whole call: the two frame buffers are its scratch, see HapGpuDecodeSequence) */
@@ -457,7 +484,7 @@ unsigned int HapGpuEncodeSequence(HapGpuContext *ctx, HapSequenceWriter *w, unsi
     pinned[1] = batches > 1 ? (uint8_t *)hapgpu_rt_pinned_scratch(ctx->rt, P_SEQ1, stride * batch) : pinned[0];
     if (!pinned[0] || !pinned[1]) {
         hapgpu_rt_unlock(ctx->rt);
-        free(outs); free(caps); free(used[0]); free(used[1]); free(res);
+        free(outs); free(caps); free(used[0]); free(used[1]); free(res[0]); free(res[1]);
         return HapResult_Internal_Error;
     }
     memset(&job, 0, sizeof(job));
@@ -475,31 +502,34 @@ unsigned int HapGpuEncodeSequence(HapGpuContext *ctx, HapSequenceWriter *w, unsi
         }
         /* (the helper may still be writing batch b - 1 from the OTHER buffer: the GPU fills this one meanwhile) */
         rc = hapb_encode_rgba(ctx, n, rgba_frames + done, width, height, row_bytes, texture_count, formats, compressors,
-                              chunk_counts, outs, caps, used[b & 1u], res, flags);
+                              chunk_counts, outs, caps, used[b & 1u], res[b & 1u], flags);
         if (thread_live) {
             pthread_join(thread, NULL);
             thread_live = 0;
+            publish_batch(results, frame_bytes, pending_first, job.count, job.written, res[pending_slot], used[pending_slot]);
             if (job.result != HapResult_No_Error)
                 first_error = job.result;
         }
-        for (i = 0; i < n; i++) {
-            if (results)
-                results[done + i] = res[i];
-            if (frame_bytes)
-                frame_bytes[done + i] = res[i] == HapResult_No_Error ? used[b & 1u][i] : 0ul;
-            if (res[i] != HapResult_No_Error && rc == HapResult_No_Error)
-                rc = res[i];
-        }
+        for (i = 0; i < n; i++)
+            if (res[b & 1u][i] != HapResult_No_Error && rc == HapResult_No_Error)
+                rc = res[b & 1u][i];
         if (rc != HapResult_No_Error && first_error == HapResult_No_Error)
             first_error = rc;
-        if (first_error != HapResult_No_Error)
+        if (first_error != HapResult_No_Error) {
+            /* nothing of this batch goes to the file: a frame that failed, or the batch before it could not be written */
+            publish_batch(results, frame_bytes, done, n, 0u, res[b & 1u], used[b & 1u]);
             break;
+        }
         job.writer = w; job.count = n; job.base = base; job.stride = stride; job.used = used[b & 1u];
         job.result = HapResult_Internal_Error;
+        job.written = 0;
+        pending_first = done;
+        pending_slot = b & 1u;
         if (b + 1u < batches && pthread_create(&thread, NULL, write_main, &job) == 0) {
             thread_live = 1;
         } else {
             write_main(&job);
+            publish_batch(results, frame_bytes, done, n, job.written, res[b & 1u], used[b & 1u]);
             if (job.result != HapResult_No_Error)
                 first_error = job.result;
         }
@@ -507,10 +537,11 @@ unsigned int HapGpuEncodeSequence(HapGpuContext *ctx, HapSequenceWriter *w, unsi
     }
     if (thread_live) {
         pthread_join(thread, NULL);
+        publish_batch(results, frame_bytes, pending_first, job.count, job.written, res[pending_slot], used[pending_slot]);
         if (job.result != HapResult_No_Error && first_error == HapResult_No_Error)
             first_error = job.result;
     }
     hapgpu_rt_unlock(ctx->rt);
-    free(outs); free(caps); free(used[0]); free(used[1]); free(res);
+    free(outs); free(caps); free(used[0]); free(used[1]); free(res[0]); free(res[1]);
     return first_error;
 }

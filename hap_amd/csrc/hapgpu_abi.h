@@ -217,6 +217,8 @@ int hapgpu_rt_device(hapgpu_rt *rt);
  * launches, then _end), 2 = launch as usual.  _end(failed): 0 = instantiated, remembered and launched. */
 int hapgpu_rt_graph_begin(hapgpu_rt *rt, uint64_t key);
 int hapgpu_rt_graph_end(hapgpu_rt *rt, uint64_t key, int failed);
+/* no more recordings for this runtime (its recorded sequences stay usable): after a capture / instantiate / launch failure */
+void hapgpu_rt_graphs_disable(hapgpu_rt *rt);
 
 /* kernels: all asynchronous on the runtime's stream; 0 = launched */
 int hapgpu_k_block_encode(hapgpu_rt *rt, const void *rgba, unsigned width, unsigned height,
@@ -230,7 +232,7 @@ int hapgpu_k_block_encode_batch_ycocg_alpha(hapgpu_rt *rt, const uint64_t *sourc
                                             unsigned height, size_t row_bytes, int wide);
 int hapgpu_k_block_decode(hapgpu_rt *rt, const void *blocks, const void *alpha, unsigned width, unsigned height,
                           unsigned hap_texture_format, void *rgba, size_t row_bytes);
-/* group_tables: 64 bytes per fragment (same indexing as frag_sizes), written for textures whose reserved bit 20 is set */
+/* group_tables: HAP_GROUP_TABLE_BYTES (96) bytes per fragment (same indexing as frag_sizes), written for textures whose reserved bit 20 is set */
 int hapgpu_k_snappy_compress(hapgpu_rt *rt, const HapGpuFrameEnc *frames, unsigned frame_count,
                              unsigned max_frags_per_texture, unsigned frag_log2,
                              void *slots, unsigned slot_stride, uint32_t *frag_sizes, uint8_t *group_tables,

@@ -333,6 +333,13 @@ extern "C" int hapgpu_rt_graph_end(hapgpu_rt *rt, uint64_t key, int failed)
     return 0;
 }
 
+extern "C" void hapgpu_rt_graphs_disable(hapgpu_rt *rt)
+{
+    if (!rt->graphs_off)
+        fprintf(stderr, "hap_amd: HIP graph of a launch sequence failed; this context launches plainly from now on\n");
+    rt->graphs_off = 1;
+}
+
 // ---- instrumentation -----------------------------------------------------------------------
 
 static hipEvent_t take_event(hapgpu_rt *rt)

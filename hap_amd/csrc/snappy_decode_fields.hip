@@ -30,6 +30,8 @@
 //      lane indices (ds_bpermute, <= 6 rounds); then 4 field reads, one 16-byte LDS store (later steps copy from
 //      it) and one 16-byte global store.
 //
+// All layouts run in ONE launch (the two textures of a Hap Q Alpha frame are units of one array; the layout is uniform
+// per wave).
 // LDS: the output ring (8 KiB) and the staged compressed bytes share one buffer -- the input is parked at its END,
 // where output written by step s never reaches the compressed bytes that later steps still read (checked per group).
 // The element records live in the same buffer too, BELOW the parked input, where output only arrives after every
@@ -47,8 +49,19 @@ constexpr unsigned kFragBytes = 8192u;
 constexpr unsigned kHalf = 128u;                       // bytes of output per half-tile
 constexpr unsigned kHalves = kFragBytes / kHalf;       // 64: one parse lane each
 constexpr unsigned kMaxFragCompressed = kFragBytes + 320u;
+// Switches of the measurement builds (tools/build_variants.sh; never set in the shipped library): LDS per wave up or
+// down (occupancy studies), the set of DPP hops, ablations that break the output on purpose.
 // ring + parked input (at the end of the buffer: see the S computation below) + alignment slack
-constexpr unsigned kBufBytes = 9344u + 32u;
+#ifndef SDF_BUF_BYTES
+#define SDF_BUF_BYTES (9344u + 32u)
+#endif
+#ifndef SDF_DYN_LDS
+#define SDF_DYN_LDS 0
+#endif
+#ifndef SDF_HOPS
+#define SDF_HOPS 15u
+#endif
+constexpr unsigned kBufBytes = SDF_BUF_BYTES;
 
 __device__ __forceinline__ int fdpp_shr(int v, int n)
 {
@@ -75,9 +88,9 @@ __device__ __forceinline__ int fwave_scan_add(int v)       // inclusive
 //   4: 16-byte blocks of 2 + 6 + 4 + 4 bytes (DXT5, YCoCg-DXT5);  2: 8-byte blocks of 4 + 4 (DXT1);
 //   6: 8-byte blocks of 2 + 6 (RGTC1)
 template <unsigned LAYOUT> struct layout_of;
-template <> struct layout_of<4u> { static constexpr unsigned fields = 4u, block = 16u, pos_shift = 1u, unit_kind = HAPGPU_UNIT_SNAPPY_FIELDS4; };
-template <> struct layout_of<2u> { static constexpr unsigned fields = 2u, block = 8u, pos_shift = 2u, unit_kind = HAPGPU_UNIT_SNAPPY_FIELDS2; };
-template <> struct layout_of<6u> { static constexpr unsigned fields = 2u, block = 8u, pos_shift = 1u, unit_kind = HAPGPU_UNIT_SNAPPY_FIELDS26; };
+template <> struct layout_of<4u> { static constexpr unsigned fields = 4u, block = 16u, pos_shift = 1u; };
+template <> struct layout_of<2u> { static constexpr unsigned fields = 2u, block = 8u, pos_shift = 2u; };
+template <> struct layout_of<6u> { static constexpr unsigned fields = 2u, block = 8u, pos_shift = 1u; };
 
 // byte offset of field k inside a block
 template <unsigned LAYOUT>
@@ -151,8 +164,8 @@ __device__ __forceinline__ uint4 load_input16(gin_t src_al, unsigned x, unsigned
 }
 
 template <unsigned LAYOUT>
-__global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDecodeUnit *__restrict__ units,
-                                                                  unsigned unit_count, HapGpuDecodeJob *jobs)
+__device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, HapGpuDecodeJob *jobs, uint8_t *buf, uint2 *masks,
+                                                   uint32_t *coffs, const unsigned lane)
 {
     constexpr unsigned PERIOD = layout_of<LAYOUT>::fields;
     constexpr unsigned kBlock = layout_of<LAYOUT>::block;
@@ -161,17 +174,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
     constexpr unsigned kHalvesPerStep = kStepBytes / kHalf;        // 8 or 4
     constexpr unsigned kPosShift = layout_of<LAYOUT>::pos_shift;    // element start positions are kept in 2- / 4-byte units
     constexpr unsigned kLitBias = kHalf;
-    __shared__ __attribute__((aligned(16))) uint8_t buf[kBufBytes];
-    __shared__ __attribute__((aligned(8))) uint2 masks[kHalves];
-    __shared__ uint32_t coffs[kHalves + 2u];                       // compressed offset | first record << 16, per half-tile
     const uint32_t *bufw = reinterpret_cast<const uint32_t *>(buf);
-
-    const unsigned lane = threadIdx.x;
-    if (blockIdx.x >= unit_count)
-        return;
-    const HapGpuDecodeUnit u = units[blockIdx.x];
-    if (u.kind != layout_of<LAYOUT>::unit_kind)
-        return;
     HapGpuDecodeJob *job = &jobs[u.job];
     const gin_t src = (gin_t)u.src;
     const gout_t dst = (gout_t)u.dst;
@@ -267,6 +270,12 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
     const unsigned rbytes = 2u * elements;
     const bool rec_in_lds = rbytes <= S - shift;
     const gout_t rec_mem = (gout_t)(((uintptr_t)dst + 1u) & ~(uintptr_t)1u);
+    // (records in memory start at the next even address: a hand-made stream of nothing but 2-byte elements and an odd
+    // `dst` would put its last record one byte behind the unit's own output -- honest streams never get near)
+    if (!rec_in_lds && rbytes + (unsigned)((uintptr_t)dst & 1u) > out_len) {
+        fail_unit(job, lane);
+        return;
+    }
 
     // 1b. the walk proper.  Straight-line code under the loop's exec mask: the three element kinds are decoded side by
     // side and selected.  Per element one signed 16-bit record,
@@ -333,7 +342,11 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
         // masks (checked below, per half-tile)
         const bool bad = max_kind == 3u || max_reach > 0 || (acc_or & (kBlock - 1u)) != 0u ||
                          ((acc_or >> 17) & ((1u << kPosShift) - 1u)) != 0u || min_off < kBlock || max_up > 60u ||
-                         crossed != 0u || overrun != 0u || cp != cend || p != obegin + out_g;
+                         crossed != 0u ||
+#ifndef SDF_UNSAFE
+                         overrun != 0u ||
+#endif
+                         cp != cend || p != obegin + out_g;
         if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
             fail_unit(job, lane);
             return;
@@ -472,22 +485,33 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
 #pragma unroll
             for (unsigned k = 0; k < PERIOD; k++) {
                 int v = state[s][k];
-                int t = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);      // row_shr:1
-                v = v == want1 ? t : v;
-                t = __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);          // row_shr:2
-                v = v == want2 ? t : v;
-                t = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);          // row_shr:4
-                v = v == want4 ? t : v;
-                t = __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);          // row_shr:8
-                v = v == want8 ? t : v;
+                int t;
+                if (SDF_HOPS & 1u) {
+                    t = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);      // row_shr:1
+                    v = v == want1 ? t : v;
+                }
+                if (SDF_HOPS & 2u) {
+                    t = __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);      // row_shr:2
+                    v = v == want2 ? t : v;
+                }
+                if (SDF_HOPS & 4u) {
+                    t = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);      // row_shr:4
+                    v = v == want4 ? t : v;
+                }
+                if (SDF_HOPS & 8u) {
+                    t = __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);      // row_shr:8
+                    v = v == want8 ? t : v;
+                }
                 state[s][k] = v;
             }
     }
     //     Then pointer doubling (a chain is at most 63 links long: 6 rounds); the columns of all steps advance together,
     //     so a round is 32 independent ds_bpermutes in flight instead of one dependent LDS round trip per step and
-    //     round.  Descriptors are self-addressed (see above): the fetched value IS the new descriptor.  (The rounds are
-    //     bound by the LDS pipe; skipping columns with nothing pending under wave-uniform branches was measured slower
-    //     -- every branch target waits for all LDS results -- and checks only every second or third round no faster.)
+    //     round.  Descriptors are self-addressed (see above): the fetched value IS the new descriptor.  (r04: a round
+    //     that fetches only for the columns that still have a pending lane -- a bit per column, one hand-written block
+    //     of compare / branch / ds_bpermute per round -- issues a quarter of the ds_bpermutes and is no faster: the
+    //     kernel is bound by vector instruction issue, not by the LDS pipe; LABNOTES.md.)
+#ifndef SDF_ABL_NOROUNDS
 #pragma unroll 1
     for (unsigned round = 0; round < 6u; round++) {
         int any = state[0][0];
@@ -504,6 +528,7 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
             for (unsigned k = 0; k < PERIOD; k++)
                 state[s][k] = __builtin_amdgcn_ds_bpermute(state[s][k], state[s][k]);   // (lane = address bits 7..2)
     }
+#endif
     // 2c. field bytes -> 16-byte block -> ring (later steps copy from it) and memory, step after step
     const unsigned nsteps = (out_len + kStepBytes - 1u) / kStepBytes;
 #pragma unroll
@@ -519,10 +544,18 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
 #pragma unroll
             for (unsigned k = 0; k < PERIOD; k++) {
                 const unsigned a = (unsigned)state[s][k] >> 8, aw = a >> 2, sh = a & 3u;
+#ifdef SDF_ABL_NOPRODREADS
+                const unsigned d0 = aw, d1 = aw + s;
+#else
                 const unsigned d0 = bufw[aw], d1 = bufw[aw + 1u];
+#endif
                 lo[k] = __builtin_amdgcn_alignbyte(d1, d0, sh);
                 if (k == 1) {
+#ifdef SDF_ABL_NOPRODREADS
+                    const unsigned d2 = aw ^ s;
+#else
                     const unsigned d2 = bufw[aw + 2u];
+#endif
                     hi1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
                 }
             }
@@ -542,7 +575,9 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
         if (active) {
             if (kBlock == 16u) {
                 const uint4 v = make_uint4(out[0], out[1], out[2 % (kBlock / 4u)], out[3 % (kBlock / 4u)]);
+#ifndef SDF_ABL_NORINGSTORE
                 *reinterpret_cast<uint4 *>(buf + opos) = v;
+#endif
                 if (dst_wide) {
                     gstore16(dst + opos, v);
                 } else {
@@ -566,6 +601,27 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
     }
 }
 
+// One launch for every field-stream unit of a batch, whatever its layout (the two textures of a Hap Q Alpha frame are
+// units of one array): the layout is uniform per wave.
+__global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDecodeUnit *__restrict__ units,
+                                                                  unsigned unit_count, HapGpuDecodeJob *jobs)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t buf[kBufBytes];
+    __shared__ __attribute__((aligned(8))) uint2 masks[kHalves];
+    __shared__ uint32_t coffs[kHalves + 2u];                       // first record << 16, per half-tile
+    const unsigned lane = threadIdx.x;
+    if (blockIdx.x >= unit_count)
+        return;
+    const HapGpuDecodeUnit u = units[blockIdx.x];
+    if (u.kind == HAPGPU_UNIT_SNAPPY_FIELDS4)
+        decode_fields_unit<4u>(u, jobs, buf, masks, coffs, lane);
+    else if (u.kind == HAPGPU_UNIT_SNAPPY_FIELDS2)
+        decode_fields_unit<2u>(u, jobs, buf, masks, coffs, lane);
+    else if (u.kind == HAPGPU_UNIT_SNAPPY_FIELDS26)
+        decode_fields_unit<6u>(u, jobs, buf, masks, coffs, lane);
+}
+
+
 } // namespace
 
 // fields_kinds: bit 0 = [2, 6, 4, 4] units present (DXT5 / YCoCg-DXT5), bit 1 = [4, 4] units (DXT1), bit 2 = [2, 6] (RGTC1)
@@ -574,11 +630,7 @@ extern "C" int hapgpu_launch_snappy_decode_fields(const HapGpuDecodeUnit *units,
 {
     if (unit_count == 0)
         return 0;
-    if (fields_kinds & 1u)
-        hipLaunchKernelGGL((snappy_decode_fields_kernel<4u>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs);
-    if (fields_kinds & 2u)
-        hipLaunchKernelGGL((snappy_decode_fields_kernel<2u>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs);
-    if (fields_kinds & 4u)
-        hipLaunchKernelGGL((snappy_decode_fields_kernel<6u>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs);
+    if (fields_kinds & 7u)
+        hipLaunchKernelGGL(snappy_decode_fields_kernel, dim3(unit_count), dim3(64), SDF_DYN_LDS, stream, units, unit_count, jobs);
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }

@@ -1746,13 +1746,27 @@ def test_block_compressor_writes_exactly_the_bytes_of_its_scalar_definition(ctx,
     assert fi == len(frag_sizes) and at == len(frame)
 
 
-def test_plain_hap_h_encode_takes_the_fast_path_by_default(ctx, hap):
-    """HapEncode through hap.h writes the private fragment table unless HAP_AMD_FRAGMENT_INDEX=0 says otherwise: its
-    frames carry the version-3 table, both checkers decode them (unknown sections are skipped, hap.c:701-703), and this
-    library decodes them with the block-per-lane kernel -- no fallback to the generic path."""
+def test_plain_hap_h_encode_writes_the_private_table_on_request_only(ctx, hap, monkeypatch):
+    """HapEncode through hap.h writes nothing the Hap specification does not name unless HAP_AMD_FRAGMENT_INDEX=1 asks
+    for the private fragment table (not every parser of the frames skips unknown sections the way the
+    reference does, hap.c:701-703).  Without it the frame has the reference's sections only and decodes everywhere;
+    with it the frame carries the version-3 table, both checkers still decode it, and this library decodes it with the
+    block-per-lane kernel -- no fallback to the generic path."""
     tex = D.oracle_bc_encode(D.rgba(1024, 512, frame=11), L.FMT_YCOCG)
-    r, frame = hap.HapEncode([tex], [L.FMT_YCOCG], [1], [8])
+    monkeypatch.delenv("HAP_AMD_FRAGMENT_INDEX", raising=False)
+    r, plain = hap.HapEncode([tex], [L.FMT_YCOCG], [1], [8])
     assert r == 0
+    assert find_fragment_table(plain, 0, 4000)[0] < 0
+    _check_frame_structure(plain, tex, L.FMT_YCOCG, 8)
+    assert int.from_bytes(plain[4:7], "little") == 5 * 8 + 8           # hap.c:272: only the three sections the reference writes
+    for name, api in CHECKERS:
+        assert api.decode(plain, 0, len(tex)) == (0, tex, L.FMT_YCOCG), name
+    assert hap.HapDecode(plain, 0, outputBufferBytes=len(tex)) == (0, tex, L.FMT_YCOCG)
+    monkeypatch.setenv("HAP_AMD_FRAGMENT_INDEX", "0")
+    assert hap.HapEncode([tex], [L.FMT_YCOCG], [1], [8]) == (0, plain)
+    monkeypatch.setenv("HAP_AMD_FRAGMENT_INDEX", "1")
+    r, frame = hap.HapEncode([tex], [L.FMT_YCOCG], [1], [8])
+    assert r == 0 and len(frame) > len(plain)
     at, ver, _hdr = find_fragment_table(frame, 0, 4000)
     assert at > 0 and ver == 3
     for name, api in CHECKERS:
@@ -1806,6 +1820,8 @@ def test_encode_sequence_to_file_matches_frame_by_frame(ctx, hap, tmp_path, batc
         broken = list(src[:6]) + [None] + list(src[7:])
         r, nbytes, res = ctx.encode_sequence(writer, broken, w, h, w * 4, fmts, [1, 1], chunks, batch=2)
         assert r == hap.HapResult.Bad_Arguments and res[:6] == [0] * 6 and res[6] == hap.HapResult.Bad_Arguments
+        # (only what is in the file reports a size; the picture beside the broken one was encoded but never written)
+        assert all(b > 0 for b in nbytes[:6]) and nbytes[6:] == [0] * (n - 6) and all(x != 0 for x in res[6:])
     reader = hap.SequenceReader(path2)
     assert reader.frame_count == 6
     reader.close()
