@@ -36,13 +36,14 @@ import torch  # noqa: E402
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 CONFIGS = {
     # name: (width, height, texture formats, chunk counts, default frames per batch)
+    "C1": (1920, 1080, [0x83F0], [1], 1),
     "C2": (3840, 2160, [0x83F0], [1], 60),
     "C3": (3840, 2160, [0x83F3], [8], 60),
     "C4": (7680, 4320, [0x01], [24], 60),
     "C5": (16384, 16384, [0x01, 0x8DBB], [64, 64], 4),
 }
 BLOCK_BYTES = {0x83F0: 8, 0x8DBB: 8, 0x83F3: 16, 0x01: 16}
-ROUND_TAG = "r03"        # profiles/<round>_traffic_<cfg>.json is what roofline.traffic quotes
+ROUND_TAG = "r04"        # profiles/<round>_traffic_<cfg>.json is what roofline.traffic quotes
 
 
 def parse_args():
@@ -61,7 +62,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--foreign-frames", type=int, default=24,
                     help="also time decoding of N frames made by the CPU reference encoder (no fragment table); 0 = skip")
-    ap.add_argument("--c5-frames", type=int, default=2,
+    ap.add_argument("--c5-frames", type=int, default=4,
                     help="also time N frames of C5 (16K Hap Q Alpha, the north-star's target config) at N=1; 0 = skip")
     ap.add_argument("--no-extras", action="store_true",
                     help="the timed pipeline only: no size-for-speed option, texture->RGBA, host-pointer, foreign-frame, CPU "
@@ -337,11 +338,19 @@ def main():
         line["roofline"] = stream.roofline(kernels, args.config)
         line["kernels"] = kernels
         line["cpu_baseline"] = extras.get("cpu_baseline")
+        if not args.no_extras:
+            try:
+                stream.used = stream.encode()
+                stream.decode(stream.used)
+                line["per_call_hap_h"] = per_call_object(hap_amd, stream, dev)
+            except Exception as exc:
+                line["per_call_hap_h"] = {"error": repr(exc)}
         if args.c5_frames and args.config != "C5":
             del stream
             torch.cuda.empty_cache()
             try:
-                line["c5"] = side_config(hap_amd, ctx, dev, "C5", args.c5_frames, flags, fence)
+                line["c5"] = side_config(hap_amd, ctx, dev, "C5", args.c5_frames, flags, fence,
+                                         reference_frames=0 if args.no_cpu_baseline else 1)
             except Exception as exc:
                 line["c5"] = {"error": repr(exc)}
             for small in ("C2", "C3"):
@@ -349,6 +358,12 @@ def main():
                     line[small.lower()] = side_config(hap_amd, ctx, dev, small, CONFIGS[small][4], flags, fence)
                 except Exception as exc:
                     line[small.lower()] = {"error": repr(exc)}
+            for name, fn in (("c1", lambda: c1_object(hap_amd, ctx, dev)), ("bc7_opaque", lambda: opaque_object(hap_amd, ctx, dev, fence))):
+                torch.cuda.empty_cache()
+                try:
+                    line[name] = fn()
+                except Exception as exc:
+                    line[name] = {"error": repr(exc)}
     else:
         per_rank = [len(frames_of_rank(nf_total, r, world, args.scaling)) for r in range(world)]
         line["config"] = {"workload": "%s: %dx%d %s, %s chunks, Snappy, %d-frame stream, device-resident" % (
@@ -359,6 +374,8 @@ def main():
                            else "a whole stream per GPU, no data-path collective"}
         line["other_scaling_mode"] = other
         line["c5_chunk_groups"] = groups
+        line["rccl_ranks_seen"] = int(dist.get_world_size())
+        line["collective_backend"] = str(dist.get_backend())
         kernels, _ratio = stream.kernel_table(prof, args.steps, args.config)
         line["roofline"] = stream.roofline(kernels, args.config)
         line["roofline"]["note"] = "rank 0's launches (%d frames per step)" % stream.nf
@@ -455,7 +472,7 @@ def smaller_option(stream, hap_amd):
             "note": "encode / decode of the same frames with 64 KiB Snappy fragments and no fragment table"}
 
 
-def side_config(hap_amd, ctx, dev, config, frames, flags, fence, steps=6):
+def side_config(hap_amd, ctx, dev, config, frames, flags, fence, steps=6, reference_frames=0):
     """The other BASELINE.json configs beside the headline, same step and timing rules: C5 = the north-star's target,
     16384x16384 Hap Q Alpha (YCoCg-DXT5 + RGTC1, 64 + 64 chunks, two-texture frame); C2 / C3 = the 4K configs."""
     s = Stream(hap_amd, ctx, dev, config, list(range(frames)), flags)
@@ -465,16 +482,28 @@ def side_config(hap_amd, ctx, dev, config, frames, flags, fence, steps=6):
     kernels, ratio = s.kernel_table(prof, steps, config)
     enc_ms, dec_ms = s.split_rates()
     total = frames * steps
-    return {"workload": "%s: %dx%d %s, %s chunks, Snappy, %d frames per step, device-resident" % (
+    res = {"workload": "%s: %dx%d %s, %s chunks, Snappy, %d frames per step, device-resident" % (
                 config, s.w, s.h, "+".join("%#x" % f for f in s.fmts), "+".join(map(str, s.chunks)), frames),
             "value": round(total * s.rgba_bytes / elapsed / 1e9, 2), "unit": "GB/s", "fps": round(total / elapsed, 2),
             "steps": steps, "timed_regions": 2, "ms_per_step": round(elapsed / steps * 1e3, 3), "snappy_ratio": round(ratio, 4),
+            "compressed_bytes_per_step": int(sum(s.used)),
             "bit_exact": s.bit_exact(),
             "encode_only": {"rgba_GBps": round(frames * s.rgba_bytes / (enc_ms * 1e-3) / 1e9, 2), "ms": round(enc_ms, 3)},
             "decode_only": {"rgba_GBps": round(frames * s.rgba_bytes / (dec_ms * 1e-3) / 1e9, 2), "ms": round(dec_ms, 3),
                             "texture_GBps": round(frames * sum(s.tex_bytes) / (dec_ms * 1e-3) / 1e9, 2)},
             "roofline": s.roofline(kernels, config, kernel="snappy_decode"),
             "kernels": kernels}
+    if reference_frames:
+        # the same textures as the reference encoder writes them (libsnappy streams, no table): every existing Hap file
+        try:
+            s.used = s.encode()
+            s.decode(s.used)
+            res["decode_of_reference_encoded_frames"] = decode_foreign(ctx, dev, s.fmts, s.chunks, s.dec, s.tex_bytes, s.cap,
+                                                                       min(reference_frames, frames), s.rgba_bytes,
+                                                                       with_whole_stream=False)
+        except Exception as exc:
+            res["decode_of_reference_encoded_frames"] = {"error": repr(exc)}
+    return res
 
 
 def c5_chunk_groups(hap_amd, ctx, dist, dev, rank, world, fence, reps=3):
@@ -585,6 +614,251 @@ def c5_chunk_groups(hap_amd, ctx, dist, dev, rank, world, fence, reps=3):
             "ms": {k: round(v, 3) for k, v in t.items()}}
 
 
+_PERCALL = {}
+
+
+def percall_lib():
+    """tools/percall_loop.c compiled against hap_amd/libhap_amd.so: a plain C client that calls hap.h once per frame
+    (no Python or ctypes time inside the loop).  None when no C compiler is at hand: the callers then loop in Python
+    and say so."""
+    if "lib" not in _PERCALL:
+        _PERCALL["lib"] = None
+        try:
+            import subprocess
+            import tempfile
+            d = tempfile.mkdtemp(prefix="hap_percall_")
+            so = os.path.join(d, "libpercall.so")
+            subprocess.run(["gcc", "-O2", "-std=c99", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "tools", "percall_loop.c"), "-o", so, "-L", os.path.join(ROOT, "hap_amd"),
+                            "-l:libhap_amd.so", "-Wl,-rpath," + os.path.join(ROOT, "hap_amd")], check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            lib = C.CDLL(so)
+            lib.percall_decode.restype = C.c_double
+            lib.percall_encode.restype = C.c_double
+            _PERCALL["lib"] = lib
+        except Exception:
+            pass
+    return _PERCALL["lib"]
+
+
+def _addr(buf):
+    return buf.data_ptr() if hasattr(buf, "data_ptr") else buf.ctypes.data
+
+
+def percall_times(hap_amd, textures, tex_bytes, fmts, chunks, frames, cap, outs, reps, table):
+    """hap.h HapEncode (texture bytes in, as the reference takes them) and HapDecode, ONE CALL PER FRAME, every buffer
+    where the caller put it (device tensors or host arrays).  textures[f][t]; returns (encode s, decode s per texture
+    index, used bytes, ok).  `table`: HAP_AMD_FRAGMENT_INDEX for the calls (plain hap.h writes the private table on
+    request only)."""
+    n, count = len(textures), len(fmts)
+    old = os.environ.get("HAP_AMD_FRAGMENT_INDEX")
+    os.environ["HAP_AMD_FRAGMENT_INDEX"] = "1" if table else "0"
+    try:
+        lib = percall_lib()
+        used = (C.c_ulong * n)()
+        if lib is not None:
+            tp = (C.c_void_p * (n * count))(*[_addr(textures[f][t]) for f in range(n) for t in range(count)])
+            tb = (C.c_ulong * count)(*tex_bytes)
+            cf = (C.c_uint * count)(*fmts); cc = (C.c_uint * count)(*([1] * count)); ck = (C.c_uint * count)(*chunks)
+            fp = (C.c_void_p * n)(*[_addr(b) for b in frames])
+            lib.percall_encode(tp, tb, C.c_uint(count), cf, cc, ck, C.c_uint(n), fp, C.c_ulong(cap), used, C.c_uint(1))   # warm
+            t_enc = lib.percall_encode(tp, tb, C.c_uint(count), cf, cc, ck, C.c_uint(n), fp, C.c_ulong(cap), used, C.c_uint(reps))
+            if t_enc < 0:
+                raise RuntimeError("HapEncode failed: %r" % t_enc)
+            fb = (C.c_ulong * n)(*[int(u) for u in used])
+            t_dec = []
+            for t in range(count):
+                op = (C.c_void_p * n)(*[_addr(outs[t][f]) for f in range(n)])
+                lib.percall_decode(fp, fb, C.c_uint(n), C.c_uint(t), op, C.c_ulong(tex_bytes[t]), C.c_uint(1))
+                d = lib.percall_decode(fp, fb, C.c_uint(n), C.c_uint(t), op, C.c_ulong(tex_bytes[t]), C.c_uint(reps))
+                if d < 0:
+                    raise RuntimeError("HapDecode failed: %r" % d)
+                t_dec.append(d / reps)
+            return t_enc / reps, t_dec, [int(u) for u in used], "C"
+        # no compiler: the same calls through ctypes (their time includes Python's)
+        def enc_all():
+            for f in range(n):
+                r, u = hap_amd.HapEncode(list(textures[f]), fmts, [1] * count, chunks, outputBuffer=frames[f], outputBufferBytes=cap)
+                if r != 0:
+                    raise RuntimeError("HapEncode failed: %r" % r)
+                used[f] = u
+        enc_all()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            enc_all()
+        t_enc = (time.perf_counter() - t0) / reps
+        t_dec = []
+        for t in range(count):
+            def dec_all():
+                for f in range(n):
+                    r, _u, _fm = hap_amd.HapDecode(frames[f][: used[f]], t, outputBuffer=outs[t][f])
+                    if r != 0:
+                        raise RuntimeError("HapDecode failed: %r" % r)
+            dec_all()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                dec_all()
+            t_dec.append((time.perf_counter() - t0) / reps)
+        return t_enc, t_dec, [int(u) for u in used], "python"
+    finally:
+        if old is None:
+            del os.environ["HAP_AMD_FRAGMENT_INDEX"]
+        else:
+            os.environ["HAP_AMD_FRAGMENT_INDEX"] = old
+
+
+def c1_object(hap_amd, ctx, dev):
+    """BASELINE.json configs[0]: HapDecode() of ONE 1920x1080 Hap1 (DXT1) frame with a single Snappy chunk -- and the
+    HapEncode that made it -- through plain hap.h, one call, device and host pointers, beside the unmodified reference
+    on one host thread.  One 1 MB chunk is 127 fragments of work and two completion round trips per call: this is the
+    case where a CPU can win, and the line says which way it went."""
+    import numpy as np
+    from hap_amd import synth
+    w, h, fmts, chunks, _n = CONFIGS["C1"]
+    tb = [(w // 4) * (h // 4) * 8]
+    cap = hap_amd.HapMaxEncodedLength(tb, fmts, chunks)
+    rgba = synth.rgba_frame(w, h, 0, device=dev)
+    tex = torch.empty(tb[0], dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    if ctx.compress_rgba(rgba, w, h, w * 4, fmts[0], tex) != (0, tb[0]):
+        raise RuntimeError("block encode failed")
+    ctx.synchronize()
+    out = {"workload": "C1: one %dx%d Hap1 (DXT1) frame, 1 chunk, Snappy, plain hap.h HapEncode / HapDecode, one call" % (w, h),
+           "texture_bytes": tb[0]}
+    tex_host = tex.cpu().numpy()
+    reps = 20
+    for where in ("device_pointers", "host_pointers"):
+        leg = {}
+        for table in (False, True):
+            if where == "device_pointers":
+                textures = [[tex]]
+                frames = [torch.empty(cap, dtype=torch.uint8, device=dev)]
+                outs = [[torch.zeros(tb[0], dtype=torch.uint8, device=dev)]]
+                torch.cuda.synchronize()
+            else:
+                textures = [[tex_host]]
+                frames = [np.zeros(cap, dtype=np.uint8)]
+                outs = [[np.zeros(tb[0], dtype=np.uint8)]]
+            t_enc, t_dec, used, loop = percall_times(hap_amd, textures, tb, fmts, chunks, frames, cap, outs, reps, table)
+            got = outs[0][0].cpu().numpy() if hasattr(outs[0][0], "cpu") else outs[0][0]
+            leg["with_private_table" if table else "plain_frame"] = {
+                "encode_ms": round(t_enc * 1e3, 4), "decode_ms": round(t_dec[0] * 1e3, 4), "frame_bytes": used[0],
+                "bit_exact": bool(np.array_equal(got, tex_host))}
+            leg["loop"] = loop
+        out[where] = leg
+    # the unmodified reference, one thread, same texture (tests/_libs is checker infrastructure: outside every GPU timing)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _libs as L
+        ref = L.ref_lib()
+        lib, prefix, kind = (ref, "refbase", "reference hap.c + libsnappy 1.1.8") if ref is not None else (L.oracle_lib(), "oraclebase", "oracle/ C port")
+        enc = getattr(lib, prefix + "_encode"); enc.restype = C.c_double
+        decp = getattr(lib, prefix + "_decode_parallel"); decp.restype = C.c_double
+        ptr = (C.c_void_p * 1)(tex_host.ctypes.data)
+        lens = (C.c_ulong * 1)(tb[0]); cf = (C.c_uint * 1)(fmts[0]); cc = (C.c_uint * 1)(1); ck = (C.c_uint * 1)(chunks[0])
+        frame = np.zeros(cap, dtype=np.uint8); used = (C.c_ulong * 1)()
+        dout = np.zeros(tb[0], dtype=np.uint8)
+        te, td = [], []
+        for _ in range(15):
+            te.append(enc(C.c_uint(1), ptr, lens, cf, cc, ck, C.c_uint(1), frame.ctypes.data_as(C.c_void_p), C.c_ulong(cap), used, C.c_uint(1), C.c_uint(1)))
+            fp = (C.c_void_p * 1)(frame.ctypes.data); fl = (C.c_ulong * 1)(used[0])
+            td.append(decp(fp, fl, C.c_uint(1), C.c_uint(0), dout.ctypes.data_as(C.c_void_p), C.c_ulong(tb[0]), C.c_uint(1), C.c_uint(1)))
+        te.sort(); td.sort()
+        cpu = {"encoder": kind, "threads": 1, "encode_ms": round(te[len(te) // 2] * 1e3, 4), "decode_ms": round(td[len(td) // 2] * 1e3, 4),
+               "frame_bytes": int(used[0]), "repetitions": 15, "statistic": "median"}
+        out["cpu_reference_one_thread"] = cpu
+        gpu_dec = out["device_pointers"]["plain_frame"]["decode_ms"]
+        gpu_dec_t = out["device_pointers"]["with_private_table"]["decode_ms"]
+        host_dec = out["host_pointers"]["plain_frame"]["decode_ms"]
+        out["who_wins_decode"] = {
+            "device_pointers_plain_frame": "gpu" if gpu_dec < cpu["decode_ms"] else "cpu",
+            "device_pointers_with_private_table": "gpu" if gpu_dec_t < cpu["decode_ms"] else "cpu",
+            "host_pointers_plain_frame": "gpu" if host_dec < cpu["decode_ms"] else "cpu"}
+        out["who_wins_encode"] = {"device_pointers": "gpu" if out["device_pointers"]["plain_frame"]["encode_ms"] < cpu["encode_ms"] else "cpu",
+                                  "host_pointers": "gpu" if out["host_pointers"]["plain_frame"]["encode_ms"] < cpu["encode_ms"] else "cpu"}
+    except Exception as exc:
+        out["cpu_reference_one_thread"] = {"error": repr(exc)}
+    return out
+
+
+def per_call_object(hap_amd, stream, dev, n=16, reps=3):
+    """What a drop-in client does: one hap.h HapEncode (texture bytes in) and one HapDecode per frame, device pointers,
+    on the headline's frames -- next to the batched calls of the timed region.  Frames written by plain hap.h carry no
+    private table unless HAP_AMD_FRAGMENT_INDEX=1 asks for it: both are reported."""
+    n = min(n, stream.nf)
+    fmts, chunks, tb, cap = stream.fmts, stream.chunks, stream.tex_bytes, stream.cap
+    textures = [[stream.dec[t][f] for t in range(len(fmts))] for f in range(n)]       # the textures the last step decoded
+    want = [[textures[f][t].clone() for t in range(len(fmts))] for f in range(n)]
+    frames = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(n)]
+    outs = [[torch.zeros(tb[t], dtype=torch.uint8, device=dev) for _ in range(n)] for t in range(len(fmts))]
+    torch.cuda.synchronize()
+    res = {"workload": "hap.h HapEncode (texture bytes in) + HapDecode, one call per frame, device pointers, %d frames of the stream" % n}
+    for table in (False, True):
+        t_enc, t_dec, used, loop = percall_times(hap_amd, want, tb, fmts, chunks, frames, cap, outs, reps, table)
+        torch.cuda.synchronize()
+        ok = all(bool(torch.equal(outs[t][f], want[f][t])) for f in range(n) for t in range(len(fmts)))
+        dec = sum(t_dec)
+        res["with_private_table" if table else "plain_frames"] = {
+            "encode_ms_per_call": round(t_enc / n * 1e3, 4), "decode_ms_per_call": round(dec / n * 1e3, 4),
+            "encode_texture_GBps": round(n * sum(tb) / t_enc / 1e9, 2), "decode_texture_GBps": round(n * sum(tb) / dec / 1e9, 2),
+            "decode_rgba_GBps": round(n * stream.rgba_bytes / dec / 1e9, 2),
+            "snappy_ratio": round(sum(used) / n / sum(tb), 4), "bit_exact": ok}
+        res["loop"] = loop
+    return res
+
+
+def opaque_object(hap_amd, ctx, dev, fence, fmt=0x8E8C, n=30, steps=4):
+    """an opaque 16-byte-block format (BC7: the library has no block encoder for it, hap.c:369-375 takes the
+    bytes as they are) at 8K size through the batched calls: the position-per-lane compressor and the generic fragment
+    decoder, not the block kernels of the headline."""
+    from hap_amd import synth
+    w, h, chunks = 7680, 4320, [24]
+    tb = [(w // 4) * (h // 4) * 16]
+    cap = hap_amd.HapMaxEncodedLength(tb, [fmt], chunks)
+    # texture-like bytes: the YCoCg-DXT5 blocks of synthetic pictures stand in for BC7 blocks (opaque to the codec)
+    texs = []
+    for i in range(n):
+        t = torch.empty(tb[0], dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        if ctx.compress_rgba(synth.rgba_frame(w, h, i, device=dev), w, h, w * 4, 0x01, t) != (0, tb[0]):
+            raise RuntimeError("block encode failed")
+        texs.append(t)
+    ctx.synchronize()
+    tex_l = hap_amd.BufferList(texs)
+    frames = hap_amd.BufferList([torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(n)])
+    outs = hap_amd.BufferList([torch.zeros(tb[0], dtype=torch.uint8, device=dev) for _ in range(n)])
+    torch.cuda.synchronize()
+    flags = hap_amd.ENCODE_FRAGMENT_INDEX
+
+    def enc():
+        r, used, res = ctx.encode_frames([[t] for t in tex_l], [fmt], [1], chunks, frames, flags=flags)
+        if r != 0:
+            raise RuntimeError("opaque encode failed %r" % (res[:2],))
+        return used
+
+    def dec(used):
+        r, du, _f, dres = ctx.decode_frames(frames, used, 0, outs)
+        if r != 0 or du[0] != tb[0]:
+            raise RuntimeError("opaque decode failed %r" % (dres[:2],))
+    used = enc(); dec(used)
+    best_e = best_d = None
+    for _ in range(steps):
+        ctx.timer_start(); used = enc(); e = ctx.timer_stop()
+        ctx.timer_start(); dec(used); d = ctx.timer_stop()
+        best_e = e if best_e is None else min(best_e, e)
+        best_d = d if best_d is None else min(best_d, d)
+    torch.cuda.synchronize()
+    ok = all(bool(torch.equal(outs[i], texs[i])) for i in range(n))
+    ratio = sum(used) / n / tb[0]
+    return {"workload": "%dx%d opaque 16-byte blocks (format %#x, BC7), 24 chunks, Snappy, %d frames per call, device-resident" % (w, h, fmt, n),
+            "snappy_ratio": round(ratio, 4), "bit_exact": ok,
+            "encode_ms": round(best_e, 3), "decode_ms": round(best_d, 3),
+            "encode_texture_GBps": round(n * tb[0] / (best_e * 1e-3) / 1e9, 1), "decode_texture_GBps": round(n * tb[0] / (best_d * 1e-3) / 1e9, 1),
+            "decode_algorithmic_GBps": round(n * tb[0] * (1 + ratio) / (best_d * 1e-3) / 1e9, 1),
+            "decode_frac_of_hbm_peak": round(n * tb[0] * (1 + ratio) / (best_d * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "statistic": "best of %d calls" % steps}
+
+
 def host_pointer_path(ctx, rgba, frames, used, fmts, comps, chunks, tex_bytes, cap, w, h, flags, n=4):
     """Same calls with pageable HOST buffers (what a plain hap.h client passes): PCIe-inclusive, never `value`."""
     import numpy as np
@@ -628,7 +902,7 @@ def host_pointer_path(ctx, rgba, frames, used, fmts, comps, chunks, tex_bytes, c
     return res
 
 
-def decode_foreign(ctx, dev, fmts, chunks, dec, tex_bytes, cap, n, rgba_bytes):
+def decode_foreign(ctx, dev, fmts, chunks, dec, tex_bytes, cap, n, rgba_bytes, with_whole_stream=True):
     """Frames produced by the CPU reference encoder (libsnappy streams, no fragment table) decoded by
     the GPU: block scan, then one wavefront per 64 KiB block; the one-wavefront-per-chunk path beside it
     (DECODE_NO_BLOCK_SCAN), for a batch and for one frame.  Reported beside the headline, never part of it."""
@@ -649,36 +923,49 @@ def decode_foreign(ctx, dev, fmts, chunks, dec, tex_bytes, cap, n, rgba_bytes):
            C.c_uint(n), C.c_uint(1)) < 0:
         raise RuntimeError("reference encode failed")
     frames = [torch.from_numpy(out[i * cap: i * cap + used[i]].copy()).to(dev) for i in range(n)]
-    outs = [torch.empty(tex_bytes[0], dtype=torch.uint8, device=dev) for _ in range(n)]
+    del out
+    # entry f * T + t = texture t of frame f (one call decodes every texture of every frame)
+    outs = [torch.empty(tex_bytes[t], dtype=torch.uint8, device=dev) for _f in range(n) for t in range(count)]
     torch.cuda.synchronize()
     import hap_amd
 
     def timed(count_frames, flags):
-        fr, us, ou = frames[:count_frames], [int(u) for u in used[:count_frames]], outs[:count_frames]
-        ctx.decode_frames(fr, us, 0, ou, flags)                         # warm-up
+        fr, us, ou = frames[:count_frames], [int(u) for u in used[:count_frames]], outs[:count_frames * count]
+        call = (lambda: ctx.decode_frame_textures(fr, us, count, ou, flags)) if count > 1 else (lambda: ctx.decode_frames(fr, us, 0, ou, flags))
+        call()                                                          # warm-up
         best = None
         for _ in range(3):
             ctx.timer_start()
-            r = ctx.decode_frames(fr, us, 0, ou, flags)[0]
+            r = call()[0]
             ms = ctx.timer_stop()
             if r != 0:
                 return None
             best = ms if best is None else min(best, ms)
         return best
+
+    def same(count_frames):
+        return all(torch.equal(outs[f * count + t], dec[t][f]) for f in range(count_frames) for t in range(count))
     ms = timed(n, 0)
-    ok = ms is not None and all(torch.equal(outs[i], dec[0][i]) for i in range(n))
+    ok = ms is not None and same(n)
     for o in outs:
         o.zero_()
     one = timed(1, 0)
-    ok = ok and one is not None and torch.equal(outs[0], dec[0][0])
-    whole = timed(n, hap_amd.DECODE_NO_BLOCK_SCAN)
-    whole_one = timed(1, hap_amd.DECODE_NO_BLOCK_SCAN)
+    ok = ok and one is not None and same(1)
+    whole = timed(n, hap_amd.DECODE_NO_BLOCK_SCAN) if with_whole_stream else None
+    whole_one = timed(1, hap_amd.DECODE_NO_BLOCK_SCAN) if with_whole_stream else None
     rnd = lambda v: None if v is None else round(v, 3)
-    return {"frames": n, "ms": rnd(ms), "rgba_GBps": round(n * rgba_bytes / (ms * 1e-3) / 1e9, 2) if ms else None,
-            "texture_GBps": round(n * tex_bytes[0] / (ms * 1e-3) / 1e9, 2) if ms else None, "bit_exact": bool(ok),
-            "one_frame_ms": rnd(one),
-            "without_block_scan": {"ms": rnd(whole), "one_frame_ms": rnd(whole_one)},
-            "encoder": "reference hap.c + libsnappy 1.1.8" if ref is not None else "oracle/ C port"}
+    bsum = sum(tex_bytes)
+    res = {"frames": n, "ms": rnd(ms), "rgba_GBps": round(n * rgba_bytes / (ms * 1e-3) / 1e9, 2) if ms else None,
+           "texture_GBps": round(n * bsum / (ms * 1e-3) / 1e9, 2) if ms else None, "bit_exact": bool(ok),
+           "one_frame_ms": rnd(one), "snappy_ratio": round(sum(int(u) for u in used) / n / bsum, 4),
+           "encoder": "reference hap.c + libsnappy 1.1.8" if ref is not None else "oracle/ C port"}
+    if ms:
+        alg = n * (bsum + sum(int(u) for u in used) / n)
+        res["algorithmic_GBps"] = round(alg / (ms * 1e-3) / 1e9, 1)
+        res["frac_of_hbm_peak"] = round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+    if with_whole_stream:
+        res["without_block_scan"] = {"ms": rnd(whole), "one_frame_ms": rnd(whole_one)}
+    return res
 
 
 def measured_traffic(config, kernel, frames):
@@ -719,13 +1006,25 @@ def cpu_baseline(w, h, fmts, chunks, rgba, dec, tex_bytes, cap, budget_s):
     count = len(fmts)
     tex_host = [[dec[i][f].cpu().numpy() for i in range(count)] for f in range(sample)]
     rgba_host = rgba[0].cpu().numpy()
+    # Every figure below is the MEDIAN of `reps` >= 10 repetitions, buffers pre-faulted by an untimed
+    # pass, worker threads pinned one per CPU of the process's affinity mask (oracle/cpu_baseline.c).
+    def median(fn, reps):
+        ts = sorted(fn() for _ in range(reps))
+        if ts[0] < 0:
+            raise RuntimeError("cpu leg failed %r" % ts[0])
+        return ts[len(ts) // 2]
+    pin = getattr(lib, prefix + "_pinning", None)
+    pinned = bool(pin()) if pin is not None else False
     # block encode (oracle's scalar C, the reference has none): rows of one frame over all threads
-    out = np.zeros(tex_bytes[0], dtype=np.uint8)
-    t_bc = 0.0
-    for fmt in fmts:
-        t_bc += ora.oraclebase_bc_encode(rgba_host.ctypes.data_as(C.c_void_p), C.c_uint(w), C.c_uint(h),
-                                         C.c_size_t(w * 4), C.c_uint(fmt), out.ctypes.data_as(C.c_void_p),
-                                         C.c_uint(threads), C.c_uint(1))
+    out = np.zeros(max(tex_bytes), dtype=np.uint8)
+
+    def bc_once():
+        t = 0.0
+        for fmt in fmts:
+            t += ora.oraclebase_bc_encode(rgba_host.ctypes.data_as(C.c_void_p), C.c_uint(w), C.c_uint(h),
+                                          C.c_size_t(w * 4), C.c_uint(fmt), out.ctypes.data_as(C.c_void_p),
+                                          C.c_uint(threads), C.c_uint(1))
+        return t
     # container + Snappy: one frame per thread (the reference's encode is serial per frame)
     ptrs = (C.c_void_p * (nwork * count))(*[tex_host[f % sample][i].ctypes.data for f in range(nwork) for i in range(count)])
     lens = (C.c_ulong * count)(*tex_bytes)
@@ -733,10 +1032,13 @@ def cpu_baseline(w, h, fmts, chunks, rgba, dec, tex_bytes, cap, budget_s):
     enc_threads = min(threads, nwork)
     outbuf = np.zeros(cap * enc_threads, dtype=np.uint8)
     used = (C.c_ulong * nwork)()
-    t_enc = enc(C.c_uint(count), ptrs, lens, cf, cc, ck, C.c_uint(nwork), outbuf.ctypes.data_as(C.c_void_p),
-                C.c_ulong(cap), used, C.c_uint(enc_threads), C.c_uint(1))
-    if t_enc < 0:
-        raise RuntimeError("cpu encode failed %r" % t_enc)
+
+    def enc_once():
+        return enc(C.c_uint(count), ptrs, lens, cf, cc, ck, C.c_uint(nwork), outbuf.ctypes.data_as(C.c_void_p),
+                   C.c_ulong(cap), used, C.c_uint(enc_threads), C.c_uint(1))
+    t_first = time.perf_counter()
+    bc_once(); enc_once()                       # untimed: page faults, thread start-up
+    one_pass = time.perf_counter() - t_first
     frames = []
     for f in range(sample):
         one = np.zeros(cap, dtype=np.uint8)
@@ -750,25 +1052,48 @@ def cpu_baseline(w, h, fmts, chunks, rgba, dec, tex_bytes, cap, budget_s):
     decp = getattr(lib, prefix + "_decode_parallel"); decp.restype = C.c_double
     stride = max(tex_bytes)
     dout = np.zeros(stride * enc_threads, dtype=np.uint8)
-    t_dec = 0.0
-    for idx in range(count):
-        t = decp(fptrs, flens, C.c_uint(nwork), C.c_uint(idx), dout.ctypes.data_as(C.c_void_p),
-                 C.c_ulong(stride), C.c_uint(enc_threads), C.c_uint(1))
-        if t < 0:
-            raise RuntimeError("cpu decode failed %r" % t)
-        t_dec += t
-    t_enc /= nwork
-    t_dec /= nwork
+
+    def dec_once():
+        t = 0.0
+        for idx in range(count):
+            d = decp(fptrs, flens, C.c_uint(nwork), C.c_uint(idx), dout.ctypes.data_as(C.c_void_p),
+                     C.c_ulong(stride), C.c_uint(enc_threads), C.c_uint(1))
+            if d < 0:
+                return d
+            t += d
+        return t
+    dec_once()
+    # repetitions: at least 10, more while the budget lasts (one pass of all three legs took `one_pass` seconds)
+    reps = int(max(10, min(30, (budget_s * 0.3) / max(one_pass * 1.5, 1e-3))))
+    # each leg with its threads pinned and left to the scheduler: the CPU gets the better median
+    set_pin = [getattr(l_, n_, None) for l_, n_ in ((lib, prefix + "_set_pinning"), (ora, "oraclebase_set_pinning"))]
+    legs = {}
+    for mode in ((1, 0) if all(set_pin) else (int(pinned),)):
+        for f in set_pin:
+            if f is not None:
+                f(C.c_int(mode))
+        for name, fn in (("block_encode", bc_once), ("hap_encode", enc_once), ("hap_decode", dec_once)):
+            t = median(fn, reps)
+            if name not in legs or t < legs[name][0]:
+                legs[name] = (t, bool(mode))
+    for f in set_pin:
+        if f is not None:
+            f(C.c_int(1))
+    t_bc = legs["block_encode"][0]
+    t_enc = legs["hap_encode"][0] / nwork
+    t_dec = legs["hap_decode"][0] / nwork
+    pinned = {k: v[1] for k, v in legs.items()}
     # one hardware thread, one frame (the reference as a client would call it serially)
     one_out = np.zeros(cap, dtype=np.uint8)
     one_used = (C.c_ulong * 1)()
     p1 = (C.c_void_p * count)(*[tex_host[0][i].ctypes.data for i in range(count)])
-    t_enc1 = enc(C.c_uint(count), p1, lens, cf, cc, ck, C.c_uint(1), one_out.ctypes.data_as(C.c_void_p), C.c_ulong(cap),
-                 one_used, C.c_uint(1), C.c_uint(1))
     f1 = (C.c_void_p * 1)(frames[0].ctypes.data)
     l1 = (C.c_ulong * 1)(len(frames[0]))
-    t_dec1 = sum(decp(f1, l1, C.c_uint(1), C.c_uint(idx), dout.ctypes.data_as(C.c_void_p), C.c_ulong(stride),
-                      C.c_uint(1), C.c_uint(1)) for idx in range(count))
+    reps1 = 10
+    t_enc1 = median(lambda: enc(C.c_uint(count), p1, lens, cf, cc, ck, C.c_uint(1), one_out.ctypes.data_as(C.c_void_p), C.c_ulong(cap),
+                                one_used, C.c_uint(1), C.c_uint(1)), reps1)
+    t_dec1 = median(lambda: sum(decp(f1, l1, C.c_uint(1), C.c_uint(idx), dout.ctypes.data_as(C.c_void_p), C.c_ulong(stride),
+                                     C.c_uint(1), C.c_uint(1)) for idx in range(count)), reps1)
     sample_n = sample
     sample = 1      # t_enc / t_dec are already per frame
     rgba_bytes = w * h * 4
@@ -776,8 +1101,11 @@ def cpu_baseline(w, h, fmts, chunks, rgba, dec, tex_bytes, cap, budget_s):
     return {"value": round(rgba_bytes / per_frame / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": kind,
             "threads": {"block_encode": threads, "hap_encode": enc_threads, "hap_decode": enc_threads},
             "sample": "%d frames in flight (%d distinct) of this workload: RGBA->DXT by oracle/bc_oracle.c (the reference "
-                      "has no block encoder) + HapEncode + HapDecode by %s, %d threads, amortised per frame" % (
-                          nwork, sample_n, "unmodified reference hap.c + libsnappy 1.1.8" if kind == "reference" else "oracle/ C port", threads),
+                      "has no block encoder) + HapEncode + HapDecode by %s, %d threads, amortised per frame; median of %d "
+                      "repetitions per leg after an untimed pass" % (
+                          nwork, sample_n, "unmodified reference hap.c + libsnappy 1.1.8" if kind == "reference" else "oracle/ C port", threads, reps),
+            "repetitions": reps, "statistic": "median of each leg, pinned and unpinned threads, the faster of the two",
+            "threads_pinned": pinned,
             "ms_per_frame": {"block_encode": round(t_bc * 1e3, 2), "hap_encode": round(t_enc / sample * 1e3, 2),
                              "hap_decode": round(t_dec / sample * 1e3, 2)},
             "container_only_rgba_GBps": round(rgba_bytes / (t_enc / sample + t_dec / sample) / 1e9, 3),

@@ -11,7 +11,9 @@
  * (hap.h:113-130); encode is serial per frame in the reference (hap.c:448-476)
  * so frames are spread over threads instead.
  */
+#define _GNU_SOURCE
 #include <pthread.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -36,6 +38,50 @@ static double now_s(void)
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* ---- thread pinning ("threads pinned"; unpinned runs were erratic on the survey box) -------------
+ * Worker t of a call runs on the t-th CPU of the process's affinity mask at the time of the call; the calling thread
+ * gets its own mask back when the call returns. */
+static int g_pin = 1;
+static cpu_set_t g_allowed;
+static int g_allowed_n;
+
+void SYM(set_pinning)(int on) { g_pin = on; }
+int SYM(pinning)(void) { return g_pin; }
+
+static void pin_begin(cpu_set_t *saved)
+{
+    CPU_ZERO(saved);
+    if (!g_pin || pthread_getaffinity_np(pthread_self(), sizeof(*saved), saved) != 0) {
+        g_allowed_n = 0;
+        return;
+    }
+    g_allowed = *saved;
+    g_allowed_n = CPU_COUNT(&g_allowed);
+}
+
+static void pin_self(unsigned tid)
+{
+    int want, cpu;
+    cpu_set_t one;
+    if (!g_pin || g_allowed_n <= 0)
+        return;
+    want = (int)(tid % (unsigned)g_allowed_n);
+    for (cpu = 0; cpu < CPU_SETSIZE; cpu++)
+        if (CPU_ISSET(cpu, &g_allowed) && want-- == 0)
+            break;
+    if (cpu >= CPU_SETSIZE)
+        return;
+    CPU_ZERO(&one);
+    CPU_SET(cpu, &one);
+    (void)pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+}
+
+static void pin_end(const cpu_set_t *saved)
+{
+    if (g_pin && g_allowed_n > 0)
+        (void)pthread_setaffinity_np(pthread_self(), sizeof(*saved), saved);
 }
 
 /* ---- decode: chunk fan-out --------------------------------------------- */
@@ -110,6 +156,7 @@ static void *dec_main(void *arg)
 {
     dec_t *d = (dec_t *)arg;
     unsigned r, f;
+    pin_self(d->tid);
     for (r = 0; r < d->reps; r++)
         for (f = d->tid; f < d->nframes; f += d->threads) {
             unsigned long used = 0;
@@ -132,6 +179,8 @@ double SYM(decode_parallel)(const void *const *frames, const unsigned long *fram
     double t0;
     if (threads == 0) threads = 1;
     if (threads > 256) threads = 256;
+    cpu_set_t saved;
+    pin_begin(&saved);
     t0 = now_s();
     for (t = 0; t < threads; t++) {
         dec_t *d = &job[t];
@@ -144,6 +193,7 @@ double SYM(decode_parallel)(const void *const *frames, const unsigned long *fram
     dec_main(&job[threads - 1]);
     for (t = 0; t + 1 < threads; t++)
         pthread_join(th[t], NULL);
+    pin_end(&saved);
     for (t = 0; t < threads; t++)
         if (job[t].rc)
             return -(double)job[t].rc;
@@ -165,6 +215,7 @@ static void *enc_main(void *arg)
 {
     enc_t *e = (enc_t *)arg;
     unsigned r, f;
+    pin_self(e->tid);
     for (r = 0; r < e->reps; r++)
         for (f = e->tid; f < e->nframes; f += e->threads) {
             unsigned rc = API_ENCODE(e->count, (const void **)(e->inputs + (size_t)f * e->count),
@@ -191,6 +242,8 @@ double SYM(encode)(unsigned count, const void *const *inputs, const unsigned lon
         threads = 1;
     if (threads > 256)
         threads = 256;
+    cpu_set_t saved;
+    pin_begin(&saved);
     t0 = now_s();
     for (t = 0; t < threads; t++) {
         enc_t *e = &job[t];
@@ -204,6 +257,7 @@ double SYM(encode)(unsigned count, const void *const *inputs, const unsigned lon
     enc_main(&job[threads - 1]);
     for (t = 0; t + 1 < threads; t++)
         pthread_join(th[t], NULL);
+    pin_end(&saved);
     for (t = 0; t < threads; t++)
         if (job[t].rc)
             return -(double)job[t].rc;
@@ -214,7 +268,7 @@ double SYM(encode)(unsigned count, const void *const *inputs, const unsigned lon
 /* ---- block encode (ours only: the reference has no RGBA->DXT stage) ------- */
 typedef struct {
     const unsigned char *rgba; unsigned w, h0, h1; size_t row_bytes; unsigned char *out;
-    unsigned format, reps;
+    unsigned format, reps, tid;
 } bc_t;
 
 static void *bc_main(void *arg)
@@ -224,6 +278,7 @@ static void *bc_main(void *arg)
     size_t bpb = (b->format == 0x83F0 || b->format == 0x8DBB) ? 8 : 16;
     const unsigned char *src = b->rgba + (size_t)b->h0 * b->row_bytes;
     unsigned char *dst = b->out + (size_t)(b->h0 / 4) * (b->w / 4) * bpb;
+    pin_self(b->tid);
     for (r = 0; r < b->reps; r++) {
         if (b->format == 0x83F0) obc_encode_dxt1(src, b->w, rows, b->row_bytes, dst);
         else if (b->format == 0x83F3) obc_encode_dxt5(src, b->w, rows, b->row_bytes, dst);
@@ -243,8 +298,12 @@ double oraclebase_bc_encode(const void *rgba, unsigned w, unsigned h, size_t row
     if (threads == 0) threads = 1;
     if (threads > 256) threads = 256;
     if (threads > block_rows) threads = block_rows;
+    {
+    cpu_set_t saved;
+    pin_begin(&saved);
     t0 = now_s();
     for (t = 0; t < threads; t++) {
+        job[t].tid = t;
         job[t].rgba = (const unsigned char *)rgba; job[t].w = w; job[t].row_bytes = row_bytes;
         job[t].out = (unsigned char *)out; job[t].format = format; job[t].reps = reps;
         job[t].h0 = 4 * (unsigned)((unsigned long)block_rows * t / threads);
@@ -255,6 +314,8 @@ double oraclebase_bc_encode(const void *rgba, unsigned w, unsigned h, size_t row
     bc_main(&job[threads - 1]);
     for (t = 0; t + 1 < threads; t++)
         pthread_join(th[t], NULL);
+    pin_end(&saved);
+    }
     return now_s() - t0;
 }
 #endif
