@@ -67,6 +67,9 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true",
                     help="the timed pipeline only: no size-for-speed option, texture->RGBA, host-pointer, foreign-frame, CPU "
                          "or C5 legs (what tools/prof_bench.sh profiles, so that every dispatch belongs to the headline)")
+    ap.add_argument("--one-gpu-ranks", action="store_true",
+                    help="dry run of the multi-rank path on ONE GPU (tests): every rank uses device 0 and the collectives "
+                         "run over gloo (host copies) instead of RCCL; the codec is the real one.  Never a measurement")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="launch / rank / reduction logic only, gloo on CPU, a sleep in place of the codec (tests)")
     return ap.parse_args()
@@ -228,9 +231,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
+        if args.one_gpu_ranks:
+            local_rank = 0
         if not args.selftest_cpu:
             torch.cuda.set_device(local_rank)
-        dist.init_process_group("gloo" if args.selftest_cpu else "nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if (args.selftest_cpu or args.one_gpu_ranks) else "nccl", rank=rank, world_size=world)
         world = dist.get_world_size()
     if args.gpus != world:
         raise SystemExit("bench.py: --gpus %d but %d rank(s) were started" % (args.gpus, world))
@@ -376,6 +381,8 @@ def main():
         line["c5_chunk_groups"] = groups
         line["rccl_ranks_seen"] = int(dist.get_world_size())
         line["collective_backend"] = str(dist.get_backend())
+        if args.one_gpu_ranks:
+            line["dry_run"] = "all ranks on one GPU, gloo collectives: a functional check of the multi-rank path, not a measurement"
         kernels, _ratio = stream.kernel_table(prof, args.steps, args.config)
         line["roofline"] = stream.roofline(kernels, args.config)
         line["roofline"]["note"] = "rank 0's launches (%d frames per step)" % stream.nf
@@ -566,6 +573,9 @@ def c5_chunk_groups(hap_amd, ctx, dist, dev, rank, world, fence, reps=3):
     if dframe is None:
         dframe = torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
     dist.broadcast(dframe, src=0)
+    # (the collective runs on the backend's own stream and the library reads the frame on ITS own: without this the
+    # header fetch below can see the buffer before the broadcast has landed -- found by the two-ranks-on-one-GPU test)
+    torch.cuda.synchronize()
     frame = dframe
     ok = True
     for idx in (0, 1):

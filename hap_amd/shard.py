@@ -77,6 +77,13 @@ def _world():
     return 0, 1
 
 
+def _through_host():
+    """gloo moves device tensors for all_reduce / broadcast only: under gloo (CPU tests, and the one-GPU dry run of
+    bench.py's multi-rank path) point-to-point messages and all_gather go through host copies.  Under RCCL (nccl)
+    everything stays on the device."""
+    return dist.get_backend() == "gloo"
+
+
 def gather_variable(local, root=0):
     """Gathers 1-D uint8 tensors of different lengths on `root`: returns the list there, None
     elsewhere.  Sizes are exchanged first, then every rank posts one send and the root W-1
@@ -84,17 +91,21 @@ def gather_variable(local, root=0):
     rank, world = _world()
     if world == 1:
         return [local]
-    sizes = gather_sizes([int(local.numel())], device=local.device)
+    staged = _through_host() and local.is_cuda
+    sizes = gather_sizes([int(local.numel())], device="cpu" if staged else local.device)
+    wire = local.cpu() if staged else local
     ops, parts = [], None
     if rank == root:
-        parts = [local if r == root else torch.empty(sizes[r][0], dtype=torch.uint8, device=local.device)
+        parts = [wire if r == root else torch.empty(sizes[r][0], dtype=torch.uint8, device=wire.device)
                  for r in range(world)]
         ops = [dist.P2POp(dist.irecv, parts[r], r) for r in range(world) if r != root and sizes[r][0]]
     elif local.numel():
-        ops = [dist.P2POp(dist.isend, local, root)]
+        ops = [dist.P2POp(dist.isend, wire, root)]
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+    if staged and parts is not None:
+        parts = [local if r == root else parts[r].to(local.device) for r in range(world)]
     return parts
 
 
@@ -109,15 +120,23 @@ def exchange_slices(buf, bounds, root=None):
             if bounds[r + 1] > bounds[r]:
                 dist.broadcast(buf[bounds[r]: bounds[r + 1]], src=r)
         return buf
-    ops = []
+    ops, landing = [], {}
+    staged = _through_host() and buf.is_cuda
     if rank == root:
-        ops = [dist.P2POp(dist.irecv, buf[bounds[r]: bounds[r + 1]], r)
-               for r in range(world) if r != root and bounds[r + 1] > bounds[r]]
+        for r in range(world):
+            if r != root and bounds[r + 1] > bounds[r]:
+                piece = buf[bounds[r]: bounds[r + 1]]
+                if staged:
+                    landing[r] = torch.empty(piece.numel(), dtype=buf.dtype)
+                ops.append(dist.P2POp(dist.irecv, landing.get(r, piece), r))
     elif bounds[rank + 1] > bounds[rank]:
-        ops = [dist.P2POp(dist.isend, buf[bounds[rank]: bounds[rank + 1]], root)]
+        piece = buf[bounds[rank]: bounds[rank + 1]]
+        ops = [dist.P2POp(dist.isend, piece.cpu() if staged else piece, root)]
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+    for r, host in landing.items():
+        buf[bounds[r]: bounds[r + 1]].copy_(host)
     return buf
 
 

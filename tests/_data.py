@@ -58,6 +58,33 @@ def oracle_bc_decode(blocks, fmt, w, h):
     return out
 
 
+def quality_images():
+    """Three fixed 512 x 256 pictures the block encoder's quality is pinned on: a smooth gradient, the gradient plus
+    position-hashed noise of +-16, and hard two-colour edges with thin lines (alpha: ramp / noisy ramp / 0, 128, 255)."""
+    y, x = np.mgrid[0:256, 0:512]
+    smooth = np.stack([(x * 255) // 511, (y * 255) // 255, ((x + y) * 255) // 766, 255 - (x * 255) // 511], -1).astype(np.uint8)
+    h = (x * 0x9E3779B1 + y * 0x85EBCA77) & 0xFFFFFFFF
+    h ^= h >> 15
+    h = (h * 0x2C1B3C6D) & 0xFFFFFFFF
+    h ^= h >> 12
+    noisy = np.stack([np.clip(smooth[..., c].astype(int) + ((h >> (4 * c)) & 31) - 16, 0, 255) for c in range(4)], -1).astype(np.uint8)
+    stripe = (((x + 2 * y) >> 3) & 1) == 1
+    edge = np.where(stripe[..., None], np.array([230, 40, 20, 255]), np.array([15, 60, 200, 0])).astype(np.uint8)
+    edge[(x % 37) == 0] = (255, 255, 255, 128)
+    return {"smooth": np.ascontiguousarray(smooth), "noisy": np.ascontiguousarray(noisy), "hard_edge": np.ascontiguousarray(edge)}
+
+
+def block_quality(blocks, fmt, img):
+    """PSNR of the oracle decoder's picture against the source: (colour,), (colour, alpha) for DXT5, (alpha,) for RGTC1"""
+    h, w = img.shape[:2]
+    dec = oracle_bc_decode(blocks, fmt, w, h)
+    if fmt == L.FMT_RGTC1:
+        return (psnr(dec, img[..., 3]),)
+    if fmt == L.FMT_DXT5:
+        return (psnr(dec[..., :3], img[..., :3]), psnr(dec[..., 3], img[..., 3]))
+    return (psnr(dec[..., :3], img[..., :3]),)
+
+
 def psnr(a, b):
     d = a.astype(np.float64) - b.astype(np.float64)
     mse = float(np.mean(d * d))

@@ -92,14 +92,23 @@ def test_block_encode_extremes_and_quality(ctx):
     for fmt in BC_FORMATS:
         r, got = ctx.compress_rgba(img, 16, 16, 64, fmt)
         assert r == 0 and got == D.oracle_bc_encode(img, fmt)
-    # PSNR sanity of the algorithm itself on a smooth image (oracle decoders)
+    # quality of what the GPU wrote (oracle decoders): within 0.3 dB of the values recorded in round 4 on this picture
+    # -- 36.97 / 36.97 / 40.87 dB colour, alpha exact -- and on the three pictures the definition is pinned on
+    # (tests/test_oracle_pinning.py: QUALITY_R04)
     pic = D.rgba(512, 512, frame=1)
-    for fmt, floor in ((L.FMT_DXT1, 30.0), (L.FMT_DXT5, 30.0), (L.FMT_YCOCG, 33.0)):
+    for fmt, floor in ((L.FMT_DXT1, 36.97), (L.FMT_DXT5, 36.97), (L.FMT_YCOCG, 40.87)):
         r, blocks = ctx.compress_rgba(pic, 512, 512, 2048, fmt)
         dec = D.oracle_bc_decode(blocks, fmt, 512, 512)
-        assert D.psnr(dec[..., :3], pic[..., :3]) > floor, fmt
+        assert D.psnr(dec[..., :3], pic[..., :3]) > floor - 0.3, fmt
     r, blocks = ctx.compress_rgba(pic, 512, 512, 2048, L.FMT_RGTC1)
-    assert D.psnr(D.oracle_bc_decode(blocks, L.FMT_RGTC1, 512, 512), pic[..., 3]) > 40.0
+    assert D.psnr(D.oracle_bc_decode(blocks, L.FMT_RGTC1, 512, 512), pic[..., 3]) > 98.0
+    from test_oracle_pinning import QUALITY_R04
+    for name, img in D.quality_images().items():
+        for fmt in BC_FORMATS:
+            r, blocks = ctx.compress_rgba(img, img.shape[1], img.shape[0], img.strides[0], fmt)
+            assert r == 0
+            for g, w_ in zip(D.block_quality(blocks, fmt, img), QUALITY_R04[(name, fmt)]):
+                assert g >= w_ - 0.3, (name, fmt)
 
 
 def test_block_encode_bad_arguments(ctx, hap):
@@ -1022,6 +1031,15 @@ def test_row_bands_encoded_separately_join_into_the_whole_frame(ctx, hap, format
             r, used, fmts, res = ctx.decode_frames([joined], [len(joined)], idx, [dec], flags=flags)
             assert (r, used, fmts, res) == (0, [len(want)], [fmt], [0]) and dec.tobytes() == want
     assert b"\x46" in joined[:4096]      # the private fragment-size section survived the join
+    # G5 as bytes: the frame joined from the ranks' bands IS the frame one GPU writes for the undivided picture
+    # with the same chunk count -- headers, tables, private section and every compressed byte (no band of this picture is
+    # stored raw: a band that found no gain would keep its own raw form, hap.c:478-495, where the whole frame might not)
+    sizes = [len(D.oracle_bc_encode(img, f)) for f in formats]
+    whole = np.zeros(hap.HapMaxEncodedLength(sizes, formats, [chunks] * len(formats)) + 8192, dtype=np.uint8)
+    r, wused, wres = ctx.encode_frames_rgba([img], w, h, w * 4, formats, [1] * len(formats), [chunks] * len(formats), [whole],
+                                            flags=hap.ENCODE_FRAGMENT_INDEX)
+    assert r == 0 and wres == [0]
+    assert whole[: wused[0]].tobytes() == joined
     # the join on the device (band frames and output in HBM: what arrives over xGMI never touches the host) writes the
     # same bytes; and the group tables are carried over, so the joined frame takes the block-per-lane decoder
     dparts = [torch.from_numpy(np.frombuffer(f, dtype=np.uint8).copy()).cuda() for f in frames]
@@ -1037,6 +1055,40 @@ def test_row_bands_encoded_separately_join_into_the_whole_frame(ctx, hap, format
         n0 = ctx.table_fallbacks()
         dec = np.zeros(len(D.oracle_bc_encode(img, formats[0])), dtype=np.uint8)
         assert ctx.decode_frames([joined], [len(joined)], 0, [dec])[3] == [0] and ctx.table_fallbacks() == n0
+
+
+@pytest.mark.parametrize("fmt,block", [(L.FMT_DXT1, 8), (L.FMT_YCOCG, 16), (L.FMT_RGTC1, 8), (L.FMT_BC7, 16)])
+@pytest.mark.parametrize("chunks", [1, 3, 7, 13, 24, 63])
+def test_frames_with_the_private_table_stay_inside_hap_max_encoded_length(ctx, hap, monkeypatch, fmt, block, chunks):
+    """HapMaxEncodedLength knows nothing of the private table (it is the reference's bound, hap.c:324-353: Snappy's worst
+    case per chunk), and a frame that carries ~100 table bytes per 8 KiB fragment must still fit -- or fall back to the
+    raw form the reference would choose (hap.c:478-495).  Swept over textures that are ALMOST incompressible (random
+    bytes in which every k-th block repeats its neighbour: from 'Snappy still wins by a hair' to 'stored raw') and odd
+    chunk counts, through the batched call with the flag and through plain hap.h with HAP_AMD_FRAGMENT_INDEX=1."""
+    rng = np.random.default_rng(chunks * 131 + block)
+    nblocks = chunks * 523
+    monkeypatch.setenv("HAP_AMD_FRAGMENT_INDEX", "1")
+    kinds = set()
+    for every in (2, 3, 5, 8, 12, 20, 40, 100, 0):
+        tex = rng.integers(0, 256, (nblocks, block), dtype=np.uint8)
+        if every:
+            tex[every::every] = tex[every - 1:-1:every]          # these blocks repeat the one in front of them
+        tex = tex.tobytes()
+        cap = hap.HapMaxEncodedLength([len(tex)], [fmt], [chunks])
+        assert cap == ORA.max_encoded_length([len(tex)], [fmt], [chunks])
+        out = np.full(cap + 64, 0xA5, dtype=np.uint8)
+        r, used, res = ctx.encode_frames([[tex]], [fmt], [1], [chunks], [out[:cap]], flags=hap.ENCODE_FRAGMENT_INDEX)
+        assert (r, res) == (0, [0]) and 0 < used[0] <= cap
+        assert out[cap:].tolist() == [0xA5] * 64                 # nothing written past the bound
+        frame = out[: used[0]].tobytes()
+        kinds.add(frame[3] >> 4)
+        for name, api in CHECKERS:
+            assert api.decode(frame, 0, len(tex)) == (0, tex, fmt), (name, every)
+        r, plain = hap.HapEncode([tex], [fmt], [1], [chunks], outputBufferBytes=cap)
+        assert r == 0 and len(plain) <= cap and ORA.decode(plain, 0, len(tex)) == (0, tex, fmt)
+        dec = np.zeros(len(tex), dtype=np.uint8)
+        assert ctx.decode_frames([frame], [len(frame)], 0, [dec])[3] == [0] and dec.tobytes() == tex
+    assert kinds == {0xA, 0xC}                                   # the sweep crossed the raw / compressed decision
 
 
 @pytest.mark.parametrize("fmt", [L.FMT_DXT5, L.FMT_YCOCG, L.FMT_RGTC1, L.FMT_BC7])
@@ -1825,3 +1877,31 @@ def test_encode_sequence_to_file_matches_frame_by_frame(ctx, hap, tmp_path, batc
     reader = hap.SequenceReader(path2)
     assert reader.frame_count == 6
     reader.close()
+
+
+def test_bench_multi_rank_path_runs_with_two_ranks_on_one_gpu():
+    """`bench.py --gpus N` (N > 1) has only ever been run by the driver, if at all.  Here its whole
+    multi-rank branch executes -- the launcher, the frame split, both scaling modes, the C5 chunk-group encode / gather /
+    join / decode / gather with the real codec -- as two ranks on this one GPU, the collectives over gloo instead of
+    RCCL (--one-gpu-ranks).  A functional check of code the 8-GPU run depends on, not a measurement."""
+    import json
+    import os
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    done = subprocess.run([sys.executable, bench, "--gpus", "2", "--one-gpu-ranks", "--steps", "2", "--warmup", "1", "--frames", "6"],
+                          capture_output=True, text=True, timeout=900, env=env)
+    assert done.returncode == 0, done.stderr[-3000:]
+    lines = [json.loads(x) for x in done.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["rccl_ranks_seen"] == 2 and line["collective_backend"] == "gloo" and "dry_run" in line
+    assert line["scaling"] == "strong" and line["config"]["frames_per_rank"] == [3, 3] and line["config"]["frames_per_step"] == 6
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0
+    other = line["other_scaling_mode"]
+    assert other["scaling"] == "weak" and other["frames_per_step"] == 12 and other["value"] > 0
+    groups = line["c5_chunk_groups"]
+    assert groups["bit_exact"] is True and groups["frame_bytes"] > 0
+    assert set(groups["ms"]) >= {"encode_bands_ms", "gather_band_frames_ms", "join_on_device_ms", "decode_groups_tex0_ms",
+                                 "decode_groups_tex1_ms", "gather_slices_tex0_ms", "gather_slices_tex1_ms"}
