@@ -142,7 +142,13 @@ __global__ __launch_bounds__(256) void bc_decode_kernel(const uint8_t *__restric
             }
             px[c] = (unsigned)R | ((unsigned)G << 8) | ((unsigned)B << 16) | ((unsigned)A << 24);
         }
-        *reinterpret_cast<uint4 *>(dst + (size_t)r * row_bytes) = make_uint4(px[0], px[1], px[2], px[3]);
+        {
+            // streaming stores: the picture is written once and not read back by this kernel -- without the hint the
+            // 16-byte stores of DXT1 / DXT5 run at 0.58 / 0.62 of HBM peak, with it at 0.76 (r04, 8K pictures)
+            typedef unsigned v4u __attribute__((ext_vector_type(4)));
+            const v4u v = {px[0], px[1], px[2], px[3]};
+            __builtin_nontemporal_store(v, reinterpret_cast<v4u *>(dst + (size_t)r * row_bytes));
+        }
     }
 }
 
