@@ -649,36 +649,70 @@ static void mark_chunk(void *p, unsigned index)
 /* Unit slots to reserve behind a whole-stream unit for the block scan (snappy_decode.hip): one per 64 KiB of output.
    The output length is on the device (the stream's varint); bound it by the client's buffer and by the format's
    largest expansion (a 3-byte copy element produces 64 bytes).  Streams of one block need none. */
-static void scan_entry(HapGpuScanChunk *e, unsigned unit, unsigned long src_len, unsigned slots, uint32_t *dbpos,
-                       unsigned *seg_cursor, unsigned *word_cursor);
+static void scan_entry(HapGpuScanChunk *e, unsigned unit, unsigned long src_len, unsigned long dst_cap, uint32_t *dbpos,
+                       unsigned *seg_cursor, unsigned *word_cursor, unsigned fine_region_first, unsigned *fine_cursor);
 
 static unsigned stream_scan_segments(unsigned long src_len)
 {
     return (unsigned)(((unsigned long long)src_len + 15u + HAPGPU_SCAN_SEGMENT - 1u) / HAPGPU_SCAN_SEGMENT);
 }
 
-static unsigned stream_block_slots(unsigned long src_len, unsigned long dst_cap)
+static unsigned long long stream_output_bound(unsigned long src_len, unsigned long dst_cap)
 {
     unsigned long long bound = (unsigned long long)src_len * 22u;
-    if (bound > dst_cap)
-        bound = dst_cap;
+    return bound > dst_cap ? dst_cap : bound;
+}
+
+/* 64 KiB blocks (libsnappy's) */
+static unsigned stream_coarse_slots(unsigned long src_len, unsigned long dst_cap)
+{
+    unsigned long long bound = stream_output_bound(src_len, dst_cap);
     if (bound <= 65536u)
         return 0u;
     bound = (bound + 65535u) / 65536u;
     return bound > 4096u ? 4096u : (unsigned)bound;
 }
 
-static void scan_entry(HapGpuScanChunk *e, unsigned unit, unsigned long src_len, unsigned slots, uint32_t *dbpos,
-                       unsigned *seg_cursor, unsigned *word_cursor)
+/* 8 KiB blocks (the fragments of this library's own table-less streams): none for streams that are not scanned, or
+   too long to give every 8 KiB a slot */
+static unsigned stream_fine_slots(unsigned long src_len, unsigned long dst_cap)
 {
+    unsigned long long bound = stream_output_bound(src_len, dst_cap);
+    if (bound <= 65536u)
+        return 0u;
+    bound = (bound + HAPGPU_SCAN_FINE - 1u) / HAPGPU_SCAN_FINE;
+    return bound > 32768u ? 0u : (unsigned)bound;
+}
+
+/* unit slots directly behind a whole-stream unit: one per 64 KiB block (the 8 KiB blocks' slots lie behind all the
+   ordinary units of the call) */
+static unsigned stream_block_slots(unsigned long src_len, unsigned long dst_cap)
+{
+    return stream_coarse_slots(src_len, dst_cap);
+}
+
+/* words of block positions a scanned stream needs: one per mark + the end */
+static unsigned stream_mark_words(unsigned long src_len, unsigned long dst_cap)
+{
+    const unsigned coarse = stream_coarse_slots(src_len, dst_cap), fine = stream_fine_slots(src_len, dst_cap);
+    return (fine > coarse ? fine : coarse) + 1u;
+}
+
+static void scan_entry(HapGpuScanChunk *e, unsigned unit, unsigned long src_len, unsigned long dst_cap, uint32_t *dbpos,
+                       unsigned *seg_cursor, unsigned *word_cursor, unsigned fine_region_first, unsigned *fine_cursor)
+{
+    const unsigned coarse = stream_coarse_slots(src_len, dst_cap), fine = coarse ? stream_fine_slots(src_len, dst_cap) : 0u;
     memset(e, 0, sizeof(*e));
     e->unit = unit;
     e->seg_first = *seg_cursor;
     e->seg_count = stream_scan_segments(src_len);
-    e->slots = slots;
+    e->slots = coarse;
+    e->fine_slots = fine;
+    e->fine_unit_first = fine_region_first + *fine_cursor;
     e->bpos = (uint64_t)(uintptr_t)(dbpos + *word_cursor);
     *seg_cursor += e->seg_count;
-    *word_cursor += slots + 1u;
+    *word_cursor += stream_mark_words(src_len, dst_cap);
+    *fine_cursor += fine;
 }
 
 unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const *inputs,
@@ -695,6 +729,8 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     unsigned frag_log2_seen = 0, frag_kinds = 0, max_chunks = 0;
     int any_stream = 0, need_retry = 0;
     unsigned scan_chunks = 0, scan_segs = 0, scan_words = 0;   /* streams with BLOCK slots; their segments; bpos words */
+    unsigned fine_total = 0;                                   /* unit slots for the 8 KiB blocks of scanned streams */
+    uint32_t *dwork = NULL;                                    /* [0]: count, then the fine units the scan listed */
     unsigned far_seen = 0;
     /* (a call for several textures of the same frames: HapGpuDecodeFrameTextures hands the per-entry indices over) */
     const unsigned *const entry_index = ctx->decode_indices;
@@ -896,7 +932,8 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                     if ((p->chunks[c].codec & 0xFFu) == HAP_NIBBLE_SNAPPY && p->chunks[c].unit_count > 1u) {
                         scan_chunks += 1u;
                         scan_segs += stream_scan_segments(p->chunks[c].src_len);
-                        scan_words += p->chunks[c].unit_count;          /* slots + 1 */
+                        scan_words += stream_mark_words(p->chunks[c].src_len, output_bytes[f]);
+                        fine_total += stream_fine_slots(p->chunks[c].src_len, output_bytes[f]);
                     }
             total_chunks += (unsigned)p->chunk_count;
             if ((unsigned)p->chunk_count > max_chunks)
@@ -909,7 +946,8 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
             if (units > 1u) {
                 scan_chunks += 1u;
                 scan_segs += stream_scan_segments(p->section_length);
-                scan_words += units;
+                scan_words += stream_mark_words(p->section_length, output_bytes[f]);
+                fine_total += stream_fine_slots(p->section_length, output_bytes[f]);
             }
             any_stream = 1;
         }
@@ -930,7 +968,8 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     hchunks = (HapGpuChunkIn *)hapgpu_rt_pinned_scratch(rt, P_CHUNKS, sizeof(HapGpuChunkIn) * (total_chunks + 1u));
     djobs = (HapGpuDecodeJob *)hapgpu_rt_device_scratch(rt, D_JOBS, sizeof(HapGpuDecodeJob) * live);
     dchunks = (HapGpuChunkIn *)hapgpu_rt_device_scratch(rt, D_CHUNKS, sizeof(HapGpuChunkIn) * (total_chunks + 1u));
-    dunits = (HapGpuDecodeUnit *)hapgpu_rt_device_scratch(rt, D_UNITS, sizeof(HapGpuDecodeUnit) * (total_units + 1u));
+    /* (the fine block units of the block scan live behind the ordinary ones: [total_units, total_units + fine_total)) */
+    dunits = (HapGpuDecodeUnit *)hapgpu_rt_device_scratch(rt, D_UNITS, sizeof(HapGpuDecodeUnit) * ((size_t)total_units + fine_total + 1u));
     if (in_stage_bytes)
         in_stage = (uint8_t *)hapgpu_rt_device_scratch(rt, D_IN_STAGE, in_stage_bytes);
     if (out_stage_bytes)
@@ -941,10 +980,11 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
         goto fail_alloc;
     }
     if (scan_chunks) {
-        /* one arena: chunk table | segment summaries | block positions | joins | window records */
+        /* one arena: chunk table | segment summaries | block positions | fine work list | joins | window records */
         const size_t o_segs = align_up(sizeof(HapGpuScanChunk) * scan_chunks, 64);
         const size_t o_bpos = o_segs + sizeof(HapGpuScanSegment) * scan_segs;
-        const size_t o_joins = align_up(o_bpos + sizeof(uint32_t) * scan_words, 64);
+        const size_t o_work = align_up(o_bpos + sizeof(uint32_t) * scan_words, 64);
+        const size_t o_joins = align_up(o_work + sizeof(uint32_t) * ((size_t)fine_total + 1u), 64);
         const size_t o_recs = align_up(o_joins + (size_t)8u * scan_segs, 64);
         uint8_t *arena = (uint8_t *)hapgpu_rt_device_scratch(rt, D_SCAN, o_recs + (size_t)512u * scan_segs);
         hscan = (HapGpuScanChunk *)hapgpu_rt_pinned_scratch(rt, P_SCAN, sizeof(HapGpuScanChunk) * scan_chunks);
@@ -955,11 +995,12 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
         dscan = (HapGpuScanChunk *)arena;
         dsegs = (HapGpuScanSegment *)(arena + o_segs);
         dbpos = (uint32_t *)(arena + o_bpos);
+        dwork = (uint32_t *)(arena + o_work);
         djoins = arena + o_joins;
         drecs = arena + o_recs;
     }
     {
-        unsigned chunk_cursor = 0, unit_cursor = 0, scan_cursor = 0, seg_cursor = 0, word_cursor = 0;
+        unsigned chunk_cursor = 0, unit_cursor = 0, scan_cursor = 0, seg_cursor = 0, word_cursor = 0, fine_cursor = 0;
         request_marks marks;
         marks.count = 0;
         marks.requested = NULL;
@@ -1016,16 +1057,16 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                         const HapGpuChunkIn *ch = &p->chunks[c];
                         if ((ch->codec & 0xFFu) != HAP_NIBBLE_SNAPPY || ch->unit_count <= 1u)
                             continue;
-                        scan_entry(&hscan[scan_cursor++], unit_cursor + ch->unit_first, ch->src_len, ch->unit_count - 1u,
-                                   dbpos, &seg_cursor, &word_cursor);
+                        scan_entry(&hscan[scan_cursor++], unit_cursor + ch->unit_first, ch->src_len, output_bytes[f],
+                                   dbpos, &seg_cursor, &word_cursor, total_units, &fine_cursor);
                     }
                 }
             } else {
                 job->payload = (uint64_t)(uintptr_t)(frame_dev + p->section_offset);
                 job->payload_len = p->section_length;
                 if (scan_chunks && p->mode == HAPGPU_JOB_SNAPPY && units > 1u)
-                    scan_entry(&hscan[scan_cursor++], unit_cursor, p->section_length, units - 1u, dbpos, &seg_cursor,
-                               &word_cursor);
+                    scan_entry(&hscan[scan_cursor++], unit_cursor, p->section_length, output_bytes[f], dbpos, &seg_cursor,
+                               &word_cursor, total_units, &fine_cursor);
             }
             unit_cursor += units;
         }
@@ -1091,10 +1132,13 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
         /* streams of other encoders (no fragment table): find their independent 64 KiB blocks first */
         if (scan_chunks && scan_cursor == scan_chunks) {
             rc |= hapgpu_rt_h2d(rt, dscan, hscan, sizeof(HapGpuScanChunk) * scan_chunks);
-            rc |= hapgpu_k_scan_blocks(rt, dunits, djobs, dscan, scan_chunks, dsegs, drecs, djoins, scan_segs);
+            rc |= hapgpu_rt_zero(rt, dwork, sizeof(uint32_t));
+            rc |= hapgpu_k_scan_blocks(rt, dunits, djobs, dscan, scan_chunks, dsegs, drecs, djoins, scan_segs,
+                                       fine_total ? dwork : NULL);
         }
         rc |= hapgpu_k_snappy_decode(rt, dunits, total_units, djobs, frag_log2_seen, frag_kinds,
-                                     any_stream ? (scan_chunks ? 2 : 1) : 0);
+                                     any_stream ? (scan_chunks ? 2 : 1) : 0,
+                                     (scan_chunks && scan_cursor == scan_chunks && fine_total) ? dwork : NULL, fine_total);
         rc |= hapgpu_rt_d2h(rt, hjobs, djobs, sizeof(HapGpuDecodeJob) * live);
         rc |= hapgpu_rt_sync(rt);
         if (rc)

@@ -142,9 +142,12 @@ typedef struct HapGpuDecodeJob {
 #define HAPGPU_UNIT_SNAPPY_FIELDS4 6u   /* fragment of a field stream, 16-byte blocks of 2 + 6 + 4 + 4 bytes; aux = its group table */
 #define HAPGPU_UNIT_SNAPPY_FIELDS2 7u   /* ... 8-byte blocks of 4 + 4 bytes */
 #define HAPGPU_UNIT_SNAPPY_FIELDS26 8u  /* ... 8-byte blocks of 2 + 6 bytes */
-#define HAPGPU_UNIT_SNAPPY_BLOCK 9u     /* one 64 KiB block of another encoder's stream, found by the block scan: bare
-                                           elements, copies stay inside the block; decoded by the whole-stream kernel.
-                                           aux = its HapGpuScanChunk, reserved = block number, src = the stream */
+#define HAPGPU_UNIT_SNAPPY_BLOCK 9u     /* one 64 KiB block of another encoder's stream (or one 8 KiB block of a table-less
+                                           stream of this library), found by the block scan: bare elements, copies stay
+                                           inside the block; decoded by the whole-stream kernel.  aux = its
+                                           HapGpuScanChunk, reserved = block number (| HAPGPU_BLOCK_FINE), src = the stream */
+#define HAPGPU_BLOCK_FINE (1ull << 32)  /* flag in reserved: the unit is an 8 KiB block */
+#define HAPGPU_SCAN_FINE 8192u          /* the block scan's fine granularity (one fragment of this library's streams) */
 #define HAPGPU_UNIT_WINDOWED 0x10u       /* flag on the three fragment kinds: every copy offset is <= 3 KiB, so an 8 KiB
                                             fragment decodes through a 4 KiB LDS ring (twice the waves per CU) */
 #define HAP_FRAGMENT_WINDOW_256 12u      /* that window in 256-byte units, as written to the fragment table */
@@ -157,13 +160,29 @@ typedef struct HapGpuScanChunk {
     uint32_t unit;           /* index of the stream's whole-stream unit in the call's unit array */
     uint32_t seg_first;      /* first of its seg_count segment records */
     uint32_t seg_count;      /* >= segments the stream can touch: (src_len + 15 + 4095) / 4096 */
-    uint32_t slots;          /* unit slots reserved behind the stream unit (one per 64 KiB block) */
-    uint64_t bpos;           /* device address of slots + 1 words: compressed position where each block begins */
+    uint32_t slots;          /* unit slots for 64 KiB blocks, directly behind the stream unit */
+    uint64_t bpos;           /* device address of fine_slots + 1 words: compressed position where each 8 KiB of output
+                                begins (a 64 KiB block begins at every eighth) */
     /* written by the device (the host sends zeros) */
     uint32_t ok;             /* the element chain was followed to the stream's end and the lengths agree */
-    uint32_t expected;       /* blocks */
-    uint32_t found;          /* block starts that fall on an element boundary: all of them = BLOCK units run */
+    uint32_t expected;       /* 64 KiB blocks */
+    uint32_t found;          /* 64 KiB block starts that fall on an element boundary: all of them = BLOCK units run */
+    /* host */
+    uint32_t fine_slots;     /* unit slots for 8 KiB blocks, at fine_unit_first of the call's unit array (behind all the
+                                ordinary units): streams written by this library without a fragment table have an
+                                element boundary at every 8 KiB (its fragments) -- eight times the units of
+                                libsnappy's 64 KiB blocks */
+    /* device */
+    uint32_t expected_fine;  /* 8 KiB blocks */
+    uint32_t found_fine;     /* 8 KiB marks on element boundaries: all of them = the fine BLOCK units run first */
+    uint32_t fine_failed;    /* ... and one of them met a copy that reaches before its block (marks on element boundaries
+                                do not make a stream's 8 KiB pieces independent): the 64 KiB blocks / the stream unit
+                                of the launch's second phase decode the stream instead */
+    uint32_t fine_unit_first; /* host: index of the stream's first fine unit slot in the call's unit array */
     uint32_t reserved;
+    uint32_t probe_found;    /* of the first two 8 KiB marks (output positions 8192 and 16384): the rest of the fine
+                                marks are only looked for when both fall on element boundaries -- in a libsnappy
+                                stream they hardly ever do, and its scan then costs what it did with 64 KiB marks only */
 } HapGpuScanChunk;
 
 typedef struct HapGpuScanSegment {   /* device only */
@@ -263,14 +282,16 @@ int hapgpu_k_decode_plan(hapgpu_rt *rt, HapGpuDecodeJob *jobs, unsigned job_coun
  * (host-filled part copied to the device by the caller); segs / recs / joins: device scratch of seg_total entries /
  * seg_total * 64 words of 8 bytes / seg_total * 8 bytes */
 int hapgpu_k_scan_blocks(hapgpu_rt *rt, HapGpuDecodeUnit *units, const HapGpuDecodeJob *jobs, HapGpuScanChunk *chunks,
-                         unsigned chunk_count, HapGpuScanSegment *segs, void *recs, void *joins, unsigned seg_total);
+                         unsigned chunk_count, HapGpuScanSegment *segs, void *recs, void *joins, unsigned seg_total,
+                         uint32_t *fine_work /* [0]: count (zero on entry), then the unit indices of the 8 KiB blocks to decode */);
 /* frag_log2: fragment size of the batch's FRAGMENT units (0: none present);
  * fragment_kinds: bit g set = fragments of granularity_log2 g present */
 /* fragment_kinds bits 8 / 9 / 10: field-stream units of [2,6,4,4] / [4,4] / [2,6] blocks present */
 /* any_stream_or_copy_units: 0 none, 1 whole streams / raw copies, 2 the same with block-scanned streams among them */
 int hapgpu_k_snappy_decode(hapgpu_rt *rt, const HapGpuDecodeUnit *units, unsigned unit_count,
                            HapGpuDecodeJob *jobs, unsigned frag_log2, unsigned fragment_kinds,
-                           int any_stream_or_copy_units);
+                           int any_stream_or_copy_units,
+                           const uint32_t *fine_work, unsigned fine_slots /* the block scan's list and its capacity (0: none) */);
 
 /* measurement */
 void hapgpu_rt_set_profiling(hapgpu_rt *rt, int enable);

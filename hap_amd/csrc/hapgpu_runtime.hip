@@ -32,10 +32,11 @@ int hapgpu_launch_frame_pack(HapGpuFrameEnc *frames, unsigned frame_count, unsig
 int hapgpu_launch_frame_gather(const HapGpuCopyEntry *copies, unsigned count, hipStream_t stream);
 int hapgpu_launch_decode_plan(HapGpuDecodeJob *jobs, unsigned job_count, unsigned max_chunks, hipStream_t stream);
 int hapgpu_launch_scan_blocks(HapGpuDecodeUnit *units, const HapGpuDecodeJob *jobs, HapGpuScanChunk *chunks, unsigned chunk_count,
-                              HapGpuScanSegment *segs, void *recs, void *joins, unsigned seg_total, hipStream_t stream);
+                              HapGpuScanSegment *segs, void *recs, void *joins, unsigned seg_total, uint32_t *fine_work,
+                              hipStream_t stream);
 int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsigned unit_count, HapGpuDecodeJob *jobs,
                                 unsigned frag_log2, unsigned fragment_kinds, int any_stream_or_copy_units,
-                                hipStream_t stream);
+                                const uint32_t *fine_work, unsigned fine_slots, hipStream_t stream);
 }
 
 namespace {
@@ -569,17 +570,18 @@ extern "C" int hapgpu_k_decode_plan(hapgpu_rt *rt, HapGpuDecodeJob *jobs, unsign
 }
 
 extern "C" int hapgpu_k_scan_blocks(hapgpu_rt *rt, HapGpuDecodeUnit *units, const HapGpuDecodeJob *jobs, HapGpuScanChunk *chunks,
-                                    unsigned chunk_count, HapGpuScanSegment *segs, void *recs, void *joins, unsigned seg_total)
+                                    unsigned chunk_count, HapGpuScanSegment *segs, void *recs, void *joins, unsigned seg_total,
+                                    uint32_t *fine_work)
 {
     scoped_timing st(rt, 7);
-    return hapgpu_launch_scan_blocks(units, jobs, chunks, chunk_count, segs, recs, joins, seg_total, rt->stream);
+    return hapgpu_launch_scan_blocks(units, jobs, chunks, chunk_count, segs, recs, joins, seg_total, fine_work, rt->stream);
 }
 
 extern "C" int hapgpu_k_snappy_decode(hapgpu_rt *rt, const HapGpuDecodeUnit *units, unsigned unit_count,
                                       HapGpuDecodeJob *jobs, unsigned frag_log2, unsigned fragment_kinds,
-                                      int any_stream_or_copy_units)
+                                      int any_stream_or_copy_units, const uint32_t *fine_work, unsigned fine_slots)
 {
     scoped_timing st(rt, 5);
     return hapgpu_launch_snappy_decode(units, unit_count, jobs, frag_log2, fragment_kinds, any_stream_or_copy_units,
-                                       rt->stream);
+                                       fine_work, fine_slots, rt->stream);
 }

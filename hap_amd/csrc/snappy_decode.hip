@@ -458,9 +458,12 @@ __device__ __forceinline__ unsigned long long window_chain(bool stopper, unsigne
 // 16 bits (FRAGMENT16 units, produced by hap_amd's 16-bit granular compressor).
 // SLIDE: the unit is a fragment larger than the ring whose copies all stay within RING - 1 KiB (promised by the
 // fragment table, checked here): finished output leaves the ring in 1 KiB segments while decoding goes on.
+// phase (STREAM launches): 0 every unit; 1 the 8 KiB BLOCK units the block scan listed in `work` ([0]: how many, then
+// their indices in `units`); 2 everything else, after phase 1
 template <unsigned RING, bool STREAM, unsigned GRAN, bool SLIDE = false>
 __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpuDecodeUnit *__restrict__ units,
-                                                                    unsigned unit_count, HapGpuDecodeJob *jobs)
+                                                                    unsigned unit_count, HapGpuDecodeJob *jobs, unsigned phase,
+                                                                    const uint32_t *__restrict__ work)
 {
     // Statically sized LDS when it fits the 64 KiB static limit: the compiler then knows every LDS address
     // offset at compile time (with a dynamic array each address computation carries an extra add of the base).
@@ -474,8 +477,17 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
     const unsigned lane = threadIdx.x;
     if (blockIdx.x >= unit_count)
         return;
-    const HapGpuDecodeUnit u = units[blockIdx.x];
+    unsigned unit_index = blockIdx.x;
+    if (STREAM && phase == 1u) {
+        if (blockIdx.x >= work[0])
+            return;
+        unit_index = work[1u + blockIdx.x];
+    }
+    const HapGpuDecodeUnit u = units[unit_index];
     if (u.kind == HAPGPU_UNIT_SKIP)
+        return;
+    const bool fine_unit = STREAM && u.kind == HAPGPU_UNIT_SNAPPY_BLOCK && (u.reserved & HAPGPU_BLOCK_FINE) != 0ull;
+    if (STREAM && fine_unit != (phase == 1u))
         return;
     HapGpuDecodeJob *job = &jobs[u.job];
     if (job->status != 0)
@@ -495,17 +507,33 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
     if (STREAM && (u.kind == HAPGPU_UNIT_SNAPPY_BLOCK || u.reserved != 0u)) {
         // a stream the block scan looked at: its BLOCK units run when every block start was found, else the stream unit
         const HapGpuScanChunk *scan = (const HapGpuScanChunk *)(u.kind == HAPGPU_UNIT_SNAPPY_BLOCK ? u.aux : u.reserved);
-        const bool split = scan->ok != 0u && scan->found == scan->expected;
-        if (split != (u.kind == HAPGPU_UNIT_SNAPPY_BLOCK))
+        // 2: every 8 KiB mark was found (a table-less stream of this library: its fragments) -- the fine BLOCK units run;
+        // 1: every 64 KiB mark (libsnappy's blocks) -- the coarse ones; 0: the stream unit
+        const bool fine_on = scan->expected_fine != 0u;
+        // (fine_failed: written by the fine units of phase 1, read here by the others in phase 2)
+        const bool fine_ok = fine_on && scan->found_fine == scan->expected_fine &&
+                             (fine_unit || __hip_atomic_load(&scan->fine_failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u);
+        const unsigned mode = scan->ok == 0u ? 0u : fine_ok ? 2u : scan->found == scan->expected ? 1u : 0u;
+        const unsigned mine = u.kind != HAPGPU_UNIT_SNAPPY_BLOCK ? 0u : (u.reserved & HAPGPU_BLOCK_FINE) ? 2u : 1u;
+        if (mode != mine)
             return;
-        if (split) {
+        if (mine != 0u) {
             const uint32_t *bpos = (const uint32_t *)scan->bpos;
-            const unsigned from = bpos[u.reserved], to = bpos[u.reserved + 1u];
+            const unsigned b = (unsigned)u.reserved;
+            const unsigned marks = fine_on ? scan->expected_fine : scan->expected;          // words of bpos, + 1 for the end
+            const unsigned first = mine == 2u ? b : fine_on ? 8u * b : b;
+            const unsigned last = mine == 2u ? b + 1u : fine_on ? min(8u * b + 8u, marks) : b + 1u;
             // (the block positions live in scratch the scan fills: whatever it left there, a block never reaches
-            // outside its stream -- the frame is decoded again without the scan instead)
-            if (from > to || to > bpos[scan->expected]) {          // (the last word is the stream's end, written with `ok`)
-                if (lane == 0)
-                    atomicCAS(&jobs[u.job].status, 0u, HAPGPU_STATUS_INDEX_MISMATCH);
+            // outside its stream -- the stream is decoded by the second phase's units / the frame again without the scan)
+            const bool in_range = first < marks && last <= marks;
+            const unsigned from = in_range ? bpos[first] : 1u, to = in_range ? bpos[last] : 0u;
+            if (!in_range || from > to || to > bpos[marks]) {      // (the last word is the stream's end, written with `ok`)
+                if (lane == 0) {
+                    if (mine == 2u && phase == 1u)
+                        __hip_atomic_store(&((HapGpuScanChunk *)u.aux)->fine_failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else
+                        atomicCAS(&jobs[u.job].status, 0u, HAPGPU_STATUS_INDEX_MISMATCH);
+                }
                 return;
             }
             src += from;
@@ -783,7 +811,13 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
         failed = true;
     if (failed) {
         if (lane == 0) {
-            // (a BLOCK unit that fails -- a copy reaching before its block -- has the frame decoded again whole)
+            // (an 8 KiB BLOCK unit that fails -- the marks do not promise independent pieces -- hands the stream to the
+            // second phase's units; a 64 KiB one -- a copy reaching before its block -- has the frame decoded again whole)
+            if (fine_unit && phase == 1u) {
+                HapGpuScanChunk *scan = (HapGpuScanChunk *)u.aux;
+                __hip_atomic_store(&scan->fine_failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
             const unsigned code = (!STREAM || u.kind == HAPGPU_UNIT_SNAPPY_BLOCK)
                                       ? HAPGPU_STATUS_INDEX_MISMATCH
                                       : (job->mode == HAPGPU_JOB_SNAPPY ? kResInternal : kResBadFrame);
@@ -828,6 +862,7 @@ constexpr unsigned kScanSegment = HAPGPU_SCAN_SEGMENT;
 constexpr unsigned kScanWarmWindows = 5u;                     // > the longest element that is not a "long literal" (258 bytes)
 constexpr unsigned kScanLds = kScanSegment + 64u * kScanWarmWindows + 128u;
 constexpr unsigned kBlockOut = 65536u;
+constexpr unsigned kFine = HAPGPU_SCAN_FINE;                  // 8 KiB: the fragments of this library's own streams
 constexpr unsigned kRecNone = 0xFFu;
 constexpr unsigned kMergeSegments = 2048u;                    // segments of one stream the merge kernel tabulates (8 MiB compressed)
 
@@ -1052,8 +1087,12 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
     const HapGpuDecodeUnit u = units[sc.unit];
     const unsigned out_len = u.dst_len;
     const unsigned nblk = (out_len + kBlockOut - 1u) / kBlockOut;
+    const unsigned nfine = (out_len + kFine - 1u) / kFine;
     if (!scan_unit_wanted(u, jobs) || nblk > sc.slots)
         return;                                   // (ok stays 0: the host sent zeros)
+    // marks every 8 KiB of output when the host reserved a unit slot for each (else every 64 KiB, as for any stream)
+    const bool fine_on = sc.fine_slots != 0u && nfine <= sc.fine_slots;
+    const unsigned mark = fine_on ? kFine : kBlockOut;
     const unsigned shift = (unsigned)(u.src & 15u);
     const uint8_t *src_al = (const uint8_t *)u.src - shift;
     const unsigned in_end = shift + u.src_len;
@@ -1067,7 +1106,7 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
         } while ((b & 0x80u) && p < in_end);
         p = uniform(p);
     }
-    unsigned op = 0, found = 0, cur = 0xFFFFFFFFu;
+    unsigned op = 0, found = 0, found_fine = 0, found_probe = 0, cur = 0xFFFFFFFFu;
     unsigned long long rec = kRecNone, rec_ahead = kRecNone;
     HapGpuScanSegment sg = {}, sg_ahead = {};
     bool ok = true;
@@ -1179,10 +1218,12 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
                 ok = false;
                 break;
             }
-            if ((op & (kBlockOut - 1u)) == 0u && op < out_len) {
+            if ((op & (mark - 1u)) == 0u && op < out_len) {
                 if (lane == 0)
-                    bpos[op / kBlockOut] = p;
-                found += 1u;
+                    bpos[op / mark] = p;
+                found_fine += 1u;
+                found += (op & (kBlockOut - 1u)) == 0u ? 1u : 0u;
+                found_probe += (op == kFine || op == 2u * kFine) ? 1u : 0u;
             }
             p += h + llen;
             op += llen;
@@ -1191,10 +1232,12 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
         const bool is_tok = __builtin_amdgcn_inverse_ballot_w64(T);
         const int incl = wave_scan_add(is_tok ? (int)el.len : 0);
         const unsigned at = op + (unsigned)incl - (is_tok ? el.len : 0u);
-        const bool starts_block = is_tok && (at & (kBlockOut - 1u)) == 0u && at < out_len;
-        if (starts_block)
-            bpos[at / kBlockOut] = x;
-        found += (unsigned)__builtin_popcountll(ballot64(starts_block));
+        const bool starts_mark = is_tok && (at & (mark - 1u)) == 0u && at < out_len;
+        if (starts_mark)
+            bpos[at / mark] = x;
+        found_fine += (unsigned)__builtin_popcountll(ballot64(starts_mark));
+        found += (unsigned)__builtin_popcountll(ballot64(starts_mark && (at & (kBlockOut - 1u)) == 0u));
+        found_probe += (unsigned)__builtin_popcountll(ballot64(starts_mark && (at == kFine || at == 2u * kFine)));
         const unsigned last = 63u - (unsigned)__builtin_clzll(T);
         op += (unsigned)__builtin_amdgcn_readlane(incl, 63);
         p = ws + last + (unsigned)__builtin_amdgcn_readlane((int)el.tokbytes, (int)last);
@@ -1206,6 +1249,19 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
     if (!ok || p != in_end || op != out_len)
         return;
     HapGpuScanChunk *state = chunks + c;
+    // the 64 KiB blocks' unit slots follow the stream unit; the 8 KiB blocks' lie behind all ordinary units of the call
+    for (unsigned b = lane; fine_on && b < nfine; b += 64u) {
+        HapGpuDecodeUnit w;
+        w.src = (uint64_t)src_al;
+        w.dst = u.dst + (uint64_t)b * kFine;
+        w.src_len = 0;
+        w.dst_len = min(kFine, out_len - b * kFine);
+        w.kind = HAPGPU_UNIT_SNAPPY_BLOCK;
+        w.job = u.job;
+        w.aux = (uint64_t)state;
+        w.reserved = (uint64_t)b | HAPGPU_BLOCK_FINE;
+        units[sc.fine_unit_first + b] = w;
+    }
     for (unsigned b = lane; b < nblk; b += 64u) {
         HapGpuDecodeUnit w;
         w.src = (uint64_t)src_al;
@@ -1219,18 +1275,23 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
         units[sc.unit + 1u + b] = w;
     }
     if (lane == 0) {
-        bpos[nblk] = in_end;
+        bpos[fine_on ? nfine : nblk] = in_end;
         units[sc.unit].reserved = (uint64_t)state;
         state->expected = nblk;
+        state->expected_fine = fine_on ? nfine : 0u;
         atomicAdd(&state->found, found);
+        atomicAdd(&state->found_fine, found_fine);
+        atomicAdd(&state->probe_found, found_probe);
         state->ok = 1u;
     }
 }
 
+// pass 0: the 64 KiB marks, and of the 8 KiB marks the first two (the probe); pass 1: the other 8 KiB marks, for the
+// streams whose probe marks both fell on element boundaries
 __global__ __launch_bounds__(64) void scan_find_kernel(const HapGpuDecodeUnit *units, HapGpuScanChunk *chunks, unsigned chunk_count,
                                                        const HapGpuScanSegment *__restrict__ segs,
                                                        const unsigned long long *__restrict__ recs, const uint2 *__restrict__ joins,
-                                                       unsigned seg_total)
+                                                       unsigned seg_total, unsigned pass)
 {
     const unsigned lane = threadIdx.x, g = blockIdx.x;
     if (g >= seg_total)
@@ -1241,6 +1302,8 @@ __global__ __launch_bounds__(64) void scan_find_kernel(const HapGpuDecodeUnit *u
     const uint2 join = joins[g];
     const unsigned merge_window = join.x, base_op = join.y;
     if (!sc.ok || merge_window >= 64u)
+        return;
+    if (pass == 1u && (sc.expected_fine == 0u || sc.probe_found != min(2u, sc.expected_fine - 1u)))
         return;
     const HapGpuDecodeUnit u = units[sc.unit];
     const unsigned shift = (unsigned)(u.src & 15u);
@@ -1254,10 +1317,18 @@ __global__ __launch_bounds__(64) void scan_find_kernel(const HapGpuDecodeUnit *u
     const bool usable = lane >= merge_window && entry != kRecNone;
     const unsigned first_op = (unsigned)__builtin_amdgcn_readlane((int)abs_op, (int)merge_window);
     const unsigned exit_op = base_op + sg.cum_total;
-    unsigned found = 0;
-    // block starts V with first_op <= V < exit_op belong to elements that start in this segment's recorded windows
-    for (unsigned long long V = ((unsigned long long)first_op + kBlockOut - 1u) / kBlockOut * kBlockOut;
-         V < exit_op && V < out_len; V += kBlockOut) {
+    unsigned found = 0, found_fine = 0;
+    // (the merge kernel, which ran before, decided the granularity of the marks)
+    const unsigned mark = sc.expected_fine != 0u ? kFine : kBlockOut;
+    // marks V with first_op <= V < exit_op belong to elements that start in this segment's recorded windows
+    unsigned found_probe = 0;
+    for (unsigned long long V = ((unsigned long long)first_op + mark - 1u) / mark * mark;
+         V < exit_op && V < out_len; V += mark) {
+        // (with 8 KiB marks: pass 0 takes the multiples of 64 KiB and the two probe marks, pass 1 the others)
+        const bool early = (V & (kBlockOut - 1u)) == 0ull || V == kFine || V == 2u * kFine;
+        if (mark == kFine && early != (pass == 0u))
+            continue;
+        const bool is_probe = mark == kFine && (V == kFine || V == 2u * kFine);
         const unsigned long long m = ballot64(usable && abs_op <= (unsigned)V);
         if (m == 0ull)
             continue;
@@ -1279,8 +1350,10 @@ __global__ __launch_bounds__(64) void scan_find_kernel(const HapGpuDecodeUnit *u
                     break;
                 if (op == (unsigned)V) {
                     if (lane == 0)
-                        bpos[V / kBlockOut] = p;
-                    found += 1u;
+                        bpos[V / mark] = p;
+                    found_fine += 1u;
+                    found += (V & (kBlockOut - 1u)) == 0ull ? 1u : 0u;
+                    found_probe += is_probe ? 1u : 0u;
                 }
                 p += h + llen;
                 op += llen;
@@ -1291,8 +1364,11 @@ __global__ __launch_bounds__(64) void scan_find_kernel(const HapGpuDecodeUnit *u
             const unsigned at = op + (unsigned)incl - (is_tok ? el.len : 0u);
             const bool hit = is_tok && at == (unsigned)V;
             if (hit)
-                bpos[V / kBlockOut] = x;
-            found += (unsigned)__builtin_popcountll(ballot64(hit));
+                bpos[V / mark] = x;
+            const unsigned hits = (unsigned)__builtin_popcountll(ballot64(hit));
+            found_fine += hits;
+            found += (V & (kBlockOut - 1u)) == 0ull ? hits : 0u;
+            found_probe += is_probe ? hits : 0u;
             const unsigned last = 63u - (unsigned)__builtin_clzll(T);
             op += (unsigned)__builtin_amdgcn_readlane(incl, 63);
             p = ws + last + (unsigned)__builtin_amdgcn_readlane((int)el.tokbytes, (int)last);
@@ -1300,6 +1376,28 @@ __global__ __launch_bounds__(64) void scan_find_kernel(const HapGpuDecodeUnit *u
     }
     if (lane == 0 && found)
         atomicAdd(&chunks[c].found, found);
+    if (lane == 0 && found_fine)
+        atomicAdd(&chunks[c].found_fine, found_fine);
+    if (lane == 0 && found_probe)
+        atomicAdd(&chunks[c].probe_found, found_probe);
+}
+
+// After the find passes: the streams whose 8 KiB marks were all found put their fine units on the list the decode
+// launch's first phase works through (one wavefront per stream).
+__global__ __launch_bounds__(64) void scan_decide_kernel(const HapGpuScanChunk *chunks, unsigned chunk_count, uint32_t *work)
+{
+    const unsigned lane = threadIdx.x, c = blockIdx.x;
+    if (c >= chunk_count)
+        return;
+    const HapGpuScanChunk sc = chunks[c];
+    if (!sc.ok || sc.expected_fine == 0u || sc.found_fine != sc.expected_fine || sc.expected_fine > sc.fine_slots)
+        return;
+    unsigned base = 0;
+    if (lane == 0)
+        base = atomicAdd(&work[0], sc.expected_fine);
+    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    for (unsigned b = lane; b < sc.expected_fine; b += 64u)
+        work[1u + base + b] = sc.fine_unit_first + b;
 }
 
 } // namespace
@@ -1325,7 +1423,7 @@ extern "C" int hapgpu_launch_snappy_decode_fields(const HapGpuDecodeUnit *units,
 // BLOCK units; the decode launch that follows must include the stream kernel.
 extern "C" int hapgpu_launch_scan_blocks(HapGpuDecodeUnit *units, const HapGpuDecodeJob *jobs, HapGpuScanChunk *chunks,
                                          unsigned chunk_count, HapGpuScanSegment *segs, void *recs, void *joins,
-                                         unsigned seg_total, hipStream_t stream)
+                                         unsigned seg_total, uint32_t *fine_work, hipStream_t stream)
 {
     if (chunk_count == 0 || seg_total == 0)
         return 0;
@@ -1334,13 +1432,17 @@ extern "C" int hapgpu_launch_scan_blocks(HapGpuDecodeUnit *units, const HapGpuDe
     hipLaunchKernelGGL(scan_merge_kernel, dim3(chunk_count), dim3(64), 0, stream, units, jobs, chunks, chunk_count, segs,
                        (const unsigned long long *)recs, (uint2 *)joins);
     hipLaunchKernelGGL(scan_find_kernel, dim3(seg_total), dim3(64), 0, stream, units, chunks, chunk_count, segs,
-                       (const unsigned long long *)recs, (const uint2 *)joins, seg_total);
+                       (const unsigned long long *)recs, (const uint2 *)joins, seg_total, 0u);
+    hipLaunchKernelGGL(scan_find_kernel, dim3(seg_total), dim3(64), 0, stream, units, chunks, chunk_count, segs,
+                       (const unsigned long long *)recs, (const uint2 *)joins, seg_total, 1u);
+    if (fine_work)
+        hipLaunchKernelGGL(scan_decide_kernel, dim3(chunk_count), dim3(64), 0, stream, chunks, chunk_count, fine_work);
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 
 extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsigned unit_count, HapGpuDecodeJob *jobs,
                                            unsigned frag_log2, unsigned fragment_kinds, int any_stream_or_copy_units,
-                                           hipStream_t stream)
+                                           const uint32_t *fine_work, unsigned fine_slots, hipStream_t stream)
 {
     if (unit_count == 0)
         return 0;
@@ -1365,18 +1467,25 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
             once = true;
         }
         const unsigned ring_log2 = ring_forced ? ring_forced : any_stream_or_copy_units == 2 ? 11u : 15u;
-        if (ring_log2 == 11)
-            hipLaunchKernelGGL((snappy_decode_fragment_kernel<2048u, true, 1u>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs);
-        else if (ring_log2 == 12)
-            hipLaunchKernelGGL((snappy_decode_fragment_kernel<4096u, true, 1u>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs);
-        else if (ring_log2 == 13)
-            hipLaunchKernelGGL((snappy_decode_fragment_kernel<8192u, true, 1u>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs);
-        else if (ring_log2 == 14)
-            hipLaunchKernelGGL((snappy_decode_fragment_kernel<16384u, true, 1u>), dim3(unit_count), dim3(64), fragment_dynamic_lds(16384u), stream, units, unit_count, jobs);
-        else if (ring_log2 == 15)
-            hipLaunchKernelGGL((snappy_decode_fragment_kernel<32768u, true, 1u>), dim3(unit_count), dim3(64), fragment_dynamic_lds(32768u), stream, units, unit_count, jobs);
-        else
-            hipLaunchKernelGGL((snappy_decode_fragment_kernel<65536u, true, 1u>), dim3(unit_count), dim3(64), fragment_dynamic_lds(65536u), stream, units, unit_count, jobs);
+        // with the block scan: the 8 KiB blocks it listed first (phase 1, over the list's capacity: the count is on the
+        // device), then the ordinary units (phase 2) -- a stream whose 8 KiB pieces turned out not to be independent is
+        // decoded by its 64 KiB blocks or whole in the second launch
+        const bool two = any_stream_or_copy_units == 2 && fine_work != nullptr && fine_slots != 0u;
+        for (unsigned phase = two ? 1u : any_stream_or_copy_units == 2 ? 2u : 0u; phase <= (any_stream_or_copy_units == 2 ? 2u : 0u); phase++) {
+            const dim3 grid(phase == 1u ? fine_slots : unit_count);
+            if (ring_log2 == 11)
+                hipLaunchKernelGGL((snappy_decode_fragment_kernel<2048u, true, 1u>), grid, dim3(64), 0, stream, units, grid.x, jobs, phase, fine_work);
+            else if (ring_log2 == 12)
+                hipLaunchKernelGGL((snappy_decode_fragment_kernel<4096u, true, 1u>), grid, dim3(64), 0, stream, units, grid.x, jobs, phase, fine_work);
+            else if (ring_log2 == 13)
+                hipLaunchKernelGGL((snappy_decode_fragment_kernel<8192u, true, 1u>), grid, dim3(64), 0, stream, units, grid.x, jobs, phase, fine_work);
+            else if (ring_log2 == 14)
+                hipLaunchKernelGGL((snappy_decode_fragment_kernel<16384u, true, 1u>), grid, dim3(64), fragment_dynamic_lds(16384u), stream, units, grid.x, jobs, phase, fine_work);
+            else if (ring_log2 == 15)
+                hipLaunchKernelGGL((snappy_decode_fragment_kernel<32768u, true, 1u>), grid, dim3(64), fragment_dynamic_lds(32768u), stream, units, grid.x, jobs, phase, fine_work);
+            else
+                hipLaunchKernelGGL((snappy_decode_fragment_kernel<65536u, true, 1u>), grid, dim3(64), fragment_dynamic_lds(65536u), stream, units, grid.x, jobs, phase, fine_work);
+        }
     }
     static bool once16 = false;
     if (!once16 && frag_log2 == 16) {
@@ -1389,22 +1498,22 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
     do {                                                                                                                        \
         if (fragment_kinds & 1u)                                                                                                \
             hipLaunchKernelGGL((snappy_decode_fragment_kernel<RINGBYTES, false, 1u>), dim3(unit_count), dim3(64),               \
-                               fragment_dynamic_lds(RINGBYTES), stream, units, unit_count, jobs);                               \
+                               fragment_dynamic_lds(RINGBYTES), stream, units, unit_count, jobs, 0u, nullptr);                               \
         if (fragment_kinds & 2u)                                                                                                \
             hipLaunchKernelGGL((snappy_decode_fragment_kernel<RINGBYTES, false, 2u>), dim3(unit_count), dim3(64),               \
-                               fragment_dynamic_lds(RINGBYTES), stream, units, unit_count, jobs);                               \
+                               fragment_dynamic_lds(RINGBYTES), stream, units, unit_count, jobs, 0u, nullptr);                               \
         if (fragment_kinds & 4u)                                                                                                \
             hipLaunchKernelGGL((snappy_decode_fragment_kernel<RINGBYTES, false, 4u>), dim3(unit_count), dim3(64),               \
-                               fragment_dynamic_lds(RINGBYTES), stream, units, unit_count, jobs);                               \
+                               fragment_dynamic_lds(RINGBYTES), stream, units, unit_count, jobs, 0u, nullptr);                               \
     } while (0)
     // 8 KiB fragments whose table promises a 3 KiB match window: 4 KiB ring, twice the waves per CU
     if (frag_log2 == 13u) {
         if (fragment_kinds & 16u)
-            hipLaunchKernelGGL((snappy_decode_fragment_kernel<4096u, false, 1u, true>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs);
+            hipLaunchKernelGGL((snappy_decode_fragment_kernel<4096u, false, 1u, true>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs, 0u, nullptr);
         if (fragment_kinds & 32u)
-            hipLaunchKernelGGL((snappy_decode_fragment_kernel<4096u, false, 2u, true>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs);
+            hipLaunchKernelGGL((snappy_decode_fragment_kernel<4096u, false, 2u, true>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs, 0u, nullptr);
         if (fragment_kinds & 64u)
-            hipLaunchKernelGGL((snappy_decode_fragment_kernel<4096u, false, 4u, true>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs);
+            hipLaunchKernelGGL((snappy_decode_fragment_kernel<4096u, false, 4u, true>), dim3(unit_count), dim3(64), 0, stream, units, unit_count, jobs, 0u, nullptr);
     }
     switch (frag_log2) {
     case 0: break;
