@@ -1905,3 +1905,35 @@ def test_bench_multi_rank_path_runs_with_two_ranks_on_one_gpu():
     assert groups["bit_exact"] is True and groups["frame_bytes"] > 0
     assert set(groups["ms"]) >= {"encode_bands_ms", "gather_band_frames_ms", "join_on_device_ms", "decode_groups_tex0_ms",
                                  "decode_groups_tex1_ms", "gather_slices_tex0_ms", "gather_slices_tex1_ms"}
+
+
+@pytest.mark.parametrize("fmt,chunks", [(L.FMT_YCOCG, 3), (L.FMT_DXT1, 1), (L.FMT_RGTC1, 2), (L.FMT_BC7, 5)])
+def test_table_less_frames_of_this_library_decode_as_their_8k_fragments(ctx, hap, fmt, chunks):
+    """What plain hap.h HapEncode writes by default: no private section, chunks that are concatenations of independent
+    8 KiB fragments.  The block scan finds an element boundary at every 8 KiB of output and the frame decodes as those
+    pieces (the same bytes as through the checker, no second pass); the reference-made frame of the same texture --
+    libsnappy's 64 KiB blocks -- keeps decoding as before, in the same call."""
+    w, h = 1024, 1024
+    tex = D.oracle_bc_encode(D.rgba(w, h, frame=17), L.FMT_YCOCG if fmt == L.FMT_BC7 else fmt)     # (BC7: opaque bytes)
+    if fmt == L.FMT_RGTC1:
+        tex = tex * 2                                                                              # chunks beyond 64 KiB each
+    out = np.zeros(hap.HapMaxEncodedLength([len(tex)], [fmt], [chunks]), dtype=np.uint8)
+    r, used, res = ctx.encode_frames([[tex]], [fmt], [1], [chunks], [out], flags=0)
+    assert (r, res) == (0, [0])
+    plain = out[: used[0]].tobytes()
+    assert find_fragment_table(plain, 0, 4000)[0] < 0 and plain[3] >> 4 == 0xC
+    for name, api in CHECKERS:
+        assert api.decode(plain, 0, len(tex)) == (0, tex, fmt), name
+    theirs = _encode_with(ORA, tex, fmt, L.COMP_SNAPPY, chunks)
+    n0 = ctx.table_fallbacks()
+    decs = [np.zeros(len(tex), dtype=np.uint8) for _ in range(3)]
+    r, du, df, dr = ctx.decode_frames([plain, theirs, plain], [len(plain), len(theirs), len(plain)], 0, decs)
+    assert (r, dr, df) == (0, [0] * 3, [fmt] * 3) and all(d.tobytes() == tex for d in decs)
+    assert ctx.table_fallbacks() == n0
+    assert hap.HapDecode(plain, 0, outputBufferBytes=len(tex)) == (0, tex, fmt)
+    # damage inside a fragment: the verdict is the checker's whatever path the pieces took
+    bad = bytearray(plain)
+    bad[len(bad) // 2] ^= 0x5A
+    want = ORA.decode(bytes(bad), 0, len(tex))
+    got = hap.HapDecode(bytes(bad), 0, outputBufferBytes=len(tex))
+    assert got[0] == want[0] and (got[0] != 0 or got[1] == want[1])
