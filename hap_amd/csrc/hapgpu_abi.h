@@ -154,7 +154,9 @@ typedef struct HapGpuDecodeJob {
 
 /* Block scan of another encoder's Snappy stream (snappy_decode.hip): the stream's compressed bytes are looked at in
    segments of HAPGPU_SCAN_SEGMENT bytes (of the 16-byte aligned address range that holds them). */
+#ifndef HAPGPU_SCAN_SEGMENT
 #define HAPGPU_SCAN_SEGMENT 4096u
+#endif
 typedef struct HapGpuScanChunk {
     /* filled by the host */
     uint32_t unit;           /* index of the stream's whole-stream unit in the call's unit array */

@@ -859,7 +859,10 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
 // copy reaching before its block -- the BLOCK unit's own offset check catches: the frame is then decoded again
 // without the scan, as after a fragment table that lied.  An 8K frame's 24 chunks become 528 units.
 constexpr unsigned kScanSegment = HAPGPU_SCAN_SEGMENT;
-constexpr unsigned kScanWarmWindows = 5u;                     // > the longest element that is not a "long literal" (258 bytes)
+// (5 windows -- longer than the longest element that is not a "long literal", 258 bytes -- let libsnappy's streams
+// join; the streams of this library's block compressor, with their long literal runs in noisy areas, need more: with 5
+// the merge kernel walked enough windows itself to take 0.22 ms for one 8K frame, with 12 it takes 0.05)
+constexpr unsigned kScanWarmWindows = 12u;
 constexpr unsigned kScanLds = kScanSegment + 64u * kScanWarmWindows + 128u;
 constexpr unsigned kBlockOut = 65536u;
 constexpr unsigned kFine = HAPGPU_SCAN_FINE;                  // 8 KiB: the fragments of this library's own streams
