@@ -26,9 +26,9 @@
 //      the fragment go back to LDS.
 //   3. EMIT.  a: lane = unit, 8 steps: popcounts of the masks below the unit give its output offset; fields of
 //      literal runs store their bytes at their final place.  b: lane = ELEMENT, 64 at a time in stream order (a fifth
-//      of the fields start an element: a tag per field, predicated away, was half the kernel): a running maximum over
-//      one marker per half-tile finds the element's half-tile, whose masks give field, stream offset, length and kind;
-//      one to three tag bytes per element.
+//      of the fields start an element: a tag per field, predicated away, was half the kernel): phase 2 left a list
+//      of (half-tile, field) per element; the half-tile's masks give stream offset, length and kind; one to three tag
+//      bytes per element.
 //   4. GROUP TABLE: the N elements of the fragment in 64 groups of ceil(N / 64); the first element of every group
 //      leaves its stream offset behind during 3b; differences of neighbours are the 12-bit entries.
 //
@@ -316,15 +316,13 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
     __syncthreads();
 
     // (the table has served: its first half now holds the candidates of every unit, for the lanes that will write the
-    // elements; its second half, cleared here, one byte per element: which half-tile it belongs to)
+    // elements; its second half, one byte per element in stream order: the field of its half-tile it starts at, | 0x80
+    // for the first element of a half-tile -- written by phase 2)
     {
         uint32_t *hd_tab = reinterpret_cast<uint32_t *>(table);
 #pragma unroll
         for (unsigned s = 0; s < kSteps; s++)
             hd_tab[64u * s + lane] = HD[s];
-        uint4 *marker16 = reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(table) + 2048u);
-        marker16[2u * lane] = make_uint4(0, 0, 0, 0);
-        marker16[2u * lane + 1u] = make_uint4(0, 0, 0, 0);
     }
     // ---- 2. choose: lane = half-tile ----
     unsigned counts_and_bytes = 0;          // inclusive scan over the half-tiles: elements << 16 | bytes (for the group table)
@@ -415,6 +413,21 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
         if (lane == 63u)
             frag_sizes[f] = incl;
         counts_and_bytes = both;
+        // the elements in stream order, for the lanes of phase 3b: element (first ordinal of the half-tile + j) is the
+        // j-th set bit of S -- a loop over the busiest half-tile's elements, five instructions a turn (finding the r-th
+        // set bit per element in phase 3b instead cost 45 instructions per element pass)
+        {
+            uint8_t *elfield = reinterpret_cast<uint8_t *>(table) + 2048u;
+            unsigned left = S, at = (both >> 16) - count, first = 0x80u;
+            while (__builtin_amdgcn_ballot_w64(left != 0u) != 0ull) {
+                if (left != 0u) {
+                    elfield[at] = (uint8_t)(first | (unsigned)__builtin_ctz(left));
+                    left &= left - 1u;
+                    at += 1u;
+                    first = 0u;
+                }
+            }
+        }
     }
     __syncthreads();
 
@@ -455,9 +468,9 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
     }
 
     // ---- 3b. emit the elements' tags: lane = element, 64 at a time in stream order ----
-    // The half-tile of element e: every half-tile marked the place of its first element; a running maximum over the
-    // markers is the half-tile.  Its masks then give the element's field (set bit number e - first of S), its stream
-    // offset (the bytes of what lies below), its length (fields up to the next start) and its kind.  The elements whose
+    // The field of element e comes from the list phase 2 left, its half-tile from a count of the first-of-half-tile
+    // marks up to it; the half-tile's masks then give its
+    // stream offset (the bytes of what lies below), its length (fields up to the next start) and its kind.  The elements whose
     // ordinal is a multiple of G = ceil(N / 64) begin the groups of the fragment table (version 3): their offsets go to
     // bounds[].
     {
@@ -466,47 +479,28 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
         const unsigned elements = (unsigned)__builtin_amdgcn_readlane((int)both, 63) >> 16;        // >= 1
         const unsigned G = (elements + 63u) >> 6;
         const unsigned inv = (1u << 20) / G + 1u;                              // x / G = (x inv) >> 20 for x < 2^11 + 32
-        uint8_t *marker = reinterpret_cast<uint8_t *>(table) + 2048u;
         const uint32_t *hd_tab = reinterpret_cast<const uint32_t *>(table);
         {
-            const unsigned word7 = masks[lane * 8u + 7u];
-            if (masks[lane * 8u] != 0u)                                        // (a half-tile with elements)
-                marker[word7 >> 16] = (uint8_t)(lane + 1u);
             bounds[lane] = (uint16_t)stream_bytes;                             // (groups beyond the last element: empty)
             if (lane < 2u)
                 bounds[64u + lane] = (uint16_t)stream_bytes;
         }
         __syncthreads();
         constexpr unsigned FO = LAYOUT == 4u ? 0x0C080200u : LAYOUT == 2u ? 0x0C080400u : 0x0A080200u;   // fo(k), a byte each
-        unsigned carry = 0;                                                    // half-tile (+ 1) of the element before the pass
+        const uint8_t *elfield = reinterpret_cast<const uint8_t *>(table) + 2048u;
+        unsigned carry = 0;                                                    // half-tiles begun before the pass
 #pragma unroll 1
         for (unsigned e0 = 0; e0 < elements; e0 += 64u) {
             const unsigned e = e0 + lane;
-            int own = e < elements ? (int)marker[e] : 0;
-            own = max(own, __builtin_amdgcn_update_dpp(own, own, 0x111, 0xF, 0xF, false));     // running maximum over the lanes
-            own = max(own, __builtin_amdgcn_update_dpp(own, own, 0x112, 0xF, 0xF, false));
-            own = max(own, __builtin_amdgcn_update_dpp(own, own, 0x114, 0xF, 0xF, false));
-            own = max(own, __builtin_amdgcn_update_dpp(own, own, 0x118, 0xF, 0xF, false));
-            own = max(own, __builtin_amdgcn_update_dpp(own, own, 0x142, 0xA, 0xF, false));     // row_bcast:15 -> rows 1, 3
-            own = max(own, __builtin_amdgcn_update_dpp(own, own, 0x143, 0xC, 0xF, false));     // row_bcast:31 -> rows 2, 3
-            own = max(own, (int)carry);
-            carry = (unsigned)__builtin_amdgcn_readlane(own, 63);
+            const unsigned info = e < elements ? elfield[e] : 0u;
+            // the half-tile of an element: how many half-tiles have begun up to it (every half-tile has an element)
+            const unsigned begun = (unsigned)scan_add((int)(info >> 7)) + carry;
+            carry = (unsigned)__builtin_amdgcn_readlane((int)begun, 63);
             if (e < elements) {
-                const unsigned h = (unsigned)own - 1u;
+                const unsigned h = begun - 1u, q = info & 31u;
                 const uint4 ma = *reinterpret_cast<const uint4 *>(&masks[h * 8u]);
                 const uint4 mb = *reinterpret_cast<const uint4 *>(&masks[h * 8u + 4u]);
                 const unsigned S = ma.x, L = ma.y, X3 = ma.z, D0 = ma.w, D1 = mb.x, Hm = mb.y, Sx1 = mb.z, CS = S & ~L;
-                // position of set bit number (e - the half-tile's first ordinal) of S
-                unsigned r = e - (mb.w >> 16), q = 0, c = popc(S & 0xFFFFu);
-                if (r >= c) { q = 16u; r -= c; }
-                c = popc((S >> q) & 0xFFu);
-                if (r >= c) { q += 8u; r -= c; }
-                c = popc((S >> q) & 0xFu);
-                if (r >= c) { q += 4u; r -= c; }
-                c = popc((S >> q) & 0x3u);
-                if (r >= c) { q += 2u; r -= c; }
-                if (r >= ((S >> q) & 1u))
-                    q += 1u;
                 const unsigned under = (1u << q) - 1u;
                 const unsigned off = (mb.w & 0xFFFFu) + 4u * popc(L & under) + 2u * popc(L & UL::big32 & under) -
                                      2u * popc(L & UL::small32 & under) + popc(S & under) + popc(CS & under) + popc(X3 & under);

@@ -1,10 +1,12 @@
 """gpurun_out/evidence (tools/evidence_round.sh) -> profiles/<round>_*: the files the documentation and bench.py quote.
    python tools/evidence_collect.py r03"""
 import json, os, shutil, subprocess, sys
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ev, prof = os.path.join(root, "gpurun_out", "evidence"), os.path.join(root, "profiles")
-for cfg, frames in (("c4", 30), ("c5", 2)):
+for cfg, frames in (("c4", 30), ("c5", 4), ("c2", 60), ("c3", 60)):
+    if not os.path.isdir(os.path.join(ev, cfg)):
+        continue
     src = os.path.join(ev, cfg)
     for a, b in (("kernel_stats.csv", "kernel_stats"), ("pmc_summary.txt", "pmc_summary"), ("traffic_summary.txt", "traffic_summary"),
                  ("command.txt", "command"), ("bench_trace.json", "bench_under_rocprof")):
