@@ -470,9 +470,10 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
         }
     }
     // 2b. sources produced in the same step: follow the chains to a literal or to an earlier step.
-    //     First the hops to a lane 1, 2, 4, 8 below in the same row of 16, taken with DPP moves (the vector unit has
-    //     slack, the LDS pipe does not): runs of copies at distance 1, 2 or 4 blocks -- the common ones -- collapse to
-    //     the lane in front of their row.
+    //     First the hops to a lane 1, 2, 4, 8 below in the same row of 16, taken with DPP moves: runs of copies at
+    //     distance 1, 2 or 4 blocks -- the common ones -- collapse to the lane in front of their row.  (Three
+    //     instructions a hop, left to the compiler: the two-instruction form -- v_cmp into VCC, v_cndmask_b32_dpp -- was
+    //     written out for all 32 columns in r04 and is 3-5 % SLOWER: every pair goes through the one VCC.)
     {
         const unsigned row_lane = lane & 15u;
         // the descriptor "pending, copies from the lane m below" -- or a value no descriptor has, where that lane lies in another row
