@@ -19,7 +19,11 @@ object: the north-star's 16K Hap Q Alpha target config timed the same way.
 Extra objects on the JSON line: "roofline" for the dominant kernel (HIP events recorded on the
 library's own stream around every launch of the timed region) and "cpu_baseline" (the
 unmodified reference hap.c + libsnappy from oracle/_ref when present, else the C port in
-oracle/, plus the oracle's scalar block encoder -- the reference has no RGBA stage).
+oracle/, plus the oracle's scalar block encoder -- the reference has no RGBA stage; medians of
+>= 10 repetitions).  Beside them, never part of `value`: "c5" / "c2" / "c3" (the other BASELINE
+configs), "c1" (configs[0]: one 1080p DXT1 frame through plain hap.h, one call, next to the
+reference on one CPU thread), "per_call_hap_h" (one hap.h call per 8K frame from a C client),
+"bc7_opaque" (an opaque format), frames made by the reference encoder, host-pointer rates.
 """
 import argparse
 import ctypes as C

@@ -20,11 +20,12 @@
 //                         scan below with a 2 KiB ring, or one unit per chunk with a 32 KiB ring; older
 //                         bytes are re-read from memory), for fragment tables of version 1, and as the
 //                         fallback whenever a table turns out not to describe its streams.
-//   scan_walk_kernel / scan_merge_kernel / scan_find_kernel
-//                         the block scan: where in the compressed bytes of another encoder's stream
-//                         each 64 KiB block of output begins (libsnappy's blocks are independent),
-//                         found in parallel over 4 KiB segments of compressed bytes without producing
-//                         output -- see the comment in front of them.
+//   scan_walk_kernel / scan_merge_kernel / scan_find_kernel / scan_decide_kernel
+//                         the block scan: where in the compressed bytes of a stream without a table each
+//                         64 KiB block of output begins (libsnappy's blocks are independent) -- or each
+//                         8 KiB (the fragments of this library's own table-less frames) --, found in
+//                         parallel over 4 KiB segments of compressed bytes without producing output: see
+//                         the comment in front of them.
 //
 // Frames written by this library with the version-3 table ("field streams": DXT5, YCoCg-DXT5, DXT1,
 // large RGTC1 planes) are decoded by the block-per-lane kernel of snappy_decode_fields.hip instead.
@@ -858,6 +859,15 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
 // small ring; otherwise they return at once and the stream unit runs as before.  What the scan does not check -- a
 // copy reaching before its block -- the BLOCK unit's own offset check catches: the frame is then decoded again
 // without the scan, as after a fragment table that lied.  An 8K frame's 24 chunks become 528 units.
+//
+// r04: marks every 8 KiB as well.  What plain hap.h HapEncode of THIS library writes has no table, but its chunks are
+// concatenations of independent 8 KiB fragments: an element boundary at every 8 KiB of output, 4056 units per 8K
+// frame instead of 528.  bpos[] is indexed by 8 KiB mark when the host reserved slots for them (a 64 KiB block begins
+// at every eighth); the find kernel runs twice -- pass 0 takes the 64 KiB marks and the first two 8 KiB marks (the
+// probe), pass 1 the other 8 KiB marks, only for streams whose probe marks both fell on element boundaries (libsnappy's
+// hardly ever do: its scan costs what it did); scan_decide_kernel lists the fine units of the streams whose marks were
+// ALL found, and the decode launch runs that list as a first phase.  Marks on element boundaries do not make pieces
+// independent: a fine unit that fails hands its stream to the 64 KiB blocks / the stream unit of the second phase.
 constexpr unsigned kScanSegment = HAPGPU_SCAN_SEGMENT;
 // (5 windows -- longer than the longest element that is not a "long literal", 258 bytes -- let libsnappy's streams
 // join; the streams of this library's block compressor, with their long literal runs in noisy areas, need more: with 5

@@ -27,6 +27,14 @@
  * it (reference hap.c:701-703, HapVideoDRAFT.md:34), hap_amd's decoder uses it
  * to decode one chunk with many wavefronts.  The table also records the
  * granularity (1, 2 or 4 bytes) that every element of the streams honours.
+ * The flag is off unless asked for -- also for plain hap.h HapEncode, where the
+ * environment variable HAP_AMD_FRAGMENT_INDEX=1 stands in for it: whether every
+ * OTHER parser of a frame skips unknown sections is not something this library
+ * can know ("The private section").  Frames written without it
+ * still consist of independent 8 KiB Snappy fragments; hap_amd's decoder finds
+ * them with a scan (an element boundary at every 8 KiB of a chunk's output) and
+ * decodes them one wavefront per fragment -- about a fifth of the speed the
+ * table gives.
  *
  * Section 0x46, version 1:  [1][log2 F][granularity log2][match window / 256 B][LE32 compressed size x fragments]
  *               version 3:  [3][13][granularity log2 | fields per block << 4][window][LE32 size x fragments]
@@ -52,7 +60,8 @@ extern "C" {
 typedef struct HapGpuContext HapGpuContext;
 
 /* Encode flags */
-#define HAPGPU_ENCODE_FRAGMENT_INDEX 0x1u   /* emit the private fragment-size section (type 0x46) */
+#define HAPGPU_ENCODE_FRAGMENT_INDEX 0x1u   /* emit the private fragment-size section (type 0x46): for frames that only
+                                               this library or hap.c-based readers will parse */
 #define HAPGPU_ENCODE_COARSE_MATCHES 0x2u   /* Snappy elements on 32-bit boundaries for every texture format, not just
                                                DXT1 (whose blocks are two 32-bit fields).  Kept for formats without a
                                                field layout (BC7, BC6H); for DXT5 / YCoCg-DXT5 / RGTC1 the default
