@@ -836,10 +836,12 @@ def opaque_object(hap_amd, ctx, dev, fence, fmt=0x8E8C, n=30, steps=4):
     texs = []
     for i in range(n):
         t = torch.empty(tb[0], dtype=torch.uint8, device=dev)
-        torch.cuda.synchronize()
-        if ctx.compress_rgba(synth.rgba_frame(w, h, i, device=dev), w, h, w * 4, 0x01, t) != (0, tb[0]):
+        picture = synth.rgba_frame(w, h, i, device=dev)
+        torch.cuda.synchronize()              # (torch made the picture on ITS stream; the library reads it on its own)
+        if ctx.compress_rgba(picture, w, h, w * 4, 0x01, t) != (0, tb[0]):
             raise RuntimeError("block encode failed")
         texs.append(t)
+        del picture
     ctx.synchronize()
     tex_l = hap_amd.BufferList(texs)
     frames = hap_amd.BufferList([torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(n)])

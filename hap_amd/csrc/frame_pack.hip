@@ -170,9 +170,9 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
                         itab[4] = (uint8_t)(with_tiles ? HAP_FRAGMENT_TABLE_VERSION_FIELDS : HAP_FRAGMENT_TABLE_VERSION);
                         itab[5] = (uint8_t)frag_log2;
                         // granularity_log2 of the element streams (version 3: | block layout << 4;
-                        // compressor code 4 -> 4 = [2,6,4,4], 10 -> 2 = [4,4], 2 -> 6 = [2,6])
+                        // compressor code 4 -> 4 = [2,6,4,4], 10 -> 2 = [4,4], 2 -> 6 = [2,6], 12 -> 8 = [4,4,4,4])
                         const unsigned code = (tex.reserved >> 16) & 0xFu;
-                        itab[6] = (uint8_t)((tex.reserved & 0xFu) | (with_tiles ? (code == 4u ? 4u : code == 10u ? 2u : 6u) << 4 : 0u));
+                        itab[6] = (uint8_t)((tex.reserved & 0xFu) | (with_tiles ? (code == 4u ? 4u : code == 10u ? 2u : code == 12u ? 8u : 6u) << 4 : 0u));
                         itab[7] = (uint8_t)(tex.reserved >> 8);   // match window in 256-byte units, 0 = whole fragment
                     }
                 }

@@ -158,6 +158,11 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
             else if (t->gran_log2 == 1u && t->format == HapTextureFormat_A_RGTC1 && ctx->rgtc1_fields == 26u &&
                      (t->chunk_bytes & 7u) == 0 && t->bytes >= ((size_t)2u << 20))
                 t->field_period = 2u;       /* [2, 6]: endpoints, indices */
+            else if ((flags & HAPGPU_ENCODE_COARSE_MATCHES) && t->gran_log2 == 2u && (t->chunk_bytes & 15u) == 0 &&
+                     (t->format == HapTextureFormat_RGBA_BPTC_UNORM || t->format == HapTextureFormat_RGB_BPTC_UNSIGNED_FLOAT ||
+                      t->format == HapTextureFormat_RGB_BPTC_SIGNED_FLOAT))
+                t->field_period = 12u;      /* opaque 16-byte blocks as four dwords (the size-for-speed option): the block
+                                               kernels instead of the position-per-lane ones */
             /* (RGTC1 planes of 2 MiB and more -- block rows longer than a fragment -- take their natural [2, 6] layout:
                same size as the position-per-lane kernel there (0.171 against 0.169 of an 8K alpha plane).  Smaller
                ones stay with positions per lane: their matches start inside the index bytes of the row above, which
@@ -165,12 +170,13 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
         }
         /* field streams (fragment table version 3): with the table requested, the block compressor's streams come with
            a group table per fragment (96 bytes: where each of the decoder's 64 lanes starts reading) */
-        t->half_tiles = ((t->field_period == 4u || t->field_period == 10u || t->field_period == 2u) && (flags & HAPGPU_ENCODE_FRAGMENT_INDEX) &&
+        t->half_tiles = ((t->field_period == 4u || t->field_period == 10u || t->field_period == 2u || t->field_period == 12u) && (flags & HAPGPU_ENCODE_FRAGMENT_INDEX) &&
                          !ctx->no_half_tiles) ? 1u : 0u;
         if (t->half_tiles)
             any_half_tiles = 1;
         if (t->compressor == HapCompressorSnappy)
-            gran_mask |= t->field_period == 4u ? 32u : t->field_period == 10u ? 64u : t->field_period == 2u ? 16u : 1u << t->gran_log2;
+            gran_mask |= t->field_period == 4u ? 32u : t->field_period == 10u ? 64u : t->field_period == 2u ? 16u
+                         : t->field_period == 12u ? 128u : 1u << t->gran_log2;
         if (t->compressor == HapCompressorSnappy) {
             /* header choice uses the layout that will actually be written (hap.c:425-428) */
             size_t ilen = hapf_instructions_length(t->chunk_count);
@@ -1042,7 +1048,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                     if (p->frag_tiles_offset && p->frag_fields && !(flags & HAPGPU_DECODE_IGNORE_HALF_TILES)) {
                         job->fields_period = p->frag_fields;
                         job->group_tables = (uint64_t)(uintptr_t)(frame_dev + p->frag_tiles_offset);
-                        frag_kinds |= p->frag_fields == 4u ? 0x100u : p->frag_fields == 2u ? 0x200u : 0x400u;
+                        frag_kinds |= p->frag_fields == 4u ? 0x100u : p->frag_fields == 2u ? 0x200u : p->frag_fields == 8u ? 0x800u : 0x400u;
                     } else if (p->frag_log2 == 13u && p->frag_window256 != 0 && p->frag_window256 <= HAP_FRAGMENT_WINDOW_256)
                         frag_kinds |= 16u << p->frag_gran_log2;
                     else

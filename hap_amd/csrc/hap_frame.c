@@ -291,7 +291,7 @@ static void plan_complex(hapf_reader *r, hapf_texture_plan *plan, int want_chunk
             plan->frag_entries = (frag_bytes - 4u) / 4u;
             plan->frag_table_offset = base + (uint64_t)frags + 4u;
         } else if (fh[0] == HAP_FRAGMENT_TABLE_VERSION_FIELDS && fh[1] == 13u && (frag_bytes - 4u) % (4u + HAP_GROUP_TABLE_BYTES) == 0u &&
-                   ((fh[2] >> 4) == 4u || (fh[2] >> 4) == 2u || (fh[2] >> 4) == 6u)) {
+                   ((fh[2] >> 4) == 4u || (fh[2] >> 4) == 2u || (fh[2] >> 4) == 6u || (fh[2] >> 4) == 8u)) {
             /* version 3: [3][13][granularity log2 | fields per block << 4][window] + u32 x N + 96-byte group table x N */
             plan->frag_log2 = 13u;
             plan->frag_gran_log2 = (fh[2] & 15u) <= 2u ? (fh[2] & 15u) : 0u;

@@ -52,7 +52,7 @@ typedef struct hapf_texture_plan {
     uint32_t frag_log2;
     uint32_t frag_gran_log2;/* 1: the table promises 16-bit granular element streams */
     uint32_t frag_window256;/* copy offsets never exceed this many 256-byte units (0: no promise) */
-    uint32_t frag_fields;   /* table version 3 ("field streams"): block layout, 4 = [2,6,4,4], 2 = [4,4], 6 = [2,6]; else 0 */
+    uint32_t frag_fields;   /* table version 3 ("field streams"): block layout, 4 = [2,6,4,4], 2 = [4,4], 6 = [2,6], 8 = [4,4,4,4]; else 0 */
     uint64_t frag_tiles_offset; /* frame offset of the group tables (96 bytes per fragment entry), 0 if absent */
     unsigned unit_count;    /* filled by the batch layer: GPU work units reserved for this texture */
 } hapf_texture_plan;

@@ -59,7 +59,7 @@ typedef struct HapGpuTexEnc {
     uint32_t reserved;       /* bit 20: "field stream": no element crosses a 128-byte half-tile and the compressor
                                 writes every fragment's group table (fragment table version 3);
                                 bits 16..19: fields per block for the field-per-lane compressor (0: position per lane,
-                                2: RGTC1 layout, 4: DXT5 / YCoCg-DXT5, 10: DXT1); bits 8..15: match window in 256-byte units (0 = whole fragment); bits 0..7:
+                                2: RGTC1 layout, 4: DXT5 / YCoCg-DXT5, 10: DXT1, 12: opaque 16-byte blocks); bits 8..15: match window in 256-byte units (0 = whole fragment); bits 0..7:
                                 granularity_log2 of the element stream: 0 = bytes, 1 = every position, offset
                                 and length even (lets the decoder move 16 bits per lane) */
 } HapGpuTexEnc;
@@ -129,7 +129,7 @@ typedef struct HapGpuDecodeJob {
     /* results */
     uint64_t bytes_used;
     uint32_t status;         /* HapResult or HAPGPU_STATUS_* */
-    uint32_t fields_period;  /* 4 / 2 / 6: the table is version 3 and promises [2,6,4,4] / [4,4] / [2,6] field streams; 0 otherwise */
+    uint32_t fields_period;  /* 4 / 2 / 6 / 8: the table is version 3 and promises [2,6,4,4] / [4,4] / [2,6] / [4,4,4,4] field streams; 0 otherwise */
     uint64_t group_tables;     /* device address of the group tables inside the frame (96 bytes per fragment entry), or 0 */
 } HapGpuDecodeJob;
 
@@ -142,6 +142,7 @@ typedef struct HapGpuDecodeJob {
 #define HAPGPU_UNIT_SNAPPY_FIELDS4 6u   /* fragment of a field stream, 16-byte blocks of 2 + 6 + 4 + 4 bytes; aux = its group table */
 #define HAPGPU_UNIT_SNAPPY_FIELDS2 7u   /* ... 8-byte blocks of 4 + 4 bytes */
 #define HAPGPU_UNIT_SNAPPY_FIELDS26 8u  /* ... 8-byte blocks of 2 + 6 bytes */
+#define HAPGPU_UNIT_SNAPPY_FIELDS44 10u /* ... 16-byte blocks of 4 + 4 + 4 + 4 bytes (opaque formats) */
 #define HAPGPU_UNIT_SNAPPY_BLOCK 9u     /* one 64 KiB block of another encoder's stream (or one 8 KiB block of a table-less
                                            stream of this library), found by the block scan: bare elements, copies stay
                                            inside the block; decoded by the whole-stream kernel.  aux = its
@@ -257,7 +258,7 @@ int hapgpu_k_block_decode(hapgpu_rt *rt, const void *blocks, const void *alpha, 
 int hapgpu_k_snappy_compress(hapgpu_rt *rt, const HapGpuFrameEnc *frames, unsigned frame_count,
                              unsigned max_frags_per_texture, unsigned frag_log2,
                              void *slots, unsigned slot_stride, uint32_t *frag_sizes, uint8_t *group_tables,
-                             unsigned granularity_mask /* bit g (0..2) set: some position-per-lane texture has granularity_log2 == g; bit 4 / 5 / 6: some texture uses the field-per-lane kernel ([2,6] / [2,6,4,4] / [4,4] fields per block); bits 8..: textures per frame */);
+                             unsigned granularity_mask /* bit g (0..2) set: some position-per-lane texture has granularity_log2 == g; bit 4 / 5 / 6 / 7: some texture uses the field-per-lane kernel ([2,6] / [2,6,4,4] / [4,4] / [4,4,4,4] fields per block); bits 8..: textures per frame */);
 /* copies: one entry per fragment, then (from index extra_first) chunks_per_frame entries per frame for the
  * group tables of field streams */
 int hapgpu_k_frame_pack(hapgpu_rt *rt, HapGpuFrameEnc *frames, unsigned frame_count,

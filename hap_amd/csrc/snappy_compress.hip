@@ -522,11 +522,11 @@ extern "C" int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsig
                                    (uint8_t *)slots, slot_stride, frag_sizes);                                                  \
         } while (0)
         // block textures: the block-per-lane kernels of snappy_compress_blocks.hip
-        if (granularity_mask & 0x70u) {
+        if (granularity_mask & 0xF0u) {
             if (frag_log2 != 13u)
                 return 1;
             const unsigned layouts = ((granularity_mask & 32u) ? 1u : 0u) | ((granularity_mask & 64u) ? 2u : 0u) |
-                                     ((granularity_mask & 16u) ? 4u : 0u);
+                                     ((granularity_mask & 16u) ? 4u : 0u) | ((granularity_mask & 128u) ? 8u : 0u);
             if (hapgpu_launch_snappy_compress_blocks(frames, frame_count, max_frags_per_texture, textures, slots, slot_stride,
                                                      frag_sizes, group_tables, layouts, stream))
                 return 4;

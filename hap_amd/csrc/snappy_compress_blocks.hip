@@ -45,7 +45,8 @@ constexpr unsigned kTableBits = 9u;                 // oracle/field_stream_oracl
 constexpr unsigned kDistances = 4u;
 
 // Layout of a 16-byte unit: field k begins at fo(k) and has fs(k) bytes; copy distances are multiples of `block`.
-//   4: DXT5 / YCoCg-DXT5 [2, 6, 4, 4], one block;  2: DXT1 [4, 4] x 2 blocks;  6: RGTC1 [2, 6] x 2 blocks.
+//   4: DXT5 / YCoCg-DXT5 [2, 6, 4, 4], one block;  2: DXT1 [4, 4] x 2 blocks;  6: RGTC1 [2, 6] x 2 blocks;
+//   8: an opaque 16-byte block [4, 4, 4, 4].
 // (`code` is what the host puts into HapGpuTexEnc.reserved bits 16..19 for the layout.)
 template <unsigned LAYOUT> struct unit_layout;
 template <> struct unit_layout<4u> {
@@ -64,6 +65,13 @@ template <> struct unit_layout<2u> {
     __device__ static constexpr unsigned fo(unsigned k) { return 4u * k; }
     __device__ static constexpr unsigned fs(unsigned) { return 4u; }
     __device__ static constexpr unsigned cls(unsigned k) { return (k & 1u) ? 1u : 0u; }
+};
+template <> struct unit_layout<8u> {     // opaque 16-byte blocks (BC7, BC6H): four dwords, distances in whole blocks
+    static constexpr unsigned block = 16u, code = 12u;
+    static constexpr unsigned small32 = 0u, big32 = 0u, run3_12 = 0xFFFFFFFFu, run15_61 = 0u;
+    __device__ static constexpr unsigned fo(unsigned k) { return 4u * k; }
+    __device__ static constexpr unsigned fs(unsigned) { return 4u; }
+    __device__ static constexpr unsigned cls(unsigned k) { return k == 1u ? 1u : k == 3u ? 3u : 0u; }
 };
 template <> struct unit_layout<6u> {
     static constexpr unsigned block = 8u, code = 2u;
@@ -140,7 +148,7 @@ __device__ __forceinline__ unsigned differ_nibble(unsigned acc, const uint4 x, c
     unsigned t0, t1, t2, t3;
     if (LAYOUT == 4u) {
         t0 = d0 & 0xFFFFu; t1 = (d0 & 0xFFFF0000u) | d1; t2 = d2; t3 = d3;
-    } else if (LAYOUT == 2u) {
+    } else if (LAYOUT == 2u || LAYOUT == 8u) {
         t0 = d0; t1 = d1; t2 = d2; t3 = d3;
     } else {
         t0 = d0 & 0xFFFFu; t1 = (d0 & 0xFFFF0000u) | d1; t2 = d2 & 0xFFFFu; t3 = (d2 & 0xFFFF0000u) | d3;
@@ -156,7 +164,7 @@ __device__ __forceinline__ unsigned differ_nibble(unsigned acc, const uint4 x, c
 template <unsigned LAYOUT>
 __device__ __forceinline__ void index_field(const uint4 x, unsigned k, unsigned &lo, unsigned &hi)
 {
-    if (LAYOUT == 2u) {
+    if (LAYOUT == 2u || LAYOUT == 8u) {
         lo = k == 1u ? x.y : x.w;
         hi = 0u;
     } else if (k == 1u) {
@@ -373,7 +381,7 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
                 // a copy is at most 64 bytes: the one that runs across field 16 (byte 64 of the half-tile) is cut there
                 // if it is longer -- both pieces then fit.  a: its first field (the last start below 16; field 0 always
                 // starts an element), b: the next start, or the end of the data
-                constexpr unsigned FO = LAYOUT == 4u ? 0x0C080200u : LAYOUT == 2u ? 0x0C080400u : 0x0A080200u;   // fo(k), a byte each
+                constexpr unsigned FO = LAYOUT == 4u ? 0x0C080200u : (LAYOUT == 2u || LAYOUT == 8u) ? 0x0C080400u : 0x0A080200u;   // fo(k), a byte each
                 const unsigned a = 31u - (unsigned)__builtin_clz((S & 0xFFFFu) | 1u);
                 const unsigned b = 17u + (unsigned)__builtin_ctz(((S | ~valid) >> 17) | 0x8000u);
                 const unsigned bytes = (b >> 2) * 16u + ((FO >> (8u * (b & 3u))) & 0xFFu) - (a >> 2) * 16u - ((FO >> (8u * (a & 3u))) & 0xFFu);
@@ -447,7 +455,8 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
                        2u * popc(L & UL::small32 & below) + popc(S & below) + popc(CS & below) + popc(X3 & below);
         const unsigned sj = S >> j4, lj = L >> j4, xj = X3 >> j4;
         const uint4 xs = X[s];
-        const unsigned fw[4] = {xs.x, LAYOUT == 2u ? xs.y : xs.x >> 16, xs.z, LAYOUT == 4u ? xs.w : LAYOUT == 2u ? xs.w : xs.z >> 16};
+        constexpr bool kDwords = LAYOUT == 2u || LAYOUT == 8u;
+        const unsigned fw[4] = {xs.x, kDwords ? xs.y : xs.x >> 16, xs.z, LAYOUT == 4u ? xs.w : kDwords ? xs.w : xs.z >> 16};
 #pragma unroll
         for (unsigned k = 0; k < 4u; k++) {
             const unsigned is_s = bit_mask(sj, k), is_l = bit_mask(lj, k), x3 = bit_mask(xj, k);
@@ -486,7 +495,7 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
                 bounds[64u + lane] = (uint16_t)stream_bytes;
         }
         __syncthreads();
-        constexpr unsigned FO = LAYOUT == 4u ? 0x0C080200u : LAYOUT == 2u ? 0x0C080400u : 0x0A080200u;   // fo(k), a byte each
+        constexpr unsigned FO = LAYOUT == 4u ? 0x0C080200u : (LAYOUT == 2u || LAYOUT == 8u) ? 0x0C080400u : 0x0A080200u;   // fo(k), a byte each
         const uint8_t *elfield = reinterpret_cast<const uint8_t *>(table) + 2048u;
         unsigned carry = 0;                                                    // half-tiles begun before the pass
 #pragma unroll 1
@@ -548,7 +557,7 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
 
 } // namespace
 
-// layouts: bit 0 = [2,6,4,4] textures present, bit 1 = [4,4], bit 2 = [2,6]
+// layouts: bit 0 = [2,6,4,4] textures present, bit 1 = [4,4], bit 2 = [2,6], bit 3 = [4,4,4,4]
 extern "C" int hapgpu_launch_snappy_compress_blocks(const HapGpuFrameEnc *frames, unsigned frame_count,
                                                     unsigned max_frags_per_texture, unsigned textures, void *slots,
                                                     unsigned slot_stride, uint32_t *frag_sizes, uint8_t *group_tables,
@@ -565,6 +574,9 @@ extern "C" int hapgpu_launch_snappy_compress_blocks(const HapGpuFrameEnc *frames
                            frag_sizes, group_tables);
     if (layouts & 4u)
         hipLaunchKernelGGL((snappy_compress_blocks_kernel<6u>), grid, block, 0, stream, frames, (uint8_t *)slots, slot_stride,
+                           frag_sizes, group_tables);
+    if (layouts & 8u)
+        hipLaunchKernelGGL((snappy_compress_blocks_kernel<8u>), grid, block, 0, stream, frames, (uint8_t *)slots, slot_stride,
                            frag_sizes, group_tables);
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }

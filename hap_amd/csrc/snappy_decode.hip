@@ -249,7 +249,8 @@ __global__ __launch_bounds__(64) void decode_expand_kernel(HapGpuDecodeJob *jobs
     const bool fields = job->fields_period != 0u && job->group_tables != 0u;
     if (fields)       // field stream (table version 3): block-per-lane decoder, with the fragment's group table
         kind = job->fields_period == 4u ? HAPGPU_UNIT_SNAPPY_FIELDS4
-             : job->fields_period == 2u ? HAPGPU_UNIT_SNAPPY_FIELDS2 : HAPGPU_UNIT_SNAPPY_FIELDS26;
+             : job->fields_period == 2u ? HAPGPU_UNIT_SNAPPY_FIELDS2
+             : job->fields_period == 8u ? HAPGPU_UNIT_SNAPPY_FIELDS44 : HAPGPU_UNIT_SNAPPY_FIELDS26;
     unsigned long long run = c.plan_hdr;
     for (unsigned base = 0; base < per_chunk; base += 64u) {
         const unsigned k = base + lane;
@@ -1460,8 +1461,8 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
     if (unit_count == 0)
         return 0;
     // field streams (fragment table version 3): the block-per-lane decoder of snappy_decode_fields.hip
-    if ((fragment_kinds >> 8) & 7u) {
-        if (hapgpu_launch_snappy_decode_fields(units, unit_count, jobs, (fragment_kinds >> 8) & 7u, stream) != 0)
+    if ((fragment_kinds >> 8) & 15u) {
+        if (hapgpu_launch_snappy_decode_fields(units, unit_count, jobs, (fragment_kinds >> 8) & 15u, stream) != 0)
             return 4;
         fragment_kinds &= 0xFFu;
         if (fragment_kinds == 0u)

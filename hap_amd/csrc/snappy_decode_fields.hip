@@ -86,17 +86,18 @@ __device__ __forceinline__ int fwave_scan_add(int v)       // inclusive
 
 // Block layouts ("fields per block" nibble of the fragment table, include/hap_gpu.h):
 //   4: 16-byte blocks of 2 + 6 + 4 + 4 bytes (DXT5, YCoCg-DXT5);  2: 8-byte blocks of 4 + 4 (DXT1);
-//   6: 8-byte blocks of 2 + 6 (RGTC1)
+//   6: 8-byte blocks of 2 + 6 (RGTC1);  8: 16-byte blocks of 4 + 4 + 4 + 4 (opaque formats: BC7, BC6H)
 template <unsigned LAYOUT> struct layout_of;
 template <> struct layout_of<4u> { static constexpr unsigned fields = 4u, block = 16u, pos_shift = 1u; };
 template <> struct layout_of<2u> { static constexpr unsigned fields = 2u, block = 8u, pos_shift = 2u; };
 template <> struct layout_of<6u> { static constexpr unsigned fields = 2u, block = 8u, pos_shift = 1u; };
+template <> struct layout_of<8u> { static constexpr unsigned fields = 4u, block = 16u, pos_shift = 2u; };
 
 // byte offset of field k inside a block
 template <unsigned LAYOUT>
 __device__ __forceinline__ constexpr unsigned field_pos(unsigned k)
 {
-    return LAYOUT == 4u ? (k == 0u ? 0u : k == 1u ? 2u : k == 2u ? 8u : 12u) : LAYOUT == 2u ? 4u * k : 2u * k;
+    return LAYOUT == 4u ? (k == 0u ? 0u : k == 1u ? 2u : k == 2u ? 8u : 12u) : (LAYOUT == 2u || LAYOUT == 8u) ? 4u * k : 2u * k;
 }
 
 // positions (in units of 1 << pos_shift bytes) at which an element may start, as a mask over one 32-bit word of the
@@ -567,8 +568,9 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
                 out[3] = lo[3 % PERIOD];
             }
         } else {
+            // [4, 4] and [4, 4, 4, 4]: every field is one dword at any byte address
 #pragma unroll
-            for (unsigned k = 0; k < 2; k++) {
+            for (unsigned k = 0; k < PERIOD; k++) {
                 const unsigned a = (unsigned)state[s][k] >> 8, aw = a >> 2, sh = a & 3u;
                 out[k] = __builtin_amdgcn_alignbyte(bufw[aw + 1u], bufw[aw], sh);
             }
@@ -620,18 +622,21 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
         decode_fields_unit<2u>(u, jobs, buf, masks, coffs, lane);
     else if (u.kind == HAPGPU_UNIT_SNAPPY_FIELDS26)
         decode_fields_unit<6u>(u, jobs, buf, masks, coffs, lane);
+    else if (u.kind == HAPGPU_UNIT_SNAPPY_FIELDS44)
+        decode_fields_unit<8u>(u, jobs, buf, masks, coffs, lane);
 }
 
 
 } // namespace
 
-// fields_kinds: bit 0 = [2, 6, 4, 4] units present (DXT5 / YCoCg-DXT5), bit 1 = [4, 4] units (DXT1), bit 2 = [2, 6] (RGTC1)
+// fields_kinds: bit 0 = [2, 6, 4, 4] units present (DXT5 / YCoCg-DXT5), bit 1 = [4, 4] units (DXT1), bit 2 = [2, 6] (RGTC1),
+// bit 3 = [4, 4, 4, 4] (opaque 16-byte blocks)
 extern "C" int hapgpu_launch_snappy_decode_fields(const HapGpuDecodeUnit *units, unsigned unit_count, HapGpuDecodeJob *jobs,
                                                   unsigned fields_kinds, hipStream_t stream)
 {
     if (unit_count == 0)
         return 0;
-    if (fields_kinds & 7u)
+    if (fields_kinds & 15u)
         hipLaunchKernelGGL(snappy_decode_fields_kernel, dim3(unit_count), dim3(64), SDF_DYN_LDS, stream, units, unit_count, jobs);
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }

@@ -13,6 +13,10 @@
  * half-tile, every element starts and ends on a block-field boundary, copy offsets are whole blocks; the table lists
  * the bytes of 64 groups of equally many elements, one group per decoder lane.
  *
+ * Layouts (the "fields per block" nibble of the table): 4 = DXT5 / YCoCg-DXT5 [2, 6, 4, 4]; 2 = DXT1 [4, 4], two blocks
+ * per unit; 6 = RGTC1 [2, 6], two blocks per unit; 8 = opaque 16-byte blocks (BC7, BC6H) taken as four dwords, copy
+ * distances in whole blocks (the size-for-speed option HAPGPU_ENCODE_COARSE_MATCHES).
+ *
  * Algorithm, per fragment of <= 8 KiB (units of 16 bytes = 4 fields; 32 fields = one half-tile):
  *   a. field i matches at distance d (1..4 blocks) when its bytes equal the same field d blocks back;
  *      a 2-byte field only counts next to a neighbouring field that matches at the same distance, and never makes a
@@ -39,6 +43,7 @@ typedef struct {
 static const ofs_layout k_layout4 = {{0, 2, 8, 12}, {2, 6, 4, 4}, 16, {0, 1, 0, 3}};   /* DXT5 / YCoCg-DXT5 */
 static const ofs_layout k_layout2 = {{0, 4, 8, 12}, {4, 4, 4, 4}, 8, {0, 1, 0, 1}};    /* DXT1, two blocks per unit */
 static const ofs_layout k_layout6 = {{0, 2, 8, 10}, {2, 6, 2, 6}, 8, {0, 1, 0, 1}};    /* RGTC1, two blocks per unit */
+static const ofs_layout k_layout8 = {{0, 4, 8, 12}, {4, 4, 4, 4}, 16, {0, 1, 0, 3}};   /* opaque 16-byte blocks (BC7, BC6H): four dwords */
 
 #define OFS_TABLE_BITS 9u
 #define OFS_STEP_UNITS 64u
@@ -65,7 +70,7 @@ static unsigned fpos(const ofs_layout *L, unsigned i) { return (i >> 2) * 16u + 
 unsigned ofs_compress_fragment(const uint8_t *src, unsigned n, unsigned layout, unsigned window_bytes, uint8_t *out,
                                uint8_t *group_table)
 {
-    const ofs_layout *L = layout == 4u ? &k_layout4 : layout == 2u ? &k_layout2 : &k_layout6;
+    const ofs_layout *L = layout == 4u ? &k_layout4 : layout == 2u ? &k_layout2 : layout == 8u ? &k_layout8 : &k_layout6;
     static uint8_t eq[OFS_DISTANCES][2048];
     static uint16_t hd[2048];                      /* table candidate of a field: distance in blocks, 0 = none */
     uint64_t table[1u << OFS_TABLE_BITS];

@@ -1761,18 +1761,25 @@ def _own_frame_sections(frame, chunks):
 
 @pytest.mark.parametrize("fmt,layout,shape,chunks", [
     (L.FMT_YCOCG, 4, (1024, 256), 4), (L.FMT_DXT5, 4, (1000, 260), 5), (L.FMT_YCOCG, 4, (2048, 1024), 3),
-    (L.FMT_DXT1, 2, (1024, 256), 2), (L.FMT_DXT1, 2, (1028, 252), 3), (L.FMT_RGTC1, 6, (4096, 1028), 2)])
+    (L.FMT_DXT1, 2, (1024, 256), 2), (L.FMT_DXT1, 2, (1028, 252), 3), (L.FMT_RGTC1, 6, (4096, 1028), 2),
+    (L.FMT_BC7, 8, (1024, 256), 4), (L.FMT_BC6U, 8, (1000, 260), 5)])
 def test_block_compressor_writes_exactly_the_bytes_of_its_scalar_definition(ctx, hap, fmt, layout, shape, chunks):
     """The Snappy stage for block textures (snappy_compress_blocks.hip, in place of hap.c:453) is defined by
     oracle/field_stream_oracle.c: every chunk's stream, every fragment size and every group table of the frame are
-    the scalar code's, for the three unit layouts, short last fragments and 8-byte tails included -- and both checkers
-    decode the frame to the texture."""
+    the scalar code's, for the unit layouts, short last fragments and 8-byte tails included -- and both checkers
+    decode the frame to the texture.  (Layout 8: opaque 16-byte blocks -- BC7, BC6H; YCoCg-DXT5 bytes stand in for
+    them -- through the same kernels as four dwords, the size-for-speed option HAPGPU_ENCODE_COARSE_MATCHES; the frame
+    then decodes through the block-per-lane kernel as well.)"""
     w, h = shape
-    tex = D.oracle_bc_encode(D.rgba(w, h, frame=3), fmt)
+    tex = D.oracle_bc_encode(D.rgba(w, h, frame=3), L.FMT_YCOCG if layout == 8 else fmt)
     out = np.zeros(hap.HapMaxEncodedLength([len(tex)], [fmt], [chunks]) + 65536, dtype=np.uint8)
-    r, used, res = ctx.encode_frames([[tex]], [fmt], [1], [chunks], [out], flags=hap.ENCODE_FRAGMENT_INDEX)
+    r, used, res = ctx.encode_frames([[tex]], [fmt], [1], [chunks], [out],
+                                     flags=hap.ENCODE_FRAGMENT_INDEX | (hap.ENCODE_COARSE_MATCHES if layout == 8 else 0))
     assert r == 0 and res == [0]
     frame = out[: used[0]].tobytes()
+    n0 = ctx.table_fallbacks()
+    dec = np.zeros(len(tex), dtype=np.uint8)
+    assert ctx.decode_frames([frame], [len(frame)], 0, [dec])[3] == [0] and dec.tobytes() == tex and ctx.table_fallbacks() == n0
     for name, api in CHECKERS:
         assert api.decode(frame, 0, len(tex)) == (0, tex, fmt), name
     limited = ORA.chunk_count(_encode_with(ORA, tex, fmt, L.COMP_SNAPPY, chunks), 0)[1]

@@ -290,7 +290,8 @@ def test_ycocg_blocks_are_dxt5_blocks_a_hap_q_shader_reconstructs():
 
 
 # ---- the scalar definition of the GPU's block compressor (oracle/field_stream_oracle.c) ----
-@pytest.mark.parametrize("fmt,layout,block", [(L.FMT_YCOCG, 4, 16), (L.FMT_DXT5, 4, 16), (L.FMT_DXT1, 2, 8), (L.FMT_RGTC1, 6, 8)])
+@pytest.mark.parametrize("fmt,layout,block", [(L.FMT_YCOCG, 4, 16), (L.FMT_DXT5, 4, 16), (L.FMT_DXT1, 2, 8), (L.FMT_RGTC1, 6, 8),
+                                              (L.FMT_YCOCG, 8, 16)])      # (layout 8: opaque 16-byte blocks as four dwords)
 def test_field_stream_definition_is_snappy_and_keeps_its_promises(fmt, layout, block):
     """What ofs_compress_fragment writes is an ordinary Snappy stream (libsnappy and the restatement decode it to the
     input) that keeps the promises of the fragment table version 3: the group bytes add up, every group holds the same
@@ -299,7 +300,7 @@ def test_field_stream_definition_is_snappy_and_keeps_its_promises(fmt, layout, b
     o = L.oracle_lib()
     o.ofs_compress_fragment.restype = C.c_uint
     tex = D.oracle_bc_encode(D.rgba(1024, 512, frame=9), fmt)
-    starts = {4: (0, 2, 8, 12), 2: (0, 4), 6: (0, 2)}[layout]
+    starts = {4: (0, 2, 8, 12), 2: (0, 4), 6: (0, 2), 8: (0, 4, 8, 12)}[layout]
     rng = np.random.default_rng(7)
     sizes = [8192, 8192, 8192, 8192, 4096, 1024 + 3 * block, block, 8192 - block, 128, 128 + block]
     total_in = total_out = 0
