@@ -33,6 +33,8 @@ while time.time() - t0 < budget:
     # ours: encode a batch, decode the batch, compare; the checker must agree on the first frame
     outs = [np.zeros(cap, dtype=np.uint8) for _ in range(nf)]
     flags = hap_amd.ENCODE_FRAGMENT_INDEX if rng.integers(0, 4) else 0
+    if rng.integers(0, 3) == 0:
+        flags |= hap_amd.ENCODE_COARSE_MATCHES          # (BC7 / BC6H: the block kernels with four dwords per block)
     r, used, res = ctx.encode_frames([[t] for t in texs], [fmt], [1], [chunks], outs, flags=flags)
     ok = r == 0 and all(x == 0 for x in res)
     if ok:
