@@ -641,9 +641,12 @@ def percall_lib():
     if "lib" not in _PERCALL:
         _PERCALL["lib"] = None
         try:
+            import atexit
+            import shutil
             import subprocess
             import tempfile
             d = tempfile.mkdtemp(prefix="hap_percall_")
+            atexit.register(shutil.rmtree, d, True)
             so = os.path.join(d, "libpercall.so")
             subprocess.run(["gcc", "-O2", "-std=c99", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"),
                             os.path.join(ROOT, "tools", "percall_loop.c"), "-o", so, "-L", os.path.join(ROOT, "hap_amd"),

@@ -13,7 +13,7 @@ import _data as D
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C4"
 nfrag = int(sys.argv[2]) if len(sys.argv) > 2 else 600
 w, h, fmt, layout = {"C4": (7680, 1024, L.FMT_YCOCG, 4), "C5y": (16384, 512, L.FMT_YCOCG, 4),
-                     "C5a": (16384, 512, L.FMT_RGTC1, 6), "C2": (3840, 2160, L.FMT_DXT1, 2)}[cfg]
+                     "C5a": (16384, 512, L.FMT_RGTC1, 6), "C2": (3840, 2160, L.FMT_DXT1, 2), "C3": (3840, 2160, L.FMT_DXT5, 4)}[cfg]
 cache = "/tmp/resolve_stats_%s.tex" % cfg
 if os.path.exists(cache):
     tex = np.fromfile(cache, dtype=np.uint8)
