@@ -26,16 +26,23 @@ if "--large" in sys.argv:
         tex = D.oracle_bc_encode(big, fmt)
         out = np.zeros(hap_amd.HapMaxEncodedLength([len(tex)], [fmt], [chunks]), dtype=np.uint8)
         r, used, _ = ctx.encode_frames([[tex]], [fmt], [1], [chunks], [out], flags=1)
-        assert r == 0 and (bytes([0x46, 2, 13]) in out[:512].tobytes() or bytes([0x46, 1, 13]) in out[:512].tobytes())
+        assert r == 0 and (bytes([0x46, 3, 13]) in out[:512].tobytes() or bytes([0x46, 1, 13]) in out[:512].tobytes())
         bases = [(out[:used[0]].tobytes(), len(tex))] + bases
         r, used, _ = ctx.encode_frames([[tex]], [fmt], [1], [chunks], [out], flags=3)
         bases = [(out[:used[0]].tobytes(), len(tex))] + bases
-# another encoder's streams with several 64 KiB blocks per chunk: the block scan and its BLOCK units
+# another encoder's streams with several 64 KiB blocks per chunk: the block scan and its BLOCK units; and this library's
+# own table-less frames (8 KiB marks, the fine units of the launch's first phase), also with 64 KiB fragments (marks on
+# element boundaries, pieces not independent: handed over to the second phase)
 if "--blocks" in sys.argv:
     wide = D.rgba(1024, 512, 4)
     for fmt, chunks in ((L.FMT_DXT5, 2), (L.FMT_YCOCG, 1)):
         tex = D.oracle_bc_encode(wide, fmt)
         bases = [(ORA.encode([tex], [fmt], [1], [chunks])[1], len(tex))] * 3 + bases
+        out = np.zeros(hap_amd.HapMaxEncodedLength([len(tex)], [fmt], [chunks]) + 65536, dtype=np.uint8)
+        for flags in (0, 0, hap_amd.ENCODE_SMALLER_FILES):
+            r, used, _ = ctx.encode_frames([[tex]], [fmt], [1], [chunks], [out], flags=flags)
+            assert r == 0
+            bases = [(out[:used[0]].tobytes(), len(tex))] + bases
 a = D.oracle_bc_encode(img, L.FMT_YCOCG); b = D.oracle_bc_encode(img, L.FMT_RGTC1)
 bases.append((ORA.encode([a, b], [L.FMT_YCOCG, L.FMT_RGTC1], [1, 1], [2, 2])[1], len(a)))
 def oracle_in_child(frame, idx, cap):
