@@ -329,6 +329,11 @@ def main():
         stream.used = stream.encode()
         stream.decode(stream.used)
         line["bit_exact"] = stream.bit_exact()
+        if not args.no_extras:
+            try:
+                line["frames_to_rgba"] = frames_to_rgba(hap_amd, stream, dev)
+            except Exception as exc:
+                line["frames_to_rgba"] = {"error": repr(exc)}
         extras = {}
         if not args.no_cpu_baseline:
             for name, fn in (("host_pointer_path", lambda: host_pointer_path(ctx, stream.rgba, stream.frames, stream.used, fmts,
@@ -449,6 +454,28 @@ def texture_to_rgba(stream, dev):
         return None
     return {"us_per_frame": round(ms / n * 1e3, 2),
             "algorithmic_GBps": round((sum(stream.tex_bytes) + stream.rgba_bytes) / (ms / n * 1e-3) / 1e9, 1)}
+
+
+def frames_to_rgba(hap_amd, stream, dev):
+    """Hap frames -> RGBA8 pictures in one call (HapGpuDecodeFramesRGBA: second stage undone into scratch, then the
+    block decoder), untimed extra.  Checked here against the two-step path (decoded textures ->
+    HapGpuDecompressRGBA), which the GPU tests check against the oracle."""
+    ctx, w, h, fmts, nf = stream.ctx, stream.w, stream.h, stream.fmts, stream.nf
+    pics = hap_amd.BufferList([torch.empty(stream.rgba_bytes, dtype=torch.uint8, device=dev) for _ in range(nf)])
+    torch.cuda.synchronize()
+    r, res = ctx.decode_frames_rgba(stream.frames, stream.used, len(fmts), pics, w, h)
+    if r or any(res):
+        return {"error": "HapResult %d" % r}
+    ctx.timer_start()
+    ctx.decode_frames_rgba(stream.frames, stream.used, len(fmts), pics, w, h)
+    ms = ctx.timer_stop()
+    two_step = torch.empty(stream.rgba_bytes, dtype=torch.uint8, device=dev)
+    same = True
+    for i in (0, nf - 1):
+        ctx.decompress_rgba(stream.dec[0][i], fmts[0], w, h, rgba=two_step, alpha=(stream.dec[1][i] if len(fmts) > 1 else None))
+        same = same and bool(torch.equal(two_step, pics[i]))
+    return {"frames": nf, "ms": round(ms, 3), "fps": round(nf / (ms * 1e-3), 1),
+            "rgba_GBps": round(nf * stream.rgba_bytes / (ms * 1e-3) / 1e9, 1), "same_as_two_steps": same}
 
 
 def coarse_option(stream, hap_amd):

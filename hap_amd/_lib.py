@@ -48,6 +48,7 @@ def _load():
         "HapGpuEncodeFramesRGBA": (u, [vp, u, P(vp), u, u, ul, u, P(u), P(u), P(u), P(vp), P(ul), P(ul), P(u), u]),
         "HapGpuDecodeFrames": (u, [vp, u, P(vp), P(ul), u, P(vp), P(ul), P(ul), P(u), P(u), u]),
         "HapGpuDecodeFrameTextures": (u, [vp, u, P(vp), P(ul), u, P(vp), P(ul), P(ul), P(u), P(u), u]),
+        "HapGpuDecodeFramesRGBA": (u, [vp, u, P(vp), P(ul), u, P(vp), u, u, ul, P(u), u]),
         "HapGpuDecodeChunkGroup": (u, [vp, vp, ul, u, u, u, vp, ul, P(ul), P(u)]),
         "HapGpuGetFrameTextureChunkLayout": (u, [vp, ul, u, u, P(ul), P(u)]),
         "HapGpuJoinChunkGroups": (u, [u, P(vp), P(ul), vp, ul, P(ul)]),

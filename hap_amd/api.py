@@ -370,6 +370,19 @@ class Context:
         r = lib.HapGpuDecodeFrameTextures(self.handle, nf, ptrs, lens, texture_count, optrs, olens, used, fmts, results, flags)
         return r, list(used), list(fmts), list(results)
 
+    def decode_frames_rgba(self, frames, frame_bytes, texture_count, rgba_frames, width, height, row_bytes=None, flags=0):
+        """Frames -> RGBA8 pictures in one call (HapGpuDecodeFramesRGBA).  Returns (result, results[])."""
+        nf = len(frames)
+        if len(rgba_frames) != nf:
+            raise ValueError("one picture per frame")
+        ptrs, infos = self._ptr_array(frames)
+        lens = (C.c_ulong * nf)(*[fb if fb is not None else infos[i][1] for i, fb in enumerate(frame_bytes)])
+        optrs, _oinfos = self._ptr_array(rgba_frames)
+        results = (C.c_uint * nf)()
+        r = lib.HapGpuDecodeFramesRGBA(self.handle, nf, ptrs, lens, texture_count, optrs, width, height,
+                                       row_bytes or width * 4, results, flags)
+        return r, list(results)
+
     def decode_sequence(self, reader, first, count, index, outputs, batch=0):
         """Disk -> pinned double buffer -> GPU (HapGpuDecodeSequence). Returns (result, used[], formats[], results[])."""
         optrs, oinfos = self._ptr_array(outputs)

@@ -573,6 +573,22 @@ unsigned int HapGpuDecodeFrameTextures(HapGpuContext *context, unsigned int fram
     return r;
 }
 
+unsigned int HapGpuDecodeFramesRGBA(HapGpuContext *context, unsigned int frameCount,
+                                    const void *const *inputBuffers, const unsigned long *inputBuffersBytes,
+                                    unsigned int textureCount, void *const *rgbaFrames, unsigned int width,
+                                    unsigned int height, unsigned long rowBytes, unsigned int *results,
+                                    unsigned int flags)
+{
+    unsigned r;
+    if (!context)
+        return HapResult_Bad_Arguments;
+    hapgpu_rt_lock(context->rt);
+    r = hapb_decode_rgba(context, frameCount, inputBuffers, inputBuffersBytes, textureCount, rgbaFrames, width, height,
+                         rowBytes, results, flags);
+    hapgpu_rt_unlock(context->rt);
+    return r;
+}
+
 unsigned int HapGpuJoinChunkGroupsDevice(HapGpuContext *context, unsigned int groupCount,
                                          const void *const *groupFrames, const unsigned long *groupFramesBytes,
                                          void *outputBuffer, unsigned long outputBufferBytes,

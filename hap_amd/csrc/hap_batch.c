@@ -1223,6 +1223,130 @@ fail_alloc:
     return HapResult_Internal_Error;
 }
 
+/* ============================================================= frames to pixels */
+/* Hap frames -> RGBA8 pictures with nothing but frames going in and pixels coming out: the second stage of a slice of
+   frames is undone into a scratch of block textures (one batch through hapb_decode: texture 0, and the RGTC1 alpha
+   plane of Hap Q Alpha frames), then every picture is expanded by the block decoder on the same stream.  What a
+   player without texture sampling of its own asks of a Hap decoder (the reference leaves this step to the GPU's
+   texture units, hap.h:92-95 "the texture format the frame decodes to"). */
+#define RGBA_SLICE_BYTES ((size_t)4u << 30)     /* block textures held at a time */
+unsigned hapb_decode_rgba(HapGpuContext *ctx, unsigned frame_count, const void *const *inputs,
+                          const unsigned long *input_bytes, unsigned texture_count, void *const *rgba_frames,
+                          unsigned width, unsigned height, unsigned long row_bytes, unsigned *results, unsigned flags)
+{
+    hapgpu_rt *rt = ctx->rt;
+    size_t blocks, per_frame, alpha_off, rgba_bytes, slice, done;
+    unsigned first_error = HapResult_No_Error, f;
+    const void **in;
+    unsigned long *in_bytes, *caps, *used;
+    void **outs;
+    unsigned *idx, *fmts, *res;
+    if (frame_count == 0)
+        return HapResult_No_Error;
+    if (!results)
+        return HapResult_Bad_Arguments;
+    if (!inputs || !input_bytes || !rgba_frames || texture_count == 0 || texture_count > 2 || width == 0 ||
+        height == 0 || (width & 3u) || (height & 3u) || row_bytes < (unsigned long)width * 4ul || (row_bytes & 15u)) {
+        for (f = 0; f < frame_count; f++)
+            results[f] = HapResult_Bad_Arguments;
+        return HapResult_Bad_Arguments;
+    }
+    blocks = (size_t)(width / 4u) * (height / 4u);
+    alpha_off = align_up(blocks * 16u, 256);
+    per_frame = alpha_off + (texture_count == 2 ? align_up(blocks * 8u, 256) : 0u);
+    rgba_bytes = (size_t)row_bytes * (height - 1u) + (size_t)width * 4u;
+    slice = RGBA_SLICE_BYTES / per_frame;
+    if (slice == 0)
+        slice = 1;
+    if (slice > frame_count)
+        slice = frame_count;
+    if (slice * texture_count > 32768u)
+        slice = 32768u / texture_count;
+    in = (const void **)malloc(sizeof(*in) * slice * texture_count);
+    in_bytes = (unsigned long *)malloc(sizeof(*in_bytes) * slice * texture_count * 3u);
+    outs = (void **)malloc(sizeof(*outs) * slice * texture_count);
+    idx = (unsigned *)malloc(sizeof(*idx) * slice * texture_count * 3u);
+    if (!in || !in_bytes || !outs || !idx) {
+        free(in); free(in_bytes); free(outs); free(idx);
+        for (f = 0; f < frame_count; f++)
+            results[f] = HapResult_Internal_Error;
+        return HapResult_Internal_Error;
+    }
+    caps = in_bytes + slice * texture_count;
+    used = caps + slice * texture_count;
+    fmts = idx + slice * texture_count;
+    res = fmts + slice * texture_count;
+    for (done = 0; done < frame_count; done += slice) {
+        const unsigned n = (unsigned)(frame_count - done < slice ? frame_count - done : slice);
+        uint8_t *textures = (uint8_t *)hapgpu_rt_device_scratch(rt, D_BC_TEX, per_frame * n);
+        uint8_t *stage = NULL;
+        unsigned t;
+        int rc = 0;
+        if (!textures) {
+            for (f = 0; f < n; f++)
+                results[done + f] = HapResult_Internal_Error;
+            first_error = first_error ? first_error : HapResult_Internal_Error;
+            continue;
+        }
+        for (f = 0; f < n; f++)
+            for (t = 0; t < texture_count; t++) {
+                const size_t e = (size_t)f * texture_count + t;
+                in[e] = inputs[done + f];
+                in_bytes[e] = input_bytes[done + f];
+                outs[e] = textures + per_frame * f + (t ? alpha_off : 0u);
+                caps[e] = (unsigned long)(t ? blocks * 8u : blocks * 16u);
+                idx[e] = t;
+                used[e] = 0;
+                fmts[e] = 0;
+            }
+        ctx->decode_indices = idx;
+        hapb_decode(ctx, n * texture_count, in, in_bytes, 0, outs, caps, used, fmts, res, flags, NULL, NULL);
+        for (f = 0; f < n; f++) {
+            const size_t e = (size_t)f * texture_count;
+            const unsigned fmt = fmts[e];
+            void *dst = rgba_frames[done + f];
+            unsigned r = res[e];
+            if (r == HapResult_No_Error && texture_count == 2)
+                r = res[e + 1];
+            if (r == HapResult_No_Error && !dst)
+                r = HapResult_Bad_Arguments;
+            /* the frame must hold what the caller's geometry says: a colour texture the block decoder knows, of
+               exactly width x height, and (two textures) an RGTC1 plane of the same geometry */
+            if (r == HapResult_No_Error &&
+                ((fmt != HapTextureFormat_RGB_DXT1 && fmt != HapTextureFormat_RGBA_DXT5 && fmt != HapTextureFormat_YCoCg_DXT5) ||
+                 used[e] != blocks * (fmt == HapTextureFormat_RGB_DXT1 ? 8u : 16u) ||
+                 (texture_count == 2 && (fmts[e + 1] != HapTextureFormat_A_RGTC1 || used[e + 1] != blocks * 8u))))
+                r = HapResult_Bad_Arguments;
+            if (r == HapResult_No_Error && !is_dev(ctx, dst)) {
+                if (!stage)
+                    stage = (uint8_t *)hapgpu_rt_device_scratch(rt, D_RGBA_STAGE, align_up(rgba_bytes, 256) * n);
+                dst = stage ? stage + align_up(rgba_bytes, 256) * f : NULL;
+                if (!dst)
+                    r = HapResult_Internal_Error;
+            }
+            if (r == HapResult_No_Error) {
+                const int k = hapgpu_k_block_decode(rt, outs[e], texture_count == 2 ? outs[e + 1] : NULL, width, height,
+                                                    fmt, dst, row_bytes);
+                if (k)
+                    r = k == 1 ? HapResult_Bad_Arguments : HapResult_Internal_Error;
+                else if (dst != rgba_frames[done + f])
+                    rc |= hapgpu_rt_d2h(rt, rgba_frames[done + f], dst, rgba_bytes);
+            }
+            results[done + f] = r;
+        }
+        rc |= hapgpu_rt_sync(rt);
+        if (rc)
+            for (f = 0; f < n; f++)
+                if (results[done + f] == HapResult_No_Error)
+                    results[done + f] = HapResult_Internal_Error;
+        for (f = 0; f < n; f++)
+            if (results[done + f] != HapResult_No_Error && first_error == HapResult_No_Error)
+                first_error = results[done + f];
+    }
+    free(in); free(in_bytes); free(outs); free(idx);
+    return first_error;
+}
+
 /* ============================================================= join on the device */
 /* Sink of hapj_join for frames in device memory: header bytes are collected on the host and uploaded in one copy, the
    groups' tables and payloads become device-to-device moves of the gather kernel (pieces of at most 64 KiB, one

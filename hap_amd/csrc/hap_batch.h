@@ -62,6 +62,11 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                      unsigned *output_formats, unsigned *results, unsigned flags,
                      HapDecodeCallback callback, void *callback_info);
 
+/* frames -> RGBA8 pictures (texture_count 2: Hap Q Alpha frames, colour + RGTC1 alpha plane) */
+unsigned hapb_decode_rgba(HapGpuContext *ctx, unsigned frame_count, const void *const *inputs,
+                          const unsigned long *input_bytes, unsigned texture_count, void *const *rgba_frames,
+                          unsigned width, unsigned height, unsigned long row_bytes, unsigned *results, unsigned flags);
+
 /* groups and output in device memory: tables through the host, payloads device to device */
 unsigned hapb_join_device(HapGpuContext *ctx, unsigned group_count, const void *const *frames,
                           const unsigned long *frame_bytes, void *output, unsigned long output_bytes,

@@ -198,6 +198,24 @@ unsigned int HapGpuDecodeFrameTextures(HapGpuContext *context, unsigned int fram
                                        unsigned int *results,
                                        unsigned int flags);
 
+/* Frames in, pixels out: every frame's second stage is undone (as HapGpuDecodeFrameTextures does, in one batch) and
+ * its block texture expanded to an RGBA8 picture of width x height in rgbaFrames[f] (rowBytes: a multiple of 16,
+ * at least width * 4; device pictures 16-byte aligned; host or device).  textureCount 1: the frames hold one
+ * DXT1 / DXT5 / scaled-YCoCg-DXT5 texture (Hap, Hap Alpha, Hap Q; YCoCg is converted back to RGB the way the
+ * reference's consumers do in their shader); textureCount 2: Hap Q Alpha frames, whose RGTC1
+ * plane becomes the pictures' alpha.  The block textures live in the context's scratch only.  results[f]:
+ * HapDecode's code for the frame; Bad_Arguments for a frame whose texture is of another format or geometry than the
+ * call says (BC7 / BC6H / lone RGTC1 textures have no pixel decoder here).  The reference has no counterpart: it
+ * stops at the texture (hap.h:132-140) and leaves the pixels to the consumer's GPU. */
+unsigned int HapGpuDecodeFramesRGBA(HapGpuContext *context, unsigned int frameCount,
+                                    const void *const *inputBuffers,
+                                    const unsigned long *inputBuffersBytes,
+                                    unsigned int textureCount,
+                                    void *const *rgbaFrames,
+                                    unsigned int width, unsigned int height, unsigned long rowBytes,
+                                    unsigned int *results,
+                                    unsigned int flags);
+
 /* --- one frame split over several GPUs by chunk groups ------------------------ */
 
 /* HapDecode restricted to the chunks [firstChunk, firstChunk + chunkCount) of texture `index`:

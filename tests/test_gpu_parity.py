@@ -740,6 +740,82 @@ def test_both_textures_of_a_batch_decode_in_one_call(ctx, hap):
         ctx.decode_frame_textures(frames, lens, 2, dec0)
 
 
+def test_frames_decode_to_pictures_in_one_call(ctx, hap):
+    """HapGpuDecodeFramesRGBA: frames in, RGBA8 pictures out -- bit-exact with the oracle's pixel decoder applied to the
+    textures the reference's HapDecode gives for the same frames (frames of this library in HBM and on the host, a
+    frame of the reference encoder; Hap, Hap Alpha, Hap Q and two-texture Hap Q Alpha; strided pictures in HBM and
+    tight ones on the host)."""
+    from hap_amd import synth
+    w, h, nf = 512, 256, 4
+    nb = (w // 4) * (h // 4)
+    rgba = [synth.rgba_frame(w, h, 10 + i, device="cuda") for i in range(nf)]
+    torch.cuda.synchronize()
+    for fmts in ([L.FMT_DXT1], [L.FMT_DXT5], [L.FMT_YCOCG], [L.FMT_YCOCG, L.FMT_RGTC1]):
+        T = len(fmts)
+        sizes = [nb * (8 if f in (L.FMT_DXT1, L.FMT_RGTC1) else 16) for f in fmts]
+        cap = hap.HapMaxEncodedLength(sizes, fmts, [4] * T)
+        outs = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(nf)]
+        torch.cuda.synchronize()
+        r, used, results = ctx.encode_frames_rgba(rgba, w, h, w * 4, fmts, [1] * T, [4] * T, outs)
+        assert r == 0 and results == [0] * nf
+        tex = [[D.oracle_bc_encode(rgba[i].cpu().numpy(), f) for f in fmts] for i in range(nf)]
+        r, ref2 = REF.encode(tex[2], fmts, [1] * T, [3] * T)
+        assert r == 0
+        frames = [outs[0], outs[1][: used[1]].cpu().numpy().tobytes(), ref2, outs[3]]
+        lens = [used[0], used[1], len(ref2), used[3]]
+        want = []
+        for i in range(nf):
+            host = frames[i] if isinstance(frames[i], bytes) else frames[i][: lens[i]].cpu().numpy().tobytes()
+            code, t0, f0 = REF.decode(host, 0, sizes[0])
+            assert code == 0 and f0 == fmts[0]
+            pic = D.oracle_bc_decode(t0, fmts[0], w, h)
+            if T == 2:
+                code, t1, f1 = REF.decode(host, 1, sizes[1])
+                assert code == 0 and f1 == L.FMT_RGTC1
+                pic[..., 3] = D.oracle_bc_decode(t1, L.FMT_RGTC1, w, h)
+            want.append(pic)
+        # pictures in HBM, rows 64 bytes apart from tight
+        stride = w * 4 + 64
+        pics = [torch.full((h * stride,), 0xEE, dtype=torch.uint8, device="cuda") for _ in range(nf)]
+        torch.cuda.synchronize()
+        n0 = ctx.table_fallbacks()
+        r, res = ctx.decode_frames_rgba(frames, lens, T, pics, w, h, row_bytes=stride)
+        assert r == 0 and res == [0] * nf and ctx.table_fallbacks() == n0
+        for i in range(nf):
+            got = pics[i].cpu().numpy().reshape(h, stride)
+            assert got[:, : w * 4].tobytes() == want[i].tobytes(), (fmts, i)
+            assert (got[:-1, w * 4:] == 0xEE).all()
+        # pictures on the host
+        hpics = [np.zeros(h * w * 4, dtype=np.uint8) for _ in range(nf)]
+        r, res = ctx.decode_frames_rgba(frames, lens, T, hpics, w, h)
+        assert r == 0 and res == [0] * nf
+        assert all(hpics[i].tobytes() == want[i].tobytes() for i in range(nf))
+        # a frame that is not what the call says fails alone
+        if T == 1:
+            other = L.FMT_DXT1 if fmts[0] != L.FMT_DXT1 else L.FMT_DXT5
+            r, odd = hap.HapEncode([bytes(nb * (8 if other == L.FMT_DXT1 else 16) // 4)], [other], [1], [1])   # a quarter of the picture
+            assert r == 0
+            r, res = ctx.decode_frames_rgba([frames[0], odd, bytes(40), frames[3]], [lens[0], len(odd), 40, lens[3]], 1,
+                                            pics, w, h, row_bytes=stride)
+            assert res[0] == 0 and res[3] == 0 and res[1] == hap.HapResult.Bad_Arguments and res[2] != 0 and r == res[1]
+            assert pics[3].cpu().numpy().reshape(h, stride)[:, : w * 4].tobytes() == want[3].tobytes()
+        else:
+            # two textures asked of single-texture frames
+            r, single = hap.HapEncode([tex[0][0]], [fmts[0]], [1], [2])
+            assert r == 0
+            r, res = ctx.decode_frames_rgba([single, frames[1]], [len(single), lens[1]], 2, pics[:2], w, h, row_bytes=stride)
+            assert res[0] != 0 and res[1] == 0 and r == res[0]
+    # BC7 has no pixel decoder here; bad geometry / alignment are argument errors
+    r, b7 = hap.HapEncode([bytes(nb * 16)], [L.FMT_BC7], [1], [1])
+    assert r == 0
+    r, res = ctx.decode_frames_rgba([b7], [len(b7)], 1, pics[:1], w, h, row_bytes=stride)
+    assert r == hap.HapResult.Bad_Arguments and res == [r]
+    assert ctx.decode_frames_rgba([b7], [len(b7)], 1, pics[:1], w + 2, h)[0] == hap.HapResult.Bad_Arguments
+    assert ctx.decode_frames_rgba([b7], [len(b7)], 1, pics[:1], w, h, row_bytes=w * 4 + 4)[0] == hap.HapResult.Bad_Arguments
+    assert ctx.decode_frames_rgba([b7], [len(b7)], 3, pics[:1], w, h)[0] == hap.HapResult.Bad_Arguments
+    assert ctx.decode_frames_rgba([], [], 1, [], w, h)[0] == 0
+
+
 def test_encode_is_deterministic_and_batch_independent(ctx, hap):
     """G5 stand-in on one GPU: a frame's bytes do not depend on run, batch size or position in the batch
     (round-synchronous hash inserts with LDS atomicMax make the compressor timing-independent), so
