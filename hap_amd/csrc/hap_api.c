@@ -38,6 +38,7 @@ unsigned int HapGpuCreate(int device, HapGpuContext **context)
         c->position_lanes = getenv("HAP_AMD_POSITION_LANES") ? 1u : 0u;
         c->no_half_tiles = getenv("HAP_AMD_NO_HALF_TILES") ? 1u : 0u;
         c->no_block_scan = getenv("HAP_AMD_NO_BLOCK_SCAN") ? 1u : 0u;
+        c->no_fusion = getenv("HAP_AMD_NO_FUSION") ? 1u : 0u;
         /* RGTC1 planes of large textures go through the [2, 6] field kernel (block-per-lane decodable: 2.9x the decode
            rate at the same size); HAP_AMD_RGTC1_LAYOUT overrides: 0 = position-per-lane compressor, 44 = [4, 4] */
         c->rgtc1_fields = 26u;

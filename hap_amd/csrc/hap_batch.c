@@ -63,6 +63,7 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
     unsigned slot_stride;
     int any_snappy = 0;
     unsigned gran_mask = 0;
+    unsigned fused[2] = {0u, 0u}, fused_mask = 0u;   /* textures the second stage makes from the RGBA itself (code: reserved bits 24..26) */
     size_t stage_in_bytes = 0, stage_out_bytes = 0, frame_raw_bound = 0;
     hapgpu_rt *rt = ctx->rt;
     HapGpuFrameEnc *hframes, *dframes;
@@ -174,7 +175,18 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
                          !ctx->no_half_tiles) ? 1u : 0u;
         if (t->half_tiles)
             any_half_tiles = 1;
-        if (t->compressor == HapCompressorSnappy)
+        /* a call that starts from RGBA pictures (hapb_encode_rgba): the block compressor makes the blocks of its
+           fragment itself, one pass less over the texture and the pixel loads of one wave under the matching of the
+           others (snappy_compress_blocks.hip).  One texture per frame, 16-byte blocks for now. */
+        {
+            const HapbBlockEncodeJob *bj = ctx->block_encode_job;
+            if (bj && !ctx->no_fusion && count == 1u && t->field_period == 4u && (bj->row_bytes & 3u) == 0 &&
+                (unsigned long long)bj->row_bytes * bj->height < 0xFFFFFFFFull && bj->width / 4u >= 1u) {
+                fused[i] = t->format == HapTextureFormat_RGBA_DXT5 ? 2u : 3u;
+                fused_mask |= t->format == HapTextureFormat_RGBA_DXT5 ? 2u : 1u;
+            }
+        }
+        if (t->compressor == HapCompressorSnappy && !fused[i])
             gran_mask |= t->field_period == 4u ? 32u : t->field_period == 10u ? 64u : t->field_period == 2u ? 16u
                          : t->field_period == 12u ? 128u : 1u << t->gran_log2;
         if (t->compressor == HapCompressorSnappy) {
@@ -301,6 +313,11 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
             fe->tex_count = count;
             fe->outer_header_len = outer_header;
             fe->status = HapResult_Internal_Error;   /* overwritten by the pack kernel */
+            if (fused_mask) {
+                fe->rgba = ctx->block_encode_job->host_table[f];
+                fe->rgba_row_bytes = (uint32_t)ctx->block_encode_job->row_bytes;
+                fe->rgba_blocks_x = ctx->block_encode_job->width / 4u;
+            }
             for (i = 0; i < count; i++) {
                 HapGpuTexEnc *te = &fe->tex[i];
                 const void *src = inputs[(size_t)f * count + i];
@@ -329,7 +346,7 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
                     const int windowed = frag_log2 == 13u && !g[i].half_tiles &&
                                          g[i].bytes >= (small_blocks ? ((size_t)2u << 20) : ((size_t)1u << 20));
                     te->reserved = g[i].gran_log2 | (windowed ? (HAP_FRAGMENT_WINDOW_256 << 8) : 0u) | (g[i].field_period << 16) |
-                                   (g[i].half_tiles << 20);
+                                   (g[i].half_tiles << 20) | (fused[i] << 24);
                 }
             }
         }
@@ -344,7 +361,7 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
 #define HAPB_MIX(v) (key = (key ^ (uint64_t)(v)) * 0x100000001B3ull)
             if (stage_in_bytes == 0 && stage_out_bytes == 0 && inputs_are_device != 2 && !smaller && frag_log2 == 13u) {
                 HAPB_MIX(live); HAPB_MIX(count); HAPB_MIX(flags); HAPB_MIX(frag_log2); HAPB_MIX(ctx->byte_granular);
-                HAPB_MIX(ctx->position_lanes); HAPB_MIX(ctx->rgtc1_fields); HAPB_MIX(ctx->no_half_tiles);
+                HAPB_MIX(ctx->position_lanes); HAPB_MIX(ctx->rgtc1_fields); HAPB_MIX(ctx->no_half_tiles); HAPB_MIX(fused_mask);
                 for (i = 0; i < count; i++) {
                     HAPB_MIX(g[i].format); HAPB_MIX(g[i].compressor); HAPB_MIX(g[i].chunk_count); HAPB_MIX(g[i].bytes);
                 }
@@ -369,7 +386,8 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
                                                                                      job->row_bytes, job->wide);
                     else
                         for (i = 0; i < job->count; i++)
-                            launch_rc |= (unsigned)hapgpu_k_block_encode_batch(rt, job->device_table,
+                            if (!fused[i])
+                                launch_rc |= (unsigned)hapgpu_k_block_encode_batch(rt, job->device_table,
                                                                              job->device_table + (size_t)(1u + i) * job->frame_count,
                                                                              job->frame_count, job->width, job->height, job->row_bytes,
                                                                              job->formats[i], job->wide);
@@ -377,7 +395,7 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
                 launch_rc |= (unsigned)hapgpu_rt_h2d(rt, dframes, hframes, sizeof(HapGpuFrameEnc) * live);
                 if (any_snappy)
                     launch_rc |= (unsigned)hapgpu_k_snappy_compress(rt, dframes, live, max_frags_per_tex, frag_log2, dslots, slot_stride,
-                                                                    dfragsizes, dgrouptables, gran_mask | (count << 8));   /* bits 8..: textures per frame */
+                                                                    dfragsizes, dgrouptables, gran_mask | (count << 8) | (fused_mask << 16));   /* bits 8..15: textures per frame */
                 launch_rc |= (unsigned)hapgpu_k_frame_pack(rt, dframes, live, frag_log2, dslots, slot_stride, dfragsizes, dgrouptables,
                                                            dcopies, frags_per_frame * live, chunks_per_frame, max_chunks_per_tex, count, dpack);
                 launch_rc |= (unsigned)hapgpu_k_frame_gather(rt, dcopies, (frags_per_frame + chunks_per_frame) * live);

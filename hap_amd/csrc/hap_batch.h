@@ -16,6 +16,7 @@ struct HapGpuContext {
     unsigned position_lanes;  /* HAP_AMD_POSITION_LANES: never use the field-per-lane compressor */
     unsigned rgtc1_fields;    /* layout of RGTC1 planes for the block compressor: 26 = [2, 6] (default), 44 = [4, 4], 0 = position lanes (HAP_AMD_RGTC1_LAYOUT) */
     unsigned no_block_scan;   /* HAP_AMD_NO_BLOCK_SCAN: whole-stream units stay whole (A/B runs) */
+    unsigned no_fusion;       /* HAP_AMD_NO_FUSION: RGBA calls run the block encoder as a pass of its own (A/B runs) */
     unsigned no_half_tiles;   /* HAP_AMD_NO_HALF_TILES: fragment table version 1 even for field streams (A/B runs) */
     /* chunk marks collected from the client's HapDecodeCallback, handed to the retry of a frame whose fragment
        table turned out wrong: the callback is invoked exactly once per HapDecode, as in the reference */

@@ -61,7 +61,10 @@ typedef struct HapGpuTexEnc {
                                 bits 16..19: fields per block for the field-per-lane compressor (0: position per lane,
                                 2: RGTC1 layout, 4: DXT5 / YCoCg-DXT5, 10: DXT1, 12: opaque 16-byte blocks); bits 8..15: match window in 256-byte units (0 = whole fragment); bits 0..7:
                                 granularity_log2 of the element stream: 0 = bytes, 1 = every position, offset
-                                and length even (lets the decoder move 16 bits per lane) */
+                                and length even (lets the decoder move 16 bits per lane);
+                                bits 24..26: 0 = the texture is at src; else the block-per-lane compressor makes it from
+                                the frame's RGBA picture (1 DXT1, 2 DXT5, 3 scaled YCoCg-DXT5, 4 RGTC1 from alpha) and
+                                writes it to src on the way */
 } HapGpuTexEnc;
 
 /* [device] one frame */
@@ -75,6 +78,10 @@ typedef struct HapGpuFrameEnc {
     uint64_t bytes_used;
     uint32_t status;
     uint32_t reserved;
+    /* textures whose reserved bits 24..26 are set are made from this RGBA8 picture by the second stage itself */
+    uint64_t rgba;
+    uint32_t rgba_row_bytes; /* (the picture is smaller than 4 GiB) */
+    uint32_t rgba_blocks_x;  /* width / 4 */
 } HapGpuFrameEnc;
 
 /* [device] one byte-range move of the gather pass (one per fragment) */

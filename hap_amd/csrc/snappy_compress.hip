@@ -487,7 +487,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void snappy_compress_wg_kernel(const
 extern "C" int hapgpu_launch_snappy_compress_blocks(const HapGpuFrameEnc *frames, unsigned frame_count,
                                                     unsigned max_frags_per_texture, unsigned textures, void *slots,
                                                     unsigned slot_stride, uint32_t *frag_sizes, uint8_t *group_tables,
-                                                    unsigned layouts, hipStream_t stream);
+                                                    unsigned layouts, unsigned fused, hipStream_t stream);
 
 extern "C" int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsigned frame_count,
                                              unsigned max_frags_per_texture, unsigned frag_log2, void *slots,
@@ -510,7 +510,8 @@ extern "C" int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsig
                 once2 = true;
             }
         }
-        const unsigned textures = (granularity_mask >> 8) == 1u ? 1u : 2u;      // bits 8..: textures per frame (0 = unknown)
+        const unsigned textures = ((granularity_mask >> 8) & 0xFFu) == 1u ? 1u : 2u;      // bits 8..15: textures per frame (0 = unknown)
+        const unsigned fused = (granularity_mask >> 16) & 0xFu;                 // bits 16..19: textures made from RGBA on the way
         const dim3 grid(max_frags_per_texture, textures, frame_count), block(64 * kWgWaves);
 #define HAP_LAUNCH_COMPRESS(G)                                                                                                  \
         do {                                                                                                                    \
@@ -522,13 +523,13 @@ extern "C" int hapgpu_launch_snappy_compress(const HapGpuFrameEnc *frames, unsig
                                    (uint8_t *)slots, slot_stride, frag_sizes);                                                  \
         } while (0)
         // block textures: the block-per-lane kernels of snappy_compress_blocks.hip
-        if (granularity_mask & 0xF0u) {
+        if ((granularity_mask & 0xF0u) | fused) {
             if (frag_log2 != 13u)
                 return 1;
             const unsigned layouts = ((granularity_mask & 32u) ? 1u : 0u) | ((granularity_mask & 64u) ? 2u : 0u) |
                                      ((granularity_mask & 16u) ? 4u : 0u) | ((granularity_mask & 128u) ? 8u : 0u);
             if (hapgpu_launch_snappy_compress_blocks(frames, frame_count, max_frags_per_texture, textures, slots, slot_stride,
-                                                     frag_sizes, group_tables, layouts, stream))
+                                                     frag_sizes, group_tables, layouts, fused, stream))
                 return 4;
         }
         if (granularity_mask & 1u)

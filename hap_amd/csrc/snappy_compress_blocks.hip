@@ -36,6 +36,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "hapgpu_abi.h"
+#include "bc_encode_core.hpp"
 
 namespace {
 
@@ -94,6 +95,16 @@ struct __attribute__((packed)) pk_u128 { uint32_t a, b, c, d; };
 __device__ __forceinline__ void put8(gdst_t p, unsigned v) { *p = (uint8_t)v; }
 __device__ __forceinline__ void put16(gdst_t p, unsigned v) { reinterpret_cast<pk_u16 __attribute__((address_space(1))) *>(p)->v = (uint16_t)v; }
 __device__ __forceinline__ void put32(gdst_t p, unsigned v) { reinterpret_cast<pk_u32 __attribute__((address_space(1))) *>(p)->v = v; }
+__device__ __forceinline__ void put64(gdst_t p, uint2 v)
+{
+    pk_u64 __attribute__((address_space(1))) *q = reinterpret_cast<pk_u64 __attribute__((address_space(1))) *>(p);
+    q->a = v.x; q->b = v.y;
+}
+__device__ __forceinline__ void put128(gdst_t p, uint4 v)
+{
+    pk_u128 __attribute__((address_space(1))) *q = reinterpret_cast<pk_u128 __attribute__((address_space(1))) *>(p);
+    q->a = v.x; q->b = v.y; q->c = v.z; q->d = v.w;
+}
 __device__ __forceinline__ uint4 get128(gsrc_t p)
 {
     const pk_u128 __attribute__((address_space(1))) *q = reinterpret_cast<const pk_u128 __attribute__((address_space(1))) *>(p);
@@ -185,7 +196,11 @@ __device__ __forceinline__ unsigned table_slot(unsigned lo, unsigned hi, unsigne
     return (z * 0x9E3779B1u) >> (32u - kTableBits);
 }
 
-template <unsigned LAYOUT>
+// FUSED >= 0: the texture does not exist yet -- the wave makes its fragment's blocks from the frame's RGBA picture
+// itself (bc_encode_core.hpp format FUSED), step by step, hands them to the match phase through a small LDS ring and
+// leaves them at tex.src on the way (chunks that Snappy does not shrink are stored from there).  The RGBA loads of
+// a step are issued a step ahead: a wave is reading pixels while its neighbours on the SIMD are matching or emitting.
+template <unsigned LAYOUT, int FUSED>
 __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpuFrameEnc *__restrict__ frames,
                                                                     uint8_t *__restrict__ slots, unsigned slot_stride,
                                                                     uint32_t *__restrict__ frag_sizes,
@@ -202,7 +217,8 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
     const unsigned tex_count = frames[blockIdx.z].tex_count;
     const unsigned x = blockIdx.x;
     if ((blockIdx.y >= tex_count) | (tex.compressor != 1u) | (((tex.reserved >> 16) & 0xFu) != UL::code) |
-        (x >= tex.chunk_count * tex.frags_per_chunk) | (tex.src == 0) | (tex.chunk_bytes == 0))
+        (x >= tex.chunk_count * tex.frags_per_chunk) | (tex.src == 0) | (tex.chunk_bytes == 0) |
+        (((tex.reserved >> 24) & 7u) != (unsigned)(FUSED + 1)))
         return;
     const unsigned chunk = x / tex.frags_per_chunk, fj = x - chunk * tex.frags_per_chunk;
     const unsigned begin = fj * kFragBytes;
@@ -232,6 +248,50 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
     // load the last unit again (no lane-varying branch around the loads; what they compute is masked out)
     const unsigned last = n - (B == 16u ? 16u : 8u);
 
+    // fused: where the lane's block(s) of step 0 lie in the picture, and the pixels of that step
+    constexpr unsigned kPerUnit = 16u / B;                       // blocks of a unit
+    __shared__ __attribute__((aligned(16))) uint4 ring[FUSED >= 0 ? 68u : 1u];   // the step's units behind the last four of the one before
+    const gsrc_t rgba = (gsrc_t)frames[blockIdx.z].rgba;
+    const unsigned row_bytes = frames[blockIdx.z].rgba_row_bytes, blocks_x = frames[blockIdx.z].rgba_blocks_x;
+    unsigned bx[kPerUnit], by[kPerUnit], first_off = 0u;
+    unsigned pix[2][kPerUnit][16];
+    auto load_pixels = [&](unsigned (&p)[kPerUnit][16], unsigned s) {
+#pragma unroll
+        for (unsigned j = 0; j < kPerUnit; j++) {
+            const bool there = (64u * s + lane) * 16u + (j + 1u) * B <= n;
+            const unsigned at = there ? (4u * by[j]) * row_bytes + 16u * bx[j] : first_off;     // (no lane-varying branch around the loads)
+#pragma unroll
+            for (unsigned r = 0; r < 4u; r++) {
+                const uint4 v = get128(rgba + (at + r * row_bytes));
+                p[j][4u * r] = v.x; p[j][4u * r + 1u] = v.y; p[j][4u * r + 2u] = v.z; p[j][4u * r + 3u] = v.w;
+            }
+        }
+    };
+    auto next_blocks = [&]() {
+#pragma unroll
+        for (unsigned j = 0; j < kPerUnit; j++) {
+            bx[j] += 64u * kPerUnit;
+            while (bx[j] >= blocks_x) {
+                bx[j] -= blocks_x;
+                by[j] += 1u;
+            }
+        }
+    };
+    if (FUSED >= 0) {
+        const unsigned first_block = (unsigned)(((uint64_t)chunk * tex.chunk_bytes + begin) / B);
+        {
+            const unsigned fy = first_block / blocks_x, fx = first_block - fy * blocks_x;
+            first_off = (4u * fy) * row_bytes + 16u * fx;
+        }
+#pragma unroll
+        for (unsigned j = 0; j < kPerUnit; j++) {
+            const unsigned b = first_block + kPerUnit * lane + j;
+            by[j] = b / blocks_x;
+            bx[j] = b - by[j] * blocks_x;
+        }
+        load_pixels(pix[0], 0u);
+    }
+
     // ---- 1. match ----
     uint4 X[kSteps];
     unsigned HD[kSteps];                 // table candidates of the unit's two index fields: distance in blocks, 0 = none
@@ -246,7 +306,40 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
         }
         const unsigned pc = min(pos, last);
         uint4 xs, Y[kDistances];
-        if (B == 16u) {
+        if (FUSED >= 0) {
+            if (s + 1u < kSteps && 64u * (s + 1u) * 16u < n) {
+                next_blocks();
+                load_pixels(pix[(s + 1u) & 1u], s + 1u);
+            }
+            if (B == 16u) {
+                xs = hapbc::block_of<FUSED>(pix[s & 1u][0]);
+                if (pos + 16u <= n)
+                    put128((gdst_t)(uintptr_t)(src + pos), xs);
+            } else {
+                const uint4 lo = hapbc::block_of<FUSED>(pix[s & 1u][0]), hi = hapbc::block_of<FUSED>(pix[s & 1u][kPerUnit - 1u]);
+                xs = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                if (pos + 16u <= n)
+                    put128((gdst_t)(uintptr_t)(src + pos), xs);
+                else if (pos + 8u <= n)
+                    put64((gdst_t)(uintptr_t)(src + pos), make_uint2(lo.x, lo.y));
+            }
+            // the neighbours 1..4 blocks back: through the ring (a wave's LDS accesses complete in order)
+            ring[4u + lane] = xs;
+            __syncthreads();
+            const uint8_t *rb = reinterpret_cast<const uint8_t *>(ring) + (4u + lane) * 16u;
+#pragma unroll
+            for (unsigned d = 0; d < kDistances; d++) {
+                if (B == 16u) {
+                    Y[d] = *reinterpret_cast<const uint4 *>(rb - (d + 1u) * 16u);
+                } else {
+                    const uint2 ylo = *reinterpret_cast<const uint2 *>(rb - (d + 1u) * 8u), yhi = *reinterpret_cast<const uint2 *>(rb - (d + 1u) * 8u + 8u);
+                    Y[d] = make_uint4(ylo.x, ylo.y, yhi.x, yhi.y);
+                }
+            }
+            __syncthreads();
+            if (lane >= 60u)
+                ring[lane - 60u] = xs;
+        } else if (B == 16u) {
             xs = get128(src + pc);
 #pragma unroll
             for (unsigned d = 0; d < kDistances; d++) {
@@ -557,26 +650,36 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
 
 } // namespace
 
-// layouts: bit 0 = [2,6,4,4] textures present, bit 1 = [4,4], bit 2 = [2,6], bit 3 = [4,4,4,4]
+// layouts: bit 0 = [2,6,4,4] textures present, bit 1 = [4,4], bit 2 = [2,6], bit 3 = [4,4,4,4];
+// fused: textures made from the frames' RGBA pictures on the way (HapGpuTexEnc.reserved bits 24..26): bit 0 = scaled
+// YCoCg-DXT5, bit 1 = DXT5, bit 2 = DXT1, bit 3 = RGTC1
 extern "C" int hapgpu_launch_snappy_compress_blocks(const HapGpuFrameEnc *frames, unsigned frame_count,
                                                     unsigned max_frags_per_texture, unsigned textures, void *slots,
                                                     unsigned slot_stride, uint32_t *frag_sizes, uint8_t *group_tables,
-                                                    unsigned layouts, hipStream_t stream)
+                                                    unsigned layouts, unsigned fused, hipStream_t stream)
 {
-    if (frame_count == 0 || max_frags_per_texture == 0 || layouts == 0)
+    if (frame_count == 0 || max_frags_per_texture == 0 || (layouts | fused) == 0)
         return 0;
     const dim3 grid(max_frags_per_texture, textures, frame_count), block(64);
+#define HAP_LAUNCH_BLOCKS(L, F)                                                                                                  \
+    hipLaunchKernelGGL((snappy_compress_blocks_kernel<L, F>), grid, block, 0, stream, frames, (uint8_t *)slots, slot_stride,    \
+                       frag_sizes, group_tables)
+    if (fused & 1u)
+        HAP_LAUNCH_BLOCKS(4u, hapbc::kFmtYCoCg);
+    if (fused & 2u)
+        HAP_LAUNCH_BLOCKS(4u, hapbc::kFmtDXT5);
+    if (fused & 4u)
+        HAP_LAUNCH_BLOCKS(2u, hapbc::kFmtDXT1);
+    if (fused & 8u)
+        HAP_LAUNCH_BLOCKS(6u, hapbc::kFmtRGTC1);
     if (layouts & 1u)
-        hipLaunchKernelGGL((snappy_compress_blocks_kernel<4u>), grid, block, 0, stream, frames, (uint8_t *)slots, slot_stride,
-                           frag_sizes, group_tables);
+        HAP_LAUNCH_BLOCKS(4u, -1);
     if (layouts & 2u)
-        hipLaunchKernelGGL((snappy_compress_blocks_kernel<2u>), grid, block, 0, stream, frames, (uint8_t *)slots, slot_stride,
-                           frag_sizes, group_tables);
+        HAP_LAUNCH_BLOCKS(2u, -1);
     if (layouts & 4u)
-        hipLaunchKernelGGL((snappy_compress_blocks_kernel<6u>), grid, block, 0, stream, frames, (uint8_t *)slots, slot_stride,
-                           frag_sizes, group_tables);
+        HAP_LAUNCH_BLOCKS(6u, -1);
     if (layouts & 8u)
-        hipLaunchKernelGGL((snappy_compress_blocks_kernel<8u>), grid, block, 0, stream, frames, (uint8_t *)slots, slot_stride,
-                           frag_sizes, group_tables);
+        HAP_LAUNCH_BLOCKS(8u, -1);
+#undef HAP_LAUNCH_BLOCKS
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
