@@ -42,6 +42,7 @@ def _load():
         "HapGpuSetFragmentLog2": (u, [vp, u]),
         "HapGpuSynchronize": (u, [vp]),
         "HapGpuTableFallbackCount": (ul, [vp]),
+        "HapGpuPlacementRetryCount": (ul, [vp]),
         "HapGpuCompressRGBA": (u, [vp, vp, u, u, ul, u, vp, ul, P(ul)]),
         "HapGpuDecompressRGBA": (u, [vp, vp, ul, u, vp, ul, u, u, vp, ul]),
         "HapGpuEncodeFrames": (u, [vp, u, u, P(vp), P(ul), P(u), P(u), P(u), P(vp), P(ul), P(ul), P(u), u]),

@@ -258,6 +258,10 @@ class Context:
     def synchronize(self):
         return lib.HapGpuSynchronize(self.handle)
 
+    def placement_retries(self):
+        """frames encoded a second time because one of their chunks did not shrink (HapGpuPlacementRetryCount)"""
+        return int(lib.HapGpuPlacementRetryCount(self.handle))
+
     def table_fallbacks(self):
         """frames decoded a second time because their fragment table did not describe their streams"""
         return int(lib.HapGpuTableFallbackCount(self.handle))

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64) void frame_chunk_sums_kernel(const HapGpuFrameE
     if (tex.compressor == 1u) {
         const uint32_t *fs = frag_sizes + tex.frag_first + (size_t)i * tex.frags_per_chunk;
         for (unsigned k = lane; k < tex.frags_per_chunk; k += 64u)
-            sum += fs[k];
+            sum += fs[k] & ~HAPGPU_FRAG_PUBLISHED;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1)
             sum += __shfl_xor(sum, d);
@@ -126,6 +126,8 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
     unsigned long long sections_total = 0;
     unsigned extra_at = extra_first + blockIdx.x * chunks_per_frame;      // this frame's group table moves
     ChunkPack *pk = packs + (size_t)blockIdx.x * chunks_per_frame;
+    // placed streams (HapGpuTexEnc.reserved bit 27) lie where this kernel's sums put them only if every chunk shrank
+    int not_placed = (frame.reserved & 1u) != 0u && ((frame.tex[0].reserved >> 27) & 1u) != 0u;
 
     for (unsigned t = 0; t < frame.tex_count; t++) {
         const HapGpuTexEnc tex = frame.tex[t];
@@ -190,6 +192,8 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
                     run += tile_total;
                     if (i < n) {
                         const bool raw = csize >= cb;
+                        if (raw && t == 0u && ((tex.reserved >> 27) & 1u))
+                            not_placed = 1;
                         ctab[i] = raw ? (uint8_t)HAP_NIBBLE_NONE : (uint8_t)HAP_NIBBLE_SNAPPY;   // hap.c:465,470
                         put32(stab + 4u * i, (unsigned)stored);                                  // hap.c:472
                         uint8_t *at = payload + off;
@@ -211,6 +215,8 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
                 }
             }
         }
+        if (!complex_frame && t == 0u && tex.compressor == 1u && ((tex.reserved >> 27) & 1u))
+            not_placed = 1;
         if (!complex_frame) {
             // whole texture stored as-is, reference hap.c:490-495
             for (unsigned i = tid; i < n; i += 256u) {
@@ -232,7 +238,11 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
         pk += n;
         __syncthreads();
     }
-    if (tid == 0) {
+    not_placed = __syncthreads_or(not_placed);
+    if (tid == 0 && not_placed) {
+        frame.bytes_used = 0;
+        frame.status = HAPGPU_STATUS_NOT_PLACED;
+    } else if (tid == 0) {
         if (frame.outer_header_len)
             write_section((uint8_t *)frame.dst, frame.outer_header_len, (unsigned)sections_total, HAP_SECTION_MULTI);   // hap.c:598
         frame.bytes_used = frame.outer_header_len + sections_total;
@@ -267,7 +277,7 @@ __global__ __launch_bounds__(64) void frame_moves_kernel(const HapGpuFrameEnc *f
         unsigned len = 0;
         if (k < fpc) {
             if (pk.how == 0u) {
-                len = fs[k];
+                len = fs[k] & ~HAPGPU_FRAG_PUBLISHED;
             } else {
                 len = begin < cb ? min(frag_bytes, cb - begin) : 0u;
                 if (pk.how == 2u && last_chunk && k + 1u == fpc)      // bytes not divisible by the chunk count: keep the tail
@@ -289,7 +299,8 @@ __global__ __launch_bounds__(64) void frame_moves_kernel(const HapGpuFrameEnc *f
             e.reserved = 0;
             e.src = pk.how == 0u ? (uint64_t)(slots + (size_t)f * slot_stride) : (uint64_t)(tsrc + (size_t)i * cb + begin);
             e.dst = pk.dst + at;
-            e.len = len;
+            // (a placed stream is where it belongs already)
+            e.len = (t == 0u && ((tex.reserved >> 27) & 1u) && pk.how == 0u) ? 0u : len;
             copies[f] = e;
             if (pk.itab)
                 put32((uint8_t *)pk.itab + 4u * k, pk.how == 0u ? len : 0u);

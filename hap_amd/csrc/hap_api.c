@@ -39,6 +39,8 @@ unsigned int HapGpuCreate(int device, HapGpuContext **context)
         c->no_half_tiles = getenv("HAP_AMD_NO_HALF_TILES") ? 1u : 0u;
         c->no_block_scan = getenv("HAP_AMD_NO_BLOCK_SCAN") ? 1u : 0u;
         c->no_fusion = getenv("HAP_AMD_NO_FUSION") ? 1u : 0u;
+        c->no_placing = getenv("HAP_AMD_NO_PLACING") ? 1u : 0u;
+        c->placing_min_frames = getenv("HAP_AMD_PLACING_MIN_FRAMES") ? (unsigned)atoi(getenv("HAP_AMD_PLACING_MIN_FRAMES")) : 12u;
         /* RGTC1 planes of large textures go through the [2, 6] field kernel (block-per-lane decodable: 2.9x the decode
            rate at the same size); HAP_AMD_RGTC1_LAYOUT overrides: 0 = position-per-lane compressor, 44 = [4, 4] */
         c->rgtc1_fields = 26u;
@@ -176,6 +178,17 @@ unsigned long HapGpuTableFallbackCount(HapGpuContext *context)
                 n += g_pool[i]->table_fallbacks;
         pthread_mutex_unlock(&g_pool_lock);
     }
+    return n;
+}
+
+unsigned long HapGpuPlacementRetryCount(HapGpuContext *context)
+{
+    unsigned long n;
+    if (!context)
+        return 0;
+    hapgpu_rt_lock(context->rt);
+    n = context->placement_retries;
+    hapgpu_rt_unlock(context->rt);
     return n;
 }
 

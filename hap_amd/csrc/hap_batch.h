@@ -17,9 +17,14 @@ struct HapGpuContext {
     unsigned rgtc1_fields;    /* layout of RGTC1 planes for the block compressor: 26 = [2, 6] (default), 44 = [4, 4], 0 = position lanes (HAP_AMD_RGTC1_LAYOUT) */
     unsigned no_block_scan;   /* HAP_AMD_NO_BLOCK_SCAN: whole-stream units stay whole (A/B runs) */
     unsigned no_fusion;       /* HAP_AMD_NO_FUSION: RGBA calls run the block encoder as a pass of its own (A/B runs) */
+    unsigned placing_min_frames; /* HAP_AMD_PLACING_MIN_FRAMES (default 12): batches below it gather (with most of a frame in flight at
+                                    once its wavefronts wait for each other longer than the gather pass takes) */
+    unsigned no_placing;      /* HAP_AMD_NO_PLACING: compressed fragments go to slots and are gathered (A/B runs; also set
+                                 while a frame whose chunks did not all shrink is encoded again) */
     unsigned no_half_tiles;   /* HAP_AMD_NO_HALF_TILES: fragment table version 1 even for field streams (A/B runs) */
     /* chunk marks collected from the client's HapDecodeCallback, handed to the retry of a frame whose fragment
        table turned out wrong: the callback is invoked exactly once per HapDecode, as in the reference */
+    unsigned long placement_retries; /* frames encoded a second time, through slots (a chunk of theirs was stored raw) */
     unsigned long table_fallbacks;   /* frames decoded again without their fragment table (it did not match) */
     const unsigned char *preset_marks;
     unsigned preset_count;

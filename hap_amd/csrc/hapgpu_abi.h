@@ -64,8 +64,16 @@ typedef struct HapGpuTexEnc {
                                 and length even (lets the decoder move 16 bits per lane);
                                 bits 24..26: 0 = the texture is at src; else the block-per-lane compressor makes it from
                                 the frame's RGBA picture (1 DXT1, 2 DXT5, 3 scaled YCoCg-DXT5, 4 RGTC1 from alpha) and
-                                writes it to src on the way */
+                                writes it to src on the way;
+                                bit 27: "placed": the block-per-lane compressor writes every fragment's stream at its final
+                                place in the frame (the sizes of everything before it: frag_sizes entries with
+                                HAPGPU_FRAG_PUBLISHED set, chunk_acc words of the chunks before) instead of a slot, on the
+                                assumption that every chunk shrinks; the pack kernel reports HAPGPU_STATUS_NOT_PLACED
+                                for a frame where one did not (or a wavefront gave up waiting), and the host encodes that
+                                frame again through slots.  First texture of a frame only. */
 } HapGpuTexEnc;
+#define HAPGPU_FRAG_PUBLISHED 0x80000000u
+#define HAPGPU_STATUS_NOT_PLACED 0x7E50u
 
 /* [device] one frame */
 typedef struct HapGpuFrameEnc {
@@ -82,6 +90,9 @@ typedef struct HapGpuFrameEnc {
     uint64_t rgba;
     uint32_t rgba_row_bytes; /* (the picture is smaller than 4 GiB) */
     uint32_t rgba_blocks_x;  /* width / 4 */
+    /* textures whose reserved bit 27 is set: one 64-bit word per chunk of the frame (zero before the launch), in which
+       the compressor's wavefronts add up fragments << 32 | bytes as they learn their sizes */
+    uint64_t chunk_acc;
 } HapGpuFrameEnc;
 
 /* [device] one byte-range move of the gather pass (one per fragment) */

@@ -213,9 +213,18 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
     __shared__ uint16_t bounds[66];                      // stream offset of every group's first element (+ the end)
 
     const unsigned lane = threadIdx.x;
-    const HapGpuTexEnc tex = frames[blockIdx.z].tex[blockIdx.y < 2u ? blockIdx.y : 0u];
-    const unsigned tex_count = frames[blockIdx.z].tex_count;
-    const unsigned x = blockIdx.x;
+    // Single-texture launches take their frames interleaved: consecutive workgroups work on different frames, so the
+    // fragments of one frame that are in flight together are few -- a placed stream waits for the sizes of everything
+    // before it in its frame, and with a whole frame in flight every wavefront waited for the slowest of 4000.
+#ifdef PLC_NO_INTERLEAVE
+    const unsigned zf = blockIdx.z, x = blockIdx.x;
+#else
+    const unsigned linear = blockIdx.z * gridDim.x + blockIdx.x;
+    const unsigned zf = gridDim.y == 1u ? linear % gridDim.z : blockIdx.z;
+    const unsigned x = gridDim.y == 1u ? linear / gridDim.z : blockIdx.x;
+#endif
+    const HapGpuTexEnc tex = frames[zf].tex[blockIdx.y < 2u ? blockIdx.y : 0u];
+    const unsigned tex_count = frames[zf].tex_count;
     if ((blockIdx.y >= tex_count) | (tex.compressor != 1u) | (((tex.reserved >> 16) & 0xFu) != UL::code) |
         (x >= tex.chunk_count * tex.frags_per_chunk) | (tex.src == 0) | (tex.chunk_bytes == 0) |
         (((tex.reserved >> 24) & 7u) != (unsigned)(FUSED + 1)))
@@ -225,7 +234,8 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
     const unsigned n = min(kFragBytes, tex.chunk_bytes - begin);          // whole blocks (host-checked)
     const gsrc_t src = (gsrc_t)(tex.src + (uint64_t)chunk * tex.chunk_bytes + begin);
     const unsigned f = tex.frag_first + x;
-    const gdst_t out = (gdst_t)((uintptr_t)slots + (size_t)f * slot_stride);
+    gdst_t out = (gdst_t)((uintptr_t)slots + (size_t)f * slot_stride);
+    const bool placed = ((tex.reserved >> 27) & 1u) != 0u && blockIdx.y == 0u;
     const unsigned window = ((tex.reserved >> 8) & 0xFFu) ? ((tex.reserved >> 8) & 0xFFu) * 256u : 0xFFFFFFFFu;
     const bool want_sizes = ((tex.reserved >> 20) & 1u) != 0u && group_tables != nullptr;
 
@@ -251,8 +261,8 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
     // fused: where the lane's block(s) of step 0 lie in the picture, and the pixels of that step
     constexpr unsigned kPerUnit = 16u / B;                       // blocks of a unit
     __shared__ __attribute__((aligned(16))) uint4 ring[FUSED >= 0 ? 68u : 1u];   // the step's units behind the last four of the one before
-    const gsrc_t rgba = (gsrc_t)frames[blockIdx.z].rgba;
-    const unsigned row_bytes = frames[blockIdx.z].rgba_row_bytes, blocks_x = frames[blockIdx.z].rgba_blocks_x;
+    const gsrc_t rgba = (gsrc_t)frames[zf].rgba;
+    const unsigned row_bytes = frames[zf].rgba_row_bytes, blocks_x = frames[zf].rgba_blocks_x;
     unsigned bx[kPerUnit], by[kPerUnit], first_off = 0u;
     unsigned pix[2][kPerUnit][16];
     auto load_pixels = [&](unsigned (&p)[kPerUnit][16], unsigned s) {
@@ -511,8 +521,16 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
         const unsigned base = incl - total;
         *reinterpret_cast<uint4 *>(&masks[lane * 8u]) = make_uint4(S, L, X3, D0);
         *reinterpret_cast<uint4 *>(&masks[lane * 8u + 4u]) = make_uint4(D1, Hm, Sx1, base | (((both >> 16) - count) << 16));
-        if (lane == 63u)
-            frag_sizes[f] = incl;
+        if (lane == 63u) {
+            if (placed) {
+                // the size is out before the bytes are: whoever comes later in the frame can place itself.  (Relaxed,
+                // device scope: nobody reads anything else this wave wrote; an acquire / release pair at this scope
+                // writes back and invalidates a whole L2 every time -- 12 times the kernel's duration)
+                __hip_atomic_store(&frag_sizes[f], incl | HAPGPU_FRAG_PUBLISHED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                frag_sizes[f] = incl;
+            }
+        }
         counts_and_bytes = both;
         // the elements in stream order, for the lanes of phase 3b: element (first ordinal of the half-tile + j) is the
         // j-th set bit of S -- a loop over the busiest half-tile's elements, five instructions a turn (finding the r-th
@@ -531,6 +549,91 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
         }
     }
     __syncthreads();
+
+    // ---- placed streams: where the fragment's bytes go in the frame ----
+    // payload of the texture's section + a varint per chunk up to this one + the bytes of every fragment before this
+    // one: whole chunks from their accumulators (complete when they have counted all their fragments), the fragments
+    // of this chunk from their published sizes.  Everything waited for belongs to wavefronts dispatched earlier.
+    if (placed) {
+        const unsigned long long *acc = reinterpret_cast<const unsigned long long *>(frames[zf].chunk_acc);
+        const uint32_t *mine = frag_sizes + tex.frag_first + chunk * tex.frags_per_chunk;
+        unsigned long long sum = 0;
+        unsigned in_chunk = 0;
+        unsigned tries = 0;
+        bool settled = true;
+        // (group after group of 64 words, oldest first, each polled on its own until it is complete: what is waited for
+        // is almost always the nearest neighbours only.  These loads are served by the memory side and their number is
+        // what counts: fetching five groups at once "to save latency" made the kernel 17 % slower)
+#ifndef PLC_ABL
+#define PLC_ABL 0
+#endif
+        for (unsigned c0 = 0; c0 < chunk && settled && PLC_ABL != 3; c0 += 64u) {
+            const unsigned c = c0 + lane;
+            for (;;) {
+                const unsigned long long v = c < chunk ? __hip_atomic_load(&acc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                       : (1ull << 32);
+                if (PLC_ABL == 1 || __builtin_amdgcn_ballot_w64((unsigned)(v >> 32) == 0u) == 0ull) {
+                    sum += v & 0xFFFFFFFFull;
+                    settled = PLC_ABL == 1 || __builtin_amdgcn_ballot_w64((unsigned)(v >> 32) != 1u) == 0ull;      // (2: a chunk that gave up)
+                    break;
+                }
+                if (++tries > (1u << 18)) {
+                    settled = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(16);
+            }
+        }
+        for (unsigned k0 = 0; k0 < fj && settled && PLC_ABL != 3; k0 += 64u) {
+            const unsigned k = k0 + lane;
+            for (;;) {
+                const unsigned v = k < fj ? __hip_atomic_load(&mine[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : HAPGPU_FRAG_PUBLISHED;
+                if (PLC_ABL == 1 || __builtin_amdgcn_ballot_w64((v & HAPGPU_FRAG_PUBLISHED) == 0u) == 0ull) {
+                    in_chunk += v & ~HAPGPU_FRAG_PUBLISHED;
+                    break;
+                }
+                if (++tries > (1u << 18)) {
+                    settled = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(16);
+            }
+        }
+        const unsigned own_bytes = (unsigned)__builtin_amdgcn_readlane((int)counts_and_bytes, 63) & 0xFFFFu;
+        if (settled) {
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                sum += __shfl_xor(sum, d);
+                in_chunk += __shfl_xor(in_chunk, d);
+            }
+            // the chunk's last fragment has just added up the whole chunk: its total, for the chunks behind
+            // (plain stores and loads only: read-modify-writes from every wavefront on a few words were served one
+            // after the other, 60 ns each)
+            if (fj + 1u == tex.frags_per_chunk && lane == 0u)
+                __hip_atomic_store(const_cast<unsigned long long *>(&acc[chunk]), (1ull << 32) | (in_chunk + own_bytes), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            sum += in_chunk;
+            const unsigned n_chunks = tex.chunk_count, fpc = tex.frags_per_chunk;
+            const bool with_tiles = tex.emit_index && want_sizes;
+            const unsigned index_len = tex.emit_index ? 8u + (with_tiles ? 4u + HAP_GROUP_TABLE_BYTES : 4u) * n_chunks * fpc : 0u;
+            const unsigned cb = tex.chunk_bytes;
+            const unsigned vlen = cb < (1u << 7) ? 1u : cb < (1u << 14) ? 2u : cb < (1u << 21) ? 3u : cb < (1u << 28) ? 4u : 5u;
+            const unsigned long long at = frames[zf].dst + frames[zf].outer_header_len + tex.header_len + 4u +
+                                          (5u * n_chunks + 8u + index_len) + (unsigned long long)vlen * (chunk + 1u) + sum;
+            const unsigned at_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)at);
+            const unsigned at_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(at >> 32));
+            if (PLC_ABL == 0)
+                out = (gdst_t)(uintptr_t)(((unsigned long long)at_hi << 32) | at_lo);
+            else if (at_hi == 0x12345u && at_lo == 77u)      // (measurement builds: the sums stay live, the bytes go to the slot)
+                out += 1;
+        } else if (lane == 0u) {
+            // (never seen; a frame with such a fragment is encoded again through slots, and the chunks behind it need
+            // not wait for the total)
+            __hip_atomic_fetch_or(const_cast<uint32_t *>(&frames[zf].reserved), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (fj + 1u == tex.frags_per_chunk)
+                __hip_atomic_store(const_cast<unsigned long long *>(&acc[chunk]), 2ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 
     // ---- 3a. emit the literal bytes: lane = unit ----
     // popcounts of the masks below the unit give its output offset; a field that is part of a literal run stores its

@@ -107,6 +107,12 @@ unsigned int HapGpuSynchronize(HapGpuContext *context);
  * block start: table and scan are only ever hints, results are the same either way.  For tests and tools. */
 unsigned long HapGpuTableFallbackCount(HapGpuContext *context);
 
+/* Number of frames this context has encoded a second time: the block compressor writes a frame's compressed fragments
+ * straight to their final places on the assumption that every chunk shrinks; a frame with a chunk that did not (stored
+ * uncompressed, reference hap.c:460-466) is encoded again with the fragments gathered afterwards.  Same bytes either
+ * way.  For tests and tools. */
+unsigned long HapGpuPlacementRetryCount(HapGpuContext *context);
+
 /* RGBA8 (row-major, rowBytes stride, width/height multiples of 4) -> block
  * compressed texture.  textureFormat is one of RGB_DXT1, RGBA_DXT5,
  * YCoCg_DXT5, A_RGTC1 (A_RGTC1 compresses the alpha channel).  rgba and

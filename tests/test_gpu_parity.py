@@ -816,6 +816,105 @@ def test_frames_decode_to_pictures_in_one_call(ctx, hap):
     assert ctx.decode_frames_rgba([], [], 1, [], w, h)[0] == 0
 
 
+def _context_with(hap, **env):
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return hap.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def test_fragments_placed_by_the_compressor_give_the_same_frames(hap):
+    """The block compressor writes a frame's compressed fragments straight to their final places (batches of a dozen
+    frames and more; here forced for every batch) instead of slots that a gather pass empties: byte for byte the same
+    frames, from RGBA pictures (blocks made on the way, and as a pass of their own) and from textures, every block
+    layout, with and without the private table, frames in HBM and on the host; the reference decodes them."""
+    from hap_amd import synth
+    placed = _context_with(hap, HAP_AMD_PLACING_MIN_FRAMES="1")
+    gathered = _context_with(hap, HAP_AMD_NO_PLACING="1")
+    unfused = _context_with(hap, HAP_AMD_PLACING_MIN_FRAMES="1", HAP_AMD_NO_FUSION="1")
+    w, h, nf = 1024, 512, 5
+    nb = (w // 4) * (h // 4)
+    rgba = [synth.rgba_frame(w, h, 40 + i, device="cuda") for i in range(nf)]
+    torch.cuda.synchronize()
+    r0 = placed.placement_retries()
+    for fmt, chunks, flags in ((L.FMT_YCOCG, 7, hap.ENCODE_FRAGMENT_INDEX), (L.FMT_YCOCG, 1, 0), (L.FMT_DXT5, 3, hap.ENCODE_FRAGMENT_INDEX),
+                               (L.FMT_DXT1, 5, hap.ENCODE_FRAGMENT_INDEX), (L.FMT_DXT1, 2, 0), (L.FMT_RGTC1, 3, hap.ENCODE_FRAGMENT_INDEX)):
+        size = nb * (8 if fmt in (L.FMT_DXT1, L.FMT_RGTC1) else 16)
+        cap = hap.HapMaxEncodedLength([size], [fmt], [chunks])
+        frames = {}
+        for name, c in (("placed", placed), ("gathered", gathered), ("unfused", unfused)):
+            outs = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(nf)]
+            torch.cuda.synchronize()
+            r, used, res = c.encode_frames_rgba(rgba, w, h, w * 4, [fmt], [1], [chunks], outs, flags=flags)
+            assert r == 0 and res == [0] * nf, (name, fmt)
+            frames[name] = [o[:u].cpu().numpy().tobytes() for o, u in zip(outs, used)]
+        assert frames["placed"] == frames["gathered"] and frames["unfused"] == frames["gathered"], (fmt, chunks)
+        tex = [D.oracle_bc_encode(rgba[i].cpu().numpy(), fmt) for i in range(nf)]
+        for i in (0, nf - 1):
+            assert REF.decode(frames["placed"][i], 0, size) == (0, tex[i], fmt)
+        # from textures, into host buffers
+        houts = [np.zeros(cap, dtype=np.uint8) for _ in range(nf)]
+        r, used, res = placed.encode_frames([[t] for t in tex], [fmt], [1], [chunks], houts, flags=flags)
+        assert r == 0 and res == [0] * nf
+        assert [o[:u].tobytes() for o, u in zip(houts, used)] == frames["gathered"]
+    # opaque 16-byte blocks under the size-for-speed option (layout [4,4,4,4])
+    tex7 = [np.frombuffer(D.oracle_bc_encode(rgba[i].cpu().numpy(), L.FMT_YCOCG), dtype=np.uint8).copy() for i in range(nf)]
+    cap = hap.HapMaxEncodedLength([nb * 16], [L.FMT_BC7], [4])
+    got = {}
+    for name, c in (("placed", placed), ("gathered", gathered)):
+        houts = [np.zeros(cap, dtype=np.uint8) for _ in range(nf)]
+        r, used, res = c.encode_frames([[t] for t in tex7], [L.FMT_BC7], [1], [4], houts,
+                                       flags=hap.ENCODE_FRAGMENT_INDEX | hap.ENCODE_COARSE_MATCHES)
+        assert r == 0 and res == [0] * nf
+        got[name] = [o[:u].tobytes() for o, u in zip(houts, used)]
+    assert got["placed"] == got["gathered"]
+    assert placed.placement_retries() == r0          # every chunk shrank: nothing was encoded twice
+    for c in (placed, gathered, unfused):
+        c.close()
+
+
+def test_a_chunk_that_does_not_shrink_sends_its_frame_through_slots(hap):
+    """A chunk that Snappy does not shrink is stored as it is (reference hap.c:460-466) and everything behind it lies
+    elsewhere than the placing wavefronts assumed: such frames are encoded a second time, through slots -- same bytes as
+    without placing, counted by HapGpuPlacementRetryCount, the other frames of the batch untouched."""
+    placed = _context_with(hap, HAP_AMD_PLACING_MIN_FRAMES="1")
+    gathered = _context_with(hap, HAP_AMD_NO_PLACING="1")
+    w, h = 1024, 256
+    size = (w // 4) * (h // 4) * 16
+    rng = np.random.RandomState(11)
+    flat = D.oracle_bc_encode(D.rgba(w, h, frame=3), L.FMT_YCOCG)
+    noise = rng.randint(0, 256, size, dtype=np.uint8).tobytes()
+    half = flat[: size // 2] + noise[size // 2:]                 # chunks 0, 1 shrink, chunks 2, 3 do not
+    tail = noise[: size // 4] + flat[size // 4:]                 # the first chunk does not
+    textures = [flat, half, noise, tail, flat]
+    for fmt, chunks, flags in ((L.FMT_YCOCG, 4, hap.ENCODE_FRAGMENT_INDEX), (L.FMT_DXT5, 4, 0), (L.FMT_YCOCG, 1, 0)):
+        cap = hap.HapMaxEncodedLength([size], [fmt], [chunks])
+        got = {}
+        r0 = placed.placement_retries()
+        for name, c in (("placed", placed), ("gathered", gathered)):
+            douts = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in textures]
+            dtex = [torch.from_numpy(np.frombuffer(t, dtype=np.uint8).copy()).cuda() for t in textures]
+            torch.cuda.synchronize()
+            r, used, res = c.encode_frames([[t] for t in dtex], [fmt], [1], [chunks], douts, flags=flags)
+            assert r == 0 and res == [0] * len(textures), name
+            got[name] = [o[:u].cpu().numpy().tobytes() for o, u in zip(douts, used)]
+        assert got["placed"] == got["gathered"]
+        # 4 chunks: half, noise and tail have one that does not shrink; one chunk: only the noise does not (and is stored
+        # as a plain section, hap.c:478-495)
+        assert placed.placement_retries() - r0 == (3 if chunks == 4 else 1)
+        for t, frame in zip(textures, got["placed"]):
+            assert REF.decode(frame, 0, size) == (0, t, fmt)
+    placed.close()
+    gathered.close()
+
+
 def test_encode_is_deterministic_and_batch_independent(ctx, hap):
     """G5 stand-in on one GPU: a frame's bytes do not depend on run, batch size or position in the batch
     (round-synchronous hash inserts with LDS atomicMax make the compressor timing-independent), so
