@@ -197,6 +197,8 @@ class Stream:
         bsum = sum(self.tex_bytes)
         frame_bytes = sum(self.used) / max(nf, 1)
         per_step = {"block_encode": nf * blocks * (64 + sum(BLOCK_BYTES[f] for f in self.fmts)),
+                    # RGBA -> compressed fragments in one kernel: SURVEY 8d "fused encode", 64 + c b per block
+                    "encode_fused": nf * (blocks * 64 + frame_bytes),
                     "snappy_compress": nf * (bsum + frame_bytes),
                     "frame_gather": nf * 2 * frame_bytes,
                     "snappy_decode": nf * (frame_bytes + bsum)}
@@ -326,6 +328,11 @@ def main():
         line["texture_to_rgba"] = None if args.no_extras else texture_to_rgba(stream, dev)
         line["coarse_matches_option"] = None if args.no_extras else coarse_option(stream, hap_amd)
         line["smaller_files_option"] = None if args.no_extras else smaller_option(stream, hap_amd)
+        if not args.no_extras:
+            try:
+                line["separate_passes"] = separate_passes(hap_amd, stream, local_rank, args.config, fence)
+            except Exception as exc:
+                line["separate_passes"] = {"error": repr(exc)}
         stream.used = stream.encode()
         stream.decode(stream.used)
         line["bit_exact"] = stream.bit_exact()
@@ -476,6 +483,38 @@ def frames_to_rgba(hap_amd, stream, dev):
         same = same and bool(torch.equal(two_step, pics[i]))
     return {"frames": nf, "ms": round(ms, 3), "fps": round(nf / (ms * 1e-3), 1),
             "rgba_GBps": round(nf * stream.rgba_bytes / (ms * 1e-3) / 1e9, 1), "same_as_two_steps": same}
+
+
+def separate_passes(hap_amd, stream, device_index, config, fence, steps=6):
+    """The same step with the block encoder as a pass of its own, the compressor reading the texture it wrote and a gather
+    pass placing the fragments (a context made under HAP_AMD_NO_FUSION / HAP_AMD_NO_PLACING: what the calls that start
+    from textures, two-texture frames and small batches run): reported beside the default, never `value`.  Carries the
+    block encoder's own roofline (64 + b bytes per block)."""
+    keys = ("HAP_AMD_NO_FUSION", "HAP_AMD_NO_PLACING")
+    old = {k: os.environ.get(k) for k in keys}
+    for k in keys:
+        os.environ[k] = "1"
+    try:
+        ctx2 = hap_amd.Context(device_index)
+    finally:
+        for k in keys:
+            if old[k] is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = old[k]
+    ctx1, stream.ctx = stream.ctx, ctx2
+    try:
+        elapsed, prof = stream.timed(steps, 2, fence)
+        kernels, _ratio = stream.kernel_table(prof, steps, config)
+        # (traffic: this round's PMC passes over the same command under the same two variables, tools/prof_bench.sh <cfg> <n> sep)
+        roof = stream.roofline(kernels, config + "sep", kernel="block_encode") if "block_encode" in kernels else None
+        same = stream.bit_exact()
+    finally:
+        stream.ctx = ctx1
+        ctx2.close()
+    ms = elapsed / steps * 1e3
+    return {"rgba_GBps": round(stream.nf * stream.rgba_bytes / (ms * 1e-3) / 1e9, 2), "ms_per_step": round(ms, 3), "bit_exact": same,
+            "kernels_ms": {k: v["ms_avg"] for k, v in kernels.items()}, "roofline": roof}
 
 
 def coarse_option(stream, hap_amd):

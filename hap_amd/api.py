@@ -33,7 +33,7 @@ DECODE_IGNORE_FRAGMENT_INDEX = 0x1
 DECODE_IGNORE_HALF_TILES = 0x2
 DECODE_NO_BLOCK_SCAN = 0x4
 KERNEL_CLASSES = ["block_encode", "snappy_compress", "frame_pack", "frame_gather", "decode_plan", "snappy_decode",
-                  "block_decode", "block_scan"]
+                  "block_decode", "block_scan", "encode_fused"]
 
 
 def _addr_len(buf):

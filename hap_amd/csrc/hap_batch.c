@@ -64,6 +64,7 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
     unsigned slot_stride;
     int any_snappy = 0;
     unsigned gran_mask = 0;
+    size_t placed_extent = 0;
     unsigned placed = 0u;                            /* texture 0's fragments are written where they belong in the frame (bit 27) */
     uint64_t *dacc = NULL;
     unsigned fused[2] = {0u, 0u}, fused_mask = 0u;   /* textures the second stage makes from the RGBA itself (code: reserved bits 24..26) */
@@ -221,6 +222,17 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
        its wavefronts learn the sizes of what lies before them from each other (snappy_compress_blocks.hip) */
     placed = (!ctx->no_placing && count == 1u && g[0].compressor == HapCompressorSnappy && g[0].field_period != 0u && frag_log2 == 13u) ? 1u : 0u;
     slot_stride = (unsigned)align_up(frag_bytes + frag_bytes / 32u + 64u + HAPGPU_SLOT_SCRATCH_BYTES, 16);
+    /* how far placed fragments can reach into the frame buffer if nothing shrinks (the frame is then encoded again, but
+       the bytes have been written): the chunked layout's headers and tables + every fragment at its largest (what a slot
+       holds).  The bound hap.h asks of the client's buffer covers it except for chunks of a few hundred bytes with the
+       private table requested; buffers that do not are served through slots. */
+    if (placed) {
+        const size_t frags = (size_t)g[0].chunk_count * g[0].fpc;
+        size_t ilen = hapf_instructions_length(g[0].chunk_count);
+        if (flags & HAPGPU_ENCODE_FRAGMENT_INDEX)
+            ilen += 8u + (g[0].half_tiles ? 4u + HAP_GROUP_TABLE_BYTES : 4u) * frags;
+        placed_extent = outer_header + 8u + 4u + ilen + 5u * (size_t)g[0].chunk_count + g[0].bytes + frags * (frag_bytes / 32u + 64u);
+    }
 
     /* per-frame checks; frames that fail are left out of the launch */
     live_index = (unsigned *)malloc(sizeof(unsigned) * frame_count);
@@ -259,6 +271,8 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
                 continue;
             }
             live_index[live++] = f;
+            if (output_bytes[f] < placed_extent)
+                placed = 0u;
             if (!inputs_are_device) {
                 int staged = 0;
                 for (i = 0; i < count; i++)
@@ -273,7 +287,7 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
                 stage_off_out[f] = out_total + 1;
                 /* (+8 per texture: a section written in the chunked form may exceed header + bytes by up to
                    header_len - 1 bytes, see the comparison in frame_pack_kernel / hap.c:478) */
-                out_total += align_up(frame_raw_bound + 8u * count, 256);
+                out_total += align_up(frame_raw_bound + 8u * count > placed_extent ? frame_raw_bound + 8u * count : placed_extent, 256);
             }
         }
         stage_in_bytes = in_total;

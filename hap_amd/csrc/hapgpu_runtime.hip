@@ -537,7 +537,7 @@ extern "C" int hapgpu_k_snappy_compress(hapgpu_rt *rt, const HapGpuFrameEnc *fra
                                         unsigned slot_stride, uint32_t *frag_sizes, uint8_t *group_tables,
                                         unsigned granularity_mask)
 {
-    scoped_timing st(rt, 1);
+    scoped_timing st(rt, ((granularity_mask >> 16) & 0xFu) ? 8 : 1);      // (8: the block encoder runs inside, HapGpuKernel_EncodeFused)
     return hapgpu_launch_snappy_compress(frames, frame_count, max_frags_per_texture, frag_log2, slots, slot_stride,
                                          frag_sizes, group_tables, granularity_mask, rt->stream);
 }

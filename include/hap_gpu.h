@@ -285,7 +285,8 @@ enum HapGpuKernelClass {
     HapGpuKernel_SnappyDecode = 5,
     HapGpuKernel_BlockDecode = 6,
     HapGpuKernel_BlockScan = 7,       /* finding the 64 KiB blocks of other encoders' Snappy streams */
-    HapGpuKernel_ClassCount = 8
+    HapGpuKernel_EncodeFused = 8,     /* RGBA -> blocks -> Snappy fragments in one kernel (the calls that start from pictures) */
+    HapGpuKernel_ClassCount = 9
 };
 
 /* enable != 0: record a start/stop event pair around every kernel launch. */

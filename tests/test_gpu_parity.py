@@ -911,6 +911,27 @@ def test_a_chunk_that_does_not_shrink_sends_its_frame_through_slots(hap):
         assert placed.placement_retries() - r0 == (3 if chunks == 4 else 1)
         for t, frame in zip(textures, got["placed"]):
             assert REF.decode(frame, 0, size) == (0, t, fmt)
+        # frames that go to host buffers are staged in HBM: the staging of a frame must hold what its wavefronts write
+        # before the frame turns out not to shrink (it once held the stored-as-is size only: the frame behind was damaged)
+        houts = [np.zeros(cap, dtype=np.uint8) for _ in textures]
+        r, used, res = placed.encode_frames([[t] for t in textures], [fmt], [1], [chunks], houts, flags=flags)
+        assert r == 0 and res == [0] * len(textures)
+        assert [o[:u].tobytes() for o, u in zip(houts, used)] == got["gathered"]
+    # chunks of a few hundred bytes with the private table: the client's buffer (HapMaxEncodedLength) is smaller than
+    # what placed fragments could reach if nothing shrank -- such calls go through slots, same frames
+    small = [noise[:2048], flat[:2048], noise[2048:4096]]
+    cap = hap.HapMaxEncodedLength([2048], [L.FMT_YCOCG], [16])
+    got = {}
+    r0 = placed.placement_retries()
+    for name, c in (("placed", placed), ("gathered", gathered)):
+        douts = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in small]
+        torch.cuda.synchronize()
+        r, used, res = c.encode_frames([[t] for t in small], [L.FMT_YCOCG], [1], [16], douts, flags=hap.ENCODE_FRAGMENT_INDEX)
+        assert r == 0 and res == [0] * len(small)
+        got[name] = [o[:u].cpu().numpy().tobytes() for o, u in zip(douts, used)]
+    assert got["placed"] == got["gathered"] and placed.placement_retries() == r0
+    for t, frame in zip(small, got["placed"]):
+        assert REF.decode(frame, 0, 2048) == (0, t, L.FMT_YCOCG)
     placed.close()
     gathered.close()
 

@@ -4,7 +4,7 @@ import json, os, shutil, subprocess, sys
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ev, prof = os.path.join(root, "gpurun_out", "evidence"), os.path.join(root, "profiles")
-for cfg, frames in (("c4", 30), ("c5", 4), ("c2", 60), ("c3", 60)):
+for cfg, frames in (("c4", 30), ("c4sep", 30), ("c5", 4), ("c2", 60), ("c3", 60)):
     if not os.path.isdir(os.path.join(ev, cfg)):
         continue
     src = os.path.join(ev, cfg)

@@ -6,10 +6,13 @@ export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 CFG=${1:-C4}; FRAMES=${2:-30}
 tag=$(echo $CFG | tr A-Z a-z)
+# third argument "sep": the same command with the block encoder as a pass of its own and the fragments gathered
+# (HAP_AMD_NO_FUSION / HAP_AMD_NO_PLACING) -> gpurun_out/prof_<cfg>sep
+if [ "$3" = sep ]; then export HAP_AMD_NO_FUSION=1 HAP_AMD_NO_PLACING=1; tag=${tag}sep; fi
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 rm -rf $OUT; mkdir -p $OUT
 CMD="python bench.py --config $CFG --steps 2 --warmup 1 --frames $FRAMES --no-extras"
-echo "$CMD" > $OUT/command.txt
+echo "${3:+HAP_AMD_NO_FUSION=1 HAP_AMD_NO_PLACING=1 }$CMD" > $OUT/command.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb_trace -o r -- $CMD > $OUT/bench_trace.json 2> /tmp/pb_trace.err
 cp $(find /tmp/pb_trace -name "*kernel_stats.csv") $OUT/kernel_stats.csv
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d /tmp/pb_pmc1 -o r -- $CMD > /dev/null 2> /tmp/pb_pmc1.err

@@ -48,8 +48,34 @@ while time.time() - t0 < budget:
         decs = [np.zeros(n, dtype=np.uint8) for _ in range(nf)]
         r, du, df, dr = ctx.decode_frames(foreign, [len(e) for e in foreign], 0, decs)
         ok = r == 0 and all(decs[i].tobytes() == texs[i] for i in range(nf))
+    # pictures: blocks made inside the compressor (DXT5 / YCoCg), or by the block encoder's own pass; noise pictures
+    # give chunks that do not shrink (frames encoded again through slots when the fragments were placed)
+    if ok and rng.integers(0, 3) == 0:
+        pf = [L.FMT_DXT1, L.FMT_DXT5, L.FMT_YCOCG][int(rng.integers(0, 3))]
+        w, h = 4 * int(rng.integers(1, 160)), 4 * int(rng.integers(1, 120))
+        pics = []
+        for i in range(nf):
+            if rng.integers(0, 3) == 0:
+                pics.append(rng.integers(0, 256, (h, w, 4), dtype=np.uint8))
+            else:
+                pics.append(D.rgba(w, h, frame=int(rng.integers(0, 1000))))
+        ptex = [D.oracle_bc_encode(p, pf) for p in pics]
+        pn = len(ptex[0])
+        pcap = hap_amd.HapMaxEncodedLength([pn], [pf], [chunks]) + 4096
+        pouts = [np.zeros(pcap, dtype=np.uint8) for _ in range(nf)]
+        r, used, res = ctx.encode_frames_rgba([np.ascontiguousarray(p).reshape(-1) for p in pics], w, h, w * 4, [pf], [1], [chunks], pouts, flags=flags & hap_amd.ENCODE_FRAGMENT_INDEX)
+        ok = r == 0 and all(x == 0 for x in res)
+        if ok:
+            pe = [pouts[i][: used[i]].tobytes() for i in range(nf)]
+            ok = all(ORA.decode(pe[i], 0, pn) == (0, ptex[i], pf) for i in range(nf))
+            decs = [np.zeros(pn, dtype=np.uint8) for _ in range(nf)]
+            r, du, df, dr = ctx.decode_frames(pe, [len(e) for e in pe], 0, decs)
+            ok = ok and r == 0 and all(decs[i].tobytes() == ptex[i] for i in range(nf))
+        if not ok:
+            print("  (pictures %dx%d fmt %#x)" % (w, h, pf))
     rounds += 1; frames += nf
     if not ok:
         fails += 1
         print("FAIL round", rounds, "fmt", hex(fmt), "blocks", nblocks, "chunks", chunks, "frames", nf, "flags", flags)
-print("stress: %d rounds, %d frames, %d failures, fallbacks %d, %.0f s" % (rounds, frames, fails, ctx.table_fallbacks(), time.time() - t0))
+print("stress: %d rounds, %d frames, %d failures, fallbacks %d, placement retries %d, %.0f s" % (
+    rounds, frames, fails, ctx.table_fallbacks(), ctx.placement_retries(), time.time() - t0))

@@ -6,7 +6,11 @@ the kernels of the class (one launch of the class = one launch of each).  FETCH_
 import json, re, sys
 src, cfg, frames = sys.argv[1], sys.argv[2], int(sys.argv[3])
 rnd = sys.argv[4] if len(sys.argv) > 4 else "r03"
-classes = {"block_encode": ["bc_encode"], "snappy_compress": ["snappy_compress"], "frame_pack": ["frame_chunk_sums", "frame_pack", "frame_moves"],
+# (regular expressions over the kernel names; the block compressor with the block encoder inside -- second template
+# argument 0..3 -- is bench.py's class "encode_fused")
+FUSED = r"snappy_compress_blocks_kernel<\d+u?, ?[0-3]>"
+classes = {"block_encode": ["bc_encode"], "snappy_compress": [r"snappy_compress(?!_blocks_kernel<\d+u?, ?[0-3]>)"], "encode_fused": [FUSED],
+           "frame_pack": ["frame_chunk_sums", "frame_pack", "frame_moves"],
            "frame_gather": ["frame_gather"], "decode_plan": ["decode_plan", "decode_expand"], "snappy_decode": ["snappy_decode"]}
 cur, vals = None, {}
 for line in open(src + "/traffic_summary.txt"):
@@ -22,8 +26,8 @@ out = {"config": cfg, "frames_per_launch": frames, "command": open(src + "/comma
 # launches of each class per step, from the bench line of the same command (C5 decodes two textures: two launches)
 line = json.loads([x for x in open(src + "/bench_traffic.json") if x.startswith("{")][-1])
 for cls, pats in classes.items():
-    f = sum(v.get("FETCH_SIZE", 0) for k, v in vals.items() if any(p in k for p in pats))
-    w = sum(v.get("WRITE_SIZE", 0) for k, v in vals.items() if any(p in k for p in pats))
+    f = sum(v.get("FETCH_SIZE", 0) for k, v in vals.items() if any(re.search(p, k) for p in pats))
+    w = sum(v.get("WRITE_SIZE", 0) for k, v in vals.items() if any(re.search(p, k) for p in pats))
     per_step = max(1, round(line["kernels"].get(cls, {}).get("launches", line["steps"]) / line["steps"]))
     if f or w:
         out["kernels"][cls] = {"fetch_kib": round(f / per_step, 1), "write_kib": round(w / per_step, 1), "launches_per_step": per_step}
