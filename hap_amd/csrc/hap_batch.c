@@ -28,6 +28,14 @@ enum {
 #define P_SCAN P_FRAMES
 enum { P_FRAMES = 0, P_JOBS, P_CHUNKS, P_PREFIX, P_PTRS, P_BC_PTRS, P_PREFIX2 };   /* (8, 9: hap_sequence.c) */
 
+#ifdef HAPB_TRACE
+#include <stdio.h>
+#include <time.h>
+static double hapb_now_us(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+#define HAPB_MARK(name) do { double t_ = hapb_now_us(); fprintf(stderr, "  [decode %u] %-10s +%.1f us\n", frame_count, name, t_ - hapb_t0); hapb_t0 = t_; } while (0)
+#else
+#define HAPB_MARK(name) do { } while (0)
+#endif
 #define PREFIX_BYTES 2048u   /* headers + tables of a frame with up to ~400 chunks; larger ones are fetched on demand */
 #define COPY_PIECE 65536u
 
@@ -831,6 +839,9 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     unsigned client_marks_count = 0;
     int rc = 0;
 
+#ifdef HAPB_TRACE
+    double hapb_t0 = hapb_now_us();
+#endif
     ctx->decode_indices = NULL;
     if (frame_count == 0)
         return HapResult_No_Error;
@@ -948,6 +959,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
         }
     }
 
+    HAPB_MARK("prefixes");
     /* 2. plan on the host: sections and tables only (hap_frame.c) */
     for (f = 0; f < frame_count; f++) {
         hapf_texture_plan *p = &plans[f];
@@ -1149,6 +1161,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
             }
             unit_cursor += units;
         }
+        HAPB_MARK("host plan");
         rc |= hapgpu_rt_h2d(rt, djobs, hjobs, sizeof(HapGpuDecodeJob) * live);
         if (total_chunks)
             rc |= hapgpu_rt_h2d(rt, dchunks, hchunks, sizeof(HapGpuChunkIn) * total_chunks);
@@ -1219,7 +1232,9 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                                      any_stream ? (scan_chunks ? 2 : 1) : 0,
                                      (scan_chunks && scan_cursor == scan_chunks && fine_total) ? dwork : NULL, fine_total);
         rc |= hapgpu_rt_d2h(rt, hjobs, djobs, sizeof(HapGpuDecodeJob) * live);
+        HAPB_MARK("launched");
         rc |= hapgpu_rt_sync(rt);
+        HAPB_MARK("completed");
         if (rc)
             goto fail_alloc;
     }
@@ -1274,6 +1289,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     }
 
 finish:
+    HAPB_MARK("results");
     for (f = 0; f < frame_count; f++) {
         if (results[f] != HapResult_No_Error && first_error == HapResult_No_Error)
             first_error = results[f];

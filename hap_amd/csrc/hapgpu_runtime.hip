@@ -227,9 +227,53 @@ extern "C" void *hapgpu_rt_pinned_scratch(hapgpu_rt *rt, int slot, size_t bytes)
     return rt->pin[slot];
 }
 
+// Small transfers between the pinned scratch and device memory as a kernel on the stream's own queue: descriptors going
+// up and result words coming back are a few KiB each, and as copies they travel through the DMA engines -- every one of
+// them a hand-over between engines in front of and behind the kernels (HAP_AMD_COPY_KERNELS=0 keeps hipMemcpyAsync).
+__global__ __launch_bounds__(256) void small_copy_kernel(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, size_t bytes)
+{
+    const size_t i = ((size_t)blockIdx.x * 256u + threadIdx.x) * 16u;
+    if (i + 16u <= bytes && (((uintptr_t)dst | (uintptr_t)src) & 15u) == 0) {
+        *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(src + i);
+    } else if (i < bytes) {
+        const size_t n = bytes - i < 16u ? bytes - i : 16u;
+        for (size_t k = 0; k < n; k++)
+            dst[i + k] = src[i + k];
+    }
+}
+
+static bool in_pinned_scratch(const hapgpu_rt *rt, const void *p, size_t bytes)
+{
+    for (int i = 0; i < kSlots; i++)
+        if (rt->pin[i] && (const uint8_t *)p >= (const uint8_t *)rt->pin[i] &&
+            (const uint8_t *)p + bytes <= (const uint8_t *)rt->pin[i] + rt->pin_cap[i])
+            return true;
+    return false;
+}
+
+static const size_t kSmallCopyBytes = (size_t)1 << 20;
+static bool copy_kernels_enabled()
+{
+    static int on = -1;
+    if (on < 0) {
+        const char *v = getenv("HAP_AMD_COPY_KERNELS");
+        on = (v && v[0] == '0') ? 0 : 1;
+    }
+    return on != 0;
+}
+
+static int small_copy(hapgpu_rt *rt, void *dst, const void *src, size_t bytes)
+{
+    hipLaunchKernelGGL(small_copy_kernel, dim3((unsigned)((bytes + 4095u) / 4096u)), dim3(256), 0, rt->stream, (uint8_t *)dst,
+                       (const uint8_t *)src, bytes);
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}
+
 extern "C" int hapgpu_rt_h2d(hapgpu_rt *rt, void *dst, const void *src, size_t bytes)
 {
     if (!bytes) return 0;
+    if (bytes <= kSmallCopyBytes && copy_kernels_enabled() && in_pinned_scratch(rt, src, bytes))
+        return small_copy(rt, dst, src, bytes);
     hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, rt->stream);
     if (e != hipSuccess) { complain("hipMemcpyAsync(H2D)", e); return 4; }
     return 0;
@@ -238,6 +282,8 @@ extern "C" int hapgpu_rt_h2d(hapgpu_rt *rt, void *dst, const void *src, size_t b
 extern "C" int hapgpu_rt_d2h(hapgpu_rt *rt, void *dst, const void *src, size_t bytes)
 {
     if (!bytes) return 0;
+    if (bytes <= kSmallCopyBytes && copy_kernels_enabled() && in_pinned_scratch(rt, dst, bytes))
+        return small_copy(rt, dst, src, bytes);
     hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, rt->stream);
     if (e != hipSuccess) { complain("hipMemcpyAsync(D2H)", e); return 4; }
     return 0;

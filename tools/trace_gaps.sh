@@ -10,7 +10,9 @@ rows = list(csv.DictReader(open(glob.glob('/tmp/tg/**/*kernel_trace.csv', recurs
 rows = [r for r in rows if 'at::native' not in r['Kernel_Name'] and 'elementwise' not in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # last step = last 14 or so kernels: print the tail
-tail = rows[-16:]
+# the last step: the kernels up to the last decode launch
+last = max(i for i, r in enumerate(rows) if 'snappy_decode_fields_kernel' in r['Kernel_Name'])
+tail = rows[max(0, last - 17):last + 2]
 t0 = int(tail[0]['Start_Timestamp']); prev_end = None
 for r in tail:
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
