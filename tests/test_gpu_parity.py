@@ -880,6 +880,36 @@ def test_fragments_placed_by_the_compressor_give_the_same_frames(hap):
         c.close()
 
 
+def test_pictures_with_a_row_pitch_and_odd_geometry_through_the_fused_encoder(ctx, hap):
+    """The compressor that makes its blocks from the picture itself addresses pixels by block number: pictures whose
+    rows are further apart than their width, that start 4 bytes off a 16-byte boundary, that are narrower than a
+    wavefront's 64 blocks or whose fragments wrap around several block rows -- same frames as from the oracle's
+    textures, decoded by the reference."""
+    for w, h, chunks in ((4, 4, 1), (8, 36, 2), (252, 64, 3), (260, 128, 5), (1028, 96, 4), (2048, 32, 1)):
+        pitch = w * 4 + 48
+        for fmt in (L.FMT_YCOCG, L.FMT_DXT5):
+            pics = [D.rgba(w, h, frame=7 + i) for i in range(3)]
+            tex = [D.oracle_bc_encode(p, fmt) for p in pics]
+            size = len(tex[0])
+            cap = hap.HapMaxEncodedLength([size], [fmt], [chunks])
+            bufs = []
+            for p in pics:
+                raw = torch.full((4 + h * pitch,), 0x5A, dtype=torch.uint8, device="cuda")
+                raw[4:].view(h, pitch)[:, : w * 4] = torch.from_numpy(p.reshape(h, w * 4)).cuda()
+                bufs.append(raw[4:])
+            outs = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in pics]
+            torch.cuda.synchronize()
+            r, used, res = ctx.encode_frames_rgba(bufs, w, h, pitch, [fmt], [1], [chunks], outs, flags=hap.ENCODE_FRAGMENT_INDEX)
+            assert r == 0 and res == [0] * 3, (w, h, fmt)
+            want = [np.zeros(cap, dtype=np.uint8) for _ in pics]
+            r, wused, res = ctx.encode_frames([[t] for t in tex], [fmt], [1], [chunks], want, flags=hap.ENCODE_FRAGMENT_INDEX)
+            assert r == 0 and res == [0] * 3
+            for i in range(3):
+                frame = outs[i][: used[i]].cpu().numpy().tobytes()
+                assert frame == want[i][: wused[i]].tobytes(), (w, h, fmt, i)
+                assert REF.decode(frame, 0, size) == (0, tex[i], fmt)
+
+
 def test_a_chunk_that_does_not_shrink_sends_its_frame_through_slots(hap):
     """A chunk that Snappy does not shrink is stored as it is (reference hap.c:460-466) and everything behind it lies
     elsewhere than the placing wavefronts assumed: such frames are encoded a second time, through slots -- same bytes as
