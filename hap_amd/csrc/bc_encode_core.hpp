@@ -252,7 +252,11 @@ __device__ __forceinline__ uint2 ycocg_colour_block(const unsigned (&cc)[16])
         unsigned pos2 = 0;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const unsigned dot = (unsigned)__builtin_amdgcn_sdot2(__builtin_bit_cast(pk_i16, cc[i]), dir2, kDotOffset, false);   // 1 .. 2^18
+            // (the offset from a scalar register: the compiler's choice, v_dot2c, accumulates into its destination and
+            // pays a v_mov of the constant per pixel; the wait states a dot product needs before another VALU
+            // instruction reads its result are part of the statement, the compiler does not see into it)
+            unsigned dot;                                                                                                        // 1 .. 2^18
+            asm("v_dot2_i32_i16 %0, %1, %2, %3\n\ts_nop 2" : "=v"(dot) : "v"(cc[i]), "v"(__builtin_bit_cast(unsigned, dir2)), "s"(kDotOffset));
             const int pos = min(max((int)(__umul24(dot, sm) + Km) >> 24, 0), 3);
             pos2 = __builtin_amdgcn_alignbit((unsigned)pos, pos2, 2);
         }
