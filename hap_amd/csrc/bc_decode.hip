@@ -105,10 +105,10 @@ __device__ __forceinline__ void decode_palette(uint2 blk, bool dxt1_modes, unsig
 
 // FMT: 0 DXT1, 1 DXT5, 2 YCoCg-DXT5; HAS_ALPHA: separate RGTC1 plane supplies A (Hap Q Alpha)
 template <int FMT, bool HAS_ALPHA>
-__global__ __launch_bounds__(256) void bc_decode_kernel(const uint8_t *__restrict__ blocks,
-                                                        const uint8_t *__restrict__ alpha_blocks,
-                                                        unsigned blocks_x, unsigned blocks_total,
-                                                        uint8_t *__restrict__ rgba, size_t row_bytes)
+__device__ __forceinline__ void bc_decode_body(const uint8_t *__restrict__ blocks,
+                                               const uint8_t *__restrict__ alpha_blocks,
+                                               unsigned blocks_x, unsigned blocks_total,
+                                               uint8_t *__restrict__ rgba, size_t row_bytes)
 {
     const unsigned id = blockIdx.x * 256u + threadIdx.x;
     if (id >= blocks_total)
@@ -233,6 +233,39 @@ __global__ __launch_bounds__(256) void bc_decode_kernel(const uint8_t *__restric
     }
 }
 
+template <int FMT, bool HAS_ALPHA>
+__global__ __launch_bounds__(256) void bc_decode_kernel(const uint8_t *__restrict__ blocks,
+                                                        const uint8_t *__restrict__ alpha_blocks,
+                                                        unsigned blocks_x, unsigned blocks_total,
+                                                        uint8_t *__restrict__ rgba, size_t row_bytes)
+{
+    bc_decode_body<FMT, HAS_ALPHA>(blocks, alpha_blocks, blocks_x, blocks_total, rgba, row_bytes);
+}
+
+// pictures of one geometry in one launch: picture blockIdx.z; table = [textures][alpha planes][pictures], `pictures`
+// device addresses each; texture address 0 = not this launch's format: skip
+template <int FMT, bool HAS_ALPHA>
+__global__ __launch_bounds__(256) void bc_decode_batch_kernel(const uint64_t *__restrict__ table, unsigned pictures,
+                                                              unsigned blocks_x, unsigned blocks_total, size_t row_bytes)
+{
+    const uint8_t *blocks = (const uint8_t *)table[blockIdx.z];
+    if (!blocks)
+        return;
+    bc_decode_body<FMT, HAS_ALPHA>(blocks, (const uint8_t *)table[pictures + blockIdx.z], blocks_x, blocks_total,
+                                   (uint8_t *)table[2u * pictures + blockIdx.z], row_bytes);
+}
+
+template <int FMT>
+void launch_batch(const uint64_t *table, unsigned pictures, bool alpha, unsigned bx, unsigned by, size_t row_bytes, hipStream_t stream)
+{
+    const unsigned total = bx * by;
+    const dim3 grid((total + 255u) / 256u, 1, pictures), block(256);
+    if (alpha)
+        hipLaunchKernelGGL((bc_decode_batch_kernel<FMT, true>), grid, block, 0, stream, table, pictures, bx, total, row_bytes);
+    else
+        hipLaunchKernelGGL((bc_decode_batch_kernel<FMT, false>), grid, block, 0, stream, table, pictures, bx, total, row_bytes);
+}
+
 template <int FMT>
 void launch(const void *blocks, const void *alpha, unsigned bx, unsigned by, void *rgba, size_t row_bytes, hipStream_t stream)
 {
@@ -262,6 +295,25 @@ extern "C" int hapgpu_launch_block_decode(const void *blocks, const void *alpha,
     case 0x83F0: launch<0>(blocks, alpha, bx, by, rgba, row_bytes, stream); break;
     case 0x83F3: launch<1>(blocks, alpha, bx, by, rgba, row_bytes, stream); break;
     case 0x01: launch<2>(blocks, alpha, bx, by, rgba, row_bytes, stream); break;
+    default: return 1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}
+
+// The same for `pictures` textures of one format and geometry: table (device memory) = texture addresses, alpha plane
+// addresses (read when with_alpha), picture addresses, `pictures` of each; a texture address of 0 skips the picture.
+// Alignment as above (the host checks it per picture).
+extern "C" int hapgpu_launch_block_decode_batch(const uint64_t *table, unsigned pictures, int with_alpha, unsigned width,
+                                                unsigned height, unsigned format, size_t row_bytes, hipStream_t stream)
+{
+    if (!table || pictures == 0 || pictures > 65535u || width == 0 || height == 0 || (width & 3u) || (height & 3u) ||
+        row_bytes < (size_t)width * 4u || (row_bytes & 15u))
+        return 1;
+    const unsigned bx = width / 4u, by = height / 4u;
+    switch (format) {
+    case 0x83F0: launch_batch<0>(table, pictures, with_alpha != 0, bx, by, row_bytes, stream); break;
+    case 0x83F3: launch_batch<1>(table, pictures, with_alpha != 0, bx, by, row_bytes, stream); break;
+    case 0x01: launch_batch<2>(table, pictures, with_alpha != 0, bx, by, row_bytes, stream); break;
     default: return 1;
     }
     return hipGetLastError() == hipSuccess ? 0 : 4;

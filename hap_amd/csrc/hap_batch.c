@@ -1390,38 +1390,64 @@ unsigned hapb_decode_rgba(HapGpuContext *ctx, unsigned frame_count, const void *
             }
         ctx->decode_indices = idx;
         hapb_decode(ctx, n * texture_count, in, in_bytes, 0, outs, caps, used, fmts, res, flags, NULL, NULL);
-        for (f = 0; f < n; f++) {
-            const size_t e = (size_t)f * texture_count;
-            const unsigned fmt = fmts[e];
-            void *dst = rgba_frames[done + f];
-            unsigned r = res[e];
-            if (r == HapResult_No_Error && texture_count == 2)
-                r = res[e + 1];
-            if (r == HapResult_No_Error && !dst)
-                r = HapResult_Bad_Arguments;
-            /* the frame must hold what the caller's geometry says: a colour texture the block decoder knows, of
-               exactly width x height, and (two textures) an RGTC1 plane of the same geometry */
-            if (r == HapResult_No_Error &&
-                ((fmt != HapTextureFormat_RGB_DXT1 && fmt != HapTextureFormat_RGBA_DXT5 && fmt != HapTextureFormat_YCoCg_DXT5) ||
-                 used[e] != blocks * (fmt == HapTextureFormat_RGB_DXT1 ? 8u : 16u) ||
-                 (texture_count == 2 && (fmts[e + 1] != HapTextureFormat_A_RGTC1 || used[e + 1] != blocks * 8u))))
-                r = HapResult_Bad_Arguments;
-            if (r == HapResult_No_Error && !is_dev(ctx, dst)) {
-                if (!stage)
-                    stage = (uint8_t *)hapgpu_rt_device_scratch(rt, D_RGBA_STAGE, align_up(rgba_bytes, 256) * n);
-                dst = stage ? stage + align_up(rgba_bytes, 256) * f : NULL;
-                if (!dst)
-                    r = HapResult_Internal_Error;
+        {
+            /* one block-decode launch per texture format present in the slice: [textures][alpha planes][pictures] in a
+               small device table, pictures of other formats (or that failed) with a texture address of 0 */
+            uint64_t *htab = (uint64_t *)hapgpu_rt_pinned_scratch(rt, P_BC_PTRS, sizeof(uint64_t) * 9u * n);
+            uint64_t *dtab = (uint64_t *)hapgpu_rt_device_scratch(rt, D_BC_PTRS, sizeof(uint64_t) * 9u * n);
+            static const unsigned kinds[3] = {HapTextureFormat_RGB_DXT1, HapTextureFormat_RGBA_DXT5, HapTextureFormat_YCoCg_DXT5};
+            unsigned present = 0, k;
+            if (!htab || !dtab) {
+                for (f = 0; f < n; f++)
+                    results[done + f] = HapResult_Internal_Error;
+                first_error = first_error ? first_error : HapResult_Internal_Error;
+                continue;
             }
-            if (r == HapResult_No_Error) {
-                const int k = hapgpu_k_block_decode(rt, outs[e], texture_count == 2 ? outs[e + 1] : NULL, width, height,
-                                                    fmt, dst, row_bytes);
-                if (k)
-                    r = k == 1 ? HapResult_Bad_Arguments : HapResult_Internal_Error;
-                else if (dst != rgba_frames[done + f])
-                    rc |= hapgpu_rt_d2h(rt, rgba_frames[done + f], dst, rgba_bytes);
+            memset(htab, 0, sizeof(uint64_t) * 9u * n);
+            for (f = 0; f < n; f++) {
+                const size_t e = (size_t)f * texture_count;
+                const unsigned fmt = fmts[e];
+                void *dst = rgba_frames[done + f];
+                unsigned r = res[e];
+                if (r == HapResult_No_Error && texture_count == 2)
+                    r = res[e + 1];
+                if (r == HapResult_No_Error && !dst)
+                    r = HapResult_Bad_Arguments;
+                /* the frame must hold what the caller's geometry says: a colour texture the block decoder knows, of
+                   exactly width x height, and (two textures) an RGTC1 plane of the same geometry */
+                if (r == HapResult_No_Error &&
+                    ((fmt != HapTextureFormat_RGB_DXT1 && fmt != HapTextureFormat_RGBA_DXT5 && fmt != HapTextureFormat_YCoCg_DXT5) ||
+                     used[e] != blocks * (fmt == HapTextureFormat_RGB_DXT1 ? 8u : 16u) ||
+                     (texture_count == 2 && (fmts[e + 1] != HapTextureFormat_A_RGTC1 || used[e + 1] != blocks * 8u))))
+                    r = HapResult_Bad_Arguments;
+                if (r == HapResult_No_Error && !is_dev(ctx, dst)) {
+                    if (!stage)
+                        stage = (uint8_t *)hapgpu_rt_device_scratch(rt, D_RGBA_STAGE, align_up(rgba_bytes, 256) * n);
+                    dst = stage ? stage + align_up(rgba_bytes, 256) * f : NULL;
+                    if (!dst)
+                        r = HapResult_Internal_Error;
+                } else if (r == HapResult_No_Error && ((uintptr_t)dst & 15u)) {
+                    r = HapResult_Bad_Arguments;
+                }
+                if (r == HapResult_No_Error) {
+                    k = fmt == HapTextureFormat_RGB_DXT1 ? 0u : fmt == HapTextureFormat_RGBA_DXT5 ? 1u : 2u;
+                    present |= 1u << k;
+                    htab[(size_t)k * 3u * n + f] = (uint64_t)(uintptr_t)outs[e];
+                    htab[(size_t)k * 3u * n + n + f] = texture_count == 2 ? (uint64_t)(uintptr_t)outs[e + 1] : 0u;
+                    htab[(size_t)k * 3u * n + 2u * n + f] = (uint64_t)(uintptr_t)dst;
+                }
+                results[done + f] = r;
             }
-            results[done + f] = r;
+            if (present) {
+                rc |= hapgpu_rt_h2d(rt, dtab, htab, sizeof(uint64_t) * 9u * n);
+                for (k = 0; k < 3u; k++)
+                    if (present & (1u << k))
+                        rc |= hapgpu_k_block_decode_batch(rt, dtab + (size_t)k * 3u * n, n, texture_count == 2, width, height, kinds[k],
+                                                          row_bytes);
+                for (f = 0; f < n; f++)
+                    if (results[done + f] == HapResult_No_Error && stage && !is_dev(ctx, rgba_frames[done + f]))
+                        rc |= hapgpu_rt_d2h(rt, rgba_frames[done + f], stage + align_up(rgba_bytes, 256) * f, rgba_bytes);
+            }
         }
         rc |= hapgpu_rt_sync(rt);
         if (rc)

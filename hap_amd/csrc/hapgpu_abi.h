@@ -272,6 +272,10 @@ int hapgpu_k_block_encode_batch_ycocg_alpha(hapgpu_rt *rt, const uint64_t *sourc
                                             unsigned height, size_t row_bytes, int wide);
 int hapgpu_k_block_decode(hapgpu_rt *rt, const void *blocks, const void *alpha, unsigned width, unsigned height,
                           unsigned hap_texture_format, void *rgba, size_t row_bytes);
+/* pictures of one format and geometry in one launch; table: DEVICE array of device addresses, [textures][alpha planes]
+   [pictures], `pictures` entries each (texture 0 = skip the picture) */
+int hapgpu_k_block_decode_batch(hapgpu_rt *rt, const uint64_t *table, unsigned pictures, int with_alpha, unsigned width,
+                                unsigned height, unsigned hap_texture_format, size_t row_bytes);
 /* group_tables: HAP_GROUP_TABLE_BYTES (96) bytes per fragment (same indexing as frag_sizes), written for textures whose reserved bit 20 is set */
 int hapgpu_k_snappy_compress(hapgpu_rt *rt, const HapGpuFrameEnc *frames, unsigned frame_count,
                              unsigned max_frags_per_texture, unsigned frag_log2,

@@ -571,6 +571,15 @@ extern "C" int hapgpu_k_block_encode_batch_ycocg_alpha(hapgpu_rt *rt, const uint
                                                         row_bytes, wide, rt->stream);
 }
 
+extern "C" int hapgpu_launch_block_decode_batch(const uint64_t *table, unsigned pictures, int with_alpha, unsigned width,
+                                                unsigned height, unsigned format, size_t row_bytes, hipStream_t stream);
+extern "C" int hapgpu_k_block_decode_batch(hapgpu_rt *rt, const uint64_t *table, unsigned pictures, int with_alpha,
+                                           unsigned width, unsigned height, unsigned hap_texture_format, size_t row_bytes)
+{
+    scoped_timing st(rt, 6);
+    return hapgpu_launch_block_decode_batch(table, pictures, with_alpha, width, height, hap_texture_format, row_bytes, rt->stream);
+}
+
 extern "C" int hapgpu_k_block_decode(hapgpu_rt *rt, const void *blocks, const void *alpha, unsigned width,
                                      unsigned height, unsigned hap_texture_format, void *rgba, size_t row_bytes)
 {
