@@ -189,13 +189,21 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
             any_half_tiles = 1;
         /* a call that starts from RGBA pictures (hapb_encode_rgba): the block compressor makes the blocks of its
            fragment itself, one pass less over the texture and the pixel loads of one wave under the matching of the
-           others (snappy_compress_blocks.hip).  One texture per frame, 16-byte blocks for now. */
+           others (snappy_compress_blocks.hip).  One texture per frame. */
         {
             const HapbBlockEncodeJob *bj = ctx->block_encode_job;
-            if (bj && !ctx->no_fusion && count == 1u && t->field_period == 4u && (bj->row_bytes & 3u) == 0 &&
+            if (bj && !ctx->no_fusion && count == 1u && (bj->row_bytes & 3u) == 0 &&
                 (unsigned long long)bj->row_bytes * bj->height < 0xFFFFFFFFull && bj->width / 4u >= 1u) {
-                fused[i] = t->format == HapTextureFormat_RGBA_DXT5 ? 2u : 3u;
-                fused_mask |= t->format == HapTextureFormat_RGBA_DXT5 ? 2u : 1u;
+                /* (code: HapGpuTexEnc.reserved bits 24..26; mask bit: which kernel the launcher starts) */
+                if (t->field_period == 4u && t->format == HapTextureFormat_YCoCg_DXT5) {
+                    fused[i] = 3u; fused_mask |= 1u;
+                } else if (t->field_period == 4u && t->format == HapTextureFormat_RGBA_DXT5) {
+                    fused[i] = 2u; fused_mask |= 2u;
+                }
+                /* (DXT1, two blocks to a lane: built and measured -- 115 registers once the match stage's units are read
+                   back from the texture instead of kept; 60 4K frames 0.663 against 0.658 ms, 60 1080p frames 0.241
+                   against 0.233: its block encoder is further from its instruction-issue limit than the 16-byte ones',
+                   nothing to win.  The kernel keeps the two-pass form; the launcher does not start it.) */
             }
         }
         if (t->compressor == HapCompressorSnappy && !fused[i])

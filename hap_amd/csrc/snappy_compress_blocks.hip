@@ -258,33 +258,33 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
     // load the last unit again (no lane-varying branch around the loads; what they compute is masked out)
     const unsigned last = n - (B == 16u ? 16u : 8u);
 
-    // fused: where the lane's block(s) of step 0 lie in the picture, and the pixels of that step
-    constexpr unsigned kPerUnit = 16u / B;                       // blocks of a unit
+    // fused: a step of 64 units is made in kSub passes of 64 consecutive BLOCKS (one pass for 16-byte blocks, two for
+    // 8-byte ones): the lane makes block 64 (kSub s + sub) + lane of the fragment from its four pixel rows -- loaded
+    // one pass ahead -- and puts it into an LDS ring, where the lane that owns the unit finds its blocks and their
+    // neighbours.  A pass keeps sixteen pixel registers alive however many blocks a unit has.
+    constexpr unsigned kSub = 16u / B;
     __shared__ __attribute__((aligned(16))) uint4 ring[FUSED >= 0 ? 68u : 1u];   // the step's units behind the last four of the one before
     const gsrc_t rgba = (gsrc_t)frames[zf].rgba;
     const unsigned row_bytes = frames[zf].rgba_row_bytes, blocks_x = frames[zf].rgba_blocks_x;
-    unsigned bx[kPerUnit], by[kPerUnit], first_off = 0u;
-    unsigned pix[2][kPerUnit][16];
-    auto load_pixels = [&](unsigned (&p)[kPerUnit][16], unsigned s) {
+    unsigned bx[kSub], by[kSub], first_off = 0u;
+    unsigned pix[2][16];
+    // pass t = kSub s + sub: its pixels
+    auto load_pixels = [&](unsigned (&p)[16], unsigned t) {
+        const unsigned sub = t % kSub;
+        const bool there = (64u * t + lane + 1u) * B <= n;
+        const unsigned at = there ? (4u * by[sub]) * row_bytes + 16u * bx[sub] : first_off;     // (no lane-varying branch around the loads)
 #pragma unroll
-        for (unsigned j = 0; j < kPerUnit; j++) {
-            const bool there = (64u * s + lane) * 16u + (j + 1u) * B <= n;
-            const unsigned at = there ? (4u * by[j]) * row_bytes + 16u * bx[j] : first_off;     // (no lane-varying branch around the loads)
-#pragma unroll
-            for (unsigned r = 0; r < 4u; r++) {
-                const uint4 v = get128(rgba + (at + r * row_bytes));
-                p[j][4u * r] = v.x; p[j][4u * r + 1u] = v.y; p[j][4u * r + 2u] = v.z; p[j][4u * r + 3u] = v.w;
-            }
+        for (unsigned r = 0; r < 4u; r++) {
+            const uint4 v = get128(rgba + (at + r * row_bytes));
+            p[4u * r] = v.x; p[4u * r + 1u] = v.y; p[4u * r + 2u] = v.z; p[4u * r + 3u] = v.w;
         }
     };
-    auto next_blocks = [&]() {
-#pragma unroll
-        for (unsigned j = 0; j < kPerUnit; j++) {
-            bx[j] += 64u * kPerUnit;
-            while (bx[j] >= blocks_x) {
-                bx[j] -= blocks_x;
-                by[j] += 1u;
-            }
+    // the block of pass t + kSub from the block of pass t
+    auto next_block = [&](unsigned sub) {
+        bx[sub] += 64u * kSub;
+        while (bx[sub] >= blocks_x) {
+            bx[sub] -= blocks_x;
+            by[sub] += 1u;
         }
     };
     if (FUSED >= 0) {
@@ -294,21 +294,25 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
             first_off = (4u * fy) * row_bytes + 16u * fx;
         }
 #pragma unroll
-        for (unsigned j = 0; j < kPerUnit; j++) {
-            const unsigned b = first_block + kPerUnit * lane + j;
+        for (unsigned j = 0; j < kSub; j++) {
+            const unsigned b = first_block + 64u * j + lane;
             by[j] = b / blocks_x;
             bx[j] = b - by[j] * blocks_x;
         }
         load_pixels(pix[0], 0u);
     }
 
+    // (the fused kernel for 8-byte blocks has no registers left for the fragment's units between the match and the
+    // emit walk: it reads them back from the texture it has just written)
+    constexpr bool kKeepX = !(FUSED >= 0 && B == 8u);
     // ---- 1. match ----
-    uint4 X[kSteps];
+    uint4 X[kKeepX ? kSteps : 1u];
     unsigned HD[kSteps];                 // table candidates of the unit's two index fields: distance in blocks, 0 = none
 #pragma unroll
     for (unsigned s = 0; s < kSteps; s++) {
         const unsigned pos = (64u * s + lane) * 16u;
-        X[s] = make_uint4(0, 0, 0, 0);
+        if (kKeepX)
+            X[s] = make_uint4(0, 0, 0, 0);
         HD[s] = 0u;
         if (64u * s * 16u >= n) {                  // (uniform) nothing left: half-tiles of this step read as empty
             masks[64u * s + lane] = 0u;
@@ -317,26 +321,32 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
         const unsigned pc = min(pos, last);
         uint4 xs, Y[kDistances];
         if (FUSED >= 0) {
-            if (s + 1u < kSteps && 64u * (s + 1u) * 16u < n) {
-                next_blocks();
-                load_pixels(pix[(s + 1u) & 1u], s + 1u);
+            uint4 made = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (unsigned sub = 0; sub < kSub; sub++) {
+                const unsigned t = kSub * s + sub;
+                if (t + 1u < kSub * kSteps && 64u * (t + 1u) * B < n) {
+                    if (t + 1u >= kSub)
+                        next_block((t + 1u) % kSub);
+                    load_pixels(pix[(t + 1u) & 1u], t + 1u);
+                }
+                const uint4 blk = hapbc::block_of<FUSED>(pix[t & 1u]);
+                made = blk;
+                const unsigned bpos = (64u * t + lane) * B;
+                if (B == 16u) {
+                    if (bpos + 16u <= n)
+                        put128((gdst_t)(uintptr_t)(src + bpos), blk);
+                    ring[4u + lane] = blk;
+                } else {
+                    if (bpos + 8u <= n)
+                        put64((gdst_t)(uintptr_t)(src + bpos), make_uint2(blk.x, blk.y));
+                    reinterpret_cast<uint2 *>(ring)[8u + 64u * sub + lane] = make_uint2(blk.x, blk.y);
+                }
             }
-            if (B == 16u) {
-                xs = hapbc::block_of<FUSED>(pix[s & 1u][0]);
-                if (pos + 16u <= n)
-                    put128((gdst_t)(uintptr_t)(src + pos), xs);
-            } else {
-                const uint4 lo = hapbc::block_of<FUSED>(pix[s & 1u][0]), hi = hapbc::block_of<FUSED>(pix[s & 1u][kPerUnit - 1u]);
-                xs = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                if (pos + 16u <= n)
-                    put128((gdst_t)(uintptr_t)(src + pos), xs);
-                else if (pos + 8u <= n)
-                    put64((gdst_t)(uintptr_t)(src + pos), make_uint2(lo.x, lo.y));
-            }
-            // the neighbours 1..4 blocks back: through the ring (a wave's LDS accesses complete in order)
-            ring[4u + lane] = xs;
+            // the unit and the neighbours 1..4 blocks back: from the ring (a wave's LDS accesses complete in order)
             __syncthreads();
             const uint8_t *rb = reinterpret_cast<const uint8_t *>(ring) + (4u + lane) * 16u;
+            xs = B == 16u ? made : *reinterpret_cast<const uint4 *>(rb);       // (a 16-byte block is the lane's own unit)
 #pragma unroll
             for (unsigned d = 0; d < kDistances; d++) {
                 if (B == 16u) {
@@ -370,7 +380,8 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
                 }
             }
         }
-        X[s] = xs;
+        if (kKeepX)
+            X[s] = xs;
         unsigned differ = 0;
 #pragma unroll
         for (unsigned d = 0; d < kDistances; d++)
@@ -650,7 +661,14 @@ __global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpu
         unsigned off = (masks[hh * 8u + 7u] & 0xFFFFu) + 4u * popc(L & below) + 2u * popc(L & UL::big32 & below) -
                        2u * popc(L & UL::small32 & below) + popc(S & below) + popc(CS & below) + popc(X3 & below);
         const unsigned sj = S >> j4, lj = L >> j4, xj = X3 >> j4;
-        const uint4 xs = X[s];
+        uint4 xs;
+        if (kKeepX) {
+            xs = X[s];
+        } else {
+            const unsigned pos = (64u * s + lane) * 16u;
+            const uint2 lo = get64(src + min(pos, last)), hi = get64(src + min(pos + 8u, last));
+            xs = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
         constexpr bool kDwords = LAYOUT == 2u || LAYOUT == 8u;
         const unsigned fw[4] = {xs.x, kDwords ? xs.y : xs.x >> 16, xs.z, LAYOUT == 4u ? xs.w : kDwords ? xs.w : xs.z >> 16};
 #pragma unroll
@@ -771,10 +789,8 @@ extern "C" int hapgpu_launch_snappy_compress_blocks(const HapGpuFrameEnc *frames
         HAP_LAUNCH_BLOCKS(4u, hapbc::kFmtYCoCg);
     if (fused & 2u)
         HAP_LAUNCH_BLOCKS(4u, hapbc::kFmtDXT5);
-    if (fused & 4u)
-        HAP_LAUNCH_BLOCKS(2u, hapbc::kFmtDXT1);
-    if (fused & 8u)
-        HAP_LAUNCH_BLOCKS(6u, hapbc::kFmtRGTC1);
+    if (fused & 12u)          // (DXT1 / RGTC1: the fused form was no faster than the two passes, hap_batch.c; not instantiated)
+        return 1;
     if (layouts & 1u)
         HAP_LAUNCH_BLOCKS(4u, -1);
     if (layouts & 2u)
