@@ -910,15 +910,26 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                 ((uint8_t *)(hptr + 2u * frame_count))[f] = (uint8_t)(dev_frame && TEXTURE_INDEX(f) > 0);
                 far += dev_frame && TEXTURE_INDEX(f) > 0;
             }
-            rc |= hapgpu_rt_h2d(rt, dptr, hptr, up_bytes);
-            if (far) {
-                rc |= hapgpu_k_gather_prefixes_far(rt, dptr, dptr + frame_count, frame_count, PREFIX_BYTES, dprefix,
-                                                   (const uint8_t *)(dptr + 2u * frame_count), dprefix + block,
-                                                   (uint64_t *)(dprefix + 2u * block));
-                rc |= hapgpu_rt_d2h(rt, prefix, dprefix, 2u * block + sizeof(uint64_t) * frame_count);
+            if (hapgpu_rt_pinned_is_mapped(rt)) {
+                /* the kernel reads the pointers from, and writes the prefixes to, the pinned buffers themselves: one
+                   launch instead of a copy up, a launch and a copy back */
+                if (far)
+                    rc |= hapgpu_k_gather_prefixes_far(rt, hptr, hptr + frame_count, frame_count, PREFIX_BYTES, prefix,
+                                                       (const uint8_t *)(hptr + 2u * frame_count), prefix + block,
+                                                       (uint64_t *)(prefix + 2u * block));
+                else
+                    rc |= hapgpu_k_gather_prefixes(rt, hptr, hptr + frame_count, frame_count, PREFIX_BYTES, prefix);
             } else {
-                rc |= hapgpu_k_gather_prefixes(rt, dptr, dptr + frame_count, frame_count, PREFIX_BYTES, dprefix);
-                rc |= hapgpu_rt_d2h(rt, prefix, dprefix, block);
+                rc |= hapgpu_rt_h2d(rt, dptr, hptr, up_bytes);
+                if (far) {
+                    rc |= hapgpu_k_gather_prefixes_far(rt, dptr, dptr + frame_count, frame_count, PREFIX_BYTES, dprefix,
+                                                       (const uint8_t *)(dptr + 2u * frame_count), dprefix + block,
+                                                       (uint64_t *)(dprefix + 2u * block));
+                    rc |= hapgpu_rt_d2h(rt, prefix, dprefix, 2u * block + sizeof(uint64_t) * frame_count);
+                } else {
+                    rc |= hapgpu_k_gather_prefixes(rt, dptr, dptr + frame_count, frame_count, PREFIX_BYTES, dprefix);
+                    rc |= hapgpu_rt_d2h(rt, prefix, dprefix, block);
+                }
             }
             far_seen = far;
         }

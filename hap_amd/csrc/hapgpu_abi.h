@@ -246,6 +246,8 @@ int hapgpu_rt_h2d(hapgpu_rt *rt, void *dst, const void *src, size_t bytes);
 int hapgpu_rt_d2h(hapgpu_rt *rt, void *dst, const void *src, size_t bytes);
 int hapgpu_rt_d2d(hapgpu_rt *rt, void *dst, const void *src, size_t bytes);
 int hapgpu_rt_zero(hapgpu_rt *rt, void *dst, size_t bytes);
+/* 1: kernels may be handed pinned-scratch addresses directly (no copy in front of or behind them) */
+int hapgpu_rt_pinned_is_mapped(hapgpu_rt *rt);
 int hapgpu_rt_sync(hapgpu_rt *rt);
 void hapgpu_rt_lock(hapgpu_rt *rt);
 void hapgpu_rt_unlock(hapgpu_rt *rt);

@@ -262,6 +262,13 @@ static bool copy_kernels_enabled()
     return on != 0;
 }
 
+// 1: kernels may read and write the pinned scratch in place (it is mapped into the device's address space)
+extern "C" int hapgpu_rt_pinned_is_mapped(hapgpu_rt *rt)
+{
+    (void)rt;
+    return copy_kernels_enabled() ? 1 : 0;
+}
+
 static int small_copy(hapgpu_rt *rt, void *dst, const void *src, size_t bytes)
 {
     hipLaunchKernelGGL(small_copy_kernel, dim3((unsigned)((bytes + 4095u) / 4096u)), dim3(256), 0, rt->stream, (uint8_t *)dst,
