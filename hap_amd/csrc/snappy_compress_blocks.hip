@@ -200,8 +200,11 @@ __device__ __forceinline__ unsigned table_slot(unsigned lo, unsigned hi, unsigne
 // itself (bc_encode_core.hpp format FUSED), step by step, hands them to the match phase through a small LDS ring and
 // leaves them at tex.src on the way (chunks that Snappy does not shrink are stored from there).  The RGBA loads of
 // a step are issued a step ahead: a wave is reading pixels while its neighbours on the SIMD are matching or emitting.
+#ifndef SCB_MIN_WAVES
+#define SCB_MIN_WAVES 1          // (measurement builds: waves per SIMD the register allocation must leave room for)
+#endif
 template <unsigned LAYOUT, int FUSED>
-__global__ __launch_bounds__(64) void snappy_compress_blocks_kernel(const HapGpuFrameEnc *__restrict__ frames,
+__global__ __launch_bounds__(64, SCB_MIN_WAVES) void snappy_compress_blocks_kernel(const HapGpuFrameEnc *__restrict__ frames,
                                                                     uint8_t *__restrict__ slots, unsigned slot_stride,
                                                                     uint32_t *__restrict__ frag_sizes,
                                                                     uint8_t *__restrict__ group_tables)
