@@ -198,8 +198,8 @@ __device__ __forceinline__ unsigned table_slot(unsigned lo, unsigned hi, unsigne
 
 // FUSED >= 0: the texture does not exist yet -- the wave makes its fragment's blocks from the frame's RGBA picture
 // itself (bc_encode_core.hpp format FUSED), step by step, hands them to the match phase through a small LDS ring and
-// leaves them at tex.src on the way (chunks that Snappy does not shrink are stored from there).  The RGBA loads of
-// a step are issued a step ahead: a wave is reading pixels while its neighbours on the SIMD are matching or emitting.
+// leaves them at tex.src on the way (chunks that Snappy does not shrink are stored from there).  A wave is reading
+// pixels while its neighbours on the SIMD are matching or emitting.
 #ifndef SCB_MIN_WAVES
 #define SCB_MIN_WAVES 1          // (measurement builds: waves per SIMD the register allocation must leave room for)
 #endif
@@ -262,15 +262,23 @@ __global__ __launch_bounds__(64, SCB_MIN_WAVES) void snappy_compress_blocks_kern
     const unsigned last = n - (B == 16u ? 16u : 8u);
 
     // fused: a step of 64 units is made in kSub passes of 64 consecutive BLOCKS (one pass for 16-byte blocks, two for
-    // 8-byte ones): the lane makes block 64 (kSub s + sub) + lane of the fragment from its four pixel rows -- loaded
-    // one pass ahead -- and puts it into an LDS ring, where the lane that owns the unit finds its blocks and their
+    // 8-byte ones): the lane makes block 64 (kSub s + sub) + lane of the fragment from its four pixel rows (loaded
+    // a pass ahead where registers allow) and puts it into an LDS ring, where the lane that owns the unit finds its blocks and their
     // neighbours.  A pass keeps sixteen pixel registers alive however many blocks a unit has.
     constexpr unsigned kSub = 16u / B;
     __shared__ __attribute__((aligned(16))) uint4 ring[FUSED >= 0 ? 68u : 1u];   // the step's units behind the last four of the one before
     const gsrc_t rgba = (gsrc_t)frames[zf].rgba;
     const unsigned row_bytes = frames[zf].rgba_row_bytes, blocks_x = frames[zf].rgba_blocks_x;
     unsigned bx[kSub], by[kSub], first_off = 0u;
-    unsigned pix[2][16];
+    // Pixels a pass ahead of their use -- where that does not cost a wave: the YCoCg kernel has 88 registers without
+    // the second pixel buffer (five waves per SIMD) and 112 with it (four), and five waves that wait for their pixels
+    // beat four that do not (60 8K frames 2.78 -> 2.72 ms); the DXT5 kernel has four either way.
+#ifdef SCB_PREFETCH
+    constexpr bool kPrefetch = SCB_PREFETCH != 0;
+#else
+    constexpr bool kPrefetch = FUSED != hapbc::kFmtYCoCg;
+#endif
+    unsigned pix[kPrefetch ? 2 : 1][16];
     // pass t = kSub s + sub: its pixels
     auto load_pixels = [&](unsigned (&p)[16], unsigned t) {
         const unsigned sub = t % kSub;
@@ -328,12 +336,18 @@ __global__ __launch_bounds__(64, SCB_MIN_WAVES) void snappy_compress_blocks_kern
 #pragma unroll
             for (unsigned sub = 0; sub < kSub; sub++) {
                 const unsigned t = kSub * s + sub;
-                if (t + 1u < kSub * kSteps && 64u * (t + 1u) * B < n) {
+                if (!kPrefetch) {
+                    if (t > 0u) {
+                        if (t >= kSub)
+                            next_block(t % kSub);
+                        load_pixels(pix[0], t);
+                    }
+                } else if (t + 1u < kSub * kSteps && 64u * (t + 1u) * B < n) {
                     if (t + 1u >= kSub)
                         next_block((t + 1u) % kSub);
                     load_pixels(pix[(t + 1u) & 1u], t + 1u);
                 }
-                const uint4 blk = hapbc::block_of<FUSED>(pix[t & 1u]);
+                const uint4 blk = hapbc::block_of<FUSED>(pix[kPrefetch ? t & 1u : 0u]);
                 made = blk;
                 const unsigned bpos = (64u * t + lane) * B;
                 if (B == 16u) {
