@@ -40,6 +40,7 @@ unsigned int HapGpuCreate(int device, HapGpuContext **context)
         c->no_block_scan = getenv("HAP_AMD_NO_BLOCK_SCAN") ? 1u : 0u;
         c->no_fusion = getenv("HAP_AMD_NO_FUSION") ? 1u : 0u;
         c->no_placing = getenv("HAP_AMD_NO_PLACING") ? 1u : 0u;
+        c->placing_holdoff_calls = getenv("HAP_AMD_PLACING_HOLDOFF") ? (unsigned)atoi(getenv("HAP_AMD_PLACING_HOLDOFF")) : 8u;
         c->placing_min_frames = getenv("HAP_AMD_PLACING_MIN_FRAMES") ? (unsigned)atoi(getenv("HAP_AMD_PLACING_MIN_FRAMES")) : 12u;
         /* RGTC1 planes of large textures go through the [2, 6] field kernel (block-per-lane decodable: 2.9x the decode
            rate at the same size); HAP_AMD_RGTC1_LAYOUT overrides: 0 = position-per-lane compressor, 44 = [4, 4] */

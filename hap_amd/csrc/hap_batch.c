@@ -318,6 +318,10 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
        8 the same, 16 0.885 against 0.914, 60 2.90 against 3.08) */
     if (live < ctx->placing_min_frames)
         placed = 0u;
+    if (placed && ctx->placing_holdoff) {
+        ctx->placing_holdoff -= 1u;
+        placed = 0u;
+    }
 
     /* scratch */
     hframes = (HapGpuFrameEnc *)hapgpu_rt_pinned_scratch(rt, P_FRAMES, sizeof(HapGpuFrameEnc) * live);
@@ -498,19 +502,52 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
            than the wavefronts assumed): once more, through slots.  The textures are where they were -- the client's, or
            the scratch the RGBA call's kernels filled. */
         if (placed) {
-            const HapbBlockEncodeJob *job = ctx->block_encode_job;
-            ctx->block_encode_job = NULL;
-            ctx->no_placing = 1u;
+            unsigned again = 0;
             for (f = 0; f < frame_count; f++)
-                if (results[f] == HAPGPU_STATUS_NOT_PLACED) {
-                    ctx->placement_retries += 1;
-                    hapb_encode(ctx, 1, count, inputs + (size_t)f * count, input_bytes, formats, compressors, chunk_counts,
-                                outputs + f, output_bytes + f, output_used + f, results + f, flags, inputs_are_device == 2 ? 1 : inputs_are_device);
+                again += results[f] == HAPGPU_STATUS_NOT_PLACED;
+            if (again) {
+                /* all of them in one batch */
+                const HapbBlockEncodeJob *job = ctx->block_encode_job;
+                const void **rin = (const void **)malloc(sizeof(void *) * (size_t)again * count);
+                void **rout = (void **)malloc(sizeof(void *) * again);
+                unsigned long *rcap = (unsigned long *)malloc(sizeof(unsigned long) * again * 2u);
+                unsigned *rres = (unsigned *)malloc(sizeof(unsigned) * again * 2u);
+                if (rin && rout && rcap && rres) {
+                    unsigned long *rused = rcap + again;
+                    unsigned *rmap = rres + again, m = 0;
+                    for (f = 0; f < frame_count; f++)
+                        if (results[f] == HAPGPU_STATUS_NOT_PLACED) {
+                            for (i = 0; i < count; i++)
+                                rin[(size_t)m * count + i] = inputs[(size_t)f * count + i];
+                            rout[m] = outputs[f];
+                            rcap[m] = output_bytes[f];
+                            rmap[m++] = f;
+                        }
+                    ctx->block_encode_job = NULL;
+                    ctx->no_placing = 1u;
+                    hapb_encode(ctx, again, count, rin, input_bytes, formats, compressors, chunk_counts, rout, rcap, rused, rres, flags,
+                                inputs_are_device == 2 ? 1 : inputs_are_device);
+                    ctx->no_placing = 0u;
+                    ctx->block_encode_job = job;
+                    for (m = 0; m < again; m++) {
+                        results[rmap[m]] = rres[m];
+                        output_used[rmap[m]] = rused[m];
+                    }
+                } else {
+                    for (f = 0; f < frame_count; f++)
+                        if (results[f] == HAPGPU_STATUS_NOT_PLACED)
+                            results[f] = HapResult_Internal_Error;
+                }
+                free(rin); free(rout); free(rcap); free(rres);
+                ctx->placement_retries += again;
+                for (f = 0; f < frame_count; f++)
                     if (results[f] != HapResult_No_Error && first_error == HapResult_No_Error)
                         first_error = results[f];
-                }
-            ctx->no_placing = 0u;
-            ctx->block_encode_job = job;
+                /* content that does not shrink tends to stay: a call that had to encode most of its frames twice
+                   keeps the next calls from trying (and then tries again) */
+                if (2u * again > live)
+                    ctx->placing_holdoff = ctx->placing_holdoff_calls;
+            }
         }
     }
     free(live_index); free(stage_off_in); free(stage_off_out);

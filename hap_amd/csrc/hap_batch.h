@@ -19,6 +19,8 @@ struct HapGpuContext {
     unsigned no_fusion;       /* HAP_AMD_NO_FUSION: RGBA calls run the block encoder as a pass of its own (A/B runs) */
     unsigned placing_min_frames; /* HAP_AMD_PLACING_MIN_FRAMES (default 12): batches below it gather (with most of a frame in flight at
                                     once its wavefronts wait for each other longer than the gather pass takes) */
+    unsigned placing_holdoff; /* calls left that gather although they could place: the last placing call encoded most frames twice */
+    unsigned placing_holdoff_calls; /* HAP_AMD_PLACING_HOLDOFF (default 8): how many */
     unsigned no_placing;      /* HAP_AMD_NO_PLACING: compressed fragments go to slots and are gathered (A/B runs; also set
                                  while a frame whose chunks did not all shrink is encoded again) */
     unsigned no_half_tiles;   /* HAP_AMD_NO_HALF_TILES: fragment table version 1 even for field streams (A/B runs) */

@@ -304,9 +304,31 @@ extern "C" int hapgpu_rt_d2d(hapgpu_rt *rt, void *dst, const void *src, size_t b
     return 0;
 }
 
+__global__ __launch_bounds__(256) void small_zero_kernel(uint8_t *__restrict__ dst, size_t bytes)
+{
+    const size_t i = ((size_t)blockIdx.x * 256u + threadIdx.x) * 16u;
+    if (i + 16u <= bytes && ((uintptr_t)dst & 15u) == 0) {
+        *reinterpret_cast<uint4 *>(dst + i) = make_uint4(0, 0, 0, 0);
+    } else if (i < bytes) {
+        const size_t n = bytes - i < 16u ? bytes - i : 16u;
+        for (size_t k = 0; k < n; k++)
+            dst[i + k] = 0;
+    }
+}
+
 extern "C" int hapgpu_rt_zero(hapgpu_rt *rt, void *dst, size_t bytes)
 {
     if (!bytes) return 0;
+    // (a kernel of this library's own, whatever the size: hipMemsetAsync recorded into a HIP graph did not do its work in
+    // order when the graph was launched a second time -- small buffers, ROCm 7.2: the compressor's published sizes were
+    // wiped under its waiting wavefronts, every frame of the call was encoded twice.  HAP_AMD_MEMSET_NODES=1: the old way)
+    if (bytes <= ((size_t)1 << 40) && !getenv("HAP_AMD_MEMSET_NODES")) {
+        for (size_t done = 0; done < bytes; done += (size_t)1 << 30) {      // (2^18 workgroups of 4 KiB a launch)
+            const size_t part = bytes - done < ((size_t)1 << 30) ? bytes - done : (size_t)1 << 30;
+            hipLaunchKernelGGL(small_zero_kernel, dim3((unsigned)((part + 4095u) / 4096u)), dim3(256), 0, rt->stream, (uint8_t *)dst + done, part);
+        }
+        return hipGetLastError() == hipSuccess ? 0 : 4;
+    }
     hipError_t e = hipMemsetAsync(dst, 0, bytes, rt->stream);
     if (e != hipSuccess) { complain("hipMemsetAsync", e); return 4; }
     return 0;

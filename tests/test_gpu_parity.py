@@ -914,7 +914,7 @@ def test_a_chunk_that_does_not_shrink_sends_its_frame_through_slots(hap):
     """A chunk that Snappy does not shrink is stored as it is (reference hap.c:460-466) and everything behind it lies
     elsewhere than the placing wavefronts assumed: such frames are encoded a second time, through slots -- same bytes as
     without placing, counted by HapGpuPlacementRetryCount, the other frames of the batch untouched."""
-    placed = _context_with(hap, HAP_AMD_PLACING_MIN_FRAMES="1")
+    placed = _context_with(hap, HAP_AMD_PLACING_MIN_FRAMES="1", HAP_AMD_PLACING_HOLDOFF="0")
     gathered = _context_with(hap, HAP_AMD_NO_PLACING="1")
     w, h = 1024, 256
     size = (w // 4) * (h // 4) * 16
@@ -963,6 +963,31 @@ def test_a_chunk_that_does_not_shrink_sends_its_frame_through_slots(hap):
     for t, frame in zip(small, got["placed"]):
         assert REF.decode(frame, 0, 2048) == (0, t, L.FMT_YCOCG)
     placed.close()
+    # content that does not shrink tends to stay that way: a call that encoded most of its frames twice keeps the next
+    # eight from placing; then the context tries again
+    wary = _context_with(hap, HAP_AMD_PLACING_MIN_FRAMES="1")
+    cap = hap.HapMaxEncodedLength([size], [L.FMT_YCOCG], [4])
+    counts = []
+    for call in range(11):
+        douts = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(3)]
+        dtex = [torch.from_numpy(np.frombuffer(t, dtype=np.uint8).copy()).cuda() for t in (noise, half, flat)]
+        torch.cuda.synchronize()
+        r0 = wary.placement_retries()
+        r, used, res = wary.encode_frames([[t] for t in dtex], [L.FMT_YCOCG], [1], [4], douts, flags=0)
+        assert r == 0 and res == [0, 0, 0]
+        counts.append(wary.placement_retries() - r0)
+    assert counts == [2] + [0] * 8 + [2, 0]
+    wary.close()
+    # the same small call again and again is a recorded launch sequence replayed: nothing is encoded twice (the memset
+    # nodes of a recorded sequence once wiped the published sizes under the waiting wavefronts on every replay)
+    steady = _context_with(hap, HAP_AMD_PLACING_MIN_FRAMES="1")
+    for call in range(6):
+        douts = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(3)]
+        dtex = [torch.from_numpy(np.frombuffer(flat, dtype=np.uint8).copy()).cuda() for _ in range(3)]
+        torch.cuda.synchronize()
+        r, used, res = steady.encode_frames([[t] for t in dtex], [L.FMT_YCOCG], [1], [4], douts, flags=0)
+        assert r == 0 and res == [0, 0, 0] and steady.placement_retries() == 0, call
+    steady.close()
     gathered.close()
 
 
