@@ -39,6 +39,11 @@ while time.time() - t0 < budget:
     ok = r == 0 and all(x == 0 for x in res)
     if ok:
         encoded = [outs[i][: used[i]].tobytes() for i in range(nf)]
+        # the same call twice more: the second records the launch sequence, the third replays it -- same frames
+        for _again in range(2):
+            outs2 = [np.zeros(cap, dtype=np.uint8) for _ in range(nf)]
+            r2, used2, res2 = ctx.encode_frames([[t] for t in texs], [fmt], [1], [chunks], outs2, flags=flags)
+            ok = ok and r2 == 0 and [outs2[i][: used2[i]].tobytes() for i in range(nf)] == encoded
         decs = [np.zeros(n, dtype=np.uint8) for _ in range(nf)]
         r, du, df, dr = ctx.decode_frames(encoded, [len(e) for e in encoded], 0, decs)
         ok = r == 0 and all(decs[i].tobytes() == texs[i] for i in range(nf)) and ORA.decode(encoded[0], 0, n) == (0, texs[0], fmt)
@@ -67,6 +72,12 @@ while time.time() - t0 < budget:
         ok = r == 0 and all(x == 0 for x in res)
         if ok:
             pe = [pouts[i][: used[i]].tobytes() for i in range(nf)]
+            dpics = [torch.from_numpy(np.ascontiguousarray(p).reshape(-1)).cuda() for p in pics]
+            for _again in range(3):                   # device buffers: the recorded sequence (plain, recorded, replayed)
+                dout = [torch.zeros(pcap, dtype=torch.uint8, device="cuda") for _ in range(nf)]
+                torch.cuda.synchronize()
+                r2, used2, res2 = ctx.encode_frames_rgba(dpics, w, h, w * 4, [pf], [1], [chunks], dout, flags=flags & hap_amd.ENCODE_FRAGMENT_INDEX)
+                ok = ok and r2 == 0 and [dout[i][: used2[i]].cpu().numpy().tobytes() for i in range(nf)] == pe
             ok = all(ORA.decode(pe[i], 0, pn) == (0, ptex[i], pf) for i in range(nf))
             decs = [np.zeros(pn, dtype=np.uint8) for _ in range(nf)]
             r, du, df, dr = ctx.decode_frames(pe, [len(e) for e in pe], 0, decs)
