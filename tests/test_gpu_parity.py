@@ -910,6 +910,37 @@ def test_pictures_with_a_row_pitch_and_odd_geometry_through_the_fused_encoder(ct
                 assert REF.decode(frame, 0, size) == (0, tex[i], fmt)
 
 
+def test_recorded_launch_sequences_survive_growing_scratch(hap):
+    """A batched encode of a geometry seen before replays its recorded launch sequence (a HIP graph) with the addresses
+    of the context's scratch arenas inside: a larger call in between makes the arenas grow and move -- the small
+    geometry's next call must not replay the stale recording.  Same frames before and after, placing and gathering."""
+    from hap_amd import synth
+    for env in ({"HAP_AMD_PLACING_MIN_FRAMES": "1"}, {"HAP_AMD_NO_PLACING": "1"}, {"HAP_AMD_NO_FUSION": "1", "HAP_AMD_PLACING_MIN_FRAMES": "1"}):
+        c = _context_with(hap, **env)
+        fmt = L.FMT_YCOCG
+
+        def run(w, h, nf, chunks):
+            rgba = [synth.rgba_frame(w, h, 70 + i, device="cuda") for i in range(nf)]
+            cap = hap.HapMaxEncodedLength([(w // 4) * (h // 4) * 16], [fmt], [chunks])
+            frames = None
+            for _ in range(3):                        # plain, recorded, replayed
+                outs = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(nf)]
+                torch.cuda.synchronize()
+                r, used, res = c.encode_frames_rgba(rgba, w, h, w * 4, [fmt], [1], [chunks], outs, flags=hap.ENCODE_FRAGMENT_INDEX)
+                assert r == 0 and res == [0] * nf
+                got = [o[:u].cpu().numpy().tobytes() for o, u in zip(outs, used)]
+                assert frames is None or got == frames
+                frames = got
+            return frames
+        small = run(256, 128, 3, 2)
+        run(2048, 1024, 6, 8)                         # every arena grows
+        assert run(256, 128, 3, 2) == small
+        tex = D.oracle_bc_encode(synth.rgba_frame(256, 128, 70, device="cpu").numpy(), fmt)
+        assert REF.decode(small[0], 0, len(tex)) == (0, tex, fmt)
+        assert c.placement_retries() == 0
+        c.close()
+
+
 def test_a_chunk_that_does_not_shrink_sends_its_frame_through_slots(hap):
     """A chunk that Snappy does not shrink is stored as it is (reference hap.c:460-466) and everything behind it lies
     elsewhere than the placing wavefronts assumed: such frames are encoded a second time, through slots -- same bytes as
