@@ -366,7 +366,10 @@ extern "C" int hapgpu_rt_graph_begin(hapgpu_rt *rt, uint64_t key)
     for (auto &g : rt->graphs)
         if (g.key == k)
             return hipGraphLaunch(g.exec, rt->stream) == hipSuccess ? 1 : 2;
-    if (hipStreamBeginCapture(rt->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    // (relaxed: this thread makes no call between here and the end of the recording that a capture could object to, and
+    // in thread-local mode ROCm 7.2 still refused ANOTHER thread's hipStreamSynchronize of another context's stream
+    // while this one was recording -- two contexts, two threads: "operation not permitted when stream is capturing")
+    if (hipStreamBeginCapture(rt->stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
         (void)hipGetLastError();
         return 2;
     }

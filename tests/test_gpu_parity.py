@@ -941,6 +941,49 @@ def test_recorded_launch_sequences_survive_growing_scratch(hap):
         c.close()
 
 
+def test_two_contexts_place_their_fragments_at_the_same_time(hap):
+    """Two host threads, a context each, batches whose wavefronts wait for each other's published sizes on the same GPU at
+    the same time (the kernels of the two streams share the compute units): neither starves the other, every frame
+    equals the gathered one."""
+    import threading
+    from hap_amd import synth
+    w, h, nf, chunks, fmt = 1024, 512, 6, 5, L.FMT_YCOCG
+    cap = hap.HapMaxEncodedLength([(w // 4) * (h // 4) * 16], [fmt], [chunks])
+    rgba = [synth.rgba_frame(w, h, 90 + i, device="cuda") for i in range(nf)]
+    torch.cuda.synchronize()
+    ref_ctx = _context_with(hap, HAP_AMD_NO_PLACING="1")
+    outs = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(nf)]
+    torch.cuda.synchronize()
+    r, used, res = ref_ctx.encode_frames_rgba(rgba, w, h, w * 4, [fmt], [1], [chunks], outs, flags=hap.ENCODE_FRAGMENT_INDEX)
+    assert r == 0 and res == [0] * nf
+    want = [o[:u].cpu().numpy().tobytes() for o, u in zip(outs, used)]
+    ref_ctx.close()
+    errors = []
+
+    def work(k):
+        try:
+            c = _ctxs[k]
+            for it in range(12):
+                mine = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(nf)]
+                torch.cuda.synchronize()
+                r, used, res = c.encode_frames_rgba(rgba, w, h, w * 4, [fmt], [1], [chunks], mine, flags=hap.ENCODE_FRAGMENT_INDEX)
+                if r != 0 or res != [0] * nf or [o[:u].cpu().numpy().tobytes() for o, u in zip(mine, used)] != want:
+                    errors.append((k, it, r, res))
+                    return
+        except Exception as exc:                   # noqa: BLE001 -- reported by the assertion below
+            errors.append((k, repr(exc)))
+
+    _ctxs = [_context_with(hap, HAP_AMD_PLACING_MIN_FRAMES="1") for _ in range(2)]
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in threads]
+    [t.join(120) for t in threads]
+    assert not any(t.is_alive() for t in threads), "a placing call did not return"
+    assert errors == []
+    assert sum(c.placement_retries() for c in _ctxs) == 0
+    for c in _ctxs:
+        c.close()
+
+
 def test_a_chunk_that_does_not_shrink_sends_its_frame_through_slots(hap):
     """A chunk that Snappy does not shrink is stored as it is (reference hap.c:460-466) and everything behind it lies
     elsewhere than the placing wavefronts assumed: such frames are encoded a second time, through slots -- same bytes as
