@@ -458,13 +458,15 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
                     launch_rc |= (unsigned)hapgpu_k_frame_gather(rt, dcopies, (frags_per_frame + chunks_per_frame) * live);
                 launch_rc |= (unsigned)hapgpu_rt_d2h(rt, hframes, dframes, sizeof(HapGpuFrameEnc) * live);
                 if (graph == 0) {
+                    /* (a recording can also be invalidated from outside -- another thread of the process synchronising the
+                       device while it runs: then the launches themselves report errors.  Either way nothing has run.) */
                     const int ended = hapgpu_rt_graph_end(rt, key, launch_rc != 0);
-                    if (ended != 0 && launch_rc == 0) {
+                    if (ended != 0 || launch_rc != 0) {
                         hapgpu_rt_graphs_disable(rt);
                         graph = 2;
+                        launch_rc = 0;
                         continue;
                     }
-                    launch_rc |= (unsigned)ended;
                 }
                 break;
             }

@@ -69,7 +69,7 @@ struct hapgpu_rt {
     // which moves whenever a scratch arena is reallocated (a recorded graph holds the arenas' addresses)
     std::vector<recorded_graph> graphs;
     uint64_t generation;
-    int graphs_off;      // HAP_AMD_NO_GRAPHS
+    int graphs_off;      // unless HAP_AMD_GRAPHS=1
     int recording;
 };
 
@@ -107,7 +107,15 @@ extern "C" int hapgpu_rt_create(int device, hapgpu_rt **out)
     memset(rt->pin_cap, 0, sizeof(rt->pin_cap));
     rt->profiling = 0;
     rt->generation = 1;
-    rt->graphs_off = getenv("HAP_AMD_NO_GRAPHS") != NULL;
+    // Recording the batched encode's launch sequence as a HIP graph is OPT-IN (HAP_AMD_GRAPHS=1): measured on an
+    // MI355X it buys nothing (60 8K frames 3.721 against 3.726 ms per step, 8 frames 0.689 / 0.694, one 1080p frame
+    // 0.060 against 0.055 -- slower), and a library that records behind its client's back is a bad neighbour: while a
+    // stream of the process is being captured, hipDeviceSynchronize() in ANY thread fails and invalidates the
+    // recording, and memset nodes of a replayed graph ran late (see hapgpu_rt_zero).
+    {
+        const char *g = getenv("HAP_AMD_GRAPHS");
+        rt->graphs_off = !(g && g[0] != '0') || getenv("HAP_AMD_NO_GRAPHS") != NULL;
+    }
     rt->recording = 0;
     pthread_mutex_init(&rt->lock, NULL);
     if ((e = hipStreamCreateWithFlags(&rt->stream, hipStreamNonBlocking)) != hipSuccess) {

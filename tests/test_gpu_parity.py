@@ -916,7 +916,7 @@ def test_recorded_launch_sequences_survive_growing_scratch(hap):
     geometry's next call must not replay the stale recording.  Same frames before and after, placing and gathering."""
     from hap_amd import synth
     for env in ({"HAP_AMD_PLACING_MIN_FRAMES": "1"}, {"HAP_AMD_NO_PLACING": "1"}, {"HAP_AMD_NO_FUSION": "1", "HAP_AMD_PLACING_MIN_FRAMES": "1"}):
-        c = _context_with(hap, **env)
+        c = _context_with(hap, HAP_AMD_GRAPHS="1", **env)        # (recording is opt-in)
         fmt = L.FMT_YCOCG
 
         def run(w, h, nf, chunks):
@@ -1039,7 +1039,7 @@ def test_a_chunk_that_does_not_shrink_sends_its_frame_through_slots(hap):
     placed.close()
     # content that does not shrink tends to stay that way: a call that encoded most of its frames twice keeps the next
     # eight from placing; then the context tries again
-    wary = _context_with(hap, HAP_AMD_PLACING_MIN_FRAMES="1")
+    wary = _context_with(hap, HAP_AMD_PLACING_MIN_FRAMES="1", HAP_AMD_GRAPHS="1")
     cap = hap.HapMaxEncodedLength([size], [L.FMT_YCOCG], [4])
     counts = []
     for call in range(11):
@@ -1054,7 +1054,7 @@ def test_a_chunk_that_does_not_shrink_sends_its_frame_through_slots(hap):
     wary.close()
     # the same small call again and again is a recorded launch sequence replayed: nothing is encoded twice (the memset
     # nodes of a recorded sequence once wiped the published sizes under the waiting wavefronts on every replay)
-    steady = _context_with(hap, HAP_AMD_PLACING_MIN_FRAMES="1")
+    steady = _context_with(hap, HAP_AMD_PLACING_MIN_FRAMES="1", HAP_AMD_GRAPHS="1")
     for call in range(6):
         douts = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(3)]
         dtex = [torch.from_numpy(np.frombuffer(flat, dtype=np.uint8).copy()).cuda() for _ in range(3)]
