@@ -209,7 +209,8 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(HapGpuFrameEnc *frames,
                         e.reserved = 0;
                         e.src = (uint64_t)(group_tables + (size_t)(tex.frag_first + i * fpc) * HAP_GROUP_TABLE_BYTES);
                         e.dst = (uint64_t)(itab + 8u + 4u * n * fpc + (size_t)i * fpc * HAP_GROUP_TABLE_BYTES);
-                        e.len = with_tiles ? fpc * HAP_GROUP_TABLE_BYTES : 0u;
+                        // (a placed texture's wavefronts have written their group tables here themselves)
+                        e.len = with_tiles && !(t == 0u && ((tex.reserved >> 27) & 1u)) ? fpc * HAP_GROUP_TABLE_BYTES : 0u;
                         copies[extra_at + i] = e;
                     }
                 }

@@ -454,10 +454,9 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
                                                                     dfragsizes, dgrouptables, gran_mask | (count << 8) | (fused_mask << 16));   /* bits 8..15: textures per frame */
                 launch_rc |= (unsigned)hapgpu_k_frame_pack(rt, dframes, live, frag_log2, dslots, slot_stride, dfragsizes, dgrouptables,
                                                            dcopies, frags_per_frame * live, chunks_per_frame, max_chunks_per_tex, count, dpack);
-                /* (placed fragments of single-texture frames: only the group tables are left to move) */
-                if (placed && count == 1u)
-                    launch_rc |= (unsigned)hapgpu_k_frame_gather(rt, dcopies + (size_t)frags_per_frame * live, chunks_per_frame * live);
-                else
+                /* (placed fragments -- single-texture frames -- and their group tables are where they belong: nothing to
+                   gather.  A frame reported as not placed is encoded again as a whole.) */
+                if (!(placed && count == 1u))
                     launch_rc |= (unsigned)hapgpu_k_frame_gather(rt, dcopies, (frags_per_frame + chunks_per_frame) * live);
                 launch_rc |= (unsigned)hapgpu_rt_d2h(rt, hframes, dframes, sizeof(HapGpuFrameEnc) * live);
                 if (graph == 0) {

@@ -241,6 +241,9 @@ __global__ __launch_bounds__(64, SCB_MIN_WAVES) void snappy_compress_blocks_kern
     const bool placed = ((tex.reserved >> 27) & 1u) != 0u && blockIdx.y == 0u;
     const unsigned window = ((tex.reserved >> 8) & 0xFFu) ? ((tex.reserved >> 8) & 0xFFu) * 256u : 0xFFFFFFFFu;
     const bool want_sizes = ((tex.reserved >> 20) & 1u) != 0u && group_tables != nullptr;
+    // where the fragment's group table goes: the table array (gathered into the frame later) -- or, for a placed
+    // fragment, straight into the frame's fragment section
+    gdst_t table_at = (gdst_t)((uintptr_t)group_tables + (size_t)f * HAP_GROUP_TABLE_BYTES);
 
     // table: empty
     {
@@ -650,8 +653,15 @@ __global__ __launch_bounds__(64, SCB_MIN_WAVES) void snappy_compress_blocks_kern
                                           (5u * n_chunks + 8u + index_len) + (unsigned long long)vlen * (chunk + 1u) + sum;
             const unsigned at_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)at);
             const unsigned at_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(at >> 32));
-            if (PLC_ABL == 0)
+            if (PLC_ABL == 0) {
                 out = (gdst_t)(uintptr_t)(((unsigned long long)at_hi << 32) | at_lo);
+                // (frame_pack.hip: compressor table behind the section's three headers, the sizes, the fragment section's
+                // header and its four bytes, a size per fragment, then the group tables in fragment order)
+                if (with_tiles)
+                    table_at = (gdst_t)(uintptr_t)(frames[zf].dst + frames[zf].outer_header_len + tex.header_len + 8u + n_chunks + 4u +
+                                                   4u * n_chunks + 8u + 4u * n_chunks * fpc +
+                                                   (unsigned long long)(chunk * fpc + fj) * HAP_GROUP_TABLE_BYTES);
+            }
             else if (at_hi == 0x12345u && at_lo == 77u)      // (measurement builds: the sums stay live, the bytes go to the slot)
                 out += 1;
         } else if (lane == 0u) {
@@ -778,7 +788,7 @@ __global__ __launch_bounds__(64, SCB_MIN_WAVES) void snappy_compress_blocks_kern
             const unsigned above = (unsigned)__shfl_down((int)size, 1);
             const unsigned pair = size | (above << 12);
             if ((lane & 1u) == 0u) {
-                const gdst_t at = (gdst_t)((uintptr_t)group_tables + (size_t)f * HAP_GROUP_TABLE_BYTES + (lane >> 1) * 3u);
+                const gdst_t at = table_at + (lane >> 1) * 3u;
                 put16(at, pair);
                 put8(at + 2, pair >> 16);
             }
