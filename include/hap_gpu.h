@@ -209,7 +209,8 @@ unsigned int HapGpuDecodeFrameTextures(HapGpuContext *context, unsigned int fram
  * at least width * 4; device pictures 16-byte aligned; host or device).  textureCount 1: the frames hold one
  * DXT1 / DXT5 / scaled-YCoCg-DXT5 texture (Hap, Hap Alpha, Hap Q; YCoCg is converted back to RGB the way the
  * reference's consumers do in their shader); textureCount 2: Hap Q Alpha frames, whose RGTC1
- * plane becomes the pictures' alpha.  The block textures live in the context's scratch only.  results[f]:
+ * plane becomes the pictures' alpha.  The block textures live in the context's scratch only (at most 4 GiB of them at a
+ * time: longer batches are worked through in slices).  results[f]:
  * HapDecode's code for the frame; Bad_Arguments for a frame whose texture is of another format or geometry than the
  * call says (BC7 / BC6H / lone RGTC1 textures have no pixel decoder here).  The reference has no counterpart: it
  * stops at the texture (hap.h:132-140) and leaves the pixels to the consumer's GPU. */
