@@ -47,7 +47,7 @@ CONFIGS = {
     "C5": (16384, 16384, [0x01, 0x8DBB], [64, 64], 4),
 }
 BLOCK_BYTES = {0x83F0: 8, 0x8DBB: 8, 0x83F3: 16, 0x01: 16}
-ROUND_TAG = "r04"        # profiles/<round>_traffic_<cfg>.json is what roofline.traffic quotes
+ROUND_TAG = "r05"        # profiles/<round>_traffic_<cfg>.json is what roofline.traffic quotes
 
 
 def parse_args():
@@ -61,6 +61,10 @@ def parse_args():
                     help="strong: the stream is split over the ranks, frame f -> rank f mod N (SURVEY 8e); "
                          "weak: every rank gets a whole stream of its own")
     ap.add_argument("--no-fragment-index", action="store_true")
+    ap.add_argument("--serial", action="store_true",
+                    help="the step as one blocking encode call + one blocking decode call on one context (rounds 1-4); default: "
+                         "pipelined -- batch k + 1's encode is launched (HapGpuEncodeFramesRGBABegin) before batch k is decoded "
+                         "on a second context, so the GPU never waits for the host between calls")
     ap.add_argument("--frag-log2", type=int, default=0, help="Snappy fragment size (log2 bytes); 0 = library default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -103,9 +107,12 @@ def frames_of_rank(total, rank, world, scaling):
 class Stream:
     """One rank's share of a synthetic stream with every buffer resident in HBM, and the timed step over it."""
 
-    def __init__(self, hap_amd, ctx, dev, config, frame_ids, flags):
+    def __init__(self, hap_amd, ctx, dev, config, frame_ids, flags, ctx_dec=None):
         from hap_amd import synth
         self.hap, self.ctx = hap_amd, ctx
+        # pipelined steps: the decode calls go to a context of their own (own stream, own scratch), and the frames of
+        # consecutive batches to alternating buffers -- batch k + 1 is being written while batch k is read
+        self.ctx_dec = ctx_dec
         self.w, self.h, self.fmts, self.chunks, _n = CONFIGS[config]
         self.nf = len(frame_ids)
         self.flags = flags
@@ -117,6 +124,8 @@ class Stream:
         # the buffers stay where they are for the whole run: resolve their addresses once, as a C client would
         self.rgba = hap_amd.BufferList([synth.rgba_frame(w, h, i, device=dev) for i in frame_ids])
         self.frames = hap_amd.BufferList([torch.empty(self.cap, dtype=torch.uint8, device=dev) for _ in frame_ids])
+        self.frames_b = hap_amd.BufferList([torch.empty(self.cap, dtype=torch.uint8, device=dev) for _ in frame_ids]) \
+            if ctx_dec is not None else None
         self.dec = [hap_amd.BufferList([torch.empty(tb, dtype=torch.uint8, device=dev) for _ in frame_ids])
                     for tb in self.tex_bytes]
         # entry f * T + t = texture t of frame f: the order HapGpuDecodeFrameTextures takes
@@ -131,17 +140,31 @@ class Stream:
             raise RuntimeError("encode failed: %r %r" % (r, results[:4]))
         return used
 
-    def decode(self, used):
+    def decode(self, used, ctx=None, frames=None):
+        ctx = ctx or self.ctx
+        frames = frames if frames is not None else self.frames
         if len(self.fmts) > 1:
             # every texture of every frame in one batch (HapGpuDecodeFrameTextures)
             nt = len(self.fmts)
-            r, dused, _dfmts, dres = self.ctx.decode_frame_textures(self.frames, used, nt, self.dec_all)
+            r, dused, _dfmts, dres = ctx.decode_frame_textures(frames, used, nt, self.dec_all)
             if r != 0 or dused[:nt] != [self.tex_bytes[t] for t in range(nt)]:
                 raise RuntimeError("decode failed: %r %r" % (r, dres[:4]))
             return
-        r, dused, _dfmts, dres = self.ctx.decode_frames(self.frames, used, 0, self.dec[0])
+        r, dused, _dfmts, dres = ctx.decode_frames(frames, used, 0, self.dec[0])
         if r != 0 or dused[0] != self.tex_bytes[0]:
             raise RuntimeError("decode failed: %r %r" % (r, dres[:4]))
+
+    def begin(self, frames):
+        r = self.ctx.encode_frames_rgba_begin(self.rgba, self.w, self.h, self.w * 4, self.fmts, self.comps, self.chunks, frames,
+                                              flags=self.flags)
+        if r != 0:
+            raise RuntimeError("encode (first half) failed: %r" % r)
+
+    def finish(self):
+        r, used, results = self.ctx.encode_finish()
+        if r != 0:
+            raise RuntimeError("encode failed: %r %r" % (r, results[:4]))
+        return used
 
     def step(self):
         if self.nf == 0:
@@ -149,25 +172,50 @@ class Stream:
         self.used = self.encode()
         self.decode(self.used)
 
-    def timed(self, steps, warmup, fence):
-        """K steps between fences; returns (seconds, per-class HIP-event profile of the timed region)."""
+    def timed(self, steps, warmup, fence, pipelined=False):
+        """K steps between fences; returns (seconds, per-class HIP-event profile of the timed region).
+        pipelined: K encodes and K decodes all the same, every decode reads the frames its batch's encode wrote -- but
+        batch k + 1's encode is on the GPU's queue before the host turns to batch k's decode (its header read-back,
+        its plan, its launches, its completion), and the decode runs on a second context."""
         for _ in range(warmup):
             self.step()
-        self.ctx.set_profiling(True)
-        self.ctx.collect_profile()            # drop anything recorded so far
+        if pipelined and self.nf:
+            self.decode(self.used, self.ctx_dec)                # the decode context's scratch and code, untimed
+        ctxs = [self.ctx] + ([self.ctx_dec] if pipelined else [])
+        for c in ctxs:
+            c.set_profiling(True)
+            c.collect_profile()            # drop anything recorded so far
         fence()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            self.step()
+        if not pipelined:
+            for _ in range(steps):
+                self.step()
+        elif self.nf:
+            sets = [self.frames, self.frames_b]
+            self.begin(sets[0])
+            for k in range(steps):
+                self.used = self.finish()
+                if k + 1 < steps:
+                    self.begin(sets[(k + 1) & 1])
+                self.decode(self.used, self.ctx_dec, sets[k & 1])
+            self.last_frames = sets[(steps - 1) & 1]
+        for c in ctxs[1:]:
+            c.synchronize()
         fence()
         elapsed = time.perf_counter() - t0
-        prof = self.ctx.collect_profile()
-        self.ctx.set_profiling(False)
+        prof = {}
+        for c in ctxs:
+            for name, (n, ms) in c.collect_profile().items():
+                a = prof.get(name, (0, 0.0))
+                prof[name] = (a[0] + n, a[1] + ms)
+            c.set_profiling(False)
         return elapsed, prof
 
-    def bit_exact(self):
-        """After the timed region: every texture the last step decoded equals what the block encoder makes of the same
-        RGBA frame (the encoder itself is pinned to oracle/bc_oracle.c by the -m gpu tests at these sizes)."""
+    def bit_exact(self, reference=False):
+        """After a timed region: every texture the last step decoded equals what the block encoder makes of the same
+        RGBA frame (the encoder itself is pinned to oracle/bc_oracle.c by the -m gpu tests at these sizes).
+        reference: frame 0 as the last step wrote it is also decoded by the checker on the CPU -- the unmodified
+        reference (oracle/_ref) when it is there, else its restatement -- and must give the same textures."""
         ok = True
         for idx, fmt in enumerate(self.fmts):
             want = torch.empty(self.tex_bytes[idx], dtype=torch.uint8, device=self.dec[idx][0].device)
@@ -176,6 +224,19 @@ class Stream:
                 r = self.ctx.compress_rgba(self.rgba[i], self.w, self.h, self.w * 4, fmt, want)
                 self.ctx.synchronize()
                 ok = ok and r[0] == 0 and bool(torch.equal(want, self.dec[idx][i]))
+        if reference and self.nf and self.used:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import _libs as L
+                api = L.ref_api() or L.oracle_api()
+                frames = getattr(self, "last_frames", None) or self.frames
+                frame = frames[0][: self.used[0]].cpu().numpy()
+                for idx, fmt in enumerate(self.fmts):
+                    rc, out, f2 = api.decode_np(frame, idx, self.tex_bytes[idx])
+                    ok = ok and rc == 0 and f2 == fmt and bool((out == self.dec[idx][0].cpu().numpy()).all())
+                self.reference_checked = "reference hap.c" if L.ref_api() is not None else "oracle/ restatement"
+            except Exception as exc:           # the checker is test infrastructure: its absence is reported, not fatal
+                self.reference_checked = "unavailable: %r" % (exc,)
         return ok
 
     def split_rates(self):
@@ -276,9 +337,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    stream = Stream(hap_amd, ctx, dev, args.config, frames_of_rank(nf_total, rank, world, args.scaling), flags)
-    elapsed, prof = stream.timed(args.steps, args.warmup, fence)
+    pipelined = not args.serial
+    ctx_dec = hap_amd.Context(local_rank) if pipelined else None
+    stream = Stream(hap_amd, ctx, dev, args.config, frames_of_rank(nf_total, rank, world, args.scaling), flags, ctx_dec=ctx_dec)
+    elapsed, prof = stream.timed(args.steps, args.warmup, fence, pipelined=pipelined)
     elapsed = max_over_ranks(elapsed)
+    serial = None
+    timed_bit_exact = stream.bit_exact(reference=(rank == 0))     # what the timed region's last step left, before anything else runs
+    if pipelined:
+        # the same K steps as blocking calls on one context: what rounds 1-4 timed, and the region the per-kernel events
+        # are taken from -- in the pipelined region the encode kernel of batch k + 1 and the decode kernels of batch k
+        # share the GPU, and an event pair around one of them also times its share of the other
+        pipelined_prof = prof
+        e2, prof = stream.timed(args.steps, 1, fence)
+        serial = max_over_ranks(e2)
     total_frames = (nf_total if args.scaling == "strong" else nf_total * world) * args.steps
     rgba_bytes = stream.rgba_bytes
     value = total_frames * rgba_bytes / elapsed / 1e9
@@ -289,8 +361,9 @@ def main():
         mode = "weak" if args.scaling == "strong" else "strong"
         del stream.rgba, stream.frames, stream.dec, stream.dec_all
         torch.cuda.empty_cache()
-        s2 = Stream(hap_amd, ctx, dev, args.config, frames_of_rank(nf_total, rank, world, mode), flags)
-        e2, _p2 = s2.timed(args.steps, 1, fence)
+        del stream.frames_b
+        s2 = Stream(hap_amd, ctx, dev, args.config, frames_of_rank(nf_total, rank, world, mode), flags, ctx_dec=ctx_dec)
+        e2, _p2 = s2.timed(args.steps, 1, fence, pipelined=pipelined)
         e2 = max_over_ranks(e2)
         f2 = (nf_total if mode == "strong" else nf_total * world) * args.steps
         other = {"scaling": mode, "value": round(f2 * rgba_bytes / e2 / 1e9, 2), "unit": "GB/s", "fps": round(f2 / e2, 1),
@@ -314,7 +387,16 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "step": ("pipelined: K encodes + K decodes inside the timed region, batch k + 1's encode launched (HapGpuEncodeFramesRGBABegin) "
+                 "before batch k is decoded on a second context; frames in alternating buffers") if pipelined
+                else "serial: one blocking encode call + one blocking decode call per step, one context",
     }
+    total_frames_per_step = total_frames // args.steps
+    if serial is not None:
+        line["serial_step"] = {"ms_per_step": round(serial / args.steps * 1e3, 3),
+                               "value": round(total_frames * rgba_bytes / serial / 1e9, 2), "unit": "GB/s",
+                               "note": "the same K steps as blocking calls on one context (the step of rounds 1-4); the per-kernel "
+                                       "events and the roofline below are this region's"}
     w, h, fmts, chunks = stream.w, stream.h, stream.fmts, stream.chunks
     if world == 1:
         kernels, ratio = stream.kernel_table(prof, args.steps, args.config)
@@ -339,7 +421,9 @@ def main():
                 line["separate_passes"] = {"error": repr(exc)}
         stream.used = stream.encode()
         stream.decode(stream.used)
-        line["bit_exact"] = stream.bit_exact()
+        line["bit_exact"] = bool(timed_bit_exact and stream.bit_exact())
+        line["bit_exact_checked"] = ("every texture the timed region's last step decoded == the block encoder's; frame 0 of that step "
+                                     "decoded by: %s" % getattr(stream, "reference_checked", "-"))
         if not args.no_extras:
             try:
                 line["frames_to_rgba"] = frames_to_rgba(hap_amd, stream, dev)
@@ -362,6 +446,18 @@ def main():
         line["host_pointer_path"] = extras.get("host_pointer_path")
         line["roofline"] = stream.roofline(kernels, args.config)
         line["kernels"] = kernels
+        if not args.no_extras:
+            ms_full = elapsed / args.steps * 1e3 if pipelined else None
+            ms_full_serial = (serial if serial is not None else elapsed) / args.steps * 1e3
+            for name, fn in (("small_batch", lambda: small_batch(hap_amd, ctx, ctx_dec, dev, args.config, flags, fence, ms_full,
+                                                                   ms_full_serial, nf_total)),
+                             ("plain_frames_batched", lambda: plain_frames_batched(hap_amd, ctx, dev, args.config, nf, fence))):
+                try:
+                    line[name] = fn()
+                except Exception as exc:
+                    line[name] = {"error": repr(exc)}
+        if serial is not None:
+            line["kernels_in_pipelined_region_ms_avg"] = {k: round(ms / n, 5) for k, (n, ms) in pipelined_prof.items() if n}
         line["cpu_baseline"] = extras.get("cpu_baseline")
         if not args.no_extras:
             try:
@@ -556,6 +652,93 @@ def smaller_option(stream, hap_amd):
             "note": "encode / decode of the same frames with 64 KiB Snappy fragments and no fragment table"}
 
 
+def small_batch(hap_amd, ctx, ctx_dec, dev, config, flags, fence, ms_full, ms_full_serial, nf_full, frames=8, steps=40):
+    """What each rank of an 8-GPU strong-scaling run of the stream works on: `frames` frames per step (60 over 8 ranks:
+    8/8/8/8/7/7/7/7).  Fixed costs per call -- header read-back, host plan, small launches, completion round trips --
+    are a third of such a step when the calls block; the pipelined step hides them under the other call's kernels.
+    implied_strong_scaling_at_8 = (ms per step of the whole stream / 8) / (ms per step of 8 frames): what one GPU's
+    numbers predict for the efficiency of the 8-GPU run (nothing else is shared between the ranks)."""
+    s = Stream(hap_amd, ctx, dev, config, list(range(frames)), flags, ctx_dec=ctx_dec)
+    res = {"frames_per_step": frames, "steps": steps}
+    best = {}
+    for mode in (["pipelined"] if ctx_dec is not None else []) + ["serial"]:
+        e = min(s.timed(steps, 3, fence, pipelined=(mode == "pipelined"))[0] for _ in range(2))
+        ms = e / steps * 1e3
+        best[mode] = ms
+        res[mode] = {"ms_per_step": round(ms, 4), "fps": round(frames * steps / e, 1),
+                     "rgba_GBps": round(frames * steps * s.rgba_bytes / e / 1e9, 2)}
+    res["bit_exact"] = s.bit_exact()
+    share = nf_full / float(frames)
+    if "pipelined" in best and ms_full:
+        res["implied_strong_scaling_at_8"] = round(ms_full / share / best["pipelined"], 4)
+    if ms_full_serial:
+        res["implied_strong_scaling_at_8_serial_calls"] = round(ms_full_serial / share / best["serial"], 4)
+    return res
+
+
+def plain_frames_batched(hap_amd, ctx, dev, config, frames, fence, steps=6):
+    """The frames plain hap.h HapEncode writes by default -- nothing the Hap specification does not name, no private
+    table -- through the batched calls: same pictures, same step (blocking calls), beside the headline; never `value`.
+    Their chunks are concatenations of independent 8 KiB fragments which the decoder has to find (block scan)."""
+    s = Stream(hap_amd, ctx, dev, config, list(range(frames)), 0)
+    elapsed, prof = min((s.timed(steps, 2, fence), s.timed(steps, 0, fence)), key=lambda r: r[0])
+    kernels, ratio = s.kernel_table(prof, steps, config)
+    enc_ms, dec_ms = s.split_rates()
+    ok = s.bit_exact(reference=True)
+    return {"frames_per_step": frames, "ms_per_step": round(elapsed / steps * 1e3, 3),
+            "rgba_GBps": round(frames * steps * s.rgba_bytes / elapsed / 1e9, 2), "snappy_ratio": round(ratio, 4),
+            "encode_ms": round(enc_ms, 3), "decode_ms": round(dec_ms, 3),
+            "decode_texture_GBps": round(frames * sum(s.tex_bytes) / (dec_ms * 1e-3) / 1e9, 1),
+            "bit_exact": ok, "frame_0_decoded_by": getattr(s, "reference_checked", "-"),
+            "kernels_ms": {k: v["ms_avg"] for k, v in kernels.items()}}
+
+
+def decode_by_layout(s, steps=4):
+    """The decode launch of a two-texture stream, one texture at a time (HapGpuDecodeFrames, index 0 / 1): what the colour
+    texture and the alpha plane cost by themselves (in the step they are units of ONE launch)."""
+    out = {}
+    for idx, fmt in enumerate(s.fmts):
+        s.ctx.decode_frames(s.frames, s.used, idx, s.dec[idx])
+        s.ctx.set_profiling(True)
+        s.ctx.collect_profile()
+        for _ in range(steps):
+            r = s.ctx.decode_frames(s.frames, s.used, idx, s.dec[idx])
+            if r[0] != 0:
+                return {"error": "HapResult %d" % r[0]}
+        n, ms = s.ctx.collect_profile().get("snappy_decode", (0, 0.0))
+        s.ctx.set_profiling(False)
+        if not n:
+            continue
+        # compressed bytes of this texture: its section of every frame (the frame's tables say; cheaper: by ratio of
+        # the decoder's own counters is not available -- the section length is read from the frame header on the host)
+        comp = 0
+        for f in range(s.nf):
+            head = s.frames[f][:64].cpu().numpy().tobytes()
+            comp += _section_bytes(head, idx, len(s.fmts))
+        alg = s.nf * s.tex_bytes[idx] + comp
+        out["%#x" % fmt] = {"ms_avg": round(ms / n, 4), "algorithmic_GBps": round(alg / (ms / n * 1e-3) / 1e9, 1),
+                             "frac": round(alg / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                             "snappy_ratio": round(comp / float(s.nf * s.tex_bytes[idx]), 4)}
+    return out
+
+
+def _section_bytes(head, idx, count):
+    """bytes of texture section `idx` of a frame, from the frame's first bytes (sections: hap.c:137-212)"""
+    def sect(at):
+        ln = int.from_bytes(head[at:at + 3], "little")
+        if ln == 0:
+            return 8, int.from_bytes(head[at + 4:at + 8], "little")
+        return 4, ln
+    if count == 1:
+        return sect(0)[1]
+    h0, _l0 = sect(0)
+    h1, l1 = sect(h0)
+    if idx == 0:
+        return l1
+    # the second section starts behind the first: its header is not in the prefix -- total minus the first
+    return _l0 - (h1 + l1) - 8
+
+
 def side_config(hap_amd, ctx, dev, config, frames, flags, fence, steps=6, reference_frames=0):
     """The other BASELINE.json configs beside the headline, same step and timing rules: C5 = the north-star's target,
     16384x16384 Hap Q Alpha (YCoCg-DXT5 + RGTC1, 64 + 64 chunks, two-texture frame); C2 / C3 = the 4K configs."""
@@ -577,6 +760,11 @@ def side_config(hap_amd, ctx, dev, config, frames, flags, fence, steps=6, refere
                             "texture_GBps": round(frames * sum(s.tex_bytes) / (dec_ms * 1e-3) / 1e9, 2)},
             "roofline": s.roofline(kernels, config, kernel="snappy_decode"),
             "kernels": kernels}
+    if len(s.fmts) > 1:
+        try:
+            res["decode_by_layout"] = decode_by_layout(s)
+        except Exception as exc:
+            res["decode_by_layout"] = {"error": repr(exc)}
     if reference_frames:
         # the same textures as the reference encoder writes them (libsnappy streams, no table): every existing Hap file
         try:

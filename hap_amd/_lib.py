@@ -43,10 +43,17 @@ def _load():
         "HapGpuSynchronize": (u, [vp]),
         "HapGpuTableFallbackCount": (ul, [vp]),
         "HapGpuPlacementRetryCount": (ul, [vp]),
+        "HapGpuPlacementTimeoutCount": (ul, [vp]),
         "HapGpuCompressRGBA": (u, [vp, vp, u, u, ul, u, vp, ul, P(ul)]),
         "HapGpuDecompressRGBA": (u, [vp, vp, ul, u, vp, ul, u, u, vp, ul]),
         "HapGpuEncodeFrames": (u, [vp, u, u, P(vp), P(ul), P(u), P(u), P(u), P(vp), P(ul), P(ul), P(u), u]),
         "HapGpuEncodeFramesRGBA": (u, [vp, u, P(vp), u, u, ul, u, P(u), P(u), P(u), P(vp), P(ul), P(ul), P(u), u]),
+        "HapGpuEncodeFramesRGBABegin": (u, [vp, u, P(vp), u, u, ul, u, P(u), P(u), P(u), P(vp), P(ul), P(ul), P(u), u]),
+        "HapGpuEncodeFramesBegin": (u, [vp, u, u, P(vp), P(ul), P(u), P(u), P(u), P(vp), P(ul), P(ul), P(u), u]),
+        "HapGpuEncodeFramesFinish": (u, [vp]),
+        "HapGpuEncodeFramesRGBAOnDevices": (u, [P(vp), u, u, P(vp), u, u, ul, u, P(u), P(u), P(u), P(vp), P(ul), P(ul), P(u), u]),
+        "HapGpuEncodeFramesOnDevices": (u, [P(vp), u, u, u, P(vp), P(ul), P(u), P(u), P(u), P(vp), P(ul), P(ul), P(u), u]),
+        "HapGpuDecodeFramesOnDevices": (u, [P(vp), u, u, P(vp), P(ul), u, P(vp), P(ul), P(ul), P(u), P(u), u]),
         "HapGpuDecodeFrames": (u, [vp, u, P(vp), P(ul), u, P(vp), P(ul), P(ul), P(u), P(u), u]),
         "HapGpuDecodeFrameTextures": (u, [vp, u, P(vp), P(ul), u, P(vp), P(ul), P(ul), P(u), P(u), u]),
         "HapGpuDecodeFramesRGBA": (u, [vp, u, P(vp), P(ul), u, P(vp), u, u, ul, P(u), u]),
@@ -66,6 +73,7 @@ def _load():
         "HapGpuEncodeSequence": (u, [vp, vp, u, P(vp), u, u, ul, u, P(u), P(u), P(u), u, u, P(ul), P(u)]),
         "HapGpuSetProfiling": (u, [vp, u]),
         "HapGpuCollectProfile": (u, [vp, P(ul), P(C.c_double)]),
+        "HapGpuCollectProfileN": (u, [vp, u, P(ul), P(C.c_double)]),
         "HapGpuTimerStart": (u, [vp]),
         "HapGpuTimerStop": (u, [vp, P(C.c_double)]),
     }

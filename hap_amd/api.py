@@ -262,6 +262,10 @@ class Context:
         """frames encoded a second time because one of their chunks did not shrink (HapGpuPlacementRetryCount)"""
         return int(lib.HapGpuPlacementRetryCount(self.handle))
 
+    def placement_timeouts(self):
+        """... of which because a wavefront gave up waiting for its predecessors' sizes (HapGpuPlacementTimeoutCount)"""
+        return int(lib.HapGpuPlacementTimeoutCount(self.handle))
+
     def table_fallbacks(self):
         """frames decoded a second time because their fragment table did not describe their streams"""
         return int(lib.HapGpuTableFallbackCount(self.handle))
@@ -345,6 +349,29 @@ class Context:
                                        (C.c_uint * count)(*chunk_counts), optrs, olens, used, results, flags)
         return r, list(used), list(results)
 
+    def encode_frames_rgba_begin(self, rgba_frames, width, height, row_bytes, formats, compressors, chunk_counts,
+                                 outputs, flags=0):
+        """First half of encode_frames_rgba (HapGpuEncodeFramesRGBABegin): everything launched, nothing waited for.
+        The context takes no other call until encode_finish(), which returns what encode_frames_rgba returns."""
+        nf, count = len(rgba_frames), len(formats)
+        ptrs, _infos = self._ptr_array(rgba_frames)
+        optrs, oinfos = self._ptr_array(outputs)
+        olens = (C.c_ulong * nf)(*[i[1] for i in oinfos])
+        used = (C.c_ulong * nf)()
+        results = (C.c_uint * nf)()
+        r = lib.HapGpuEncodeFramesRGBABegin(self.handle, nf, ptrs, width, height, row_bytes, count,
+                                            (C.c_uint * count)(*formats), (C.c_uint * count)(*compressors),
+                                            (C.c_uint * count)(*chunk_counts), optrs, olens, used, results, flags)
+        self._pending = (used, results, ptrs, optrs, olens, rgba_frames, outputs)     # alive until the second half
+        return r
+
+    def encode_finish(self):
+        r = lib.HapGpuEncodeFramesFinish(self.handle)
+        pending, self._pending = getattr(self, "_pending", None), None
+        if pending is None:
+            return r, [], []
+        return r, list(pending[0]), list(pending[1])
+
     def decode_frames(self, frames, frame_bytes, index, outputs, flags=0):
         nf = len(frames)
         ptrs, infos = self._ptr_array(frames)
@@ -425,7 +452,7 @@ class Context:
         n = len(KERNEL_CLASSES)
         launches = (C.c_ulong * n)()
         ms = (C.c_double * n)()
-        lib.HapGpuCollectProfile(self.handle, launches, ms)
+        lib.HapGpuCollectProfileN(self.handle, n, launches, ms)
         return {k: (launches[i], ms[i]) for i, k in enumerate(KERNEL_CLASSES)}
 
     def timer_start(self):
@@ -435,3 +462,35 @@ class Context:
         ms = C.c_double(0)
         lib.HapGpuTimerStop(self.handle, C.byref(ms))
         return ms.value
+
+
+def _handles(contexts):
+    return (C.c_void_p * len(contexts))(*[c.handle for c in contexts])
+
+
+def encode_frames_rgba_on_devices(contexts, rgba_frames, width, height, row_bytes, formats, compressors, chunk_counts, outputs, flags=0):
+    """HapGpuEncodeFramesRGBAOnDevices: frame f -> contexts[f mod N], one host thread per context, no collective."""
+    nf, count = len(rgba_frames), len(formats)
+    ptrs, _infos = contexts[0]._ptr_array(rgba_frames)
+    optrs, oinfos = contexts[0]._ptr_array(outputs)
+    olens = (C.c_ulong * nf)(*[i[1] for i in oinfos])
+    used = (C.c_ulong * nf)()
+    results = (C.c_uint * nf)()
+    r = lib.HapGpuEncodeFramesRGBAOnDevices(_handles(contexts), len(contexts), nf, ptrs, width, height, row_bytes, count,
+                                            (C.c_uint * count)(*formats), (C.c_uint * count)(*compressors),
+                                            (C.c_uint * count)(*chunk_counts), optrs, olens, used, results, flags)
+    return r, list(used), list(results)
+
+
+def decode_frames_on_devices(contexts, frames, frame_bytes, index, outputs, flags=0):
+    """HapGpuDecodeFramesOnDevices: frame f -> contexts[f mod N]."""
+    nf = len(frames)
+    ptrs, infos = contexts[0]._ptr_array(frames)
+    lens = (C.c_ulong * nf)(*[fb if fb is not None else infos[i][1] for i, fb in enumerate(frame_bytes)])
+    optrs, oinfos = contexts[0]._ptr_array(outputs)
+    olens = (C.c_ulong * nf)(*[i[1] for i in oinfos])
+    used = (C.c_ulong * nf)()
+    fmts = (C.c_uint * nf)()
+    results = (C.c_uint * nf)()
+    r = lib.HapGpuDecodeFramesOnDevices(_handles(contexts), len(contexts), nf, ptrs, lens, index, optrs, olens, used, fmts, results, flags)
+    return r, list(used), list(fmts), list(results)

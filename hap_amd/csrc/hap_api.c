@@ -55,10 +55,14 @@ unsigned int HapGpuCreate(int device, HapGpuContext **context)
     return HapResult_No_Error;
 }
 
+unsigned int HapGpuEncodeFramesFinish(HapGpuContext *context);
+
 void HapGpuDestroy(HapGpuContext *context)
 {
     if (!context)
         return;
+    if (context->pending_encode)
+        HapGpuEncodeFramesFinish(context);
     hapgpu_rt_destroy(context->rt);
     free(context);
 }
@@ -189,6 +193,17 @@ unsigned long HapGpuPlacementRetryCount(HapGpuContext *context)
         return 0;
     hapgpu_rt_lock(context->rt);
     n = context->placement_retries;
+    hapgpu_rt_unlock(context->rt);
+    return n;
+}
+
+unsigned long HapGpuPlacementTimeoutCount(HapGpuContext *context)
+{
+    unsigned long n;
+    if (!context)
+        return 0;
+    hapgpu_rt_lock(context->rt);
+    n = context->placement_timeouts;
     hapgpu_rt_unlock(context->rt);
     return n;
 }
@@ -507,6 +522,64 @@ unsigned int HapGpuEncodeFramesRGBA(HapGpuContext *context, unsigned int frameCo
     return r;
 }
 
+/* The two halves of HapGpuEncodeFramesRGBA / HapGpuEncodeFrames (include/hap_gpu.h): everything launched, nothing waited for. */
+unsigned int HapGpuEncodeFramesRGBABegin(HapGpuContext *context, unsigned int frameCount,
+                                         const void *const *rgbaFrames, unsigned int width, unsigned int height,
+                                         unsigned long rowBytes, unsigned int count,
+                                         const unsigned int *textureFormats, const unsigned int *compressors,
+                                         const unsigned int *chunkCounts, void *const *outputBuffers,
+                                         const unsigned long *outputBuffersBytes,
+                                         unsigned long *outputBuffersBytesUsed, unsigned int *results,
+                                         unsigned int flags)
+{
+    unsigned r;
+    if (!context || frameCount > HAP_BATCH_SLICE)
+        return HapResult_Bad_Arguments;
+    hapgpu_rt_lock(context->rt);
+    context->defer_encode = 1u;
+    r = hapb_encode_rgba(context, frameCount, rgbaFrames, width, height, rowBytes, count, textureFormats,
+                         compressors, chunkCounts, outputBuffers, outputBuffersBytes, outputBuffersBytesUsed,
+                         results, flags);
+    context->defer_encode = 0u;
+    hapgpu_rt_unlock(context->rt);
+    return r;
+}
+
+unsigned int HapGpuEncodeFramesBegin(HapGpuContext *context, unsigned int frameCount, unsigned int count,
+                                     const void *const *inputBuffers, const unsigned long *inputBuffersBytes,
+                                     const unsigned int *textureFormats, const unsigned int *compressors,
+                                     const unsigned int *chunkCounts, void *const *outputBuffers,
+                                     const unsigned long *outputBuffersBytes,
+                                     unsigned long *outputBuffersBytesUsed, unsigned int *results,
+                                     unsigned int flags)
+{
+    unsigned r;
+    if (!context || frameCount > HAP_BATCH_SLICE)
+        return HapResult_Bad_Arguments;
+    hapgpu_rt_lock(context->rt);
+    context->defer_encode = 1u;
+    r = hapb_encode(context, frameCount, count, inputBuffers, inputBuffersBytes, textureFormats, compressors, chunkCounts,
+                    outputBuffers, outputBuffersBytes, outputBuffersBytesUsed, results, flags, 0);
+    context->defer_encode = 0u;
+    hapgpu_rt_unlock(context->rt);
+    return r;
+}
+
+unsigned int HapGpuEncodeFramesFinish(HapGpuContext *context)
+{
+    unsigned r = HapResult_No_Error;
+    HapbEncodePending *pd;
+    if (!context)
+        return HapResult_Bad_Arguments;
+    hapgpu_rt_lock(context->rt);
+    pd = context->pending_encode;
+    context->pending_encode = NULL;
+    if (pd)
+        r = hapb_encode_complete(context, pd);
+    hapgpu_rt_unlock(context->rt);
+    return r;
+}
+
 unsigned int HapGpuDecodeFrames(HapGpuContext *context, unsigned int frameCount,
                                 const void *const *inputBuffers, const unsigned long *inputBuffersBytes,
                                 unsigned int index, void *const *outputBuffers,
@@ -720,16 +793,25 @@ unsigned int HapGpuSetProfiling(HapGpuContext *context, unsigned int enable)
     return HapResult_No_Error;
 }
 
-unsigned int HapGpuCollectProfile(HapGpuContext *context, unsigned long *launches, double *milliseconds)
+unsigned int HapGpuCollectProfileN(HapGpuContext *context, unsigned int classCount, unsigned long *launches, double *milliseconds)
 {
     unsigned r;
     if (!context || !launches || !milliseconds)
         return HapResult_Bad_Arguments;
+    if (classCount > HapGpuKernel_ClassCount)
+        classCount = HapGpuKernel_ClassCount;
     hapgpu_rt_lock(context->rt);
-    r = hapgpu_rt_collect_profile(context->rt, launches, milliseconds, HapGpuKernel_ClassCount)
-            ? HapResult_Internal_Error : HapResult_No_Error;
+    /* (events of classes beyond the caller's arrays are drained and dropped) */
+    r = hapgpu_rt_collect_profile(context->rt, launches, milliseconds, classCount) ? HapResult_Internal_Error : HapResult_No_Error;
     hapgpu_rt_unlock(context->rt);
     return r;
+}
+
+/* The entry point of the first header (eight classes, no count argument): a client built against it has arrays of
+   eight.  New code says how many entries its arrays have (HapGpuCollectProfileN). */
+unsigned int HapGpuCollectProfile(HapGpuContext *context, unsigned long *launches, double *milliseconds)
+{
+    return HapGpuCollectProfileN(context, 8u, launches, milliseconds);
 }
 
 unsigned int HapGpuTimerStart(HapGpuContext *context)

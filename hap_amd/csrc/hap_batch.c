@@ -13,6 +13,7 @@
  * HapEncode (hap.c:506-604, 355-504) and HapDecode (hap.c:993-1040, 732-930).
  */
 #include "hap_batch.h"
+#include "measurement_guard.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -42,6 +43,19 @@ static double hapb_now_us(void) { struct timespec ts; clock_gettime(CLOCK_MONOTO
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static int is_dev(HapGpuContext *c, const void *p) { return hapgpu_rt_is_device_ptr(c->rt, p); }
+
+/* A context whose last encode call has been begun and not finished (HapGpuEncodeFramesRGBABegin) holds that call's
+   tables and scratch: it takes no other call until HapGpuEncodeFramesFinish. */
+static int context_busy(HapGpuContext *c, unsigned *results, unsigned frame_count)
+{
+    unsigned f;
+    if (!c->pending_encode)
+        return 0;
+    fprintf(stderr, "hap_amd: the context has an encode call in flight (HapGpuEncodeFramesFinish first)\n");
+    for (f = 0; results && f < frame_count; f++)
+        results[f] = HapResult_Internal_Error;
+    return 1;
+}
 
 /* ================================================================== encode */
 
@@ -89,6 +103,8 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
         return HapResult_No_Error;
     if (!results)
         return HapResult_Bad_Arguments;
+    if (context_busy(ctx, results, frame_count))
+        return HapResult_Internal_Error;
     /* frame-independent argument checks, reference hap.c:518-559 */
     {
         unsigned rc = HapResult_No_Error;
@@ -238,7 +254,7 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
        its wavefronts learn the sizes of what lies before them from each other (snappy_compress_blocks.hip) */
     /* (up to 64 chunks: their totals are one load per wavefront.  16 8K frames of 400 chunks: 0.966 ms placed against 0.880
        gathered; of 1 chunk -- 4050 fragments to look back over -- 1.110 against 1.111) */
-    placed = (!ctx->no_placing && count == 1u && g[0].compressor == HapCompressorSnappy && g[0].field_period != 0u && frag_log2 == 13u &&
+    placed = (!ctx->no_placing && !ctx->placing_off && count == 1u && g[0].compressor == HapCompressorSnappy && g[0].field_period != 0u && frag_log2 == 13u &&
               g[0].chunk_count <= 64u) ? 1u : 0u;
     slot_stride = (unsigned)align_up(frag_bytes + frag_bytes / 32u + 64u + HAPGPU_SLOT_SCRATCH_BYTES, 16);
     /* how far placed fragments can reach into the frame buffer if nothing shrinks (the frame is then encoded again, but
@@ -474,87 +490,184 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
             }
             rc |= launch_rc;
         }
-        rc |= (unsigned)hapgpu_rt_sync(rt);
-        if (rc) {
-            for (k = 0; k < live; k++)
-                results[live_index[k]] = HapResult_Internal_Error;
-            free(live_index); free(stage_off_in); free(stage_off_out);
-            return HapResult_Internal_Error;
-        }
-        /* results (+ device->host copy of staged frames) */
+        /* everything the call launches is on the stream: the rest -- waiting, reading the results, the second pass over
+           frames that were not placed -- is hapb_encode_complete's, at once or (HapGpuEncodeFramesRGBABegin / ...Finish)
+           when the client asks for the results */
         {
-            int copied = 0;
-            for (k = 0; k < live; k++) {
-                HapGpuFrameEnc *fe = &hframes[k];
-                f = live_index[k];
-                results[f] = fe->status;
-                if (fe->status == HapResult_No_Error) {
-                    output_used[f] = (unsigned long)fe->bytes_used;
-                    if (stage_off_out[f]) {
-                        if (hapgpu_rt_d2h(rt, outputs[f], out_stage + (stage_off_out[f] - 1), (size_t)fe->bytes_used))
-                            results[f] = HapResult_Internal_Error;
-                        copied = 1;
-                    }
-                }
-                if (results[f] != HapResult_No_Error && results[f] != HAPGPU_STATUS_NOT_PLACED && first_error == HapResult_No_Error)
-                    first_error = results[f];
+            HapbEncodePending *pd = (HapbEncodePending *)calloc(1, sizeof(*pd));
+            const size_t n_in = (size_t)frame_count * count;
+            if (pd) {
+                pd->inputs = (const void **)malloc(sizeof(void *) * n_in);
+                pd->outputs = (void **)malloc(sizeof(void *) * frame_count);
+                pd->output_bytes = (unsigned long *)malloc(sizeof(unsigned long) * frame_count);
             }
-            if (copied && hapgpu_rt_sync(rt))
-                first_error = HapResult_Internal_Error;
-        }
-        /* frames with a chunk that Snappy did not shrink (stored raw, hap.c:460-466: everything behind it lies elsewhere
-           than the wavefronts assumed): once more, through slots.  The textures are where they were -- the client's, or
-           the scratch the RGBA call's kernels filled. */
-        if (placed) {
-            unsigned again = 0;
-            for (f = 0; f < frame_count; f++)
-                again += results[f] == HAPGPU_STATUS_NOT_PLACED;
-            if (again) {
-                /* all of them in one batch */
-                const HapbBlockEncodeJob *job = ctx->block_encode_job;
-                const void **rin = (const void **)malloc(sizeof(void *) * (size_t)again * count);
-                void **rout = (void **)malloc(sizeof(void *) * again);
-                unsigned long *rcap = (unsigned long *)malloc(sizeof(unsigned long) * again * 2u);
-                unsigned *rres = (unsigned *)malloc(sizeof(unsigned) * again * 2u);
-                if (rin && rout && rcap && rres) {
-                    unsigned long *rused = rcap + again;
-                    unsigned *rmap = rres + again, m = 0;
-                    for (f = 0; f < frame_count; f++)
-                        if (results[f] == HAPGPU_STATUS_NOT_PLACED) {
-                            for (i = 0; i < count; i++)
-                                rin[(size_t)m * count + i] = inputs[(size_t)f * count + i];
-                            rout[m] = outputs[f];
-                            rcap[m] = output_bytes[f];
-                            rmap[m++] = f;
-                        }
-                    ctx->block_encode_job = NULL;
-                    ctx->no_placing = 1u;
-                    hapb_encode(ctx, again, count, rin, input_bytes, formats, compressors, chunk_counts, rout, rcap, rused, rres, flags,
-                                inputs_are_device == 2 ? 1 : inputs_are_device);
-                    ctx->no_placing = 0u;
-                    ctx->block_encode_job = job;
-                    for (m = 0; m < again; m++) {
-                        results[rmap[m]] = rres[m];
-                        output_used[rmap[m]] = rused[m];
-                    }
-                } else {
-                    for (f = 0; f < frame_count; f++)
-                        if (results[f] == HAPGPU_STATUS_NOT_PLACED)
-                            results[f] = HapResult_Internal_Error;
-                }
-                free(rin); free(rout); free(rcap); free(rres);
-                ctx->placement_retries += again;
-                for (f = 0; f < frame_count; f++)
-                    if (results[f] != HapResult_No_Error && first_error == HapResult_No_Error)
-                        first_error = results[f];
-                /* content that does not shrink tends to stay: a call that had to encode most of its frames twice
-                   keeps the next calls from trying (and then tries again) */
-                if (2u * again > live)
-                    ctx->placing_holdoff = ctx->placing_holdoff_calls;
+            if (!pd || !pd->inputs || !pd->outputs || !pd->output_bytes) {
+                if (pd) { free(pd->inputs); free(pd->outputs); free(pd->output_bytes); }
+                free(pd);
+                hapgpu_rt_sync(rt);
+                for (k = 0; k < live; k++)
+                    results[live_index[k]] = HapResult_Internal_Error;
+                free(live_index); free(stage_off_in); free(stage_off_out);
+                return HapResult_Internal_Error;
             }
+            memcpy(pd->inputs, inputs, sizeof(void *) * n_in);
+            memcpy(pd->outputs, outputs, sizeof(void *) * frame_count);
+            memcpy(pd->output_bytes, output_bytes, sizeof(unsigned long) * frame_count);
+            for (i = 0; i < count; i++) {
+                pd->input_bytes[i] = input_bytes[i];
+                pd->formats[i] = formats[i];
+                pd->compressors[i] = compressors[i];
+                pd->chunk_counts[i] = chunk_counts[i];
+            }
+            pd->frame_count = frame_count;
+            pd->count = count;
+            pd->flags = flags;
+            pd->inputs_are_device = inputs_are_device;
+            pd->output_used = output_used;
+            pd->results = results;
+            pd->live = live;
+            pd->placed = placed;
+            pd->first_error = first_error;
+            pd->launch_rc = rc;
+            pd->live_index = live_index;
+            pd->stage_off_out = stage_off_out;
+            pd->hframes = hframes;
+            pd->out_stage = out_stage;
+            if (ctx->block_encode_job) {
+                pd->job = *ctx->block_encode_job;
+                pd->has_job = 1;
+            }
+            free(stage_off_in);
+            if (ctx->defer_encode) {
+                ctx->pending_encode = pd;
+                return first_error;
+            }
+            return hapb_encode_complete(ctx, pd);
         }
     }
-    free(live_index); free(stage_off_in); free(stage_off_out);
+}
+
+/* The second half of hapb_encode: waits for the launches, reads the per-frame results back, copies staged frames to the
+   client's host buffers, and encodes the frames that were not placed once more.  Frees `pd`. */
+unsigned hapb_encode_complete(HapGpuContext *ctx, HapbEncodePending *pd)
+{
+    hapgpu_rt *rt = ctx->rt;
+    const unsigned frame_count = pd->frame_count, count = pd->count, live = pd->live, flags = pd->flags;
+    unsigned *const results = pd->results;
+    unsigned long *const output_used = pd->output_used;
+    unsigned first_error = pd->first_error, rc = pd->launch_rc, f, i, k;
+    rc |= (unsigned)hapgpu_rt_sync(rt);
+    if (rc) {
+        for (k = 0; k < live; k++)
+            results[pd->live_index[k]] = HapResult_Internal_Error;
+        first_error = HapResult_Internal_Error;
+        goto done;
+    }
+    /* results (+ device->host copy of staged frames) */
+    {
+        int copied = 0;
+        for (k = 0; k < live; k++) {
+            HapGpuFrameEnc *fe = &pd->hframes[k];
+            f = pd->live_index[k];
+            results[f] = fe->status;
+            if (fe->status == HAPGPU_STATUS_NOT_PLACED && (fe->reserved & 1u)) {
+                /* a wavefront gave up waiting for its predecessors (snappy_compress_blocks.hip): something keeps the
+                   grid from advancing in order -- this context gathers from now on */
+                ctx->placement_timeouts += 1u;
+                ctx->placing_off = 1u;
+            }
+            if (fe->status == HapResult_No_Error) {
+                output_used[f] = (unsigned long)fe->bytes_used;
+                if (pd->stage_off_out[f]) {
+                    if (hapgpu_rt_d2h(rt, pd->outputs[f], pd->out_stage + (pd->stage_off_out[f] - 1), (size_t)fe->bytes_used))
+                        results[f] = HapResult_Internal_Error;
+                    copied = 1;
+                }
+            }
+            if (results[f] != HapResult_No_Error && results[f] != HAPGPU_STATUS_NOT_PLACED && first_error == HapResult_No_Error)
+                first_error = results[f];
+        }
+        if (copied && hapgpu_rt_sync(rt))
+            first_error = HapResult_Internal_Error;
+    }
+    /* frames with a chunk that Snappy did not shrink (stored raw, hap.c:460-466: everything behind it lies elsewhere
+       than the wavefronts assumed): once more, through slots.  The textures are where they were -- the client's --
+       or, in a call that started from pictures, are made again from the pictures: the fused kernel of a placed call
+       does not keep them (snappy_compress_blocks.hip). */
+    if (pd->placed) {
+        unsigned again = 0;
+        for (f = 0; f < frame_count; f++)
+            again += results[f] == HAPGPU_STATUS_NOT_PLACED;
+        if (again) {
+            /* all of them in one batch */
+            const HapbBlockEncodeJob *const outer_job = ctx->block_encode_job;
+            const unsigned saved_no_placing = ctx->no_placing, saved_defer = ctx->defer_encode;
+            HapbBlockEncodeJob rjob;
+            uint64_t *rtable = NULL;
+            const void **rin = (const void **)malloc(sizeof(void *) * (size_t)again * count);
+            void **rout = (void **)malloc(sizeof(void *) * again);
+            unsigned long *rcap = (unsigned long *)malloc(sizeof(unsigned long) * again * 2u);
+            unsigned *rres = (unsigned *)malloc(sizeof(unsigned) * again * 2u);
+            if (pd->has_job)
+                rtable = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(1u + pd->job.count) * again);
+            if (rin && rout && rcap && rres && (!pd->has_job || rtable)) {
+                unsigned long *rused = rcap + again;
+                unsigned *rmap = rres + again, m = 0;
+                for (f = 0; f < frame_count; f++)
+                    if (results[f] == HAPGPU_STATUS_NOT_PLACED) {
+                        for (i = 0; i < count; i++)
+                            rin[(size_t)m * count + i] = pd->inputs[(size_t)f * count + i];
+                        rout[m] = pd->outputs[f];
+                        rcap[m] = pd->output_bytes[f];
+                        rres[m] = HapResult_Internal_Error;
+                        rused[m] = 0;
+                        if (pd->has_job) {
+                            /* the pictures and texture places of these frames, as a table of its own */
+                            unsigned t;
+                            for (t = 0; t < 1u + pd->job.count; t++)
+                                rtable[(size_t)t * again + m] = pd->job.host_table[(size_t)t * pd->job.frame_count + f];
+                        }
+                        rmap[m++] = f;
+                    }
+                ctx->block_encode_job = NULL;
+                if (pd->has_job) {
+                    rjob = pd->job;
+                    rjob.host_table = rtable;
+                    rjob.frame_count = again;
+                    ctx->block_encode_job = &rjob;
+                }
+                ctx->no_placing = 1u;
+                ctx->defer_encode = 0u;
+                hapb_encode(ctx, again, count, rin, pd->input_bytes, pd->formats, pd->compressors, pd->chunk_counts, rout, rcap, rused, rres,
+                            flags, pd->inputs_are_device);
+                ctx->defer_encode = saved_defer;
+                ctx->no_placing = saved_no_placing;
+                ctx->block_encode_job = outer_job;
+                for (m = 0; m < again; m++) {
+                    /* (a call without placing cannot report a frame as not placed) */
+                    results[rmap[m]] = rres[m] == HAPGPU_STATUS_NOT_PLACED ? HapResult_Internal_Error : rres[m];
+                    output_used[rmap[m]] = rused[m];
+                }
+            } else {
+                for (f = 0; f < frame_count; f++)
+                    if (results[f] == HAPGPU_STATUS_NOT_PLACED)
+                        results[f] = HapResult_Internal_Error;
+            }
+            free(rin); free(rout); free(rcap); free(rres); free(rtable);
+            ctx->placement_retries += again;
+            for (f = 0; f < frame_count; f++)
+                if (results[f] != HapResult_No_Error && first_error == HapResult_No_Error)
+                    first_error = results[f];
+            /* content that does not shrink tends to stay: a call that had to encode most of its frames twice
+               keeps the next calls from trying (and then tries again) */
+            if (2u * again > live)
+                ctx->placing_holdoff = ctx->placing_holdoff_calls;
+        }
+    }
+done:
+    free(pd->live_index); free(pd->stage_off_out);
+    free(pd->inputs); free(pd->outputs); free(pd->output_bytes);
+    free(pd);
     return first_error;
 }
 
@@ -568,6 +681,8 @@ unsigned hapb_compress_rgba(HapGpuContext *ctx, const void *rgba, unsigned width
     const void *src = rgba;
     void *dst = output;
     int rc = 0;
+    if (context_busy(ctx, NULL, 0))
+        return HapResult_Internal_Error;
     if (!rgba || !output || width == 0 || height == 0 || (width & 3u) || (height & 3u) ||
         row_bytes < (unsigned long)width * 4ul ||
         (format != HapTextureFormat_RGB_DXT1 && format != HapTextureFormat_RGBA_DXT5 &&
@@ -612,6 +727,8 @@ unsigned hapb_decompress_rgba(HapGpuContext *ctx, const void *texture, unsigned 
     const void *src = texture, *asrc = alpha;
     void *dst = rgba;
     int rc;
+    if (context_busy(ctx, NULL, 0))
+        return HapResult_Internal_Error;
     if (!texture || !rgba || width == 0 || height == 0 || (width & 3u) || (height & 3u) ||
         row_bytes < (unsigned long)width * 4ul ||
         (format != HapTextureFormat_RGB_DXT1 && format != HapTextureFormat_RGBA_DXT5 &&
@@ -672,6 +789,8 @@ unsigned hapb_encode_rgba(HapGpuContext *ctx, unsigned frame_count, const void *
     int wide = 1;
     if (frame_count == 0)
         return HapResult_No_Error;
+    if (context_busy(ctx, results, frame_count))
+        return HapResult_Internal_Error;
     if (!results || !rgba_frames || count == 0 || count > 2 || !formats || width == 0 || height == 0 ||
         (width & 3u) || (height & 3u) || row_bytes < (unsigned long)width * 4ul) {
         for (f = 0; results && f < frame_count; f++)
@@ -896,6 +1015,8 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
         return HapResult_No_Error;
     if (!results)
         return HapResult_Bad_Arguments;
+    if (context_busy(ctx, results, frame_count))
+        return HapResult_Internal_Error;
     if (!inputs || !input_bytes || !outputs || !output_bytes || index > 1) {
         for (f = 0; f < frame_count; f++)
             results[f] = HapResult_Bad_Arguments;
@@ -1394,6 +1515,8 @@ unsigned hapb_decode_rgba(HapGpuContext *ctx, unsigned frame_count, const void *
         return HapResult_No_Error;
     if (!results)
         return HapResult_Bad_Arguments;
+    if (context_busy(ctx, results, frame_count))
+        return HapResult_Internal_Error;
     if (!inputs || !input_bytes || !rgba_frames || texture_count == 0 || texture_count > 2 || width == 0 ||
         height == 0 || (width & 3u) || (height & 3u) || row_bytes < (unsigned long)width * 4ul || (row_bytes & 15u)) {
         for (f = 0; f < frame_count; f++)
@@ -1505,8 +1628,15 @@ unsigned hapb_decode_rgba(HapGpuContext *ctx, unsigned frame_count, const void *
                         rc |= hapgpu_k_block_decode_batch(rt, dtab + (size_t)k * 3u * n, n, texture_count == 2, width, height, kinds[k],
                                                           row_bytes);
                 for (f = 0; f < n; f++)
-                    if (results[done + f] == HapResult_No_Error && stage && !is_dev(ctx, rgba_frames[done + f]))
-                        rc |= hapgpu_rt_d2h(rt, rgba_frames[done + f], stage + align_up(rgba_bytes, 256) * f, rgba_bytes);
+                    if (results[done + f] == HapResult_No_Error && stage && !is_dev(ctx, rgba_frames[done + f])) {
+                        /* (row by row when the client's rows are longer than the picture's: what lies between them -- the
+                           rest of a larger image, perhaps -- is not this call's to overwrite) */
+                        if (row_bytes == (unsigned long)width * 4ul)
+                            rc |= hapgpu_rt_d2h(rt, rgba_frames[done + f], stage + align_up(rgba_bytes, 256) * f, rgba_bytes);
+                        else
+                            rc |= hapgpu_rt_d2h_rows(rt, rgba_frames[done + f], row_bytes, stage + align_up(rgba_bytes, 256) * f, row_bytes,
+                                                     (size_t)width * 4u, height);
+                    }
             }
         }
         rc |= hapgpu_rt_sync(rt);
@@ -1607,6 +1737,8 @@ unsigned hapb_join_device(HapGpuContext *ctx, unsigned group_count, const void *
 
     if (group_count == 0 || !frames || !frame_bytes || !output || !output_used)
         return HapResult_Bad_Arguments;
+    if (context_busy(ctx, NULL, 0))
+        return HapResult_Internal_Error;
     for (g = 0; g < group_count; g++)
         if (!frames[g] || frame_bytes[g] > 0xFFFFFFFFul || !is_dev(ctx, frames[g]))
             return HapResult_Bad_Arguments;

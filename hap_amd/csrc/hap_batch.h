@@ -27,6 +27,8 @@ struct HapGpuContext {
     /* chunk marks collected from the client's HapDecodeCallback, handed to the retry of a frame whose fragment
        table turned out wrong: the callback is invoked exactly once per HapDecode, as in the reference */
     unsigned long placement_retries; /* frames encoded a second time, through slots (a chunk of theirs was stored raw) */
+    unsigned long placement_timeouts; /* ... of which: a wavefront waited for its predecessors' sizes longer than the bound */
+    unsigned placing_off;     /* set by the first such timeout: this context gathers from then on */
     unsigned long table_fallbacks;   /* frames decoded again without their fragment table (it did not match) */
     const unsigned char *preset_marks;
     unsigned preset_count;
@@ -35,6 +37,10 @@ struct HapGpuContext {
     const struct HapbBlockEncodeJob *block_encode_job;
     /* texture index of every entry of the next hapb_decode call (NULL: its `index` argument for all) */
     const unsigned *decode_indices;
+    /* HapGpuEncodeFramesRGBABegin / HapGpuEncodeFramesFinish: the launched half of an encode call whose results have
+       not been asked for yet; while there is one the context takes no other call */
+    unsigned defer_encode;
+    struct HapbEncodePending *pending_encode;
 };
 
 typedef struct HapbBlockEncodeJob {
@@ -44,6 +50,26 @@ typedef struct HapbBlockEncodeJob {
     unsigned long row_bytes;
     int wide;
 } HapbBlockEncodeJob;
+
+/* What hapb_encode leaves for hapb_encode_complete: the call's arguments (copies: the client's arrays need not outlive
+   the first half -- except the two it fills, output_used and results) and the state of its launches. */
+typedef struct HapbEncodePending {
+    unsigned frame_count, count, flags, live, placed, first_error, launch_rc;
+    int inputs_are_device, has_job;
+    const void **inputs;
+    void **outputs;
+    unsigned long *output_bytes;
+    unsigned long input_bytes[2];
+    unsigned formats[2], compressors[2], chunk_counts[2];
+    unsigned long *output_used;       /* the client's */
+    unsigned *results;                /* the client's */
+    unsigned *live_index;
+    size_t *stage_off_out;
+    HapGpuFrameEnc *hframes;          /* pinned scratch: stays as it is while the context takes no other call */
+    uint8_t *out_stage;
+    HapbBlockEncodeJob job;           /* a call that started from pictures (has_job) */
+} HapbEncodePending;
+unsigned hapb_encode_complete(HapGpuContext *ctx, HapbEncodePending *pending);
 
 /* inputs_are_device != 0: every input pointer is known to be device memory (skips classification) */
 unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,

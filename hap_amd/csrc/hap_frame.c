@@ -292,7 +292,7 @@ static void plan_complex(hapf_reader *r, hapf_texture_plan *plan, int want_chunk
             plan->frag_table_offset = base + (uint64_t)frags + 4u;
         } else if (fh[0] == HAP_FRAGMENT_TABLE_VERSION_FIELDS && fh[1] == 13u && (frag_bytes - 4u) % (4u + HAP_GROUP_TABLE_BYTES) == 0u &&
                    ((fh[2] >> 4) == 4u || (fh[2] >> 4) == 2u || (fh[2] >> 4) == 6u || (fh[2] >> 4) == 8u)) {
-            /* version 3: [3][13][granularity log2 | fields per block << 4][window] + u32 x N + 96-byte group table x N */
+            /* version 4: [4][13][granularity log2 | fields per block << 4][window] + u32 x N + 196-byte group table x N */
             plan->frag_log2 = 13u;
             plan->frag_gran_log2 = (fh[2] & 15u) <= 2u ? (fh[2] & 15u) : 0u;
             plan->frag_fields = fh[2] >> 4;
@@ -300,6 +300,15 @@ static void plan_complex(hapf_reader *r, hapf_texture_plan *plan, int want_chunk
             plan->frag_entries = (frag_bytes - 4u) / (4u + HAP_GROUP_TABLE_BYTES);
             plan->frag_table_offset = base + (uint64_t)frags + 4u;
             plan->frag_tiles_offset = plan->frag_table_offset + 4u * (uint64_t)plan->frag_entries;
+        } else if (fh[0] == HAP_FRAGMENT_TABLE_VERSION_FIELDS_R4 && fh[1] == 13u &&
+                   (frag_bytes - 4u) % (4u + HAP_GROUP_TABLE_BYTES_R4) == 0u) {
+            /* version 3 (written until round 4: group tables without the groups' output bytes): the fragment sizes are
+               used, the group tables are not -- one wavefront per fragment through the generic kernels */
+            plan->frag_log2 = 13u;
+            plan->frag_gran_log2 = (fh[2] & 15u) <= 2u ? (fh[2] & 15u) : 0u;
+            plan->frag_window256 = fh[3];
+            plan->frag_entries = (frag_bytes - 4u) / (4u + HAP_GROUP_TABLE_BYTES_R4);
+            plan->frag_table_offset = base + (uint64_t)frags + 4u;
         }
     }
     if (want_chunks && plan->chunk_count > 0) {

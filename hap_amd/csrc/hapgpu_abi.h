@@ -26,9 +26,14 @@ extern "C" {
 #define HAP_SECTION_OFFSETS 0x04u
 #define HAP_SECTION_FRAGMENTS 0x46u   /* private: hap_gpu.h */
 #define HAP_FRAGMENT_TABLE_VERSION 1u       /* fragment sizes only */
-#define HAP_FRAGMENT_TABLE_VERSION_FIELDS 3u /* + a group table per fragment: "field streams" (version 2, one byte per
-                                                half-tile, was written by earlier builds: such tables are ignored) */
-#define HAP_GROUP_TABLE_BYTES 96u            /* 64 groups of equally many elements, 12 bits each: the bytes of the group */
+#define HAP_FRAGMENT_TABLE_VERSION_FIELDS 4u /* + a group table per fragment: "field streams".  (Version 2, one byte per
+                                                half-tile, and version 3, 96-byte group tables without the groups' output
+                                                bytes, were written by earlier builds: version 2 tables are ignored, of
+                                                version 3 the fragment sizes are used.) */
+#define HAP_FRAGMENT_TABLE_VERSION_FIELDS_R4 3u
+#define HAP_GROUP_TABLE_BYTES_R4 96u
+#define HAP_GROUP_TABLE_BYTES 196u           /* 64 groups of equally many elements, 24 bits each -- compressed bytes |
+                                                output bytes << 12 -- then LE16 element count, LE16 zero */
 #define HAP_HALF_TILE_BYTES 128u
 #define HAP_HALF_TILES_PER_FRAGMENT 64u      /* 8 KiB fragments */
 
@@ -57,7 +62,7 @@ typedef struct HapGpuTexEnc {
     uint32_t frag_first;     /* global index of this texture's first fragment */
     uint32_t emit_index;     /* write the fragment-size section */
     uint32_t reserved;       /* bit 20: "field stream": no element crosses a 128-byte half-tile and the compressor
-                                writes every fragment's group table (fragment table version 3);
+                                writes every fragment's group table (fragment table version 4);
                                 bits 16..19: fields per block for the field-per-lane compressor (0: position per lane,
                                 2: RGTC1 layout, 4: DXT5 / YCoCg-DXT5, 10: DXT1, 12: opaque 16-byte blocks); bits 8..15: match window in 256-byte units (0 = whole fragment); bits 0..7:
                                 granularity_log2 of the element stream: 0 = bytes, 1 = every position, offset
@@ -223,7 +228,7 @@ typedef struct HapGpuDecodeUnit {
     uint32_t dst_len;
     uint32_t kind;           /* HAPGPU_UNIT_* */
     uint32_t job;            /* index of the owning job (status word) */
-    uint64_t aux;            /* FIELDS units: device address of the fragment's group table (96 bytes);
+    uint64_t aux;            /* FIELDS units: device address of the fragment's group table (HAP_GROUP_TABLE_BYTES);
                                 STREAM units: number of SKIP slots that follow for the block scan's BLOCK units */
     /* reserved: fragment units: readable bytes after the fragment (<= 15); STREAM units: 0 or the HapGpuScanChunk
        that decides whether the stream unit or its BLOCK units run */
@@ -244,6 +249,7 @@ void *hapgpu_rt_device_scratch(hapgpu_rt *rt, int slot, size_t bytes);
 void *hapgpu_rt_pinned_scratch(hapgpu_rt *rt, int slot, size_t bytes);
 int hapgpu_rt_h2d(hapgpu_rt *rt, void *dst, const void *src, size_t bytes);
 int hapgpu_rt_d2h(hapgpu_rt *rt, void *dst, const void *src, size_t bytes);
+int hapgpu_rt_d2h_rows(hapgpu_rt *rt, void *dst, size_t dpitch, const void *src, size_t spitch, size_t row, size_t rows);
 int hapgpu_rt_d2d(hapgpu_rt *rt, void *dst, const void *src, size_t bytes);
 int hapgpu_rt_zero(hapgpu_rt *rt, void *dst, size_t bytes);
 /* 1: kernels may be handed pinned-scratch addresses directly (no copy in front of or behind them) */
@@ -278,7 +284,7 @@ int hapgpu_k_block_decode(hapgpu_rt *rt, const void *blocks, const void *alpha, 
    [pictures], `pictures` entries each (texture 0 = skip the picture) */
 int hapgpu_k_block_decode_batch(hapgpu_rt *rt, const uint64_t *table, unsigned pictures, int with_alpha, unsigned width,
                                 unsigned height, unsigned hap_texture_format, size_t row_bytes);
-/* group_tables: HAP_GROUP_TABLE_BYTES (96) bytes per fragment (same indexing as frag_sizes), written for textures whose reserved bit 20 is set */
+/* group_tables: HAP_GROUP_TABLE_BYTES bytes per fragment (same indexing as frag_sizes), written for textures whose reserved bit 20 is set */
 int hapgpu_k_snappy_compress(hapgpu_rt *rt, const HapGpuFrameEnc *frames, unsigned frame_count,
                              unsigned max_frags_per_texture, unsigned frag_log2,
                              void *slots, unsigned slot_stride, uint32_t *frag_sizes, uint8_t *group_tables,

@@ -304,6 +304,16 @@ extern "C" int hapgpu_rt_d2h(hapgpu_rt *rt, void *dst, const void *src, size_t b
     return 0;
 }
 
+// rows of `row` bytes from a device picture (pitch spitch) to a host one (pitch dpitch): the bytes between the rows of the
+// destination stay as they are
+extern "C" int hapgpu_rt_d2h_rows(hapgpu_rt *rt, void *dst, size_t dpitch, const void *src, size_t spitch, size_t row, size_t rows)
+{
+    if (!row || !rows) return 0;
+    hipError_t e = hipMemcpy2DAsync(dst, dpitch, src, spitch, row, rows, hipMemcpyDeviceToHost, rt->stream);
+    if (e != hipSuccess) { complain("hipMemcpy2DAsync(D2H)", e); return 4; }
+    return 0;
+}
+
 extern "C" int hapgpu_rt_d2d(hapgpu_rt *rt, void *dst, const void *src, size_t bytes)
 {
     if (!bytes) return 0;

@@ -24,6 +24,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "hapgpu_abi.h"
+#include "measurement_guard.h"
 
 namespace {
 

@@ -36,6 +36,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "hapgpu_abi.h"
+#include "measurement_guard.h"
 #include "bc_encode_core.hpp"
 
 namespace {
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(64, SCB_MIN_WAVES) void snappy_compress_blocks_kern
     constexpr unsigned B = UL::block;
     __shared__ unsigned long long table[1u << kTableBits];
     __shared__ __attribute__((aligned(16))) uint32_t masks[64u * 8u];
-    __shared__ uint16_t bounds[66];                      // stream offset of every group's first element (+ the end)
+    __shared__ uint32_t bounds[66];                      // per group: stream offset of its first element | its output position << 16 (+ the end)
 
     const unsigned lane = threadIdx.x;
     // Single-texture launches take their frames interleaved: consecutive workgroups work on different frames, so the
@@ -353,8 +354,11 @@ __global__ __launch_bounds__(64, SCB_MIN_WAVES) void snappy_compress_blocks_kern
                 const uint4 blk = hapbc::block_of<FUSED>(pix[kPrefetch ? t & 1u : 0u]);
                 made = blk;
                 const unsigned bpos = (64u * t + lane) * B;
+                // (the texture is kept for chunks that Snappy does not shrink -- they are stored from there.  A PLACED
+                // call has no use for it: a frame with such a chunk is encoded again from its picture, without placing
+                // (hap_batch.c), and r04's kernel wrote 3.7 x its algorithmic bytes for nobody)
                 if (B == 16u) {
-                    if (bpos + 16u <= n)
+                    if (bpos + 16u <= n && !placed)
                         put128((gdst_t)(uintptr_t)(src + bpos), blk);
                     ring[4u + lane] = blk;
                 } else {
@@ -584,7 +588,15 @@ __global__ __launch_bounds__(64, SCB_MIN_WAVES) void snappy_compress_blocks_kern
     // ---- placed streams: where the fragment's bytes go in the frame ----
     // payload of the texture's section + a varint per chunk up to this one + the bytes of every fragment before this
     // one: whole chunks from their accumulators (complete when they have counted all their fragments), the fragments
-    // of this chunk from their published sizes.  Everything waited for belongs to wavefronts dispatched earlier.
+    // of this chunk from their published sizes.  Everything waited for belongs to workgroups with a LOWER index.
+    // Forward progress therefore rests on an assumption HIP does not state: that the workgroups of a grid are
+    // dispatched in index order, so that a waiting wavefront never holds the slot its predecessor needs.  gfx950 (and
+    // every GCN / CDNA part so far) dispatches that way, this library is built for gfx950 only, and the wait is
+    // BOUNDED anyway: kPlacedMaxPolls polls of ~0.4 us -- two milliseconds, a hundred times what a neighbour takes to
+    // publish -- then the wavefront gives up, writes to its slot and marks the frame; the host encodes a marked frame
+    // again through slots, counts it (HapGpuPlacementTimeoutCount) and stops placing for the context's lifetime: a
+    // neighbour kernel on another stream, CU masking or a serialising profiler cost one late call, not a cliff per call.
+    constexpr unsigned kPlacedMaxPolls = 1u << 12;
     if (placed) {
         const unsigned long long *acc = reinterpret_cast<const unsigned long long *>(frames[zf].chunk_acc);
         const uint32_t *mine = frag_sizes + tex.frag_first + chunk * tex.frags_per_chunk;
@@ -595,35 +607,32 @@ __global__ __launch_bounds__(64, SCB_MIN_WAVES) void snappy_compress_blocks_kern
         // (group after group of 64 words, oldest first, each polled on its own until it is complete: what is waited for
         // is almost always the nearest neighbours only.  These loads are served by the memory side and their number is
         // what counts: fetching five groups at once "to save latency" made the kernel 17 % slower)
-#ifndef PLC_ABL
-#define PLC_ABL 0
-#endif
-        for (unsigned c0 = 0; c0 < chunk && settled && PLC_ABL != 3; c0 += 64u) {
+        for (unsigned c0 = 0; c0 < chunk && settled; c0 += 64u) {
             const unsigned c = c0 + lane;
             for (;;) {
                 const unsigned long long v = c < chunk ? __hip_atomic_load(&acc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                                        : (1ull << 32);
-                if (PLC_ABL == 1 || __builtin_amdgcn_ballot_w64((unsigned)(v >> 32) == 0u) == 0ull) {
+                if (__builtin_amdgcn_ballot_w64((unsigned)(v >> 32) == 0u) == 0ull) {
                     sum += v & 0xFFFFFFFFull;
-                    settled = PLC_ABL == 1 || __builtin_amdgcn_ballot_w64((unsigned)(v >> 32) != 1u) == 0ull;      // (2: a chunk that gave up)
+                    settled = __builtin_amdgcn_ballot_w64((unsigned)(v >> 32) != 1u) == 0ull;      // (2: a chunk that gave up)
                     break;
                 }
-                if (++tries > (1u << 18)) {
+                if (++tries > kPlacedMaxPolls) {
                     settled = false;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(16);
             }
         }
-        for (unsigned k0 = 0; k0 < fj && settled && PLC_ABL != 3; k0 += 64u) {
+        for (unsigned k0 = 0; k0 < fj && settled; k0 += 64u) {
             const unsigned k = k0 + lane;
             for (;;) {
                 const unsigned v = k < fj ? __hip_atomic_load(&mine[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : HAPGPU_FRAG_PUBLISHED;
-                if (PLC_ABL == 1 || __builtin_amdgcn_ballot_w64((v & HAPGPU_FRAG_PUBLISHED) == 0u) == 0ull) {
+                if (__builtin_amdgcn_ballot_w64((v & HAPGPU_FRAG_PUBLISHED) == 0u) == 0ull) {
                     in_chunk += v & ~HAPGPU_FRAG_PUBLISHED;
                     break;
                 }
-                if (++tries > (1u << 18)) {
+                if (++tries > kPlacedMaxPolls) {
                     settled = false;
                     break;
                 }
@@ -653,20 +662,16 @@ __global__ __launch_bounds__(64, SCB_MIN_WAVES) void snappy_compress_blocks_kern
                                           (5u * n_chunks + 8u + index_len) + (unsigned long long)vlen * (chunk + 1u) + sum;
             const unsigned at_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)at);
             const unsigned at_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(at >> 32));
-            if (PLC_ABL == 0) {
-                out = (gdst_t)(uintptr_t)(((unsigned long long)at_hi << 32) | at_lo);
-                // (frame_pack.hip: compressor table behind the section's three headers, the sizes, the fragment section's
-                // header and its four bytes, a size per fragment, then the group tables in fragment order)
-                if (with_tiles)
-                    table_at = (gdst_t)(uintptr_t)(frames[zf].dst + frames[zf].outer_header_len + tex.header_len + 8u + n_chunks + 4u +
-                                                   4u * n_chunks + 8u + 4u * n_chunks * fpc +
-                                                   (unsigned long long)(chunk * fpc + fj) * HAP_GROUP_TABLE_BYTES);
-            }
-            else if (at_hi == 0x12345u && at_lo == 77u)      // (measurement builds: the sums stay live, the bytes go to the slot)
-                out += 1;
+            out = (gdst_t)(uintptr_t)(((unsigned long long)at_hi << 32) | at_lo);
+            // (frame_pack.hip: compressor table behind the section's three headers, the sizes, the fragment section's
+            // header and its four bytes, a size per fragment, then the group tables in fragment order)
+            if (with_tiles)
+                table_at = (gdst_t)(uintptr_t)(frames[zf].dst + frames[zf].outer_header_len + tex.header_len + 8u + n_chunks + 4u +
+                                               4u * n_chunks + 8u + 4u * n_chunks * fpc +
+                                               (unsigned long long)(chunk * fpc + fj) * HAP_GROUP_TABLE_BYTES);
         } else if (lane == 0u) {
-            // (never seen; a frame with such a fragment is encoded again through slots, and the chunks behind it need
-            // not wait for the total)
+            // (a frame with such a fragment is encoded again through slots, and the chunks behind it need not wait
+            // for the total; bit 0 of the frame's reserved word tells the host that it was a timeout)
             __hip_atomic_fetch_or(const_cast<uint32_t *>(&frames[zf].reserved), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (fj + 1u == tex.frags_per_chunk)
                 __hip_atomic_store(const_cast<unsigned long long *>(&acc[chunk]), 2ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -721,7 +726,7 @@ __global__ __launch_bounds__(64, SCB_MIN_WAVES) void snappy_compress_blocks_kern
     // The field of element e comes from the list phase 2 left, its half-tile from a count of the first-of-half-tile
     // marks up to it; the half-tile's masks then give its
     // stream offset (the bytes of what lies below), its length (fields up to the next start) and its kind.  The elements whose
-    // ordinal is a multiple of G = ceil(N / 64) begin the groups of the fragment table (version 3): their offsets go to
+    // ordinal is a multiple of G = ceil(N / 64) begin the groups of the fragment table (version 4): their offsets and output positions go to
     // bounds[].
     {
         const unsigned both = counts_and_bytes;
@@ -731,9 +736,9 @@ __global__ __launch_bounds__(64, SCB_MIN_WAVES) void snappy_compress_blocks_kern
         const unsigned inv = (1u << 20) / G + 1u;                              // x / G = (x inv) >> 20 for x < 2^11 + 32
         const uint32_t *hd_tab = reinterpret_cast<const uint32_t *>(table);
         {
-            bounds[lane] = (uint16_t)stream_bytes;                             // (groups beyond the last element: empty)
+            bounds[lane] = stream_bytes | (n << 16);                           // (groups beyond the last element: empty)
             if (lane < 2u)
-                bounds[64u + lane] = (uint16_t)stream_bytes;
+                bounds[64u + lane] = stream_bytes | (n << 16);
         }
         __syncthreads();
         constexpr unsigned FO = LAYOUT == 4u ? 0x0C080200u : (LAYOUT == 2u || LAYOUT == 8u) ? 0x0C080400u : 0x0A080200u;   // fo(k), a byte each
@@ -777,20 +782,21 @@ __global__ __launch_bounds__(64, SCB_MIN_WAVES) void snappy_compress_blocks_kern
                     put8(out + off + 2, v >> 16);
                 const unsigned m = (e * inv) >> 20;
                 if (m * G == e)
-                    bounds[m] = (uint16_t)off;
+                    bounds[m] = off | ((h * 128u + (q >> 2) * 16u + ((FO >> (8u * (q & 3u))) & 0xFFu)) << 16);
             }
         }
         __syncthreads();
         if (want_sizes) {
-            // 12 bits per group, two groups in three bytes
-            const unsigned size = (unsigned)bounds[lane + 1u] - (unsigned)bounds[lane];
-            // (the shuffle on its own line: inside a conditional it would run without the lanes the others read)
-            const unsigned above = (unsigned)__shfl_down((int)size, 1);
-            const unsigned pair = size | (above << 12);
-            if ((lane & 1u) == 0u) {
-                const gdst_t at = table_at + (lane >> 1) * 3u;
-                put16(at, pair);
-                put8(at + 2, pair >> 16);
+            // fragment table version 4: 24 bits per group -- its compressed bytes | the bytes it produces << 12 -- then
+            // the element count
+            const unsigned lo = bounds[lane], hi = bounds[lane + 1u];
+            const unsigned entry = ((hi & 0xFFFFu) - (lo & 0xFFFFu)) | (((hi >> 16) - (lo >> 16)) << 12);
+            const gdst_t at = table_at + lane * 3u;
+            put16(at, entry);
+            put8(at + 2, entry >> 16);
+            if (lane == 0u) {
+                put16(table_at + 192, elements);
+                put16(table_at + 194, 0u);
             }
         }
     }

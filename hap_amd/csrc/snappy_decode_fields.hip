@@ -1,14 +1,14 @@
 // snappy_decode_fields.hip -- block-per-lane Snappy decoder for "field streams" (gfx950).
 //
 // Replaces hap_decode_chunk's snappy_uncompress (reference hap.c:606-642, call at hap.c:612) for the frames this
-// library writes itself with the fragment table version 3 (private section 0x46, include/hap_gpu.h).  Such a chunk
+// library writes itself with the fragment table version 4 (private section 0x46, include/hap_gpu.h).  Such a chunk
 // is an ordinary Snappy stream -- the reference decodes it unchanged -- whose elements obey extra rules that the
 // table announces and this kernel VERIFIES while it parses (any violation fails the unit with
 // HAPGPU_STATUS_INDEX_MISMATCH and the host decodes the frame again through the generic kernels):
 //
 //   * the stream is cut into independent 8 KiB fragments (compressed size of each in the table);
-//   * the table holds, per fragment, the bytes of 64 GROUPS of its elements: the elements in stream order,
-//     ceil(N / 64) to a group (12 bits per group);
+//   * the table holds, per fragment, the compressed bytes AND the output bytes of 64 GROUPS of its elements -- the
+//     elements in stream order, ceil(N / 64) to a group (24 bits per group) -- and N;
 //   * inside a fragment no element crosses a 128-byte "half-tile" of output;
 //   * every element starts and ends on a block FIELD boundary -- DXT5 / YCoCg-DXT5 blocks are 2 + 6 + 4 + 4 bytes
 //     (alpha endpoints, alpha indices, colour endpoints, colour indices), DXT1 blocks 4 + 4, RGTC1 blocks 2 + 6 -- and
@@ -19,12 +19,14 @@
 //
 //   1. PARSE, one lane per group: the only serial dependency of Snappy, the element chain, is 64 independent chains of
 //      EQUAL length (r03's first table gave a lane to every half-tile: the busiest of 64 set the trip count, 21
-//      elements against a mean of 6).  A first walk over the tags measures the group (bytes produced, elements); a
-//      scan gives every group its output position and its record slots; the second walk leaves per element a
-//      16-bit record {literal?, literal position | block distance} and ORs one bit into the start mask of the
-//      element's half-tile.
+//      elements against a mean of 6).  Two scans over the table's entries give every group its input position, its
+//      output position and its record slots (table version 3 listed the compressed bytes only: a first walk over the
+//      tags had to measure every group).  The walk leaves per element a 32-bit record {where its bytes come from,
+//      relative to its place in the step | 4 x block distance} and ORs one bit into the start mask of the element's
+//      half-tile.
 //   2. PRODUCE, one lane per BLOCK, 64 blocks (1 KiB of DXT5) per step: for each of its 4 fields the lane finds the
-//      owning element with one popcount of the start mask, reads the record, and turns it into a source descriptor:
+//      owning element with one popcount of the start mask, reads the record, and turns it into a source descriptor
+//      with three instructions (shift-add, subtract, minimum):
 //      literal bytes in the staged input, or the same field of block (b - distance) in the output ring.  Sources
 //      inside the current step are resolved first by DPP hops (lanes 1, 2, 4, 8 below), then by pointer doubling on
 //      lane indices (ds_bpermute, <= 6 rounds); then 4 field reads, one 16-byte LDS store (later steps copy from
@@ -42,6 +44,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "hapgpu_abi.h"
+#include "measurement_guard.h"
 
 namespace {
 
@@ -49,8 +52,10 @@ constexpr unsigned kFragBytes = 8192u;
 constexpr unsigned kHalf = 128u;                       // bytes of output per half-tile
 constexpr unsigned kHalves = kFragBytes / kHalf;       // 64: one parse lane each
 constexpr unsigned kMaxFragCompressed = kFragBytes + 320u;
-// Switches of the measurement builds (tools/build_variants.sh; never set in the shipped library): LDS per wave up or
-// down (occupancy studies), the set of DPP hops, ablations that break the output on purpose.
+// Switches of the measurement builds (tools/build_variants.sh, which defines HAP_MEASUREMENT_BUILD and writes to
+// hap_amd/variants/; measurement_guard.h refuses them in any other build): LDS per wave up or down (occupancy
+// studies), the set of DPP hops, one layout's code alone.  None changes what the kernel writes.  (The ablations of
+// round 4 that broke the output on purpose -- no rounds, no ring store, no overrun check -- are gone from the source.)
 // ring + parked input (at the end of the buffer: see the S computation below) + alignment slack
 #ifndef SDF_BUF_BYTES
 #define SDF_BUF_BYTES (9344u + 32u)
@@ -104,10 +109,6 @@ __device__ __forceinline__ constexpr unsigned field_pos(unsigned k)
 // start mask: 16-byte blocks are 8 positions with fields at 0, 1, 4, 6; [2, 6] blocks 4 positions with fields at 0, 1
 template <unsigned LAYOUT>
 __device__ __forceinline__ constexpr unsigned start_positions() { return LAYOUT == 4u ? 0x53535353u : LAYOUT == 6u ? 0x33333333u : 0xFFFFFFFFu; }
-
-// (mask & a) | (~mask & b).  (Left to the compiler: a hand-placed v_bfi_b32 made the kernel 7 % slower -- the asm
-// statement keeps the selects from being scheduled between the LDS round trips.)
-__device__ __forceinline__ int bit_select(int mask, int a, int b) { return (mask & a) | (~mask & b); }
 
 // waits for every outstanding LDS operation of the wave (one wait for a batch of reads instead of one per use)
 __device__ __forceinline__ void lds_wait() { __builtin_amdgcn_s_waitcnt(0xC07F); }     // lgkmcnt(0), vmcnt / expcnt untouched
@@ -174,7 +175,6 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
     constexpr unsigned kStepBytes = 64u * kBlock;                  // 1024 or 512
     constexpr unsigned kHalvesPerStep = kStepBytes / kHalf;        // 8 or 4
     constexpr unsigned kPosShift = layout_of<LAYOUT>::pos_shift;    // element start positions are kept in 2- / 4-byte units
-    constexpr unsigned kLitBias = kHalf;
     const uint32_t *bufw = reinterpret_cast<const uint32_t *>(buf);
     HapGpuDecodeJob *job = &jobs[u.job];
     const gin_t src = (gin_t)u.src;
@@ -194,9 +194,11 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
     const unsigned in_end = shift + total;
     const unsigned readable_end = in_end + (unsigned)(u.reserved & 15u);
     const unsigned job_status = __builtin_nontemporal_load(&job->status);
-    // 64 groups x 12 bits, packed little endian: group g sits in bits 12 g .. 12 g + 11
-    const unsigned gat = lane + (lane >> 1);
-    const unsigned gpair = (unsigned)group_table[gat] | ((unsigned)group_table[gat + 1u] << 8);
+    // fragment table version 4: 64 groups x 24 bits little endian (compressed bytes | bytes produced << 12), then the
+    // number of elements (LE16)
+    const unsigned gat = 3u * lane;
+    const unsigned gentry = (unsigned)group_table[gat] | ((unsigned)group_table[gat + 1u] << 8) | ((unsigned)group_table[gat + 2u] << 16);
+    const unsigned elements_lo = group_table[192], elements_hi = group_table[193];
     uint4 early[4];
 #pragma unroll
     for (unsigned i = 0; i < 4u; i++)
@@ -204,14 +206,25 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
     if (job_status != 0u)
         return;
 
-    // ---- group table -> where every lane starts reading ----
-    const unsigned gsz = (lane & 1u) ? gpair >> 4 : gpair & 0xFFFu;
+    // ---- group table -> where every lane starts reading, where its output begins, which record slots are its own ----
+    // (the table of version 3 listed the compressed bytes only, and a first walk over the tags measured every group:
+    // 24 instructions a turn, 7 % of the kernel)
+    const unsigned gsz = gentry & 0xFFFu, gout = gentry >> 12;
     const unsigned gincl = (unsigned)fwave_scan_add((int)gsz);
+    const unsigned oincl = (unsigned)fwave_scan_add((int)gout);
     const unsigned coff = gincl - gsz;
-    if ((unsigned)__builtin_amdgcn_readlane((int)gincl, 63) != total) {
+    const unsigned obegin = oincl - gout;                          // output position of the group's first element
+    const unsigned elements = (unsigned)__builtin_amdgcn_readfirstlane((int)(elements_lo | (elements_hi << 8)));
+    // every element is at least two bytes (a field) and every field belongs to one element: at most out_len / 4 of them
+    // (the records, 4 bytes each, then fit the unit's own output range if they have to go to memory)
+    if ((unsigned)__builtin_amdgcn_readlane((int)gincl, 63) != total || (unsigned)__builtin_amdgcn_readlane((int)oincl, 63) != out_len ||
+        elements == 0u || 4u * elements > out_len) {
         fail_unit(job, lane);
         return;
     }
+    const unsigned G = (elements + 63u) >> 6;                      // elements per group (the last groups: fewer, or none)
+    const unsigned rbase = min(lane * G, elements);                // ordinal of the group's first element
+    const unsigned count_g = min(rbase + G, elements) - rbase;
     // The input is parked at the END of the buffer: output written by the steps before step s then never reaches the
     // compressed bytes that step s reads as literals, as long as what is left of the input at any point fits between the
     // output produced so far and the end of the buffer -- true for every honest stream (<= 130 bytes per half-tile),
@@ -232,63 +245,31 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
     __syncthreads();
 
     // ---- 1. parse: lane g walks the elements of group g -- every group holds the same number of them ----
-    // 1a. measure: bytes produced and elements of the group (tags only), so that the lane knows where its group's
-    //     output begins and where its records go
     const unsigned cbegin = S + coff, cend = cbegin + gsz;
-    unsigned out_g = 0, count_g = 0;
-    {
-        unsigned cp = cbegin;
-        do {
-            if (cp < cend) {
-                const unsigned aw = cp >> 2;
-                const unsigned w = __builtin_amdgcn_alignbyte(bufw[aw + 1u], bufw[aw], cp);
-                const unsigned kind = w & 3u, up = __builtin_amdgcn_ubfe(w, 2u, 6u);
-                const bool is_lit = kind == 0u, lng = is_lit && up == 60u;
-                unsigned lm1 = lng ? __builtin_amdgcn_ubfe(w, 8u, 8u) : up;
-                lm1 = kind == 1u ? __builtin_amdgcn_ubfe(w, 2u, 3u) + 3u : lm1;
-                cp += is_lit ? lm1 + (lng ? 3u : 2u) : kind + 1u;
-                out_g += lm1 + 1u;
-                count_g += 1u;
-            }
-        } while (__builtin_amdgcn_ballot_w64(cp < cend) != 0ull);
-        // (a group that ends inside an element: the next pass stops at the same place and reports it)
-    }
-    const unsigned oincl = (unsigned)fwave_scan_add((int)min(out_g, 0xFFFFu));
-    const unsigned nincl = (unsigned)fwave_scan_add((int)count_g);
-    const unsigned obegin = oincl - min(out_g, 0xFFFFu);           // output position of the group's first element
-    const unsigned rbase = nincl - count_g;                        // ordinal of the group's first element
-    const unsigned elements = (unsigned)__builtin_amdgcn_readlane((int)nincl, 63);
-    {
-        // the output adds up; every element is at least two bytes (a field), so the records (2 bytes each) fit the
-        // unit's own output range if they have to go to memory
-        if ((unsigned)__builtin_amdgcn_readlane((int)oincl, 63) != out_len || 2u * elements > out_len ||
-            __builtin_amdgcn_ballot_w64(out_g > kFragBytes) != 0ull) {
-            fail_unit(job, lane);
-            return;
-        }
-    }
-    // records below the parked input when they fit, else in the unit's own output range (2-byte aligned) in memory
-    const unsigned rbytes = 2u * elements;
+    // records (4 bytes each) below the parked input when they fit, else in the unit's own output range (4-byte aligned) in memory
+    const unsigned rbytes = 4u * elements;
     const bool rec_in_lds = rbytes <= S - shift;
-    const gout_t rec_mem = (gout_t)(((uintptr_t)dst + 1u) & ~(uintptr_t)1u);
-    // (records in memory start at the next even address: a hand-made stream of nothing but 2-byte elements and an odd
-    // `dst` would put its last record one byte behind the unit's own output -- honest streams never get near)
-    if (!rec_in_lds && rbytes + (unsigned)((uintptr_t)dst & 1u) > out_len) {
+    const gout_t rec_mem = (gout_t)(((uintptr_t)dst + 3u) & ~(uintptr_t)3u);
+    if (!rec_in_lds && rbytes + (unsigned)(((uintptr_t)rec_mem - (uintptr_t)dst)) > out_len) {
         fail_unit(job, lane);
         return;
     }
 
-    // 1b. the walk proper.  Straight-line code under the loop's exec mask: the three element kinds are decoded side by
-    // side and selected.  Per element one signed 16-bit record,
-    //     literal:  0x8000 | (offset of its bytes in the parked input - its position in the half-tile + 128)   (negative)
-    //     copy:     4 x distance in blocks                                                                     (positive)
-    // and one bit of its half-tile's start mask (bit = position in 2- or 4-byte units).  Promise checks are
-    // accumulated and looked at once at the end.
+    // The walk.  Straight-line code under the loop's exec mask: the three element kinds are decoded side by side and
+    // selected.  Per element one 32-bit record -- everything a field's descriptor needs from its element, formed ONCE
+    // per element here instead of once per field in the lookup below (5.5 turns against 32 columns) --
+    //     bits 23..0:  literal: (address of its bytes in the parked input) - (its position in the step)
+    //                  copy:    (start of the step in the ring) - (copy offset)
+    //                  -- add the field's position in the step and either is the address the field's bytes come from
+    //     bits 31..24: copy: 4 x distance in blocks where that is below 64 (the source may lie in the same step);
+    //                  255 otherwise and for literals
+    // and one bit of its half-tile's start mask (bit = position in 2- or 4-byte units).  Promise checks are accumulated
+    // and looked at once at the end.
     constexpr unsigned kRecShift = kBlock == 16u ? 2u : 1u;       // byte offset -> 4 x blocks
     {
         unsigned cp = cbegin;
         unsigned p = obegin;                               // output position inside the fragment
-        unsigned recp = 2u * rbase;
+        unsigned recp = 4u * rbase;
         unsigned acc_or = 0;                               // OR of copy offsets (low bits) and start positions << 17
         unsigned max_kind = 0;                             // 3 = a copy-4 element
         int max_reach = 0;                                 // how far before the fragment the farthest copy reaches
@@ -298,8 +279,9 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
         uint32_t *const mask_words = reinterpret_cast<uint32_t *>(masks);
         // (two typed pointers and a uniform branch at the store: one pointer chosen between LDS and memory would make
         // every record a flat store)
-        do {
-            if (cp < cend) {
+#pragma unroll 1
+        for (unsigned turn = 0; turn < G; turn++) {        // (uniform trip count: the table says how many elements a group has)
+            if (turn < count_g) {
                 const unsigned aw = cp >> 2;
                 const unsigned w = __builtin_amdgcn_alignbyte(bufw[aw + 1u], bufw[aw], cp);     // bytes cp .. cp+3 (shift = cp & 3)
                 const unsigned kind = w & 3u, up = __builtin_amdgcn_ubfe(w, 2u, 6u);
@@ -313,7 +295,6 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
                 const unsigned adv = is_lit ? lm1 + lngv + 2u : kind + 1u;
                 const unsigned off = is_c1 ? (((w << 3) & 0x700u) | b1) : __builtin_amdgcn_ubfe(w, 8u, 16u);
                 const unsigned hp = p & (kHalf - 1u);                           // position inside the half-tile
-                const unsigned litrec = (cp - S) + lngv + (1u + kLitBias + 0x8000u) - hp;   // 0x8000 | 1 .. 128 + input bytes
                 // promises: whole blocks back (low offset bits 0), at least one, not before the fragment; no copy-4
                 // (kind 3); no literal with 2..4 length bytes (tag >> 2 in 61..63); starts on 2- / 4-byte positions;
                 // the element ends inside its half-tile
@@ -326,28 +307,27 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
                 crossed |= (hp + lm1) >> 7;
                 overrun |= (p & ~(kStepBytes - 1u)) > cp ? 1u : 0u;            // the steps before this one write up to there
                 {
-                    const uint16_t record = (uint16_t)(is_lit ? litrec : off >> kRecShift);
+                    const unsigned from = (is_lit ? cp + 1u + lngv : p - off) - (p & (kStepBytes - 1u));
+                    const unsigned record = (from & 0xFFFFFFu) | (min(offx >> kRecShift, 255u) << 24);
                     if (rec_in_lds)
-                        *reinterpret_cast<uint16_t *>(buf + recp) = record;
+                        *reinterpret_cast<uint32_t *>(buf + recp) = record;
                     else
-                        *reinterpret_cast<uint16_t __attribute__((address_space(1))) *>(rec_mem + recp) = record;
+                        *reinterpret_cast<uint32_t __attribute__((address_space(1))) *>(rec_mem + recp) = record;
                 }
-                recp += 2u;
+                recp += 4u;
                 const unsigned bit = hp >> kPosShift;                           // 0 .. 63 (2-byte positions) or 0 .. 31
-                atomicOr(&mask_words[2u * (p >> 7) + (bit >> 5)], 1u << (bit & 31u));
+                // (a table that lies may send p anywhere: the word index is kept inside the masks)
+                atomicOr(&mask_words[(2u * (p >> 7) + (bit >> 5)) & (2u * kHalves - 1u)], 1u << (bit & 31u));
                 p += lm1 + 1u;
                 cp += adv;
             }
-        } while (__builtin_amdgcn_ballot_w64(cp < cend) != 0ull);
-        // an element that overshoots its group's bytes leaves cp off the mark; starts off a field boundary show in the
-        // masks (checked below, per half-tile)
+        }
+        // an element that overshoots its group's bytes, or a group with another number of elements than the table says,
+        // leaves cp or p off the mark; starts off a field boundary show in the masks (checked below, per half-tile)
         const bool bad = max_kind == 3u || max_reach > 0 || (acc_or & (kBlock - 1u)) != 0u ||
                          ((acc_or >> 17) & ((1u << kPosShift) - 1u)) != 0u || min_off < kBlock || max_up > 60u ||
-                         crossed != 0u ||
-#ifndef SDF_UNSAFE
-                         overrun != 0u ||
-#endif
-                         cp != cend || p != obegin + out_g;
+                         crossed != 0u || overrun != 0u ||
+                         cp != cend || p != obegin + gout;
         if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
             fail_unit(job, lane);
             return;
@@ -368,7 +348,7 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
             fail_unit(job, lane);
             return;
         }
-        coffs[lane] = (sincl - starts) << 16;               // (low half: the literal records are relative to S already)
+        coffs[lane] = sincl - starts;                       // ordinal of the half-tile's first element
     }
     __syncthreads();
 
@@ -380,19 +360,16 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
     const unsigned hsub = lane / kBlocksPerHalf;                           // half-tile of the step
     // (64 positions per half-tile in two words when positions are 2 bytes; 32 four-byte positions fit one word)
     const bool upper = kPosShift == 1u && b >= kBlocksPerHalf / 2u;
-    unsigned le[PERIOD], fbias[PERIOD];
+    unsigned le[PERIOD];
+    int lanec[PERIOD];                                                     // (the field's position in the step) << 8 | 4 x lane
 #pragma unroll
     for (unsigned k = 0; k < PERIOD; k++) {
         const unsigned fb = b * kBlock + field_pos<LAYOUT>(k);             // byte position of the field in the half-tile
         const unsigned q = (fb >> kPosShift) & 31u;
         le[k] = (2u << q) - 1u;
-        fbias[k] = fb - kLitBias + 0x8000u + S;                            // + coff[half-tile] + record = literal address
+        lanec[k] = (int)(((lane * kBlock + field_pos<LAYOUT>(k)) << 8) | (lane * 4u));
     }
     const unsigned lane4s = lane * 4u + 0x80000000u;
-    unsigned ring_k[PERIOD];                                               // ring address of the lane's fields in step 0
-#pragma unroll
-    for (unsigned k = 0; k < PERIOD; k++)
-        ring_k[k] = lane * kBlock + field_pos<LAYOUT>(k);
     // 2a. every step's fields -> source descriptors ("state"): >= 0 resolved: (an address in buf) << 8 -- literal bytes, or
     //     the ring for a copy whose source block lies in an earlier step -- | 4 x the own lane; < 0 pending: sign bit |
     //     4 x (source lane in the same step).
@@ -414,18 +391,18 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
             cof[s] = (int)coffs[hh];
         }
         lds_wait();
-        int r[kMaxSteps][PERIOD];
+        unsigned r[kMaxSteps][PERIOD];
         if (rec_in_lds) {
 #pragma unroll
             for (unsigned s = 0; s < kMaxSteps; s++) {
                 const unsigned msel = upper ? my[s] : mx[s];
-                const int ebase = (upper ? (int)__builtin_popcount(mx[s]) - 1 : -1) + (cof[s] >> 16);
-                const int16_t *rb = reinterpret_cast<const int16_t *>(buf);
+                const int ebase = (upper ? (int)__builtin_popcount(mx[s]) - 1 : -1) + cof[s];
+                const uint32_t *rb = reinterpret_cast<const uint32_t *>(buf);
 #pragma unroll
                 for (unsigned k = 0; k < PERIOD; k++) {
                     // ordinal of the element that owns the field (a parsed half-tile always starts with an element: >= 0)
                     const int e = (int)__builtin_popcount(msel & le[k]) + ebase;
-                    r[s][k] = (int)rb[e];
+                    r[s][k] = rb[e];
                 }
                 if ((s & 3u) == 3u)
                     lds_wait();                                             // (at most 16 LDS results outstanding)
@@ -433,16 +410,16 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
             lds_wait();
         } else {
             // (the wave's own stores, read back past the CU's L1, which may hold these lines as they were before)
-            const int16_t __attribute__((address_space(1))) *rb = reinterpret_cast<const int16_t __attribute__((address_space(1))) *>(rec_mem);
+            const uint32_t __attribute__((address_space(1))) *rb = reinterpret_cast<const uint32_t __attribute__((address_space(1))) *>(rec_mem);
 #pragma unroll
             for (unsigned s = 0; s < kMaxSteps; s++) {
                 const unsigned msel = upper ? my[s] : mx[s];
-                const int ebase = (upper ? (int)__builtin_popcount(mx[s]) - 1 : -1) + (cof[s] >> 16);
+                const int ebase = (upper ? (int)__builtin_popcount(mx[s]) - 1 : -1) + cof[s];
 #pragma unroll
                 for (unsigned k = 0; k < PERIOD; k++) {
                     const int e = (int)__builtin_popcount(msel & le[k]) + ebase;
-                    r[s][k] = (int)__hip_atomic_load(rb + ((64u * s + lane) * kBlock < out_len ? e : 0), __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT);
+                    r[s][k] = __hip_atomic_load(rb + ((64u * s + lane) * kBlock < out_len ? e : 0), __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
@@ -450,23 +427,17 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
         // copies from, a resolved one ITSELF -- so that one ds_bpermute addressed by the descriptor fetches the next
         // descriptor of the chain for pending fields and the same descriptor again for resolved ones (directly, or
         // from the lane at the root of their chain, which holds the same value): no select after the fetch.
-#pragma unroll
-        for (unsigned s = 0; s < kMaxSteps; s++)
-            cof[s] = ((cof[s] & 0xFFFF) << 8) + (int)(lane * 4u);
+        // Three instructions a field: the record's low 24 bits + the field's position = its address if it is a literal or
+        // copies from an earlier step; the sign bit | 4 x (lane - distance) if the source block lies in this step --
+        // which wraps to a huge positive number when it does not (distance > lane; code 255 for literals): the minimum.
 #pragma unroll
         for (unsigned s = 0; s < kMaxSteps; s++) {
 #pragma unroll
             for (unsigned k = 0; k < PERIOD; k++) {
-                const int rr = r[s][k];
-                const int lit_res = cof[s] + (int)(fbias[k] << 8) + rr * 256;    // (rr = record - 0x10000 for literals)
-                // copy: source = same field, rr / 4 blocks back.  Inside this step (rr / 4 <= lane): pending = sign bit
-                // | 4 x source lane (negative); else lane4s - rr wraps to a huge positive number and the minimum is
-                // the ring address (the walk above made sure it does not lie before the fragment)
-                const int pend = (int)(lane4s - (unsigned)rr);
-                const int ring_res = (int)(((ring_k[k] + s * kStepBytes) << 8) + lane * 4u) - rr * (int)(kBlock * 64u);
-                const int cpy = min(pend, ring_res);
-                const int lit_mask = rr >> 31;                              // all ones: literal
-                state[s][k] = bit_select(lit_mask, lit_res, cpy);
+                const unsigned rr = r[s][k];
+                const int res = (int)(rr << 8) + lanec[k];
+                const int pend = (int)(lane4s - (rr >> 24));
+                state[s][k] = min(pend, res);
             }
         }
     }
@@ -513,7 +484,6 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
     //     that fetches only for the columns that still have a pending lane -- a bit per column, one hand-written block
     //     of compare / branch / ds_bpermute per round -- issues a quarter of the ds_bpermutes and is no faster: the
     //     kernel is bound by vector instruction issue, not by the LDS pipe; LABNOTES.md.)
-#ifndef SDF_ABL_NOROUNDS
 #pragma unroll 1
     for (unsigned round = 0; round < 6u; round++) {
         int any = state[0][0];
@@ -530,7 +500,6 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
             for (unsigned k = 0; k < PERIOD; k++)
                 state[s][k] = __builtin_amdgcn_ds_bpermute(state[s][k], state[s][k]);   // (lane = address bits 7..2)
     }
-#endif
     // 2c. field bytes -> 16-byte block -> ring (later steps copy from it) and memory, step after step
     const unsigned nsteps = (out_len + kStepBytes - 1u) / kStepBytes;
 #pragma unroll
@@ -545,20 +514,13 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
             unsigned lo[PERIOD], hi1 = 0;
 #pragma unroll
             for (unsigned k = 0; k < PERIOD; k++) {
-                const unsigned a = (unsigned)state[s][k] >> 8, aw = a >> 2, sh = a & 3u;
-#ifdef SDF_ABL_NOPRODREADS
-                const unsigned d0 = aw, d1 = aw + s;
-#else
+                // (v_alignbyte_b32 shifts by the low two bits of its third operand: the address itself)
+                const unsigned a = (unsigned)state[s][k] >> 8, aw = a >> 2;
                 const unsigned d0 = bufw[aw], d1 = bufw[aw + 1u];
-#endif
-                lo[k] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+                lo[k] = __builtin_amdgcn_alignbyte(d1, d0, a);
                 if (k == 1) {
-#ifdef SDF_ABL_NOPRODREADS
-                    const unsigned d2 = aw ^ s;
-#else
                     const unsigned d2 = bufw[aw + 2u];
-#endif
-                    hi1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                    hi1 = __builtin_amdgcn_alignbyte(d2, d1, a);
                 }
             }
             out[0] = (lo[0] & 0xFFFFu) | (lo[1] << 16);
@@ -571,16 +533,14 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
             // [4, 4] and [4, 4, 4, 4]: every field is one dword at any byte address
 #pragma unroll
             for (unsigned k = 0; k < PERIOD; k++) {
-                const unsigned a = (unsigned)state[s][k] >> 8, aw = a >> 2, sh = a & 3u;
-                out[k] = __builtin_amdgcn_alignbyte(bufw[aw + 1u], bufw[aw], sh);
+                const unsigned a = (unsigned)state[s][k] >> 8, aw = a >> 2;
+                out[k] = __builtin_amdgcn_alignbyte(bufw[aw + 1u], bufw[aw], a);
             }
         }
         if (active) {
             if (kBlock == 16u) {
                 const uint4 v = make_uint4(out[0], out[1], out[2 % (kBlock / 4u)], out[3 % (kBlock / 4u)]);
-#ifndef SDF_ABL_NORINGSTORE
                 *reinterpret_cast<uint4 *>(buf + opos) = v;
-#endif
                 if (dst_wide) {
                     gstore16(dst + opos, v);
                 } else {
@@ -611,11 +571,17 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
 {
     __shared__ __attribute__((aligned(16))) uint8_t buf[kBufBytes];
     __shared__ __attribute__((aligned(8))) uint2 masks[kHalves];
-    __shared__ uint32_t coffs[kHalves + 2u];                       // first record << 16, per half-tile
+    __shared__ uint32_t coffs[kHalves + 2u];                       // ordinal of the half-tile's first element
     const unsigned lane = threadIdx.x;
     if (blockIdx.x >= unit_count)
         return;
     const HapGpuDecodeUnit u = units[blockIdx.x];
+#ifdef SDF_ONLY
+    // (instruction-count studies, tools/isa_by_line.py: one layout's code alone)
+    if (u.kind != 0u)
+        decode_fields_unit<SDF_ONLY>(u, jobs, buf, masks, coffs, lane);
+    return;
+#endif
     if (u.kind == HAPGPU_UNIT_SNAPPY_FIELDS4)
         decode_fields_unit<4u>(u, jobs, buf, masks, coffs, lane);
     else if (u.kind == HAPGPU_UNIT_SNAPPY_FIELDS2)

@@ -37,17 +37,19 @@
  * table gives.
  *
  * Section 0x46, version 1:  [1][log2 F][granularity log2][match window / 256 B][LE32 compressed size x fragments]
- *               version 3:  [3][13][granularity log2 | fields per block << 4][window][LE32 size x fragments]
- *                           [96-byte group table x fragments]
- * Version 3 ("field streams": block textures, 8 KiB fragments) adds, per fragment, the compressed bytes of 64
- * groups of its elements -- the elements in stream order, ceil(N / 64) to a group, the last groups shorter or empty;
- * 12 bits per group, packed little endian -- and promises that no element crosses a 128-byte half-tile of output,
+ *               version 4:  [4][13][granularity log2 | fields per block << 4][window][LE32 size x fragments]
+ *                           [196-byte group table x fragments]
+ * Version 4 ("field streams": block textures, 8 KiB fragments) adds, per fragment, a table of 64 groups of its
+ * elements -- the elements in stream order, ceil(N / 64) to a group, the last groups shorter or empty: 24 bits per
+ * group, little endian, the group's compressed bytes | the bytes it produces << 12; then N (LE16) and two zero bytes --
+ * and promises that no element crosses a 128-byte half-tile of output,
  * that every element starts and ends on a block field boundary (2 + 6 + 4 + 4, 4 + 4, 2 + 6, or -- layout 8, opaque
  * 16-byte blocks -- 4 + 4 + 4 + 4 bytes) and that every
  * copy offset is a whole number of blocks: the decoder's 64 lanes then each walk one group -- the same number of
- * elements -- and produce one block per lane.  Every promise is checked while decoding; a frame whose table lies is
- * decoded again without it.  (Version 2, written by earlier builds, listed one size byte per half-tile; such tables
- * are ignored, the frames decode like any other encoder's.)
+ * elements, from a known input position to a known output position -- and produce one block per lane.  Every promise
+ * is checked while decoding; a frame whose table lies is decoded again without it.  (Earlier builds wrote version 2,
+ * one size byte per half-tile -- ignored: such frames decode like any other encoder's -- and version 3, 96-byte group
+ * tables without the groups' output bytes: its fragment sizes are still used, one wavefront per fragment.)
  */
 #ifndef HAP_AMD_HAP_GPU_H
 #define HAP_AMD_HAP_GPU_H
@@ -80,7 +82,7 @@ typedef struct HapGpuContext HapGpuContext;
 
 /* Decode flags */
 #define HAPGPU_DECODE_IGNORE_FRAGMENT_INDEX 0x1u /* decode as a decoder unaware of section 0x46 would */
-#define HAPGPU_DECODE_IGNORE_HALF_TILES 0x2u     /* use a version-3 table's fragment sizes only (the generic
+#define HAPGPU_DECODE_IGNORE_HALF_TILES 0x2u     /* use a version-4 table's fragment sizes only (the generic
                                                     fragment decoder), not its group tables: for A/B measurements */
 #define HAPGPU_DECODE_NO_BLOCK_SCAN 0x4u         /* decode other encoders' Snappy streams with one wavefront per
                                                     stream instead of looking for their 64 KiB blocks first: for A/B
@@ -112,6 +114,12 @@ unsigned long HapGpuTableFallbackCount(HapGpuContext *context);
  * uncompressed, reference hap.c:460-466) is encoded again with the fragments gathered afterwards.  Same bytes either
  * way.  For tests and tools. */
 unsigned long HapGpuPlacementRetryCount(HapGpuContext *context);
+
+/* ... and how many of those were retried because a wavefront waited longer than its bound (about two milliseconds)
+ * for the sizes of the fragments in front of its own: placing relies on the workgroups of a grid starting in index
+ * order, which gfx950 does but HIP does not promise.  The first such frame switches placing off for the rest of the
+ * context's life (its calls gather from then on); 0 in every run so far.  For tests and tools. */
+unsigned long HapGpuPlacementTimeoutCount(HapGpuContext *context);
 
 /* RGBA8 (row-major, rowBytes stride, width/height multiples of 4) -> block
  * compressed texture.  textureFormat is one of RGB_DXT1, RGBA_DXT5,
@@ -172,6 +180,43 @@ unsigned int HapGpuEncodeFramesRGBA(HapGpuContext *context, unsigned int frameCo
                                     unsigned int *results,
                                     unsigned int flags);
 
+/* The same two calls in two halves, for pipelines: ...Begin checks the arguments, enqueues every launch of the call on
+ * the context's stream and returns WITHOUT waiting for the GPU; HapGpuEncodeFramesFinish waits, fills
+ * outputBuffersBytesUsed[] and results[] (the two arrays must live until then; every other argument array may go
+ * once Begin has returned; the buffers themselves must of course stay) and encodes again whatever the first pass
+ * could not place.  Between the halves the context takes no other call (Internal_Error) -- the client meanwhile
+ * decodes the previous batch on ANOTHER context, parses, reads the next pictures: the encode kernels run under it
+ * and the GPU never idles between calls (bench.py's step, DESIGN.md "Pipelined step").  Begin returns errors that are
+ * known at once (then nothing is pending and Finish has nothing to do); Finish returns what the one-call form
+ * returns.  At most 32768 frames per Begin.  The reference has no counterpart: HapEncode returns when its frame is
+ * written (hap.h:98-104). */
+unsigned int HapGpuEncodeFramesRGBABegin(HapGpuContext *context, unsigned int frameCount,
+                                         const void *const *rgbaFrames,
+                                         unsigned int width, unsigned int height,
+                                         unsigned long rowBytes,
+                                         unsigned int count,
+                                         const unsigned int *textureFormats,
+                                         const unsigned int *compressors,
+                                         const unsigned int *chunkCounts,
+                                         void *const *outputBuffers,
+                                         const unsigned long *outputBuffersBytes,
+                                         unsigned long *outputBuffersBytesUsed,
+                                         unsigned int *results,
+                                         unsigned int flags);
+unsigned int HapGpuEncodeFramesBegin(HapGpuContext *context, unsigned int frameCount,
+                                     unsigned int count,
+                                     const void *const *inputBuffers,
+                                     const unsigned long *inputBuffersBytes,
+                                     const unsigned int *textureFormats,
+                                     const unsigned int *compressors,
+                                     const unsigned int *chunkCounts,
+                                     void *const *outputBuffers,
+                                     const unsigned long *outputBuffersBytes,
+                                     unsigned long *outputBuffersBytesUsed,
+                                     unsigned int *results,
+                                     unsigned int flags);
+unsigned int HapGpuEncodeFramesFinish(HapGpuContext *context);
+
 /* Batched HapDecode of texture `index` of every frame.  No callback: all
  * chunks of all frames are decoded by the GPU.  Per-frame result codes,
  * bytes used and texture formats follow HapDecode (including the hardening
@@ -222,6 +267,53 @@ unsigned int HapGpuDecodeFramesRGBA(HapGpuContext *context, unsigned int frameCo
                                     unsigned int width, unsigned int height, unsigned long rowBytes,
                                     unsigned int *results,
                                     unsigned int flags);
+
+/* --- one batch over several GPUs: independent frames per GPU ------------------- */
+
+/* HapGpuEncodeFramesRGBA / HapGpuEncodeFrames / HapGpuDecodeFrames with the batch dealt out over `contextCount`
+ * contexts -- normally one per GPU of the node (HapGpuCreate(device, ...)): frame f is worked on by context
+ * f mod contextCount, each context on a host thread of its own, no data moves between devices and there is no
+ * collective (frames are independent; a frame's buffers should live on the device that works on it, else they are
+ * reached over the fabric or staged like any host pointer).  Arguments, per-frame results and the function result are
+ * those of the single-context call, and so are the bytes written, whatever contextCount is (tests: 2, 3 and 8
+ * contexts).  The contexts may share a device.  What the reference's clients do with a pool of threads calling
+ * HapEncode / HapDecode frame by frame (hap.h:98-140). */
+unsigned int HapGpuEncodeFramesRGBAOnDevices(HapGpuContext *const *contexts, unsigned int contextCount,
+                                             unsigned int frameCount,
+                                             const void *const *rgbaFrames,
+                                             unsigned int width, unsigned int height, unsigned long rowBytes,
+                                             unsigned int count,
+                                             const unsigned int *textureFormats,
+                                             const unsigned int *compressors,
+                                             const unsigned int *chunkCounts,
+                                             void *const *outputBuffers,
+                                             const unsigned long *outputBuffersBytes,
+                                             unsigned long *outputBuffersBytesUsed,
+                                             unsigned int *results,
+                                             unsigned int flags);
+unsigned int HapGpuEncodeFramesOnDevices(HapGpuContext *const *contexts, unsigned int contextCount,
+                                         unsigned int frameCount, unsigned int count,
+                                         const void *const *inputBuffers,
+                                         const unsigned long *inputBuffersBytes,
+                                         const unsigned int *textureFormats,
+                                         const unsigned int *compressors,
+                                         const unsigned int *chunkCounts,
+                                         void *const *outputBuffers,
+                                         const unsigned long *outputBuffersBytes,
+                                         unsigned long *outputBuffersBytesUsed,
+                                         unsigned int *results,
+                                         unsigned int flags);
+unsigned int HapGpuDecodeFramesOnDevices(HapGpuContext *const *contexts, unsigned int contextCount,
+                                         unsigned int frameCount,
+                                         const void *const *inputBuffers,
+                                         const unsigned long *inputBuffersBytes,
+                                         unsigned int index,
+                                         void *const *outputBuffers,
+                                         const unsigned long *outputBuffersBytes,
+                                         unsigned long *outputBuffersBytesUsed,
+                                         unsigned int *outputTextureFormats,
+                                         unsigned int *results,
+                                         unsigned int flags);
 
 /* --- one frame split over several GPUs by chunk groups ------------------------ */
 
@@ -292,8 +384,11 @@ enum HapGpuKernelClass {
 
 /* enable != 0: record a start/stop event pair around every kernel launch. */
 unsigned int HapGpuSetProfiling(HapGpuContext *context, unsigned int enable);
-/* Drains recorded events: launches[k] and milliseconds[k] are ADDED to for
- * every class k (arrays of HapGpuKernel_ClassCount). Synchronises. */
+/* Drains recorded events: launches[k] and milliseconds[k] are ADDED to for every class k < classCount (the entries
+ * the caller's arrays have; pass HapGpuKernel_ClassCount of the header the client was built with: a later library may
+ * know more classes, and drops what the arrays have no room for). Synchronises. */
+unsigned int HapGpuCollectProfileN(HapGpuContext *context, unsigned int classCount, unsigned long *launches, double *milliseconds);
+/* The same for arrays of EIGHT entries (classes 0..7: the signature of the first release, which had no count). */
 unsigned int HapGpuCollectProfile(HapGpuContext *context, unsigned long *launches, double *milliseconds);
 /* Wall-clock bracket on the context's stream with HIP events. */
 unsigned int HapGpuTimerStart(HapGpuContext *context);

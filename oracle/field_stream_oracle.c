@@ -9,9 +9,10 @@
  *   2. the kernel's bytes are exactly the bytes of this scalar definition (same tests), which makes every
  *      matching rule below a checked statement instead of a comment.
  * The stream this writes is ordinary Snappy (literal / copy-1 / copy-2 elements) obeying the extra promises of the
- * private fragment table version 3 (include/hap_gpu.h, snappy_decode_fields.hip): no element crosses a 128-byte
+ * private fragment table version 4 (include/hap_gpu.h, snappy_decode_fields.hip): no element crosses a 128-byte
  * half-tile, every element starts and ends on a block-field boundary, copy offsets are whole blocks; the table lists
- * the bytes of 64 groups of equally many elements, one group per decoder lane.
+ * the compressed and the produced bytes of 64 groups of equally many elements, one group per decoder lane, and the
+ * number of elements.
  *
  * Layouts (the "fields per block" nibble of the table): 4 = DXT5 / YCoCg-DXT5 [2, 6, 4, 4]; 2 = DXT1 [4, 4], two blocks
  * per unit; 6 = RGTC1 [2, 6], two blocks per unit; 8 = opaque 16-byte blocks (BC7, BC6H) taken as four dwords, copy
@@ -48,7 +49,7 @@ static const ofs_layout k_layout8 = {{0, 4, 8, 12}, {4, 4, 4, 4}, 16, {0, 1, 0, 
 #define OFS_TABLE_BITS 9u
 #define OFS_STEP_UNITS 64u
 #define OFS_DISTANCES 4u
-#define OFS_GROUP_TABLE_BYTES 96u
+#define OFS_GROUP_TABLE_BYTES 196u
 
 static uint64_t field_value(const uint8_t *p, unsigned size)
 {
@@ -77,6 +78,7 @@ unsigned ofs_compress_fragment(const uint8_t *src, unsigned n, unsigned layout, 
     const unsigned units = (n + 15u) / 16u, fields = units * 4u;
     unsigned produced = 0;
     static uint16_t element_at[2048 + 1];          /* stream offset of every element, in order */
+    static uint16_t element_out[2048 + 1];         /* ... and the position of its first output byte */
     unsigned elements = 0;
 
     memset(group_table, 0, OFS_GROUP_TABLE_BYTES);
@@ -197,8 +199,9 @@ unsigned ofs_compress_fragment(const uint8_t *src, unsigned n, unsigned layout, 
             unsigned q = p + 1u;
             while (q < nv && !((S >> q) & 1u))
                 q++;
-            element_at[elements++] = (uint16_t)(o - out);
             const unsigned at = (f0 >> 2) * 16u + fpos(L, p);
+            element_at[elements] = (uint16_t)(o - out);
+            element_out[elements++] = (uint16_t)at;
             const unsigned len = (q < 32u ? fpos(L, q) : 128u) - fpos(L, p);
             if ((lit >> p) & 1u) {
                 if (len <= 60u) {
@@ -228,18 +231,24 @@ unsigned ofs_compress_fragment(const uint8_t *src, unsigned n, unsigned layout, 
         }
         produced += (unsigned)(o - start);
     }
-    /* e. the group table the decoder's lanes start from: the elements in order, in 64 groups of G = ceil(elements / 64)
-          (the last ones shorter or empty); entry g = the bytes of group g, 12 bits each, packed little endian */
+    /* e. the group table the decoder's lanes start from (fragment table version 4): the elements in order, in 64 groups
+          of G = ceil(elements / 64) (the last ones shorter or empty); entry g = 24 bits, little endian: the compressed
+          bytes of group g | the bytes it produces << 12; then the element count (LE16) and two zero bytes */
     {
         const unsigned G = (elements + 63u) / 64u;
         element_at[elements] = (uint16_t)produced;
+        element_out[elements] = (uint16_t)n;
         for (unsigned g = 0; g < 64u; g++) {
             const unsigned a = g * G < elements ? g * G : elements, b = (g + 1u) * G < elements ? (g + 1u) * G : elements;
             const unsigned size = (unsigned)element_at[b] - element_at[a];
-            const unsigned bit = 12u * g;
-            group_table[bit >> 3] |= (uint8_t)(size << (bit & 7u));
-            group_table[(bit >> 3) + 1u] |= (uint8_t)(size >> (8u - (bit & 7u)));
+            const unsigned made = (unsigned)element_out[b] - element_out[a];
+            const unsigned entry = size | (made << 12);
+            group_table[3u * g] = (uint8_t)entry;
+            group_table[3u * g + 1u] = (uint8_t)(entry >> 8);
+            group_table[3u * g + 2u] = (uint8_t)(entry >> 16);
         }
+        group_table[192] = (uint8_t)elements;
+        group_table[193] = (uint8_t)(elements >> 8);
     }
     return produced;
 }

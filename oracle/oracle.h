@@ -74,9 +74,10 @@ void obc_decode_rgtc1(const uint8_t *blocks, unsigned w, unsigned h, uint8_t *pl
 
 /* ---- Field-stream compressor (definition of the GPU's block-per-lane Snappy compressor) ---- */
 /* One fragment (n <= 8192 bytes, whole blocks) of a block texture -> Snappy elements obeying the promises of the
- * private fragment table version 3; layout 4 = [2,6,4,4] (DXT5 / YCoCg-DXT5), 2 = [4,4] (DXT1), 6 = [2,6] (RGTC1).
- * Returns the bytes written to out (capacity >= n + n / 32 + 64); group_table[96] = the bytes of 64 groups of
- * ceil(elements / 64) consecutive elements each, 12 bits per group, packed little endian.  Not thread safe. */
+ * private fragment table version 4; layout 4 = [2,6,4,4] (DXT5 / YCoCg-DXT5), 2 = [4,4] (DXT1), 6 = [2,6] (RGTC1).
+ * Returns the bytes written to out (capacity >= n + n / 32 + 64); group_table[196] = 64 groups of
+ * ceil(elements / 64) consecutive elements each, 24 bits per group little endian (compressed bytes | bytes produced
+ * << 12), then the element count (LE16) and two zero bytes.  Not thread safe. */
 unsigned ofs_compress_fragment(const uint8_t *src, unsigned n, unsigned layout, unsigned window_bytes, uint8_t *out,
                                uint8_t *group_table);
 unsigned long ofs_texture_bytes(const uint8_t *tex, unsigned long bytes, unsigned chunks, unsigned layout);

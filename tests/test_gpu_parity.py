@@ -30,8 +30,9 @@ def ctx(hap):
 
 def find_fragment_table(frame, start=0, stop=400):
     """(offset of the 0x46 type byte, version, header bytes) of the private fragment table; version 1:
-    [ver][log2 F][granularity log2][window], version 3 (field streams): [3][13][granularity | fields << 4][window]."""
-    for ver in (1, 3):
+    [ver][log2 F][granularity log2][window], version 4 (field streams): [4][13][granularity | fields << 4][window]
+    (version 3: the same header with 96-byte group tables, written until round 4)."""
+    for ver in (1, 4, 3):
         at = bytes(frame).find(bytes([0x46, ver, 13]), start, stop)
         if at > 0:
             return at, ver, bytes(frame[at + 1: at + 5])
@@ -1376,7 +1377,7 @@ def test_row_bands_encoded_separately_join_into_the_whole_frame(ctx, hap, format
     assert ctx.join_chunk_groups([frames[0]] + dparts[1:], [len(f) for f in frames], dout)[0] == hap.HapResult.Bad_Arguments
     if all(f in (L.FMT_DXT1, L.FMT_DXT5, L.FMT_YCOCG) for f in formats):
         at, ver, _hdr = find_fragment_table(joined, 0, 4000)
-        assert at > 0 and ver == 3
+        assert at > 0 and ver == 4
         n0 = ctx.table_fallbacks()
         dec = np.zeros(len(D.oracle_bc_encode(img, formats[0])), dtype=np.uint8)
         assert ctx.decode_frames([joined], [len(joined)], 0, [dec])[3] == [0] and ctx.table_fallbacks() == n0
@@ -1527,7 +1528,7 @@ def test_match_window_promise_is_checked_and_optional(ctx, hap):
     for part in (tex, small):
         out2 = np.zeros(hap.HapMaxEncodedLength([len(part)], [L.FMT_YCOCG], [2]) + 4096, dtype=np.uint8)
         r, used, res = ctx.encode_frames([[part]], [L.FMT_YCOCG], [1], [2], [out2], flags=hap.ENCODE_FRAGMENT_INDEX)
-        assert r == 0 and find_fragment_table(out2[: used[0]].tobytes())[2] == bytes([3, 13, 0x41, 0])
+        assert r == 0 and find_fragment_table(out2[: used[0]].tobytes())[2] == bytes([4, 13, 0x41, 0])
         assert hap.HapDecode(out2[: used[0]].tobytes(), 0, outputBufferBytes=len(part)) == (0, part, L.FMT_YCOCG)
     # a hand-made fragment whose copy reaches 6 KiB back, filed under a table that promises 3 KiB
     lit = bytes(range(256)) * 24                                     # 6144 literal bytes
@@ -1549,36 +1550,54 @@ def test_match_window_promise_is_checked_and_optional(ctx, hap):
     assert hap.HapDecode(bytes(honest), 0, outputBufferBytes=8192) == (0, want, L.FMT_DXT5)
 
 
-# ------------------------------------------------ field streams: fragment table version 3 --
+# ------------------------------------------------ field streams: fragment table version 4 --
+GT = 196        # bytes of a fragment's group table: 64 x 24 bits (compressed bytes | produced bytes << 12), LE16 elements, LE16 0
+
+
 def _group_table(frame):
-    """(offset of the LE32 fragment sizes, number of entries, offset of the group tables) of a version-3 table."""
+    """(offset of the LE32 fragment sizes, number of entries, offset of the group tables) of a version-4 table."""
     at, ver, _hdr = find_fragment_table(frame, 0, 4000)
-    assert ver == 3
+    assert ver == 4
     ln = int.from_bytes(frame[at - 3: at], "little")
-    n = (ln - 4) // 100
+    n = (ln - 4) // (4 + GT)
     return at + 5, n, at + 5 + 4 * n
 
 
-def _unpack_groups(table96):
-    bits = int.from_bytes(bytes(table96), "little")
-    return [(bits >> (12 * g)) & 0xFFF for g in range(64)]
+def _unpack_groups(table):
+    """(compressed bytes of the 64 groups, bytes they produce, element count)"""
+    table = bytes(table)
+    assert len(table) == GT and table[194:196] == bytes(2)
+    entries = [int.from_bytes(table[3 * g: 3 * g + 3], "little") for g in range(64)]
+    return [e & 0xFFF for e in entries], [e >> 12 for e in entries], int.from_bytes(table[192:194], "little")
 
 
-def _pack_groups(sizes):
-    assert len(sizes) == 64 and all(0 <= v < 4096 for v in sizes)
-    return sum(v << (12 * g) for g, v in enumerate(sizes)).to_bytes(96, "little")
+def _pack_groups(sizes, made, elements):
+    assert len(sizes) == 64 and len(made) == 64 and all(0 <= v < 4096 for v in list(sizes) + list(made))
+    return b"".join((c | (m << 12)).to_bytes(3, "little") for c, m in zip(sizes, made)) + elements.to_bytes(2, "little") + bytes(2)
 
 
-def _groups_of(element_sizes):
-    """The group table of a fragment whose elements have these byte sizes: 64 groups of ceil(N / 64) elements."""
-    n = len(element_sizes)
+def _element_lengths(e):
+    """(bytes of the element in the stream, bytes it produces) of one hand-made Snappy element"""
+    tag = e[0]
+    kind = tag & 3
+    if kind == 0:
+        code = tag >> 2
+        return len(e), code + 1 if code < 60 else int.from_bytes(e[1: code - 58], "little") + 1
+    return len(e), 4 + ((tag >> 2) & 7) if kind == 1 else (tag >> 2) + 1
+
+
+def _groups_of(elements):
+    """The group table of a fragment made of these elements (byte strings): 64 groups of ceil(N / 64) elements."""
+    lens = [_element_lengths(e) for e in elements]
+    n = len(lens)
     per = (n + 63) // 64
-    return _pack_groups([sum(element_sizes[g * per: (g + 1) * per]) for g in range(64)])
+    return _pack_groups([sum(c for c, _m in lens[g * per: (g + 1) * per]) for g in range(64)],
+                        [sum(m for _c, m in lens[g * per: (g + 1) * per]) for g in range(64)], n)
 
 
 def test_field_stream_table_is_described_exactly_and_every_lie_falls_back(ctx, hap):
-    """Frames of DXT5 / YCoCg-DXT5 textures written with the fragment table carry version 3 of it: for every 8 KiB
-    fragment the bytes of 64 groups of equally many elements, with the promise that no element crosses a 128-byte
+    """Frames of DXT5 / YCoCg-DXT5 textures written with the fragment table carry version 4 of it: for every 8 KiB
+    fragment the compressed and the produced bytes of 64 groups of equally many elements and their number, with the promise that no element crosses a 128-byte
     half-tile, elements start and end on field boundaries and copy offsets are whole blocks (include/hap_gpu.h).  The
     table is checked against the streams by parsing them on the CPU; then promises are broken in turn -- the block-per-
     lane decoder must notice and the frame must still decode to the right bytes through the generic kernels."""
@@ -1592,11 +1611,12 @@ def test_field_stream_table_is_described_exactly_and_every_lie_falls_back(ctx, h
     fs_at, n, gt_at = _group_table(frame)
     assert n == 4 * 8                                                            # 4 chunks x 64 KiB / 8 KiB
     frag_sizes = [int.from_bytes(frame[fs_at + 4 * i: fs_at + 4 * i + 4], "little") for i in range(n)]
-    groups = [_unpack_groups(frame[gt_at + 96 * i: gt_at + 96 * (i + 1)]) for i in range(n)]
-    assert [sum(g) for g in groups] == frag_sizes
+    tables = [_unpack_groups(frame[gt_at + GT * i: gt_at + GT * (i + 1)]) for i in range(n)]
+    groups = [t[0] for t in tables]
+    assert [sum(g) for g in groups] == frag_sizes and all(sum(t[1]) == 8192 for t in tables)
     # walk the element streams with the table: every group boundary is an element boundary, every group of a fragment
     # holds the same number of elements (the last ones fewer), offsets are whole blocks, nothing crosses a half-tile
-    payload = gt_at + 96 * n
+    payload = gt_at + GT * n
     sizes_at = frame.find(bytes([16, 0, 0, 3]), 0, 64) + 4
     chunk_sizes = [int.from_bytes(frame[sizes_at + 4 * i: sizes_at + 4 * i + 4], "little") for i in range(4)]
     at = payload
@@ -1606,6 +1626,7 @@ def test_field_stream_table_is_described_exactly_and_every_lie_falls_back(ctx, h
             produced, counts = 0, []
             for g in range(64):
                 end, count = q + groups[c * 8 + f][g], 0
+                assert produced == sum(tables[c * 8 + f][1][:g])                 # the table's output positions
                 while q < end:
                     tag = frame[q]
                     kind = tag & 3
@@ -1630,6 +1651,7 @@ def test_field_stream_table_is_described_exactly_and_every_lie_falls_back(ctx, h
             per = (sum(counts) + 63) // 64
             full = sum(counts) // per
             assert produced == 8192 and counts[:full] == [per] * full and sum(counts[full + 1:]) == 0
+            assert sum(counts) == tables[c * 8 + f][2]
         at += chunk_sizes[c]
     # decoding: the field-stream path, the generic fragment path on the same table, and no table at all agree
     before = ctx.table_fallbacks()
@@ -1646,28 +1668,63 @@ def test_field_stream_table_is_described_exactly_and_every_lie_falls_back(ctx, h
         return (r, u2, f2, res) == (0, [len(tex)], [L.FMT_YCOCG], [0]) and canary.tobytes() == tex and \
             ctx.table_fallbacks() == n0 + 1                                      # noticed, and decoded the generic way
     k = 5
+    sizes3, made3, count3 = tables[3]
     for delta_a, delta_b in ((1, -1), (-2, 2), (3, 0), (0, 200)):
         bad = bytearray(frame)
-        g3 = list(groups[3])
+        g3 = list(sizes3)
         g3[k] += delta_a
         g3[k + 1] += delta_b
-        bad[gt_at + 3 * 96: gt_at + 4 * 96] = _pack_groups(g3)
+        bad[gt_at + 3 * GT: gt_at + 4 * GT] = _pack_groups(g3, made3, count3)
         assert decodes(bad), (delta_a, delta_b)
+    # ... output bytes that move a boundary, that no longer add up; an element count that is off by one, by a group
+    for delta_a, delta_b in ((2, -2), (-16, 16), (16, 0)):
+        bad = bytearray(frame)
+        m3 = list(made3)
+        m3[k] += delta_a
+        m3[k + 1] += delta_b
+        bad[gt_at + 3 * GT: gt_at + 4 * GT] = _pack_groups(sizes3, m3, count3)
+        assert decodes(bad), (delta_a, delta_b)
+    for wrong in (count3 - 1, count3 + 1, count3 + 64, 1, 0, 4000):
+        bad = bytearray(frame)
+        bad[gt_at + 3 * GT: gt_at + 4 * GT] = _pack_groups(sizes3, made3, wrong)
+        assert decodes(bad), wrong
     bad = bytearray(frame)
     bad[gt_at - 4 * n - 2] = (bad[gt_at - 4 * n - 2] & 15) | 0x20                    # [4, 4] fields claimed for 16-byte blocks
     assert decodes(bad)
     bad = bytearray(frame)
-    bad[gt_at: gt_at + 96] = bytes(96)                                           # a fragment with an all-zero table
+    bad[gt_at: gt_at + GT] = bytes(GT)                                           # a fragment with an all-zero table
     assert decodes(bad)
     bad = bytearray(frame)                                                       # everything in the first group
-    bad[gt_at: gt_at + 96] = _pack_groups([min(frag_sizes[0], 4095)] + [frag_sizes[0] - min(frag_sizes[0], 4095)] + [0] * 62)
+    first = min(frag_sizes[0], 4095)
+    bad[gt_at: gt_at + GT] = _pack_groups([first, frag_sizes[0] - first] + [0] * 62, [4095, 4095, 2] + [0] * 61, tables[0][2])
     canary = np.full(len(tex), 0x5A, dtype=np.uint8)
     r, u2, f2, res = ctx.decode_frames([bytes(bad)], [len(bad)], 0, [canary])
     assert (r, res) == (0, [0]) and canary.tobytes() == tex                      # (right whether or not it counts as a lie)
+    # a frame with the round-4 table (version 3: 96-byte group tables without output bytes) still decodes: its fragment
+    # sizes are used, through the generic fragment kernels -- no fallback pass
+    old = bytearray(frame[: gt_at])
+    at46, _v, _h = find_fragment_table(frame, 0, 4000)
+    old[at46 - 3: at46] = (4 + (4 + 96) * n).to_bytes(3, "little")
+    old[at46 + 1] = 3
+    for i in range(n):
+        bits = sum(v << (12 * g) for g, v in enumerate(groups[i]))
+        old += bits.to_bytes(96, "little")
+    old += frame[payload:]
+    shrink = (GT - 96) * n
+    top = int.from_bytes(frame[0:3], "little")
+    assert top != 0                                                              # (4-byte headers at this size)
+    old[0:3] = (top - shrink).to_bytes(3, "little")
+    old[4:7] = (int.from_bytes(frame[4:7], "little") - shrink).to_bytes(3, "little")
+    for name, api in CHECKERS:
+        assert api.decode(bytes(old), 0, len(tex)) == (0, tex, L.FMT_YCOCG), name
+    n0 = ctx.table_fallbacks()
+    dec = np.zeros(len(tex), dtype=np.uint8)
+    r, du, df, dr = ctx.decode_frames([bytes(old)], [len(old)], 0, [dec])
+    assert (r, du, df, dr) == (0, [len(tex)], [L.FMT_YCOCG], [0]) and dec.tobytes() == tex and ctx.table_fallbacks() == n0
 
 
 def test_field_stream_promises_are_checked_on_hand_made_streams(ctx, hap):
-    """One 8 KiB fragment written by hand under a version-3 table: the honest stream decodes; then streams that are
+    """One 8 KiB fragment written by hand under a version-4 table: the honest stream decodes; then streams that are
     valid Snappy (the checker decodes them) but break one promise each -- a copy offset that is not a whole block,
     an element that starts off a field boundary, an element that crosses a half-tile, a copy-4 element, a literal
     with a 2-byte length -- must come out right all the same (generic path) and never take the process down."""
@@ -1683,10 +1740,10 @@ def test_field_stream_promises_are_checked_on_hand_made_streams(ctx, hap):
     def frame_of(halves):
         """halves: 64 lists of element byte strings, each producing 128 bytes."""
         stream = b"".join(b"".join(h) for h in halves)
-        table = _groups_of([len(e) for h in halves for e in h])
+        table = _groups_of([e for h in halves for e in h])
         chunk = bytes([0x80, 0x40]) + stream
         tables = bytes([1, 0, 0, 2, 0x0B]) + bytes([4, 0, 0, 3]) + len(chunk).to_bytes(4, "little") + \
-            bytes([104, 0, 0, 0x46, 3, 13, 0x41, 0]) + len(stream).to_bytes(4, "little") + table
+            bytes([8 + GT, 0, 0, 0x46, 4, 13, 0x41, 0]) + len(stream).to_bytes(4, "little") + table
         body = len(tables).to_bytes(3, "little") + bytes([1]) + tables + chunk
         return len(body).to_bytes(3, "little") + bytes([0xCE]) + body
 
@@ -2043,7 +2100,7 @@ def test_field_streams_that_compress_poorly_keep_their_records_in_memory(ctx, ha
     assert r == 0 and res == [0]
     frame = out[: used[0]].tobytes()
     at, ver, _hdr = find_fragment_table(frame)
-    assert at > 0 and ver == 3 and 0.45 < len(frame) / len(tex) < 1.0, (ver, len(frame) / len(tex))
+    assert at > 0 and ver == 4 and 0.45 < len(frame) / len(tex) < 1.0, (ver, len(frame) / len(tex))
     for name, api in CHECKERS:
         assert api.decode(frame, 0, len(tex)) == (0, tex, fmt), name
     dframe = torch.from_numpy(np.frombuffer(frame, dtype=np.uint8).copy()).cuda()
@@ -2063,14 +2120,14 @@ def _ofs_fragment(data, layout, window=0):
     o = L.oracle_lib()
     o.ofs_compress_fragment.restype = C.c_uint
     out = (C.c_ubyte * (8192 + 512))()
-    table = (C.c_ubyte * 96)()
+    table = (C.c_ubyte * GT)()
     n = o.ofs_compress_fragment(bytes(data), C.c_uint(len(data)), C.c_uint(layout), C.c_uint(window), out, table)
     return bytes(out[:n]), bytes(table)
 
 
 def _own_frame_sections(frame, chunks):
-    """(chunk codec bytes, chunk sizes, fragment sizes, group tables [n, 96], payload offset) of a one-texture frame
-    written with the version-3 fragment table."""
+    """(chunk codec bytes, chunk sizes, fragment sizes, group tables [n, 196], payload offset) of a one-texture frame
+    written with the version-4 fragment table."""
     fs_at, n, ht_at = _group_table(frame)
     hdr = 4 if int.from_bytes(frame[0:3], "little") else 8
     p = hdr + 4
@@ -2080,8 +2137,8 @@ def _own_frame_sections(frame, chunks):
     assert frame[p + 3] == 0x03
     sizes = [int.from_bytes(frame[p + 4 + 4 * i: p + 8 + 4 * i], "little") for i in range(chunks)]
     frag_sizes = [int.from_bytes(frame[fs_at + 4 * i: fs_at + 4 * i + 4], "little") for i in range(n)]
-    half = np.frombuffer(frame, dtype=np.uint8, count=96 * n, offset=ht_at).reshape(n, 96)
-    return codecs, sizes, frag_sizes, half, ht_at + 96 * n
+    half = np.frombuffer(frame, dtype=np.uint8, count=GT * n, offset=ht_at).reshape(n, GT)
+    return codecs, sizes, frag_sizes, half, ht_at + GT * n
 
 
 @pytest.mark.parametrize("fmt,layout,shape,chunks", [
@@ -2134,7 +2191,7 @@ def test_plain_hap_h_encode_writes_the_private_table_on_request_only(ctx, hap, m
     """HapEncode through hap.h writes nothing the Hap specification does not name unless HAP_AMD_FRAGMENT_INDEX=1 asks
     for the private fragment table (not every parser of the frames skips unknown sections the way the
     reference does, hap.c:701-703).  Without it the frame has the reference's sections only and decodes everywhere;
-    with it the frame carries the version-3 table, both checkers still decode it, and this library decodes it with the
+    with it the frame carries the version-4 table, both checkers still decode it, and this library decodes it with the
     block-per-lane kernel -- no fallback to the generic path."""
     tex = D.oracle_bc_encode(D.rgba(1024, 512, frame=11), L.FMT_YCOCG)
     monkeypatch.delenv("HAP_AMD_FRAGMENT_INDEX", raising=False)
@@ -2152,7 +2209,7 @@ def test_plain_hap_h_encode_writes_the_private_table_on_request_only(ctx, hap, m
     r, frame = hap.HapEncode([tex], [L.FMT_YCOCG], [1], [8])
     assert r == 0 and len(frame) > len(plain)
     at, ver, _hdr = find_fragment_table(frame, 0, 4000)
-    assert at > 0 and ver == 3
+    assert at > 0 and ver == 4
     for name, api in CHECKERS:
         assert api.decode(frame, 0, len(tex)) == (0, tex, L.FMT_YCOCG), name
     before = hap.Context.default_table_fallbacks() if hasattr(hap.Context, "default_table_fallbacks") else None
@@ -2269,3 +2326,171 @@ def test_table_less_frames_of_this_library_decode_as_their_8k_fragments(ctx, hap
     want = ORA.decode(bytes(bad), 0, len(tex))
     got = hap.HapDecode(bytes(bad), 0, outputBufferBytes=len(tex))
     assert got[0] == want[0] and (got[0] != 0 or got[1] == want[1])
+
+
+# ------------------------------------------------ round 5: pipelines, several contexts, placed calls from pictures --
+def _pictures_some_of_which_do_not_shrink(w, h):
+    """Five pictures: synthetic content, pure noise (no chunk of its texture shrinks), noise in the lower half (half of
+    the chunks do not), noise in the top rows only, synthetic again."""
+    rng = np.random.RandomState(5)
+    a = D.rgba(w, h, frame=21)
+    noise = rng.randint(0, 256, (h, w, 4), dtype=np.uint8)
+    lower = a.copy()
+    lower[h // 2:] = noise[h // 2:]
+    top = a.copy()
+    top[: h // 4] = noise[: h // 4]
+    return [a, noise, lower, top, D.rgba(w, h, frame=22)]
+
+
+@pytest.mark.parametrize("fmt", [L.FMT_YCOCG, L.FMT_DXT5])
+def test_a_placed_call_from_pictures_encodes_unshrinkable_frames_again_from_the_pictures(hap, fmt):
+    """A placed call that starts from RGBA pictures keeps no block texture (round 5: the fused kernel's texture store
+    was 3.7 x its algorithmic write traffic and only a frame with a chunk stored raw, hap.c:460-466, ever read it).
+    Such a frame is made a second time from its picture, without placing: same bytes as a context that never places,
+    counted as a retry, the reference decodes every frame to the oracle's blocks of the picture."""
+    placed = _context_with(hap, HAP_AMD_PLACING_MIN_FRAMES="1", HAP_AMD_PLACING_HOLDOFF="0")
+    gathered = _context_with(hap, HAP_AMD_NO_PLACING="1")
+    w, h, chunks = 1024, 256, 4
+    pics = _pictures_some_of_which_do_not_shrink(w, h)
+    size = (w // 4) * (h // 4) * 16
+    cap = hap.HapMaxEncodedLength([size], [fmt], [chunks])
+    for flags in (hap.ENCODE_FRAGMENT_INDEX, 0):
+        got = {}
+        r0 = placed.placement_retries()
+        for name, c in (("placed", placed), ("gathered", gathered)):
+            dpics = [torch.from_numpy(p).cuda() for p in pics]
+            douts = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in pics]
+            torch.cuda.synchronize()
+            r, used, res = c.encode_frames_rgba(dpics, w, h, w * 4, [fmt], [1], [chunks], douts, flags=flags)
+            assert r == 0 and res == [0] * len(pics), (name, r, res)
+            got[name] = [o[:u].cpu().numpy().tobytes() for o, u in zip(douts, used)]
+        assert got["placed"] == got["gathered"]
+        assert placed.placement_retries() - r0 == 3 and placed.placement_timeouts() == 0
+        for p, frame in zip(pics, got["placed"]):
+            assert REF.decode(frame, 0, size) == (0, D.oracle_bc_encode(p, fmt), fmt)
+        # host pictures and host frames take the same road
+        houts = [np.zeros(cap, dtype=np.uint8) for _ in pics]
+        r, used, res = placed.encode_frames_rgba(pics, w, h, w * 4, [fmt], [1], [chunks], houts, flags=flags)
+        assert r == 0 and res == [0] * len(pics)
+        assert [o[:u].tobytes() for o, u in zip(houts, used)] == got["gathered"]
+    placed.close()
+    gathered.close()
+
+
+def test_encode_in_two_halves_gives_the_same_frames_and_keeps_the_context_to_itself(hap):
+    """HapGpuEncodeFramesRGBABegin launches everything and returns; HapGpuEncodeFramesFinish waits, fills the results
+    and encodes what could not be placed again.  Same bytes as the one-call form (placed and gathered, frames that do
+    not shrink among them); between the halves the context refuses other calls; a second context decodes the previous
+    batch meanwhile -- the pipelined step of bench.py."""
+    w, h, chunks, fmt = 1024, 256, 4, L.FMT_YCOCG
+    pics = _pictures_some_of_which_do_not_shrink(w, h)
+    size = (w // 4) * (h // 4) * 16
+    cap = hap.HapMaxEncodedLength([size], [fmt], [chunks])
+    want_tex = [D.oracle_bc_encode(p, fmt) for p in pics]
+    for env in ({"HAP_AMD_PLACING_MIN_FRAMES": "1", "HAP_AMD_PLACING_HOLDOFF": "0"}, {"HAP_AMD_NO_PLACING": "1"}):
+        enc = _context_with(hap, **env)
+        dec = hap.Context(0)
+        dpics = [torch.from_numpy(p).cuda() for p in pics]
+        sets = [[torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in pics] for _ in range(2)]
+        torch.cuda.synchronize()
+        r, used1, res1 = enc.encode_frames_rgba(dpics, w, h, w * 4, [fmt], [1], [chunks], sets[0], flags=hap.ENCODE_FRAGMENT_INDEX)
+        assert r == 0 and res1 == [0] * len(pics)
+        one_call = [o[:u].cpu().numpy().tobytes() for o, u in zip(sets[0], used1)]
+        # three pipelined batches: batch k + 1 is launched, batch k is decoded by the other context, then k + 1 is finished
+        assert enc.encode_frames_rgba_begin(dpics, w, h, w * 4, [fmt], [1], [chunks], sets[1], flags=hap.ENCODE_FRAGMENT_INDEX) == 0
+        # ... the context is taken: another call fails, and does not disturb the one in flight
+        busy = enc.encode_frames_rgba(dpics, w, h, w * 4, [fmt], [1], [chunks], sets[0], flags=0)
+        assert busy[0] == hap.HapResult.Internal_Error and busy[2] == [hap.HapResult.Internal_Error] * len(pics)
+        assert enc.compress_rgba(dpics[0], w, h, w * 4, fmt, torch.zeros(size, dtype=torch.uint8, device="cuda"))[0] == hap.HapResult.Internal_Error
+        for k in range(3):
+            prev, cur = sets[k % 2], sets[(k + 1) % 2]
+            outs = [torch.zeros(size, dtype=torch.uint8, device="cuda") for _ in pics]
+            torch.cuda.synchronize()
+            r, du, df, dr = dec.decode_frames(prev, used1, 0, outs)                 # the previous batch, meanwhile
+            assert (r, dr) == (0, [0] * len(pics))
+            assert [o.cpu().numpy().tobytes() for o in outs] == want_tex
+            r, used2, res2 = enc.encode_finish()
+            assert r == 0 and res2 == [0] * len(pics) and used2 == used1
+            assert [o[:u].cpu().numpy().tobytes() for o, u in zip(cur, used2)] == one_call
+            if k < 2:
+                for o in prev:
+                    o.zero_()
+                torch.cuda.synchronize()
+                assert enc.encode_frames_rgba_begin(dpics, w, h, w * 4, [fmt], [1], [chunks], prev, flags=hap.ENCODE_FRAGMENT_INDEX) == 0
+        # nothing pending: Finish has nothing to do, and the context takes calls again
+        assert enc.encode_finish() == (0, [], [])
+        r, used3, res3 = enc.encode_frames_rgba(dpics, w, h, w * 4, [fmt], [1], [chunks], sets[0], flags=hap.ENCODE_FRAGMENT_INDEX)
+        assert r == 0 and used3 == used1
+        # arguments that fail at once leave nothing pending
+        assert enc.encode_frames_rgba_begin(dpics, w + 1, h, w * 4, [fmt], [1], [chunks], sets[0]) == hap.HapResult.Bad_Arguments
+        assert enc.encode_finish()[0] == 0
+        # a context destroyed between the halves finishes first (no crash, no leak of the stream)
+        assert enc.encode_frames_rgba_begin(dpics, w, h, w * 4, [fmt], [1], [chunks], sets[1], flags=0) == 0
+        enc.close()
+        dec.close()
+
+
+@pytest.mark.parametrize("n_ctx", [2, 3, 8])
+def test_a_batch_dealt_out_over_several_contexts_gives_the_single_context_bytes(hap, n_ctx):
+    """HapGpuEncodeFramesRGBAOnDevices / HapGpuDecodeFramesOnDevices: frame f -> context f mod N, a host thread per
+    context, no collective.  All contexts on device 0 here (the driver's 8-GPU box is not ours to use): the
+    frames, sizes, formats and per-frame results are those of one context working on the whole batch, in the caller's
+    order, with a failing frame in the middle reported at its own index."""
+    w, h, chunks, fmts = 512, 256, [3, 2], [L.FMT_YCOCG, L.FMT_RGTC1]
+    nf = 11
+    sizes = [(w // 4) * (h // 4) * 16, (w // 4) * (h // 4) * 8]
+    cap = hap.HapMaxEncodedLength(sizes, fmts, chunks)
+    pics = [torch.from_numpy(D.rgba(w, h, frame=40 + i)).cuda() for i in range(nf)]
+    single = hap.Context(0)
+    outs1 = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(nf)]
+    torch.cuda.synchronize()
+    r, used1, res1 = single.encode_frames_rgba(pics, w, h, w * 4, fmts, [1, 1], chunks, outs1, flags=hap.ENCODE_FRAGMENT_INDEX)
+    assert r == 0 and res1 == [0] * nf
+    ctxs = [hap.Context(0) for _ in range(n_ctx)]
+    outsn = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(nf)]
+    torch.cuda.synchronize()
+    r, usedn, resn = hap.encode_frames_rgba_on_devices(ctxs, pics, w, h, w * 4, fmts, [1, 1], chunks, outsn, flags=hap.ENCODE_FRAGMENT_INDEX)
+    assert r == 0 and resn == [0] * nf and usedn == used1
+    for a, b, u in zip(outs1, outsn, used1):
+        assert torch.equal(a[:u], b[:u])
+    for index in (0, 1):
+        dec1 = [torch.zeros(sizes[index], dtype=torch.uint8, device="cuda") for _ in range(nf)]
+        decn = [torch.zeros(sizes[index], dtype=torch.uint8, device="cuda") for _ in range(nf)]
+        frames = list(outsn)
+        lens = list(usedn)
+        frames[4] = torch.zeros(64, dtype=torch.uint8, device="cuda")        # not a frame
+        lens[4] = 64
+        torch.cuda.synchronize()
+        a = single.decode_frames(frames, lens, index, dec1)
+        b = hap.decode_frames_on_devices(ctxs, frames, lens, index, decn)
+        assert a == b and a[0] != 0 and a[3][4] != 0 and [x for i, x in enumerate(a[3]) if i != 4] == [0] * (nf - 1)
+        for i, (x, y) in enumerate(zip(dec1, decn)):
+            if i != 4:
+                assert torch.equal(x, y)
+                want = D.oracle_bc_encode(pics[i].cpu().numpy(), fmts[index])
+                assert x.cpu().numpy().tobytes() == want
+    # fewer frames than contexts, and none
+    r, u2, r2 = hap.encode_frames_rgba_on_devices(ctxs, pics[:1], w, h, w * 4, fmts, [1, 1], chunks, outsn[:1], flags=hap.ENCODE_FRAGMENT_INDEX)
+    assert (r, u2, r2) == (0, used1[:1], [0])
+    assert hap.encode_frames_rgba_on_devices(ctxs, [], w, h, w * 4, fmts, [1, 1], chunks, [])[0] == 0
+    for c in ctxs + [single]:
+        c.close()
+
+
+def test_pictures_decoded_into_a_larger_host_image_leave_its_other_pixels_alone(ctx, hap):
+    """HapGpuDecodeFramesRGBA with host pictures whose rows are longer than the picture (a sub-rectangle of a larger
+    image): only width x 4 bytes of every row are written (the whole span used to be copied back from an
+    uninitialised staging buffer)."""
+    w, h, fmt = 256, 64, L.FMT_YCOCG
+    img = D.rgba(w, h, frame=9)
+    tex = D.oracle_bc_encode(img, fmt)
+    r, frame = hap.HapEncode([tex], [fmt], [1], [2])
+    assert r == 0
+    stride = w * 4 + 256
+    canvas = np.full(h * stride, 0xC3, dtype=np.uint8)
+    want = D.oracle_bc_decode(tex, fmt, w, h).reshape(h, w * 4)
+    r, res = ctx.decode_frames_rgba([frame], [len(frame)], 1, [canvas], w, h, row_bytes=stride)
+    assert r == 0 and res == [0]
+    rows = canvas.reshape(h, stride)
+    assert rows[:, : w * 4].tobytes() == want.tobytes()
+    assert (rows[:, w * 4:] == 0xC3).all()

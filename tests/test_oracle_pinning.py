@@ -294,7 +294,7 @@ def test_ycocg_blocks_are_dxt5_blocks_a_hap_q_shader_reconstructs():
                                               (L.FMT_YCOCG, 8, 16)])      # (layout 8: opaque 16-byte blocks as four dwords)
 def test_field_stream_definition_is_snappy_and_keeps_its_promises(fmt, layout, block):
     """What ofs_compress_fragment writes is an ordinary Snappy stream (libsnappy and the restatement decode it to the
-    input) that keeps the promises of the fragment table version 3: the group bytes add up, every group holds the same
+    input) that keeps the promises of the fragment table version 4: the group bytes add up (compressed and produced), every group holds the same
     number of elements (the last ones fewer), no element crosses a 128-byte half-tile, elements start on field
     boundaries, copies reach back whole blocks inside the fragment, literal runs use at most one length byte."""
     o = L.oracle_lib()
@@ -308,12 +308,14 @@ def test_field_stream_definition_is_snappy_and_keeps_its_promises(fmt, layout, b
         at = int(rng.integers(0, (len(tex) - n) // block)) * block
         data = tex[at: at + n]
         out = (C.c_ubyte * (8192 + 512))()
-        table = (C.c_ubyte * 96)()
+        table = (C.c_ubyte * 196)()
         m = o.ofs_compress_fragment(data, C.c_uint(n), C.c_uint(layout), C.c_uint(0 if trial % 2 else 3072), out, table)
         stream = bytes(out[:m])
-        bits = int.from_bytes(bytes(table), "little")
-        groups = [(bits >> (12 * g)) & 0xFFF for g in range(64)]
-        assert sum(groups) == m and m <= n + n // 32 + 64
+        entries = [int.from_bytes(bytes(table[3 * g: 3 * g + 3]), "little") for g in range(64)]
+        groups = [e & 0xFFF for e in entries]
+        made = [e >> 12 for e in entries]
+        elements = int.from_bytes(bytes(table[192:194]), "little")
+        assert sum(groups) == m and m <= n + n // 32 + 64 and sum(made) == n and bytes(table[194:196]) == bytes(2)
         head = bytearray()
         v = n
         while v >= 128:
@@ -327,6 +329,7 @@ def test_field_stream_definition_is_snappy_and_keeps_its_promises(fmt, layout, b
         counts = []
         for g in range(64):
             end, count = q + groups[g], 0
+            assert produced == sum(made[:g])
             while q < end:
                 tag = stream[q]
                 kind = tag & 3
@@ -351,7 +354,7 @@ def test_field_stream_definition_is_snappy_and_keeps_its_promises(fmt, layout, b
                 count += 1
             assert q == end
             counts.append(count)
-        assert q == m and produced == n
+        assert q == m and produced == n and sum(counts) == elements
         per_group = (sum(counts) + 63) // 64
         full = sum(counts) // per_group
         assert counts[:full] == [per_group] * full and sum(counts[full + 1:]) == 0

@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")/../hap_amd/csrc"
 mkdir -p ../variants
-BASE="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result -Wno-unused-function"
+BASE="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result -Wno-unused-function -DHAP_MEASUREMENT_BUILD"
 for spec in "$@"; do
   name="${spec%%:*}"; flags="${spec#*:}"
   make -s BUILD=build_$name OUT=../variants/libhap_amd_$name.so HIPFLAGS="$BASE $flags" >/dev/null

@@ -32,7 +32,7 @@ pos2field = {}
 for u in range(8):
     for k in range(4):
         pos2field[u * 16 + FO[k]] = u * 4 + k
-out = np.zeros(8192 + 512, dtype=np.uint8); gt = np.zeros(96, dtype=np.uint8)
+out = np.zeros(8192 + 512, dtype=np.uint8); gt = np.zeros(196, dtype=np.uint8)
 rng = np.random.RandomState(1)
 frags = rng.choice(len(tex) // 8192, size=min(nfrag, len(tex) // 8192), replace=False)
 st = collections.Counter(); rounds_hist = collections.Counter(); rounds_nohop = collections.Counter()

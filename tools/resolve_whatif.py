@@ -13,7 +13,7 @@ tex = np.fromfile("/tmp/resolve_stats_%s.tex" % cfg, dtype=np.uint8)
 lib = L.oracle_lib(); lib.ofs_compress_fragment.restype = C.c_uint
 FO = (0, 2, 8, 12); FS = (2, 6, 4, 4)
 pos2field = {u * 16 + FO[k]: u * 4 + k for u in range(8) for k in range(4)}
-out = np.zeros(8192 + 512, dtype=np.uint8); gt = np.zeros(96, dtype=np.uint8)
+out = np.zeros(8192 + 512, dtype=np.uint8); gt = np.zeros(196, dtype=np.uint8)
 rng = np.random.RandomState(1)
 frags = rng.choice(len(tex) // 8192, size=min(nfrag, len(tex) // 8192), replace=False)
 lanes1 = np.arange(64); row = lanes1 & 15
