@@ -451,7 +451,8 @@ def main():
             ms_full_serial = (serial if serial is not None else elapsed) / args.steps * 1e3
             for name, fn in (("small_batch", lambda: small_batch(hap_amd, ctx, ctx_dec, dev, args.config, flags, fence, ms_full,
                                                                    ms_full_serial, nf_total)),
-                             ("plain_frames_batched", lambda: plain_frames_batched(hap_amd, ctx, dev, args.config, nf, fence))):
+                             ("plain_frames_batched", lambda: plain_frames_batched(hap_amd, ctx, dev, args.config, nf, fence)),
+                             ("fine_chunks_option", lambda: fine_chunks_option(hap_amd, ctx, dev, args.config, nf, fence))):
                 try:
                     line[name] = fn()
                 except Exception as exc:
@@ -662,11 +663,14 @@ def small_batch(hap_amd, ctx, ctx_dec, dev, config, flags, fence, ms_full, ms_fu
     res = {"frames_per_step": frames, "steps": steps}
     best = {}
     for mode in (["pipelined"] if ctx_dec is not None else []) + ["serial"]:
-        e = min(s.timed(steps, 3, fence, pipelined=(mode == "pipelined"))[0] for _ in range(2))
+        e, prof = min((s.timed(steps, 3, fence, pipelined=(mode == "pipelined")) for _ in range(2)), key=lambda r: r[0])
         ms = e / steps * 1e3
         best[mode] = ms
         res[mode] = {"ms_per_step": round(ms, 4), "fps": round(frames * steps / e, 1),
                      "rgba_GBps": round(frames * steps * s.rgba_bytes / e / 1e9, 2)}
+        if mode == "serial":
+            res[mode]["kernels_ms_per_step"] = {k: round(t / steps, 4) for k, (n, t) in prof.items() if n}
+            res[mode]["not_in_kernels_ms"] = round(ms - sum(t for _k, (n, t) in prof.items() if n) / steps, 4)
     res["bit_exact"] = s.bit_exact()
     share = nf_full / float(frames)
     if "pipelined" in best and ms_full:
@@ -689,6 +693,38 @@ def plain_frames_batched(hap_amd, ctx, dev, config, frames, fence, steps=6):
             "rgba_GBps": round(frames * steps * s.rgba_bytes / elapsed / 1e9, 2), "snappy_ratio": round(ratio, 4),
             "encode_ms": round(enc_ms, 3), "decode_ms": round(dec_ms, 3),
             "decode_texture_GBps": round(frames * sum(s.tex_bytes) / (dec_ms * 1e-3) / 1e9, 1),
+            "bit_exact": ok, "frame_0_decoded_by": getattr(s, "reference_checked", "-"),
+            "kernels_ms": {k: v["ms_avg"] for k, v in kernels.items()}}
+
+
+def fine_chunks_option(hap_amd, ctx, dev, config, frames, fence, steps=6):
+    """HAPGPU_ENCODE_FINE_CHUNKS: one chunk per 8 KiB fragment in the tables every Hap parser reads, nothing private in the
+    frame.  Same pictures, same step (blocking calls), beside the headline; never `value`."""
+    w, h, fmts, _chunks, _n = CONFIGS[config]
+    tex_bytes = [(w // 4) * (h // 4) * BLOCK_BYTES[f] for f in fmts]
+    fine = [hap_amd.fine_chunk_count(tb, f) for tb, f in zip(tex_bytes, fmts)]
+    name = config + "fine"
+    CONFIGS[name] = (w, h, fmts, fine, frames)
+    try:
+        s = Stream(hap_amd, ctx, dev, name, list(range(frames)), hap_amd.ENCODE_FINE_CHUNKS)
+        elapsed, prof = min((s.timed(steps, 2, fence), s.timed(steps, 0, fence)), key=lambda r: r[0])
+        kernels, ratio = s.kernel_table(prof, steps, name)
+        enc_ms, dec_ms = s.split_rates()
+        ok = s.bit_exact(reference=True)
+        one = hap_amd.BufferList([s.frames[0]])
+        one_out = hap_amd.BufferList([s.dec[0][0]])
+        ctx.decode_frames(one, s.used[:1], 0, one_out)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            ctx.decode_frames(one, s.used[:1], 0, one_out)
+        one_ms = (time.perf_counter() - t0) / 20 * 1e3
+    finally:
+        del CONFIGS[name]
+    return {"chunks": fine, "frames_per_step": frames, "ms_per_step": round(elapsed / steps * 1e3, 3),
+            "rgba_GBps": round(frames * steps * s.rgba_bytes / elapsed / 1e9, 2), "snappy_ratio": round(ratio, 4),
+            "encode_ms": round(enc_ms, 3), "decode_ms": round(dec_ms, 3),
+            "decode_texture_GBps": round(frames * sum(s.tex_bytes) / (dec_ms * 1e-3) / 1e9, 1),
+            "one_frame_decode_call_ms": round(one_ms, 4),
             "bit_exact": ok, "frame_0_decoded_by": getattr(s, "reference_checked", "-"),
             "kernels_ms": {k: v["ms_avg"] for k, v in kernels.items()}}
 

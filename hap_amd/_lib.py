@@ -41,6 +41,7 @@ def _load():
         "HapGpuDefaultContext": (vp, []),
         "HapGpuSetFragmentLog2": (u, [vp, u]),
         "HapGpuSynchronize": (u, [vp]),
+        "HapGpuFineChunkCount": (u, [ul, u]),
         "HapGpuTableFallbackCount": (ul, [vp]),
         "HapGpuPlacementRetryCount": (ul, [vp]),
         "HapGpuPlacementTimeoutCount": (ul, [vp]),

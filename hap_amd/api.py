@@ -29,6 +29,7 @@ class HapResult:
 ENCODE_FRAGMENT_INDEX = 0x1
 ENCODE_COARSE_MATCHES = 0x2
 ENCODE_SMALLER_FILES = 0x4
+ENCODE_FINE_CHUNKS = 0x8
 DECODE_IGNORE_FRAGMENT_INDEX = 0x1
 DECODE_IGNORE_HALF_TILES = 0x2
 DECODE_NO_BLOCK_SCAN = 0x4
@@ -494,3 +495,8 @@ def decode_frames_on_devices(contexts, frames, frame_bytes, index, outputs, flag
     results = (C.c_uint * nf)()
     r = lib.HapGpuDecodeFramesOnDevices(_handles(contexts), len(contexts), nf, ptrs, lens, index, optrs, olens, used, fmts, results, flags)
     return r, list(used), list(fmts), list(results)
+
+
+def fine_chunk_count(texture_bytes, texture_format):
+    """HapGpuFineChunkCount: the chunk count ENCODE_FINE_CHUNKS gives a texture (size buffers with it)."""
+    return int(lib.HapGpuFineChunkCount(texture_bytes, texture_format))

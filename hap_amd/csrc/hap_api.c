@@ -197,6 +197,17 @@ unsigned long HapGpuPlacementRetryCount(HapGpuContext *context)
     return n;
 }
 
+unsigned int HapGpuFineChunkCount(unsigned long textureBytes, unsigned int textureFormat)
+{
+    unsigned long want;
+    if (textureBytes == 0 || textureBytes > 0xFFFFFFFFul || hapf_nibble_from_format(textureFormat) == 0)
+        return 0;
+    want = (textureBytes + 8191ul) / 8192ul;
+    if (textureBytes < 16ul)
+        return 1;
+    return hapf_limit_chunk_count(textureBytes, textureFormat, want > 3355431ul ? 3355431u : (unsigned)want);
+}
+
 unsigned long HapGpuPlacementTimeoutCount(HapGpuContext *context)
 {
     unsigned long n;

@@ -73,6 +73,7 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
                      int inputs_are_device)
 {
     tex_geom g[2];
+    unsigned fine_counts[2] = {0u, 0u};
     unsigned i, f, first_error = HapResult_No_Error;
     unsigned outer_header = 0, frags_per_frame = 0, max_frags_per_tex = 0, live = 0, chunks_per_frame = 0;
     int any_half_tiles = 0;
@@ -131,6 +132,13 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
     }
     if (smaller)
         flags &= ~HAPGPU_ENCODE_FRAGMENT_INDEX;
+    /* HAPGPU_ENCODE_FINE_CHUNKS: one chunk per Snappy fragment (8 KiB of texture) -- the chunk size table every Hap parser
+       reads (hap.c:265-300) then says where each independently compressed piece begins */
+    if ((flags & HAPGPU_ENCODE_FINE_CHUNKS) && !smaller) {
+        for (i = 0; i < count; i++)
+            fine_counts[i] = compressors[i] == HapCompressorSnappy ? HapGpuFineChunkCount(input_bytes[i], formats[i]) : chunk_counts[i];
+        chunk_counts = fine_counts;
+    }
     /* geometry shared by every frame of the batch */
     if (count == 2) {
         size_t worst = 0;                                             /* hap.c:563-576 */
@@ -981,7 +989,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     hapf_reader *readers;
     fetch_ctx *fetchers;
     unsigned f, live = 0, first_error = HapResult_No_Error, total_units = 0, total_chunks = 0;
-    unsigned frag_log2_seen = 0, frag_kinds = 0, max_chunks = 0;
+    unsigned frag_log2_seen = 0, frag_kinds = 0, max_chunks = 0, max_stream_src = 0;
     int any_stream = 0, need_retry = 0;
     unsigned scan_chunks = 0, scan_segs = 0, scan_words = 0;   /* streams with BLOCK slots; their segments; bpos words */
     unsigned fine_total = 0;                                   /* unit slots for the 8 KiB blocks of scanned streams */
@@ -992,7 +1000,8 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
 #define TEXTURE_INDEX(f) (entry_index ? entry_index[f] : index)
     const int block_scan = !(flags & HAPGPU_DECODE_NO_BLOCK_SCAN) && !ctx->no_block_scan;
     uint8_t *prefix = NULL, *in_stage = NULL, *out_stage = NULL;
-    size_t in_stage_bytes = 0, out_stage_bytes = 0;
+    size_t in_stage_bytes = 0, out_stage_bytes = 0, prefix_bytes = PREFIX_BYTES;
+    unsigned prefix_pass;
     size_t *in_off, *out_off;
     HapGpuDecodeJob *hjobs, *djobs;
     HapGpuChunkIn *hchunks, *dchunks;
@@ -1049,94 +1058,136 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
             if (in_dev[f])
                 device_frames++;
         }
-        if (device_frames) {
-            /* one gather kernel + one copy bring every device frame's header prefix to the host -- and, for a later
-               texture of a multi-texture frame (which begins where the first one ends, far beyond the prefix), the
-               bytes at its section too: the kernel reads the two section headers in front of it itself.
-               Device block: prefixes | second prefixes | their offsets;  upload: pointers | lengths | wanted flags */
-            const size_t up_bytes = sizeof(uint64_t) * 2u * frame_count + frame_count;
-            const size_t block = (size_t)PREFIX_BYTES * frame_count;
-            uint64_t *hptr = (uint64_t *)hapgpu_rt_pinned_scratch(rt, P_PTRS, up_bytes);
-            uint64_t *dptr = (uint64_t *)hapgpu_rt_device_scratch(rt, D_PTRS, up_bytes);
-            uint8_t *dprefix = (uint8_t *)hapgpu_rt_device_scratch(rt, D_PREFIX, 2u * block + sizeof(uint64_t) * frame_count);
-            unsigned far = 0;
-            prefix = (uint8_t *)hapgpu_rt_pinned_scratch(rt, P_PREFIX, 2u * block + sizeof(uint64_t) * frame_count);
-            if (!prefix || !hptr || !dptr || !dprefix) {
-                rc = 1;
-                goto fail_alloc;
+        /* (a second pass with a longer prefix when the tables of some frame do not fit the first one -- frames of
+           thousands of chunks, HAPGPU_ENCODE_FINE_CHUNKS: one more round trip for the whole batch instead of a fetch
+           on demand per frame and table) */
+        for (prefix_pass = 0; prefix_pass < 2u; prefix_pass++) {
+            size_t need_max = 0;
+            if (device_frames) {
+                /* one gather kernel + one copy bring every device frame's header prefix to the host -- and, for a later
+                   texture of a multi-texture frame (which begins where the first one ends, far beyond the prefix), the
+                   bytes at its section too: the kernel reads the two section headers in front of it itself.
+                   Device block: prefixes | second prefixes | their offsets;  upload: pointers | lengths | wanted flags */
+                const size_t up_bytes = sizeof(uint64_t) * 2u * frame_count + frame_count;
+                const size_t block = (size_t)prefix_bytes * frame_count;
+                uint64_t *hptr = (uint64_t *)hapgpu_rt_pinned_scratch(rt, P_PTRS, up_bytes);
+                uint64_t *dptr = (uint64_t *)hapgpu_rt_device_scratch(rt, D_PTRS, up_bytes);
+                uint8_t *dprefix = (uint8_t *)hapgpu_rt_device_scratch(rt, D_PREFIX, 2u * block + sizeof(uint64_t) * frame_count);
+                unsigned far = 0;
+                prefix = (uint8_t *)hapgpu_rt_pinned_scratch(rt, P_PREFIX, 2u * block + sizeof(uint64_t) * frame_count);
+                if (!prefix || !hptr || !dptr || !dprefix) {
+                    rc = 1;
+                    goto fail_alloc;
+                }
+                for (f = 0; f < frame_count; f++) {
+                    const int dev_frame = results[f] == HapResult_No_Error && in_dev[f];
+                    hptr[f] = dev_frame ? (uint64_t)(uintptr_t)inputs[f] : 0u;
+                    hptr[frame_count + f] = input_bytes[f];
+                    ((uint8_t *)(hptr + 2u * frame_count))[f] = (uint8_t)(dev_frame && TEXTURE_INDEX(f) > 0);
+                    far += dev_frame && TEXTURE_INDEX(f) > 0;
+                }
+                if (hapgpu_rt_pinned_is_mapped(rt)) {
+                    /* the kernel reads the pointers from, and writes the prefixes to, the pinned buffers themselves: one
+                       launch instead of a copy up, a launch and a copy back */
+                    if (far)
+                        rc |= hapgpu_k_gather_prefixes_far(rt, hptr, hptr + frame_count, frame_count, prefix_bytes, prefix,
+                                                           (const uint8_t *)(hptr + 2u * frame_count), prefix + block,
+                                                           (uint64_t *)(prefix + 2u * block));
+                    else
+                        rc |= hapgpu_k_gather_prefixes(rt, hptr, hptr + frame_count, frame_count, prefix_bytes, prefix);
+                } else {
+                    rc |= hapgpu_rt_h2d(rt, dptr, hptr, up_bytes);
+                    if (far) {
+                        rc |= hapgpu_k_gather_prefixes_far(rt, dptr, dptr + frame_count, frame_count, prefix_bytes, dprefix,
+                                                           (const uint8_t *)(dptr + 2u * frame_count), dprefix + block,
+                                                           (uint64_t *)(dprefix + 2u * block));
+                        rc |= hapgpu_rt_d2h(rt, prefix, dprefix, 2u * block + sizeof(uint64_t) * frame_count);
+                    } else {
+                        rc |= hapgpu_k_gather_prefixes(rt, dptr, dptr + frame_count, frame_count, prefix_bytes, dprefix);
+                        rc |= hapgpu_rt_d2h(rt, prefix, dprefix, block);
+                    }
+                }
+                far_seen = far;
             }
             for (f = 0; f < frame_count; f++) {
-                const int dev_frame = results[f] == HapResult_No_Error && in_dev[f];
-                hptr[f] = dev_frame ? (uint64_t)(uintptr_t)inputs[f] : 0u;
-                hptr[frame_count + f] = input_bytes[f];
-                ((uint8_t *)(hptr + 2u * frame_count))[f] = (uint8_t)(dev_frame && TEXTURE_INDEX(f) > 0);
-                far += dev_frame && TEXTURE_INDEX(f) > 0;
-            }
-            if (hapgpu_rt_pinned_is_mapped(rt)) {
-                /* the kernel reads the pointers from, and writes the prefixes to, the pinned buffers themselves: one
-                   launch instead of a copy up, a launch and a copy back */
-                if (far)
-                    rc |= hapgpu_k_gather_prefixes_far(rt, hptr, hptr + frame_count, frame_count, PREFIX_BYTES, prefix,
-                                                       (const uint8_t *)(hptr + 2u * frame_count), prefix + block,
-                                                       (uint64_t *)(prefix + 2u * block));
-                else
-                    rc |= hapgpu_k_gather_prefixes(rt, hptr, hptr + frame_count, frame_count, PREFIX_BYTES, prefix);
-            } else {
-                rc |= hapgpu_rt_h2d(rt, dptr, hptr, up_bytes);
-                if (far) {
-                    rc |= hapgpu_k_gather_prefixes_far(rt, dptr, dptr + frame_count, frame_count, PREFIX_BYTES, dprefix,
-                                                       (const uint8_t *)(dptr + 2u * frame_count), dprefix + block,
-                                                       (uint64_t *)(dprefix + 2u * block));
-                    rc |= hapgpu_rt_d2h(rt, prefix, dprefix, 2u * block + sizeof(uint64_t) * frame_count);
+                if (results[f] != HapResult_No_Error)
+                    continue;
+                if (in_dev[f]) {
+                    size_t n = input_bytes[f] < prefix_bytes ? input_bytes[f] : prefix_bytes;
+                    hapf_reader_init_host(&readers[f], prefix + (size_t)prefix_bytes * f, n);
+                    fetchers[f].ctx = ctx;
+                    fetchers[f].device_frame = (const uint8_t *)inputs[f];
+                    readers[f].fetch = fetch_from_device;
+                    readers[f].user = &fetchers[f];
+                    readers[f].total_len = input_bytes[f];
                 } else {
-                    rc |= hapgpu_k_gather_prefixes(rt, dptr, dptr + frame_count, frame_count, PREFIX_BYTES, dprefix);
-                    rc |= hapgpu_rt_d2h(rt, prefix, dprefix, block);
+                    hapf_reader_init_host(&readers[f], inputs[f], input_bytes[f]);
+                    in_off[f] = in_stage_bytes + 1;
+                    in_stage_bytes += align_up(input_bytes[f], 256);
                 }
             }
-            far_seen = far;
-        }
-        for (f = 0; f < frame_count; f++) {
-            if (results[f] != HapResult_No_Error)
-                continue;
-            if (in_dev[f]) {
-                size_t n = input_bytes[f] < PREFIX_BYTES ? input_bytes[f] : PREFIX_BYTES;
-                hapf_reader_init_host(&readers[f], prefix + (size_t)PREFIX_BYTES * f, n);
-                fetchers[f].ctx = ctx;
-                fetchers[f].device_frame = (const uint8_t *)inputs[f];
-                readers[f].fetch = fetch_from_device;
-                readers[f].user = &fetchers[f];
-                readers[f].total_len = input_bytes[f];
-            } else {
-                hapf_reader_init_host(&readers[f], inputs[f], input_bytes[f]);
-                in_off[f] = in_stage_bytes + 1;
-                in_stage_bytes += align_up(input_bytes[f], 256);
+            if (device_frames)
+                rc |= hapgpu_rt_sync(rt);
+            if (rc)
+                goto fail_alloc;
+            if (far_seen) {
+                /* the second prefix is a second window of the reader -- taken only where the host, reading the same two
+                   section headers, arrives at the offset the kernel reported (anything else: the reader fetches on demand) */
+                const size_t block = (size_t)prefix_bytes * frame_count;
+                const uint64_t *far_at = (const uint64_t *)(prefix + 2u * block);
+                for (f = 0; f < frame_count; f++) {
+                    hapf_section top, first;
+                    uint64_t at;
+                    if (results[f] != HapResult_No_Error || !in_dev[f] || TEXTURE_INDEX(f) == 0 || readers[f].view_len < 16u)
+                        continue;
+                    if (hapf_read_section(readers[f].view, (uint32_t)input_bytes[f], &top) != HapResult_No_Error ||
+                        top.type != 0x0Du || top.header_len + 8u > readers[f].view_len ||
+                        hapf_read_section(readers[f].view + top.header_len, top.length, &first) != HapResult_No_Error)
+                        continue;                                  /* (the planner reports what is wrong with it) */
+                    at = (uint64_t)top.header_len + first.header_len + first.length;
+                    if (at + 16u <= readers[f].view_len || at >= input_bytes[f] || far_at[f] != at)
+                        continue;
+                    readers[f].view2_off = at;
+                    readers[f].view2 = prefix + block + (size_t)prefix_bytes * f;
+                    readers[f].view2_len = input_bytes[f] - at < prefix_bytes ? input_bytes[f] - at : prefix_bytes;
+                }
             }
-        }
-        if (device_frames)
-            rc |= hapgpu_rt_sync(rt);
-        if (rc)
-            goto fail_alloc;
-        if (far_seen) {
-            /* the second prefix is a second window of the reader -- taken only where the host, reading the same two
-               section headers, arrives at the offset the kernel reported (anything else: the reader fetches on demand) */
-            const size_t block = (size_t)PREFIX_BYTES * frame_count;
-            const uint64_t *far_at = (const uint64_t *)(prefix + 2u * block);
+
+            if (!device_frames || prefix_pass == 1u)
+                break;
             for (f = 0; f < frame_count; f++) {
-                hapf_section top, first;
-                uint64_t at;
-                if (results[f] != HapResult_No_Error || !in_dev[f] || TEXTURE_INDEX(f) == 0 || readers[f].view_len < 16u)
+                /* how far the tables of the texture asked for reach: [outer header] section header, instructions header +
+                   length (sections: hap.c:137-212) */
+                const uint8_t *v;
+                size_t have, at = 0;
+                hapf_section sec, ins;
+                if (results[f] != HapResult_No_Error || !in_dev[f])
                     continue;
-                if (hapf_read_section(readers[f].view, (uint32_t)input_bytes[f], &top) != HapResult_No_Error ||
-                    top.type != 0x0Du || top.header_len + 8u > readers[f].view_len ||
-                    hapf_read_section(readers[f].view + top.header_len, top.length, &first) != HapResult_No_Error)
-                    continue;                                  /* (the planner reports what is wrong with it) */
-                at = (uint64_t)top.header_len + first.header_len + first.length;
-                if (at + 16u <= readers[f].view_len || at >= input_bytes[f] || far_at[f] != at)
+                v = readers[f].view;
+                have = readers[f].view_len;
+                if (TEXTURE_INDEX(f) > 0) {
+                    if (!readers[f].view2)
+                        continue;
+                    v = readers[f].view2;
+                    have = readers[f].view2_len;
+                } else if (have >= 8u && v[3] == HAP_SECTION_MULTI) {
+                    at = (v[0] | v[1] | v[2]) ? 4u : 8u;
+                }
+                if (have < at + 16u || hapf_read_section(v + at, 0xFFFFFFFFu, &sec) != HapResult_No_Error || (sec.type >> 4) != HAP_NIBBLE_COMPLEX ||
+                    hapf_read_section(v + at + sec.header_len, 0xFFFFFFFFu, &ins) != HapResult_No_Error || ins.type != HAP_SECTION_INSTRUCTIONS)
                     continue;
-                readers[f].view2_off = at;
-                readers[f].view2 = prefix + block + (size_t)PREFIX_BYTES * f;
-                readers[f].view2_len = input_bytes[f] - at < PREFIX_BYTES ? input_bytes[f] - at : PREFIX_BYTES;
+                at += (size_t)sec.header_len + ins.header_len + ins.length;
+                if (at > have && at > need_max)
+                    need_max = at;
             }
+            if (need_max <= prefix_bytes || need_max > ((size_t)4u << 20))
+                break;
+            prefix_bytes = align_up(need_max, 256);
+            for (f = 0; f < frame_count; f++)
+                hapf_reader_free(&readers[f]);
+            memset(readers, 0, sizeof(*readers) * frame_count);
+            in_stage_bytes = 0;
+            memset(in_off, 0, sizeof(size_t) * frame_count);
         }
     }
 
@@ -1177,8 +1228,11 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                 else
                     ch->unit_count = 1u;
                 units += ch->unit_count;
-                if (codec == HAP_NIBBLE_SNAPPY && !per_chunk)
+                if (codec == HAP_NIBBLE_SNAPPY && !per_chunk) {
                     any_stream = 1;
+                    if (ch->src_len > max_stream_src)
+                        max_stream_src = ch->src_len;
+                }
                 if (codec == HAP_NIBBLE_NONE)
                     any_stream = 1;
             }
@@ -1195,6 +1249,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                         units += ch->unit_count;
                     }
                     any_stream = 1;
+                    max_stream_src = 0xFFFFFFFFu;
                 } else {
                     frag_log2_seen = p->frag_log2;
                 }
@@ -1214,6 +1269,8 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
             units = p->section_length ? (p->section_length + COPY_PIECE - 1) / COPY_PIECE : 1u;
             any_stream = 1;
         } else {
+            if (p->section_length > max_stream_src)
+                max_stream_src = p->section_length;
             units = 1u + (block_scan ? stream_block_slots(p->section_length, output_bytes[f]) : 0u);
             if (units > 1u) {
                 scan_chunks += 1u;
@@ -1410,7 +1467,9 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                                        fine_total ? dwork : NULL);
         }
         rc |= hapgpu_k_snappy_decode(rt, dunits, total_units, djobs, frag_log2_seen, frag_kinds,
-                                     any_stream ? (scan_chunks ? 2 : 1) : 0,
+                                     /* 3: every stream is as short as one 8 KiB fragment (frames written with
+                                        HAPGPU_ENCODE_FINE_CHUNKS): an 8 KiB ring instead of the 32 KiB one, 14 wavefronts per CU instead of 4 */
+                                     any_stream ? (scan_chunks ? 2 : (max_stream_src <= HAPGPU_SLOT_DATA_BYTES + 64u ? 3 : 1)) : 0,
                                      (scan_chunks && scan_cursor == scan_chunks && fine_total) ? dwork : NULL, fine_total);
         rc |= hapgpu_rt_d2h(rt, hjobs, djobs, sizeof(HapGpuDecodeJob) * live);
         HAPB_MARK("launched");

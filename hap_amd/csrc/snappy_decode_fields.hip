@@ -502,10 +502,11 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
     }
     // 2c. field bytes -> 16-byte block -> ring (later steps copy from it) and memory, step after step
     const unsigned nsteps = (out_len + kStepBytes - 1u) / kStepBytes;
+    // (a uniform branch around every step instead of a `break`: the compiler unrolls this form for the sixteen steps of
+    // the 8-byte layouts too -- the rolled loop indexed the descriptors' registers through M0, two moves a field)
 #pragma unroll
     for (unsigned s = 0; s < kMaxSteps; s++) {
-        if (s >= nsteps)
-            break;
+        if (s < nsteps) {
         const unsigned opos = (64u * s + lane) * kBlock;
         const bool active = opos < out_len;
         unsigned out[kBlock / 4u];
@@ -523,7 +524,7 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
                     hi1 = __builtin_amdgcn_alignbyte(d2, d1, a);
                 }
             }
-            out[0] = (lo[0] & 0xFFFFu) | (lo[1] << 16);
+            out[0] = __builtin_amdgcn_perm(lo[1], lo[0], 0x05040100u);      // bytes 0, 1 of field 0, then bytes 0, 1 of field 1
             out[1] = (lo[1] >> 16) | (hi1 << 16);
             if (LAYOUT == 4u) {
                 out[2] = lo[2 % PERIOD];
@@ -561,6 +562,7 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
             }
         }
         __syncthreads();
+        }
     }
 }
 

@@ -80,6 +80,16 @@ typedef struct HapGpuContext HapGpuContext;
                                                (libsnappy: 0.336), compressing at a fifth of the default rate; such frames
                                                decode like another encoder's (block scan, about 300 GB/s of texture) */
 
+#define HAPGPU_ENCODE_FINE_CHUNKS 0x8u      /* one second-stage chunk per Snappy fragment: the chunk counts of the call are
+                                               replaced by HapGpuFineChunkCount() -- 8 KiB of texture per chunk where the
+                                               texture divides that way (8K Hap Q: 4050 chunks).  The chunk tables every Hap
+                                               parser reads (hap.c:265-300; 5 bytes per chunk) then list every independently
+                                               compressed piece: nothing private in the frame, no scan when decoding.
+                                               Size the output buffers with HapMaxEncodedLength() for THAT chunk count.
+                                               8K Hap Q: +20 KB per frame (the private table: +810 KB); decoded one
+                                               wavefront per chunk by the generic kernel ("Frames without a
+                                               table").  May be combined with HAPGPU_ENCODE_FRAGMENT_INDEX. */
+
 /* Decode flags */
 #define HAPGPU_DECODE_IGNORE_FRAGMENT_INDEX 0x1u /* decode as a decoder unaware of section 0x46 would */
 #define HAPGPU_DECODE_IGNORE_HALF_TILES 0x2u     /* use a version-4 table's fragment sizes only (the generic
@@ -100,6 +110,10 @@ HapGpuContext *HapGpuDefaultContext(void);
 /* Log2 of the Snappy fragment size used by the compressor (10..16, default
  * 13 = 8 KiB).  Fragments are compressed independently of each other. */
 unsigned int HapGpuSetFragmentLog2(HapGpuContext *context, unsigned int log2_bytes);
+
+/* The chunk count HAPGPU_ENCODE_FINE_CHUNKS gives a texture: bytes / 8 KiB rounded up, limited like every chunk count
+ * to a divisor of the block count (hap.c:277-300).  0 for arguments HapEncode would refuse.  Needs no GPU. */
+unsigned int HapGpuFineChunkCount(unsigned long textureBytes, unsigned int textureFormat);
 
 /* Blocks until everything enqueued on the context's stream has finished. */
 unsigned int HapGpuSynchronize(HapGpuContext *context);

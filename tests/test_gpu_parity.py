@@ -2494,3 +2494,43 @@ def test_pictures_decoded_into_a_larger_host_image_leave_its_other_pixels_alone(
     rows = canvas.reshape(h, stride)
     assert rows[:, : w * 4].tobytes() == want.tobytes()
     assert (rows[:, w * 4:] == 0xC3).all()
+
+
+@pytest.mark.parametrize("fmt,shape", [(L.FMT_YCOCG, (1024, 512)), (L.FMT_DXT1, (1000, 260)), (L.FMT_RGTC1, (2048, 1024))])
+def test_fine_chunks_put_every_fragment_into_the_tables_every_parser_reads(ctx, hap, fmt, shape):
+    """HAPGPU_ENCODE_FINE_CHUNKS: one second-stage chunk per 8 KiB Snappy fragment (the chunk count of the call is
+    replaced by HapGpuFineChunkCount; hap.c:277-300 limits it to a divisor of the block count).  Nothing private in the
+    frame: only the sections the reference writes (hap.c:430-442), the reference and the restatement decode it, the
+    inspectors report the chunk count, and this library decodes it without a block scan -- device and host buffers,
+    a batch whose tables do not fit the first header read-back, and combined with the private table."""
+    w, h = shape
+    tex = D.oracle_bc_encode(D.rgba(w, h, frame=31), fmt)
+    n = hap.fine_chunk_count(len(tex), fmt)
+    block = D.BLOCK_BYTES[fmt]
+    assert n >= len(tex) // 8192 // 2 and (len(tex) // block) % n == 0 and len(tex) // n <= 2 * 8192
+    cap = hap.HapMaxEncodedLength([len(tex)], [fmt], [n])
+    for flags in (hap.ENCODE_FINE_CHUNKS, hap.ENCODE_FINE_CHUNKS | hap.ENCODE_FRAGMENT_INDEX):
+        outs = [np.zeros(cap + (65536 if flags & hap.ENCODE_FRAGMENT_INDEX else 0), dtype=np.uint8) for _ in range(3)]
+        r, used, res = ctx.encode_frames([[tex]] * 3, [fmt], [1], [7], outs, flags=flags)     # (the 7 is replaced)
+        assert r == 0 and res == [0, 0, 0] and used[0] == used[1] == used[2]
+        frame = outs[0][: used[0]].tobytes()
+        assert outs[1][: used[1]].tobytes() == frame
+        assert hap.HapGetFrameTextureChunkCount(frame, 0) == (0, n)
+        if not flags & hap.ENCODE_FRAGMENT_INDEX:
+            _check_frame_structure(frame, tex, fmt, n)        # the three sections the reference writes and nothing else
+        for name, api in CHECKERS:
+            assert api.decode(frame, 0, len(tex)) == (0, tex, fmt), name
+        n0 = ctx.table_fallbacks()
+        assert hap.HapDecode(frame, 0, outputBufferBytes=len(tex)) == (0, tex, fmt)
+        dframes = [torch.from_numpy(np.frombuffer(frame, dtype=np.uint8).copy()).cuda() for _ in range(5)]
+        decs = [torch.zeros(len(tex), dtype=torch.uint8, device="cuda") for _ in range(5)]
+        torch.cuda.synchronize()
+        r, du, df, dr = ctx.decode_frames(dframes, [len(frame)] * 5, 0, decs)
+        assert (r, dr, df, du) == (0, [0] * 5, [fmt] * 5, [len(tex)] * 5)
+        assert all(d.cpu().numpy().tobytes() == tex for d in decs) and ctx.table_fallbacks() == n0
+    # the same picture with the client's own chunk count is a different frame of the same texture; too small a buffer for
+    # the fine tables is refused like any other (hap.c:386-389)
+    small = np.zeros(hap.HapMaxEncodedLength([len(tex)], [fmt], [1]), dtype=np.uint8)
+    if hap.HapMaxEncodedLength([len(tex)], [fmt], [1]) < cap:
+        r, used, res = ctx.encode_frames([[tex]], [fmt], [1], [1], [small], flags=hap.ENCODE_FINE_CHUNKS)
+        assert res == [hap.HapResult.Buffer_Too_Small]
