@@ -1176,9 +1176,35 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                 if (have < at + 16u || hapf_read_section(v + at, 0xFFFFFFFFu, &sec) != HapResult_No_Error || (sec.type >> 4) != HAP_NIBBLE_COMPLEX ||
                     hapf_read_section(v + at + sec.header_len, 0xFFFFFFFFu, &ins) != HapResult_No_Error || ins.type != HAP_SECTION_INSTRUCTIONS)
                     continue;
-                at += (size_t)sec.header_len + ins.header_len + ins.length;
-                if (at > have && at > need_max)
-                    need_max = at;
+                /* the tables the HOST reads: compressors, sizes, offsets (hap.c:84-88).  The private section's contents
+                   are the kernels' business -- an 8K frame's is 800 KB -- only its header is looked at */
+                {
+                    const size_t ins_at = at + sec.header_len + ins.header_len, ins_end = ins_at + ins.length;
+                    size_t q = ins_at, need = 0;
+                    unsigned chunks_seen = 0;
+                    while (q + 8u <= ins_end) {
+                        hapf_section in;
+                        if (q + 8u > have) {
+                            /* a table header beyond the prefix: behind a compressor table of n entries come 4 n bytes of sizes
+                               and perhaps 4 n of offsets */
+                            need = q + 16u + 8u * (size_t)chunks_seen + 16u;
+                            break;
+                        }
+                        if (hapf_read_section(v + q, 0xFFFFFFFFu, &in) != HapResult_No_Error)
+                            break;
+                        if (in.type == HAP_SECTION_COMPRESSORS || in.type == HAP_SECTION_SIZES || in.type == HAP_SECTION_OFFSETS) {
+                            if (in.type == HAP_SECTION_COMPRESSORS)
+                                chunks_seen = in.length;
+                            if (q + in.header_len + in.length > need)
+                                need = q + in.header_len + in.length;
+                        }
+                        q += (size_t)in.header_len + in.length;
+                    }
+                    if (need > ins_end)
+                        need = ins_end;
+                    if (need > have && need > need_max)
+                        need_max = need;
+                }
             }
             if (need_max <= prefix_bytes || need_max > ((size_t)4u << 20))
                 break;
@@ -1468,7 +1494,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
         }
         rc |= hapgpu_k_snappy_decode(rt, dunits, total_units, djobs, frag_log2_seen, frag_kinds,
                                      /* 3: every stream is as short as one 8 KiB fragment (frames written with
-                                        HAPGPU_ENCODE_FINE_CHUNKS): an 8 KiB ring instead of the 32 KiB one, 14 wavefronts per CU instead of 4 */
+                                        HAPGPU_ENCODE_FINE_CHUNKS): the 2 KiB ring of the block-scan launches instead of the 32 KiB one, 30 wavefronts per CU instead of 4 */
                                      any_stream ? (scan_chunks ? 2 : (max_stream_src <= HAPGPU_SLOT_DATA_BYTES + 64u ? 3 : 1)) : 0,
                                      (scan_chunks && scan_cursor == scan_chunks && fine_total) ? dwork : NULL, fine_total);
         rc |= hapgpu_rt_d2h(rt, hjobs, djobs, sizeof(HapGpuDecodeJob) * live);
