@@ -13,7 +13,7 @@ _API_NAMES = (
     "HapDecode", "HapEncode", "HapGetFrameTextureChunkCount", "HapGetFrameTextureCount",
     "HapGetFrameTextureFormat", "HapMaxEncodedLength", "Context", "ENCODE_FRAGMENT_INDEX", "ENCODE_COARSE_MATCHES", "ENCODE_SMALLER_FILES",
     "DECODE_IGNORE_FRAGMENT_INDEX", "DECODE_IGNORE_HALF_TILES", "DECODE_NO_BLOCK_SCAN", "KERNEL_CLASSES", "HapGpuGetFrameTextureChunkLayout", "HapGpuJoinChunkGroups", "SequenceWriter", "SequenceReader", "BufferList",
-    "encode_frames_rgba_on_devices", "decode_frames_on_devices", "ENCODE_FINE_CHUNKS", "fine_chunk_count",
+    "encode_frames_rgba_on_devices", "decode_frames_on_devices", "ENCODE_FINE_CHUNKS", "fine_chunk_count", "DECODE_NO_FIELD_GUESS", "DECODE_GUESS_FIELDS",
 )
 
 

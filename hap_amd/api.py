@@ -33,6 +33,8 @@ ENCODE_FINE_CHUNKS = 0x8
 DECODE_IGNORE_FRAGMENT_INDEX = 0x1
 DECODE_IGNORE_HALF_TILES = 0x2
 DECODE_NO_BLOCK_SCAN = 0x4
+DECODE_NO_FIELD_GUESS = 0x8
+DECODE_GUESS_FIELDS = 0x10
 KERNEL_CLASSES = ["block_encode", "snappy_compress", "frame_pack", "frame_gather", "decode_plan", "snappy_decode",
                   "block_decode", "block_scan", "encode_fused"]
 

@@ -35,18 +35,19 @@ unsigned int HapGpuCreate(int device, HapGpuContext **context)
     {
         const char *e = getenv("HAP_AMD_BYTE_GRANULAR");
         c->byte_granular = (e && atoi(e) != 0) ? 1u : 0u;
-        c->position_lanes = getenv("HAP_AMD_POSITION_LANES") ? 1u : 0u;
-        c->no_half_tiles = getenv("HAP_AMD_NO_HALF_TILES") ? 1u : 0u;
+        c->position_lanes = HAP_AB_ENV("HAP_AMD_POSITION_LANES") ? 1u : 0u;
+        c->no_half_tiles = HAP_AB_ENV("HAP_AMD_NO_HALF_TILES") ? 1u : 0u;
         c->no_block_scan = getenv("HAP_AMD_NO_BLOCK_SCAN") ? 1u : 0u;
         c->no_fusion = getenv("HAP_AMD_NO_FUSION") ? 1u : 0u;
         c->no_placing = getenv("HAP_AMD_NO_PLACING") ? 1u : 0u;
         c->placing_holdoff_calls = getenv("HAP_AMD_PLACING_HOLDOFF") ? (unsigned)atoi(getenv("HAP_AMD_PLACING_HOLDOFF")) : 8u;
-        c->placing_min_frames = getenv("HAP_AMD_PLACING_MIN_FRAMES") ? (unsigned)atoi(getenv("HAP_AMD_PLACING_MIN_FRAMES")) : 12u;
+        c->placing_min_frames = getenv("HAP_AMD_PLACING_MIN_FRAMES") ? (unsigned)atoi(getenv("HAP_AMD_PLACING_MIN_FRAMES")) : 8u;
         /* RGTC1 planes of large textures go through the [2, 6] field kernel (block-per-lane decodable: 2.9x the decode
            rate at the same size); HAP_AMD_RGTC1_LAYOUT overrides: 0 = position-per-lane compressor, 44 = [4, 4] */
         c->rgtc1_fields = 26u;
-        if (getenv("HAP_AMD_RGTC1_LAYOUT")) {
-            const int v = atoi(getenv("HAP_AMD_RGTC1_LAYOUT"));
+        if (HAP_AB_ENV("HAP_AMD_RGTC1_LAYOUT")) {
+            const char *layout = HAP_AB_ENV("HAP_AMD_RGTC1_LAYOUT");
+            const int v = layout ? atoi(layout) : 26;
             if (v == 0 || v == 26 || v == 44)
                 c->rgtc1_fields = (unsigned)v;
         }

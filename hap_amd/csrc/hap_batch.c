@@ -26,6 +26,7 @@ enum {
 #define D_PACK D_PREFIX
 #define D_CHUNK_ACC D_JOBS
 #define D_SCAN D_SLOTS       /* ... and the decoder's block-scan arena in an encode-only one */
+#define D_GUESS D_FRAGSIZES  /* ... and the group tables the decoder makes for fragments that came without */
 #define P_SCAN P_FRAMES
 enum { P_FRAMES = 0, P_JOBS, P_CHUNKS, P_PREFIX, P_PTRS, P_BC_PTRS, P_PREFIX2 };   /* (8, 9: hap_sequence.c) */
 
@@ -883,6 +884,18 @@ unsigned hapb_encode_rgba(HapGpuContext *ctx, unsigned frame_count, const void *
 
 /* ================================================================== decode */
 
+/* the block layout ("fields per block" code of the fragment table) a texture format's field streams have; 0: none */
+static unsigned field_layout_of_format(unsigned format)
+{
+    switch (format) {
+    case HapTextureFormat_RGBA_DXT5:
+    case HapTextureFormat_YCoCg_DXT5: return 4u;
+    case HapTextureFormat_RGB_DXT1: return 2u;
+    case HapTextureFormat_A_RGTC1: return 6u;
+    default: return 0u;
+    }
+}
+
 typedef struct fetch_ctx {
     HapGpuContext *ctx;
     const uint8_t *device_frame;
@@ -989,7 +1002,9 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     hapf_reader *readers;
     fetch_ctx *fetchers;
     unsigned f, live = 0, first_error = HapResult_No_Error, total_units = 0, total_chunks = 0;
-    unsigned frag_log2_seen = 0, frag_kinds = 0, max_chunks = 0, max_stream_src = 0;
+    unsigned frag_log2_seen = 0, frag_kinds = 0, max_chunks = 0, max_stream_src = 0, guess_units = 0;
+    unsigned char *guess_frame = NULL;                         /* frames whose chunks may be field-stream fragments without a table */
+    uint8_t *dguess = NULL;
     int any_stream = 0, need_retry = 0;
     unsigned scan_chunks = 0, scan_segs = 0, scan_words = 0;   /* streams with BLOCK slots; their segments; bpos words */
     unsigned fine_total = 0;                                   /* unit slots for the 8 KiB blocks of scanned streams */
@@ -1039,7 +1054,8 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     job_of_frame = (unsigned *)calloc(frame_count, sizeof(unsigned));
     in_dev = (unsigned char *)calloc(frame_count, 1);
     out_dev = (unsigned char *)calloc(frame_count, 1);
-    if (!plans || !readers || !fetchers || !in_off || !out_off || !job_of_frame || !in_dev || !out_dev) {
+    guess_frame = (unsigned char *)calloc(frame_count, 1);
+    if (!plans || !readers || !fetchers || !in_off || !out_off || !job_of_frame || !in_dev || !out_dev || !guess_frame) {
         rc = 1;
         goto fail_alloc;
     }
@@ -1291,6 +1307,24 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
             total_chunks += (unsigned)p->chunk_count;
             if ((unsigned)p->chunk_count > max_chunks)
                 max_chunks = (unsigned)p->chunk_count;
+            /* no table, but every chunk as short as one fragment (HAPGPU_ENCODE_FINE_CHUNKS): candidates for the
+               block-per-lane decoder, whose starting points a pre-pass can find (snappy_decode_fields.hip) */
+            if (!p->frag_table_offset && !(flags & HAPGPU_DECODE_NO_FIELD_GUESS) && field_layout_of_format(p->format) && p->chunk_count > 1) {
+                unsigned snappy_chunks = 0;
+                int fits = 1;
+                for (c = 0; c < p->chunk_count; c++) {
+                    const HapGpuChunkIn *ch = &p->chunks[c];
+                    if ((ch->codec & 0xFFu) != HAP_NIBBLE_SNAPPY)
+                        continue;
+                    snappy_chunks++;
+                    if (ch->unit_count != 1u || ch->src_len > HAPGPU_SLOT_DATA_BYTES + 64u + 5u)
+                        fits = 0;
+                }
+                if (fits && snappy_chunks) {
+                    guess_frame[f] = 1;
+                    guess_units += snappy_chunks;
+                }
+            }
         } else if (p->mode == HAPGPU_JOB_RAW) {
             units = p->section_length ? (p->section_length + COPY_PIECE - 1) / COPY_PIECE : 1u;
             any_stream = 1;
@@ -1354,6 +1388,15 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
         djoins = arena + o_joins;
         drecs = arena + o_recs;
     }
+    /* (a lane per fragment finds the starting points: worth it from a few thousand fragments on -- one frame's are
+       decoded sooner by the generic kernel, a wavefront each) */
+    if (guess_units && (guess_units >= 4096u || (flags & HAPGPU_DECODE_GUESS_FIELDS))) {
+        dguess = (uint8_t *)hapgpu_rt_device_scratch(rt, D_GUESS, (size_t)HAP_GROUP_TABLE_BYTES * ((size_t)total_units + 1u));
+        if (!dguess) {
+            rc = 1;
+            goto fail_alloc;
+        }
+    }
     {
         unsigned chunk_cursor = 0, unit_cursor = 0, scan_cursor = 0, seg_cursor = 0, word_cursor = 0, fine_cursor = 0;
         request_marks marks;
@@ -1402,6 +1445,13 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                         frag_kinds |= 16u << p->frag_gran_log2;
                     else
                         frag_kinds |= 1u << p->frag_gran_log2;
+                }
+                if (dguess && guess_frame[f]) {
+                    const unsigned layout = field_layout_of_format(p->format);
+                    job->fields_period = layout;
+                    job->group_tables = (uint64_t)(uintptr_t)dguess;
+                    job->reserved |= 1u << 16;
+                    frag_kinds |= layout == 4u ? 0x100u : layout == 2u ? 0x200u : layout == 8u ? 0x800u : 0x400u;
                 }
                 if (p->chunk_count > 0)
                     memcpy(hchunks + chunk_cursor, p->chunks, sizeof(HapGpuChunkIn) * (size_t)p->chunk_count);
@@ -1492,6 +1542,8 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
             rc |= hapgpu_k_scan_blocks(rt, dunits, djobs, dscan, scan_chunks, dsegs, drecs, djoins, scan_segs,
                                        fine_total ? dwork : NULL);
         }
+        if (dguess)
+            rc |= hapgpu_k_guess_group_tables(rt, dunits, total_units, djobs);
         rc |= hapgpu_k_snappy_decode(rt, dunits, total_units, djobs, frag_log2_seen, frag_kinds,
                                      /* 3: every stream is as short as one 8 KiB fragment (frames written with
                                         HAPGPU_ENCODE_FINE_CHUNKS): the 2 KiB ring of the block-scan launches instead of the 32 KiB one, 30 wavefronts per CU instead of 4 */
@@ -1547,7 +1599,8 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
             }
             hapb_decode(ctx, 1, &inputs[f], &input_bytes[f], TEXTURE_INDEX(f), &outputs[f], &output_bytes[f],
                         output_used ? &output_used[f] : NULL, output_formats ? &output_formats[f] : NULL,
-                        &results[f], flags | HAPGPU_DECODE_IGNORE_FRAGMENT_INDEX | HAPGPU_DECODE_NO_BLOCK_SCAN,
+                        &results[f], (flags | HAPGPU_DECODE_IGNORE_FRAGMENT_INDEX | HAPGPU_DECODE_NO_BLOCK_SCAN | HAPGPU_DECODE_NO_FIELD_GUESS) &
+                                     ~HAPGPU_DECODE_GUESS_FIELDS,
                         frame_count == 1 ? callback : NULL, callback_info);
             ctx->preset_marks = NULL;
             ctx->preset_count = 0;
@@ -1563,7 +1616,7 @@ finish:
         hapf_reader_free(&readers[f]);
     }
     free(plans); free(readers); free(fetchers); free(in_off); free(out_off); free(job_of_frame);
-    free(in_dev); free(out_dev); free(client_marks);
+    free(in_dev); free(out_dev); free(client_marks); free(guess_frame);
     return first_error;
 
 fail_alloc:
@@ -1574,7 +1627,7 @@ fail_alloc:
         if (readers) hapf_reader_free(&readers[f]);
     }
     free(plans); free(readers); free(fetchers); free(in_off); free(out_off); free(job_of_frame);
-    free(in_dev); free(out_dev); free(client_marks);
+    free(in_dev); free(out_dev); free(client_marks); free(guess_frame);
     return HapResult_Internal_Error;
 }
 

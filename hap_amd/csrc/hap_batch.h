@@ -17,8 +17,11 @@ struct HapGpuContext {
     unsigned rgtc1_fields;    /* layout of RGTC1 planes for the block compressor: 26 = [2, 6] (default), 44 = [4, 4], 0 = position lanes (HAP_AMD_RGTC1_LAYOUT) */
     unsigned no_block_scan;   /* HAP_AMD_NO_BLOCK_SCAN: whole-stream units stay whole (A/B runs) */
     unsigned no_fusion;       /* HAP_AMD_NO_FUSION: RGBA calls run the block encoder as a pass of its own (A/B runs) */
-    unsigned placing_min_frames; /* HAP_AMD_PLACING_MIN_FRAMES (default 12): batches below it gather (with most of a frame in flight at
-                                    once its wavefronts wait for each other longer than the gather pass takes) */
+    unsigned placing_min_frames; /* HAP_AMD_PLACING_MIN_FRAMES (default 8; 12 until round 5): batches below it gather (with most of a
+                                    frame in flight at once its wavefronts wait for each other longer than the gather pass
+                                    takes; at 8 frames the two break even for a call by itself, and in a pipelined step --
+                                    the next batch's decode kernels fill the waiting wavefronts' slots -- placing wins:
+                                    0.545 against 0.559 ms per step of 8 8K frames) */
     unsigned placing_holdoff; /* calls left that gather although they could place: the last placing call encoded most frames twice */
     unsigned placing_holdoff_calls; /* HAP_AMD_PLACING_HOLDOFF (default 8): how many */
     unsigned no_placing;      /* HAP_AMD_NO_PLACING: compressed fragments go to slots and are gathered (A/B runs; also set

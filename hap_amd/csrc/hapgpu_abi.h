@@ -15,6 +15,16 @@
 extern "C" {
 #endif
 
+/* Environment switches that exist for A/B measurements only (copy kernels against hipMemcpyAsync, ring sizes, compressor
+   layouts ...) are read by measurement builds (tools/build_variants.sh, -DHAP_MEASUREMENT_BUILD); the product library does
+   not look at them: every switch it does read is listed in INTEGRATION.md and exercised by a test
+   (tests/test_cabi_cpu.py::test_every_environment_switch_is_documented_and_tested). */
+#ifdef HAP_MEASUREMENT_BUILD
+#define HAP_AB_ENV(name) getenv(name)
+#else
+#define HAP_AB_ENV(name) ((const char *)0)
+#endif
+
 /* ---- container constants (reference hap.c:41-51, 84-88) ---- */
 #define HAP_NIBBLE_NONE 0xAu
 #define HAP_NIBBLE_SNAPPY 0xBu
@@ -148,7 +158,10 @@ typedef struct HapGpuDecodeJob {
     uint32_t frag_entries;   /* number of fragment-size entries */
     uint32_t unit_count;
     uint32_t reserved;       /* bits 0..7: granularity_log2 announced by the fragment table (0 bytes, 1 16-bit,
-                                2 32-bit); bits 8..15: its match window in 256-byte units (0 = none announced) */
+                                2 32-bit); bits 8..15: its match window in 256-byte units (0 = none announced);
+                                bit 16: no table, but every chunk is as short as a fragment: group_tables is scratch
+                                (HAP_GROUP_TABLE_BYTES per unit of the CALL) that hapgpu_k_guess_group_tables fills,
+                                fields_period the layout the texture format implies */
     /* results */
     uint64_t bytes_used;
     uint32_t status;         /* HapResult or HAPGPU_STATUS_* */
@@ -329,6 +342,9 @@ int hapgpu_k_snappy_decode(hapgpu_rt *rt, const HapGpuDecodeUnit *units, unsigne
 /* measurement */
 void hapgpu_rt_set_profiling(hapgpu_rt *rt, int enable);
 int hapgpu_rt_collect_profile(hapgpu_rt *rt, unsigned long *launches, double *ms, unsigned classes);
+/* group tables for the STREAM units of jobs whose reserved bit 16 is set (fragments that came as chunks of their own,
+   without a private table): units that turn out to be field streams become FIELDS units (snappy_decode_fields.hip) */
+int hapgpu_k_guess_group_tables(hapgpu_rt *rt, HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs);
 int hapgpu_rt_timer_start(hapgpu_rt *rt);
 int hapgpu_rt_timer_stop(hapgpu_rt *rt, double *ms);
 

@@ -114,7 +114,7 @@ extern "C" int hapgpu_rt_create(int device, hapgpu_rt **out)
     // recording, and memset nodes of a replayed graph ran late (see hapgpu_rt_zero).
     {
         const char *g = getenv("HAP_AMD_GRAPHS");
-        rt->graphs_off = !(g && g[0] != '0') || getenv("HAP_AMD_NO_GRAPHS") != NULL;
+        rt->graphs_off = !(g && g[0] != '0') || HAP_AB_ENV("HAP_AMD_NO_GRAPHS") != NULL;
     }
     rt->recording = 0;
     pthread_mutex_init(&rt->lock, NULL);
@@ -264,7 +264,7 @@ static bool copy_kernels_enabled()
 {
     static int on = -1;
     if (on < 0) {
-        const char *v = getenv("HAP_AMD_COPY_KERNELS");
+        const char *v = HAP_AB_ENV("HAP_AMD_COPY_KERNELS");
         on = (v && v[0] == '0') ? 0 : 1;
     }
     return on != 0;
@@ -340,7 +340,7 @@ extern "C" int hapgpu_rt_zero(hapgpu_rt *rt, void *dst, size_t bytes)
     // (a kernel of this library's own, whatever the size: hipMemsetAsync recorded into a HIP graph did not do its work in
     // order when the graph was launched a second time -- small buffers, ROCm 7.2: the compressor's published sizes were
     // wiped under its waiting wavefronts, every frame of the call was encoded twice.  HAP_AMD_MEMSET_NODES=1: the old way)
-    if (bytes <= ((size_t)1 << 40) && !getenv("HAP_AMD_MEMSET_NODES")) {
+    if (bytes <= ((size_t)1 << 40) && !HAP_AB_ENV("HAP_AMD_MEMSET_NODES")) {
         for (size_t done = 0; done < bytes; done += (size_t)1 << 30) {      // (2^18 workgroups of 4 KiB a launch)
             const size_t part = bytes - done < ((size_t)1 << 30) ? bytes - done : (size_t)1 << 30;
             hipLaunchKernelGGL(small_zero_kernel, dim3((unsigned)((part + 4095u) / 4096u)), dim3(256), 0, rt->stream, (uint8_t *)dst + done, part);
@@ -680,6 +680,13 @@ extern "C" int hapgpu_k_scan_blocks(hapgpu_rt *rt, HapGpuDecodeUnit *units, cons
 {
     scoped_timing st(rt, 7);
     return hapgpu_launch_scan_blocks(units, jobs, chunks, chunk_count, segs, recs, joins, seg_total, fine_work, rt->stream);
+}
+
+extern "C" int hapgpu_launch_guess_group_tables(HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs, hipStream_t stream);
+extern "C" int hapgpu_k_guess_group_tables(hapgpu_rt *rt, HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs)
+{
+    scoped_timing st(rt, 7);          // (with the block scan: finding where wavefronts may start in streams that do not say)
+    return hapgpu_launch_guess_group_tables(units, unit_count, jobs, rt->stream);
 }
 
 extern "C" int hapgpu_k_snappy_decode(hapgpu_rt *rt, const HapGpuDecodeUnit *units, unsigned unit_count,

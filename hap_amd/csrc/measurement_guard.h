@@ -13,7 +13,7 @@
 #if !defined(HAP_MEASUREMENT_BUILD) && ( \
     defined(SDF_BUF_BYTES) || defined(SDF_DYN_LDS) || defined(SDF_HOPS) || defined(SDF_ONLY) || \
     defined(SDF_UNSAFE) || defined(SDF_ABL_NOROUNDS) || defined(SDF_ABL_NOPRODREADS) || defined(SDF_ABL_NORINGSTORE) || \
-    defined(SCB_MIN_WAVES) || defined(SCB_PREFETCH) || defined(PLC_ABL) || defined(PLC_NO_INTERLEAVE) || \
+    defined(SCB_MIN_WAVES) || defined(SCB_PREFETCH) || defined(SCB_ONLY_FUSED_YCOCG) || defined(PLC_ABL) || defined(PLC_NO_INTERLEAVE) || \
     defined(HAP_BLK_FAR_FIRST) || defined(HAP_WG_WAVES) || defined(HAP_WG_SUBS) || defined(HAP_WG_HASH_BITS) || \
     defined(HAP_V2_IN_BYTES) || defined(HAP_V2_OWNER_BYTES) || defined(HAP_CHAIN_ROUNDS) || defined(HAPB_TRACE))
 #error "a measurement switch is defined without HAP_MEASUREMENT_BUILD: build variants with tools/build_variants.sh, never the product library"

@@ -820,6 +820,7 @@ extern "C" int hapgpu_launch_snappy_compress_blocks(const HapGpuFrameEnc *frames
                        frag_sizes, group_tables)
     if (fused & 1u)
         HAP_LAUNCH_BLOCKS(4u, hapbc::kFmtYCoCg);
+#ifndef SCB_ONLY_FUSED_YCOCG          // (instruction-count studies, tools/isa_by_line.py: that instantiation alone)
     if (fused & 2u)
         HAP_LAUNCH_BLOCKS(4u, hapbc::kFmtDXT5);
     if (fused & 12u)          // (DXT1 / RGTC1: the fused form was no faster than the two passes, hap_batch.c; not instantiated)
@@ -832,6 +833,7 @@ extern "C" int hapgpu_launch_snappy_compress_blocks(const HapGpuFrameEnc *frames
         HAP_LAUNCH_BLOCKS(6u, -1);
     if (layouts & 8u)
         HAP_LAUNCH_BLOCKS(8u, -1);
+#endif
 #undef HAP_LAUNCH_BLOCKS
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }

@@ -1476,7 +1476,7 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
         static unsigned ring_forced = 0;
         if (!once) {
             (void)hipFuncSetAttribute((const void *)snappy_decode_fragment_kernel<65536u, true, 1u>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kFragmentTail);
-            const char *e = getenv("HAP_AMD_STREAM_RING_LOG2");
+            const char *e = HAP_AB_ENV("HAP_AMD_STREAM_RING_LOG2");
             if (e && atoi(e) >= 11 && atoi(e) <= 16)
                 ring_forced = (unsigned)atoi(e);
             once = true;

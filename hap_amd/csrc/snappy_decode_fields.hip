@@ -595,7 +595,144 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
 }
 
 
+// ---- group tables for field streams that come without one ------------------------------------------------------------
+// Frames written with HAPGPU_ENCODE_FINE_CHUNKS carry no private section: every 8 KiB fragment is a chunk of its own in
+// the tables every Hap parser reads, so its boundaries are known -- but not the 64 places inside it from which the
+// kernel above starts its lanes.  This kernel finds them: ONE LANE per fragment walks the fragment's tags (twice: count
+// the elements, then note where every G-th begins) and writes the table of version 4 into scratch; the fragment's unit
+// becomes a FIELDS unit that points there.  A lane's walk is ~450 dependent loads from memory -- slow for one fragment,
+// but 64 fragments share every wave-instruction: about a tenth of the decode itself for a batch (the host takes this road
+// from a few thousand fragments on; fewer are decoded by the generic kernel, one wavefront per fragment).
+// What is not a field stream -- another encoder's chunk of the same size, an element off a field boundary -- stays a
+// STREAM unit for the generic kernel: the walk checks the promises the table would have made.  (The kernel above checks
+// them all again; its verdict, not this one's, is what protects memory.)
+__device__ __forceinline__ unsigned load_tag32(gin_t src, unsigned cp, unsigned n)
+{
+    // bytes cp .. cp + 3 of the stream (zero beyond its end); unaligned dword loads are fine in global memory
+    struct __attribute__((packed)) unaligned32 { uint32_t v; };
+    if (cp + 4u <= n)
+        return reinterpret_cast<const unaligned32 __attribute__((address_space(1))) *>(src + cp)->v;
+    unsigned w = 0;
+    for (unsigned k = 0; k < 4u && cp + k < n; k++)
+        w |= (unsigned)src[cp + k] << (8u * k);
+    return w;
+}
+
+__global__ __launch_bounds__(64) void guess_group_tables_kernel(HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs)
+{
+    const unsigned idx = blockIdx.x * 64u + threadIdx.x;
+    if (idx >= unit_count)
+        return;
+    HapGpuDecodeUnit u = units[idx];
+    if (u.kind != HAPGPU_UNIT_SNAPPY_STREAM || u.aux != 0u || u.reserved != 0u)
+        return;
+    const HapGpuDecodeJob *job = &jobs[u.job];
+    if (!((job->reserved >> 16) & 1u) || job->group_tables == 0u || job->status != 0u)
+        return;
+    const unsigned layout = job->fields_period;
+    const unsigned block = (layout == 4u || layout == 8u) ? 16u : 8u;
+    // field starts inside a block, as a mask over its bytes: [2,6,4,4]: 0, 2, 8, 12; [4,4]: 0, 4; [2,6]: 0, 2; [4,4,4,4]: 0, 4, 8, 12
+    const unsigned starts = layout == 4u ? 0x1105u : layout == 2u ? 0x11u : layout == 6u ? 0x05u : 0x1111u;
+    const gin_t base = (gin_t)u.src;
+    // the stream's length prefix
+    unsigned hdr = 0, out_len = 0;
+    for (unsigned k = 0; k < 5u && k < u.src_len; k++) {
+        const unsigned b = base[k];
+        out_len |= (b & 0x7Fu) << (7u * k);
+        if (!(b & 0x80u)) {
+            hdr = k + 1u;
+            break;
+        }
+    }
+    if (hdr == 0u || out_len != u.dst_len || out_len == 0u || out_len > kFragBytes || (out_len % block) != 0u)
+        return;
+    const gin_t src = base + hdr;
+    const unsigned n = u.src_len - hdr;
+    if (n > kMaxFragCompressed)
+        return;
+    // first walk: count the elements, check what the table promises
+    unsigned cp = 0, p = 0, count = 0;
+    bool ok = true;
+    while (cp < n && ok) {
+        const unsigned w = load_tag32(src, cp, n);
+        const unsigned kind = w & 3u, up = (w >> 2) & 63u;
+        unsigned len, adv;
+        if (kind == 0u) {
+            ok = up <= 60u;
+            len = (up == 60u ? ((w >> 8) & 255u) : up) + 1u;
+            adv = len + (up == 60u ? 2u : 1u);
+        } else {
+            len = kind == 1u ? ((w >> 2) & 7u) + 4u : up + 1u;
+            adv = kind + 1u;
+            const unsigned off = kind == 1u ? (((w >> 5) & 7u) << 8) | ((w >> 8) & 255u) : (w >> 8) & 0xFFFFu;
+            ok = kind != 3u && off >= block && (off % block) == 0u && off <= p;
+        }
+        ok = ok && ((starts >> (p % block)) & 1u) != 0u && (p & (kHalf - 1u)) + len <= kHalf;
+        p += len;
+        cp += adv;
+        count += 1u;
+    }
+    // (an element that ends off a field boundary shows as the next one's start, or as the total)
+    if (!ok || cp != n || p != out_len || 4u * count > out_len)
+        return;
+    // second walk: where every G-th element begins
+    const unsigned G = (count + 63u) >> 6;
+    gout_t table = (gout_t)(job->group_tables + (uint64_t)idx * HAP_GROUP_TABLE_BYTES);
+    unsigned g = 0, left = G, cp0 = 0, p0 = 0;
+    cp = 0;
+    p = 0;
+    bool fits = true;
+    while (cp < n) {
+        const unsigned w = load_tag32(src, cp, n);
+        const unsigned kind = w & 3u, up = (w >> 2) & 63u;
+        const unsigned len = kind == 0u ? (up == 60u ? ((w >> 8) & 255u) : up) + 1u : kind == 1u ? ((w >> 2) & 7u) + 4u : up + 1u;
+        const unsigned adv = kind == 0u ? len + (up == 60u ? 2u : 1u) : kind + 1u;
+        p += len;
+        cp += adv;
+        if (--left == 0u || cp >= n) {
+            const unsigned cs = cp - cp0, os = p - p0;
+            fits = fits && cs < 4096u && os < 4096u;
+            const unsigned entry = cs | (os << 12);
+            table[3u * g] = (uint8_t)entry;
+            table[3u * g + 1u] = (uint8_t)(entry >> 8);
+            table[3u * g + 2u] = (uint8_t)(entry >> 16);
+            g += 1u;
+            left = G;
+            cp0 = cp;
+            p0 = p;
+        }
+    }
+    for (; g < 64u; g++) {
+        table[3u * g] = 0;
+        table[3u * g + 1u] = 0;
+        table[3u * g + 2u] = 0;
+    }
+    table[192] = (uint8_t)count;
+    table[193] = (uint8_t)(count >> 8);
+    table[194] = 0;
+    table[195] = 0;
+    if (!fits)
+        return;
+    // the unit becomes a field-stream fragment: bare elements, its table, the readable bytes behind it
+    const uint64_t end = u.src + u.src_len, section_end = job->payload + job->payload_len;
+    u.src += hdr;
+    u.src_len = n;
+    u.kind = layout == 4u ? HAPGPU_UNIT_SNAPPY_FIELDS4 : layout == 2u ? HAPGPU_UNIT_SNAPPY_FIELDS2
+           : layout == 8u ? HAPGPU_UNIT_SNAPPY_FIELDS44 : HAPGPU_UNIT_SNAPPY_FIELDS26;
+    u.aux = (uint64_t)(uintptr_t)table;
+    u.reserved = section_end > end ? (section_end - end < 15u ? section_end - end : 15u) : 0u;
+    units[idx] = u;
+}
+
 } // namespace
+
+extern "C" int hapgpu_launch_guess_group_tables(HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs, hipStream_t stream)
+{
+    if (unit_count == 0)
+        return 0;
+    hipLaunchKernelGGL(guess_group_tables_kernel, dim3((unit_count + 63u) / 64u), dim3(64), 0, stream, units, unit_count, jobs);
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}
 
 // fields_kinds: bit 0 = [2, 6, 4, 4] units present (DXT5 / YCoCg-DXT5), bit 1 = [4, 4] units (DXT1), bit 2 = [2, 6] (RGTC1),
 // bit 3 = [4, 4, 4, 4] (opaque 16-byte blocks)

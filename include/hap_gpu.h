@@ -94,6 +94,12 @@ typedef struct HapGpuContext HapGpuContext;
 #define HAPGPU_DECODE_IGNORE_FRAGMENT_INDEX 0x1u /* decode as a decoder unaware of section 0x46 would */
 #define HAPGPU_DECODE_IGNORE_HALF_TILES 0x2u     /* use a version-4 table's fragment sizes only (the generic
                                                     fragment decoder), not its group tables: for A/B measurements */
+#define HAPGPU_DECODE_NO_FIELD_GUESS 0x8u        /* frames whose chunks are each as short as one fragment (HAPGPU_ENCODE_FINE_CHUNKS)
+                                                    and carry no private table: do not look for the block-per-lane decoder's
+                                                    starting points (one lane per chunk walks its tags, then the chunk
+                                                    decodes like a fragment with a table), decode every chunk with the
+                                                    generic kernel -- what calls of fewer than 4096 such chunks do anyway */
+#define HAPGPU_DECODE_GUESS_FIELDS 0x10u         /* ... do it however few the chunks are (tests) */
 #define HAPGPU_DECODE_NO_BLOCK_SCAN 0x4u         /* decode other encoders' Snappy streams with one wavefront per
                                                     stream instead of looking for their 64 KiB blocks first: for A/B
                                                     measurements (environment HAP_AMD_NO_BLOCK_SCAN does the same) */
