@@ -1004,6 +1004,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     unsigned f, live = 0, first_error = HapResult_No_Error, total_units = 0, total_chunks = 0;
     unsigned frag_log2_seen = 0, frag_kinds = 0, max_chunks = 0, max_stream_src = 0, guess_units = 0;
     unsigned char *guess_frame = NULL;                         /* frames whose chunks may be field-stream fragments without a table */
+    int use_guess = 0;
     uint8_t *dguess = NULL;
     int any_stream = 0, need_retry = 0;
     unsigned scan_chunks = 0, scan_segs = 0, scan_words = 0;   /* streams with BLOCK slots; their segments; bpos words */
@@ -1237,7 +1238,6 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     /* 2. plan on the host: sections and tables only (hap_frame.c) */
     for (f = 0; f < frame_count; f++) {
         hapf_texture_plan *p = &plans[f];
-        unsigned units = 0;
         int c;
         if (results[f] != HapResult_No_Error)
             continue;
@@ -1250,13 +1250,45 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
         }
         if (flags & HAPGPU_DECODE_IGNORE_FRAGMENT_INDEX)
             p->frag_table_offset = 0;
+        if (p->mode == HAPGPU_JOB_COMPLEX &&
+            !(p->frag_table_offset && p->chunk_count > 0 && p->frag_entries >= (unsigned)p->chunk_count &&
+              p->frag_entries % (unsigned)p->chunk_count == 0))
+            p->frag_table_offset = 0;
+        /* no table, but every chunk as short as one fragment (HAPGPU_ENCODE_FINE_CHUNKS): candidates for the
+           block-per-lane decoder, whose starting points a pre-pass can find (snappy_decode_fields.hip) */
+        if (p->mode == HAPGPU_JOB_COMPLEX && !p->frag_table_offset && !(flags & HAPGPU_DECODE_NO_FIELD_GUESS) &&
+            field_layout_of_format(p->format) && p->chunk_count > 1) {
+            unsigned snappy_chunks = 0;
+            int fits = 1;
+            for (c = 0; c < p->chunk_count; c++) {
+                const HapGpuChunkIn *ch = &p->chunks[c];
+                if ((ch->codec & 0xFFu) != HAP_NIBBLE_SNAPPY)
+                    continue;
+                snappy_chunks++;
+                if (ch->src_len > HAPGPU_SLOT_DATA_BYTES + 64u + 5u)
+                    fits = 0;
+            }
+            if (fits && snappy_chunks) {
+                guess_frame[f] = 1;
+                guess_units += snappy_chunks;
+            }
+        }
+    }
+    /* (a lane per fragment finds the starting points: worth it from a few thousand fragments on -- one frame's are
+       decoded sooner by the generic kernel, a wavefront each) */
+    use_guess = guess_units && (guess_units >= 4096u || (flags & HAPGPU_DECODE_GUESS_FIELDS));
+    for (f = 0; f < frame_count; f++) {
+        hapf_texture_plan *p = &plans[f];
+        unsigned units = 0;
+        int c;
+        /* (the chunks of a frame on that road are not looked over for 64 KiB blocks: one unit each) */
+        const int frame_scan = block_scan && !(use_guess && guess_frame[f]);
+        if (results[f] != HapResult_No_Error)
+            continue;
         if (p->mode == HAPGPU_JOB_COMPLEX) {
             unsigned per_chunk = 0;
-            if (p->frag_table_offset && p->chunk_count > 0 && p->frag_entries >= (unsigned)p->chunk_count &&
-                p->frag_entries % (unsigned)p->chunk_count == 0)
+            if (p->frag_table_offset)
                 per_chunk = p->frag_entries / (unsigned)p->chunk_count;
-            else
-                p->frag_table_offset = 0;
             for (c = 0; c < p->chunk_count; c++) {
                 HapGpuChunkIn *ch = &p->chunks[c];
                 unsigned codec = ch->codec & 0xFFu;
@@ -1264,7 +1296,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                 ch->frag_first = per_chunk * (unsigned)c;
                 if (codec == HAP_NIBBLE_SNAPPY)
                     ch->unit_count = per_chunk ? per_chunk
-                                               : 1u + (block_scan ? stream_block_slots(ch->src_len, output_bytes[f]) : 0u);
+                                               : 1u + (frame_scan ? stream_block_slots(ch->src_len, output_bytes[f]) : 0u);
                 else if (codec == HAP_NIBBLE_NONE)
                     ch->unit_count = ch->src_len ? (ch->src_len + COPY_PIECE - 1) / COPY_PIECE : 1u;
                 else
@@ -1286,7 +1318,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                     for (c = 0; c < p->chunk_count; c++) {
                         HapGpuChunkIn *ch = &p->chunks[c];
                         if ((ch->codec & 0xFFu) == HAP_NIBBLE_SNAPPY)
-                            ch->unit_count = 1u + (block_scan ? stream_block_slots(ch->src_len, output_bytes[f]) : 0u);
+                            ch->unit_count = 1u + (frame_scan ? stream_block_slots(ch->src_len, output_bytes[f]) : 0u);
                         ch->unit_first = units;
                         units += ch->unit_count;
                     }
@@ -1307,24 +1339,6 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
             total_chunks += (unsigned)p->chunk_count;
             if ((unsigned)p->chunk_count > max_chunks)
                 max_chunks = (unsigned)p->chunk_count;
-            /* no table, but every chunk as short as one fragment (HAPGPU_ENCODE_FINE_CHUNKS): candidates for the
-               block-per-lane decoder, whose starting points a pre-pass can find (snappy_decode_fields.hip) */
-            if (!p->frag_table_offset && !(flags & HAPGPU_DECODE_NO_FIELD_GUESS) && field_layout_of_format(p->format) && p->chunk_count > 1) {
-                unsigned snappy_chunks = 0;
-                int fits = 1;
-                for (c = 0; c < p->chunk_count; c++) {
-                    const HapGpuChunkIn *ch = &p->chunks[c];
-                    if ((ch->codec & 0xFFu) != HAP_NIBBLE_SNAPPY)
-                        continue;
-                    snappy_chunks++;
-                    if (ch->unit_count != 1u || ch->src_len > HAPGPU_SLOT_DATA_BYTES + 64u + 5u)
-                        fits = 0;
-                }
-                if (fits && snappy_chunks) {
-                    guess_frame[f] = 1;
-                    guess_units += snappy_chunks;
-                }
-            }
         } else if (p->mode == HAPGPU_JOB_RAW) {
             units = p->section_length ? (p->section_length + COPY_PIECE - 1) / COPY_PIECE : 1u;
             any_stream = 1;
@@ -1388,9 +1402,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
         djoins = arena + o_joins;
         drecs = arena + o_recs;
     }
-    /* (a lane per fragment finds the starting points: worth it from a few thousand fragments on -- one frame's are
-       decoded sooner by the generic kernel, a wavefront each) */
-    if (guess_units && (guess_units >= 4096u || (flags & HAPGPU_DECODE_GUESS_FIELDS))) {
+    if (use_guess) {
         dguess = (uint8_t *)hapgpu_rt_device_scratch(rt, D_GUESS, (size_t)HAP_GROUP_TABLE_BYTES * ((size_t)total_units + 1u));
         if (!dguess) {
             rc = 1;
