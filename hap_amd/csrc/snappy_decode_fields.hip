@@ -43,6 +43,7 @@
 // HBM traffic: compressed bytes read once, output written once (algorithmic bytes b(1 + c)).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "hapgpu_abi.h"
 #include "measurement_guard.h"
 
@@ -52,6 +53,7 @@ constexpr unsigned kFragBytes = 8192u;
 constexpr unsigned kHalf = 128u;                       // bytes of output per half-tile
 constexpr unsigned kHalves = kFragBytes / kHalf;       // 64: one parse lane each
 constexpr unsigned kMaxFragCompressed = kFragBytes + 320u;
+constexpr int kGuessLdsBytes = 0;          // (see hapgpu_launch_guess_group_tables)
 // Switches of the measurement builds (tools/build_variants.sh, which defines HAP_MEASUREMENT_BUILD and writes to
 // hap_amd/variants/; measurement_guard.h refuses them in any other build): LDS per wave up or down (occupancy
 // studies), the set of DPP hops, one layout's code alone.  None changes what the kernel writes.  (The ablations of
@@ -730,7 +732,17 @@ extern "C" int hapgpu_launch_guess_group_tables(HapGpuDecodeUnit *units, unsigne
 {
     if (unit_count == 0)
         return 0;
-    hipLaunchKernelGGL(guess_group_tables_kernel, dim3((unit_count + 63u) / 64u), dim3(64), 0, stream, units, unit_count, jobs);
+    // Every lane reads its own stream, a few bytes per turn: a wavefront's 64 lanes keep 64 cache lines alive, and with
+    // sixteen wavefronts on a CU none of them survives in its 32 KiB L1 until the lane's next element (every turn then
+    // comes from the L2).  Dynamic LDS the kernel never touches keeps the wavefronts per CU down to what the L1 holds.
+    static int lds_bytes = -1;
+    if (lds_bytes < 0) {
+        const char *e = HAP_AB_ENV("HAP_AMD_GUESS_LDS");
+        lds_bytes = e ? atoi(e) : kGuessLdsBytes;
+        if (lds_bytes > 65536)
+            lds_bytes = 65536;
+    }
+    hipLaunchKernelGGL(guess_group_tables_kernel, dim3((unit_count + 63u) / 64u), dim3(64), (unsigned)lds_bytes, stream, units, unit_count, jobs);
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 
