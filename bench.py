@@ -445,6 +445,11 @@ def main():
         line["decode_of_reference_encoded_frames"] = extras.get("decode_of_reference_encoded_frames")
         line["host_pointer_path"] = extras.get("host_pointer_path")
         line["roofline"] = stream.roofline(kernels, args.config)
+        line["roofline"]["events_from"] = ("the serial region of the same K steps (each kernel runs by itself there; in the pipelined region the "
+                                           "encode kernel of one batch and the decode kernels of the other share the GPU)") if serial is not None \
+            else "the timed region"
+        line["roofline"]["profiled_as"] = "python bench.py --config %s --steps 2 --warmup 1 --frames %d --no-extras --serial (tools/prof_bench.sh -> profiles/%s_kernel_stats_%s.csv)" % (
+            args.config, nf_total, ROUND_TAG, args.config.lower())
         line["kernels"] = kernels
         if not args.no_extras:
             ms_full = elapsed / args.steps * 1e3 if pipelined else None

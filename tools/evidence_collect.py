@@ -1,10 +1,10 @@
 """gpurun_out/evidence (tools/evidence_round.sh) -> profiles/<round>_*: the files the documentation and bench.py quote.
    python tools/evidence_collect.py r03"""
 import json, os, shutil, subprocess, sys
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ev, prof = os.path.join(root, "gpurun_out", "evidence"), os.path.join(root, "profiles")
-for cfg, frames in (("c4", 30), ("c4sep", 30), ("c5", 4), ("c2", 60), ("c3", 60)):
+for cfg, frames in (("c4", 60), ("c4sep", 60), ("c5", 4), ("c2", 60), ("c3", 60)):       # (frames per launch: the bench line's)
     if not os.path.isdir(os.path.join(ev, cfg)):
         continue
     src = os.path.join(ev, cfg)

@@ -7,8 +7,8 @@
 cd $GRAFT_REPO_ROOT
 E=$GRAFT_REPO_ROOT/gpurun_out/evidence
 rm -rf $E; mkdir -p $E
-bash tools/prof_bench.sh C4 30 > /dev/null 2>&1; cp -r gpurun_out/prof_c4 $E/c4
-bash tools/prof_bench.sh C4 30 sep > /dev/null 2>&1; cp -r gpurun_out/prof_c4sep $E/c4sep
+bash tools/prof_bench.sh C4 60 > /dev/null 2>&1; cp -r gpurun_out/prof_c4 $E/c4
+bash tools/prof_bench.sh C4 60 sep > /dev/null 2>&1; cp -r gpurun_out/prof_c4sep $E/c4sep
 bash tools/prof_bench.sh C5 4 > /dev/null 2>&1; cp -r gpurun_out/prof_c5 $E/c5
 bash tools/prof_bench.sh C2 60 > /dev/null 2>&1; cp -r gpurun_out/prof_c2 $E/c2
 bash tools/prof_bench.sh C3 60 > /dev/null 2>&1; cp -r gpurun_out/prof_c3 $E/c3

@@ -1,17 +1,19 @@
 #!/bin/bash
 # Round-2 profiling recipe (gpurun box): kernel trace + stats, SQ counters and HBM traffic counters of bench.py's
 # own command, per config -- counters in their own runs, never combined with other trace domains.
-#   tools/prof_bench.sh C4 30        -> gpurun_out/prof_c4/{kernel_stats.csv, pmc_summary.txt, traffic_summary.txt, bench_*.json}
+#   tools/prof_bench.sh C4 60        -> gpurun_out/prof_c4/{kernel_stats.csv, pmc_summary.txt, traffic_summary.txt, bench_*.json}
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-CFG=${1:-C4}; FRAMES=${2:-30}
+CFG=${1:-C4}; FRAMES=${2:-60}
 tag=$(echo $CFG | tr A-Z a-z)
 # third argument "sep": the same command with the block encoder as a pass of its own and the fragments gathered
 # (HAP_AMD_NO_FUSION / HAP_AMD_NO_PLACING) -> gpurun_out/prof_<cfg>sep
 if [ "$3" = sep ]; then export HAP_AMD_NO_FUSION=1 HAP_AMD_NO_PLACING=1; tag=${tag}sep; fi
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 rm -rf $OUT; mkdir -p $OUT
-CMD="python bench.py --config $CFG --steps 2 --warmup 1 --frames $FRAMES --no-extras"
+# (--serial: blocking calls on one context, so that every kernel runs by itself and its duration is its own -- the
+# region the bench line takes its per-kernel events and roofline from; frames per launch = the bench line's)
+CMD="python bench.py --config $CFG --steps 2 --warmup 1 --frames $FRAMES --no-extras --serial"
 echo "${3:+HAP_AMD_NO_FUSION=1 HAP_AMD_NO_PLACING=1 }$CMD" > $OUT/command.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb_trace -o r -- $CMD > $OUT/bench_trace.json 2> /tmp/pb_trace.err
 cp $(find /tmp/pb_trace -name "*kernel_stats.csv") $OUT/kernel_stats.csv
