@@ -488,18 +488,15 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
     //     kernel is bound by vector instruction issue, not by the LDS pipe; LABNOTES.md.)
 #pragma unroll 1
     for (unsigned round = 0; round < 6u; round++) {
-        // (the first round is taken unasked: hardly a fragment has every chain inside a row of sixteen, and asking
-        // costs half of what the round does)
-        if (round > 0u) {
-            int any = state[0][0];
+        int any = state[0][0];
 #pragma unroll
-            for (unsigned s = 0; s < kMaxSteps; s++)
+        for (unsigned s = 0; s < kMaxSteps; s++)
 #pragma unroll
-                for (unsigned k = 0; k < PERIOD; k++)
-                    any |= state[s][k];
-            if (__builtin_amdgcn_ballot_w64(any < 0 && lane * kBlock < out_len) == 0ull)
-                break;
-        }
+            for (unsigned k = 0; k < PERIOD; k++)
+                any |= state[s][k];
+        // (r05: taking the first round unasked -- hardly a fragment needs none -- made the kernel 1.5 % SLOWER)
+        if (__builtin_amdgcn_ballot_w64(any < 0 && lane * kBlock < out_len) == 0ull)
+            break;
 #pragma unroll
         for (unsigned s = 0; s < kMaxSteps; s++)
 #pragma unroll
