@@ -26,7 +26,7 @@ if "--large" in sys.argv:
         tex = D.oracle_bc_encode(big, fmt)
         out = np.zeros(hap_amd.HapMaxEncodedLength([len(tex)], [fmt], [chunks]), dtype=np.uint8)
         r, used, _ = ctx.encode_frames([[tex]], [fmt], [1], [chunks], [out], flags=1)
-        assert r == 0 and (bytes([0x46, 3, 13]) in out[:512].tobytes() or bytes([0x46, 1, 13]) in out[:512].tobytes())
+        assert r == 0 and (bytes([0x46, 4, 13]) in out[:512].tobytes() or bytes([0x46, 1, 13]) in out[:512].tobytes())
         bases = [(out[:used[0]].tobytes(), len(tex))] + bases
         r, used, _ = ctx.encode_frames([[tex]], [fmt], [1], [chunks], [out], flags=3)
         bases = [(out[:used[0]].tobytes(), len(tex))] + bases

@@ -29,12 +29,18 @@ while time.time() - t0 < budget:
             t = bytearray(a.tobytes())
         texs.append(bytes(t))
     n = nblocks * block
+    fine = rng.integers(0, 4) == 0                      # (round 5: a chunk per fragment, decoded with and without the pre-pass)
+    if fine:
+        chunks = max(1, hap_amd.fine_chunk_count(n, fmt))
     cap = hap_amd.HapMaxEncodedLength([n], [fmt], [chunks]) + 4096
     # ours: encode a batch, decode the batch, compare; the checker must agree on the first frame
     outs = [np.zeros(cap, dtype=np.uint8) for _ in range(nf)]
     flags = hap_amd.ENCODE_FRAGMENT_INDEX if rng.integers(0, 4) else 0
     if rng.integers(0, 3) == 0:
         flags |= hap_amd.ENCODE_COARSE_MATCHES          # (BC7 / BC6H: the block kernels with four dwords per block)
+    if fine:
+        flags |= hap_amd.ENCODE_FINE_CHUNKS
+    dflags = [0, hap_amd.DECODE_GUESS_FIELDS, hap_amd.DECODE_NO_FIELD_GUESS][int(rng.integers(0, 3))]
     r, used, res = ctx.encode_frames([[t] for t in texs], [fmt], [1], [chunks], outs, flags=flags)
     ok = r == 0 and all(x == 0 for x in res)
     if ok:
@@ -45,13 +51,13 @@ while time.time() - t0 < budget:
             r2, used2, res2 = ctx.encode_frames([[t] for t in texs], [fmt], [1], [chunks], outs2, flags=flags)
             ok = ok and r2 == 0 and [outs2[i][: used2[i]].tobytes() for i in range(nf)] == encoded
         decs = [np.zeros(n, dtype=np.uint8) for _ in range(nf)]
-        r, du, df, dr = ctx.decode_frames(encoded, [len(e) for e in encoded], 0, decs)
+        r, du, df, dr = ctx.decode_frames(encoded, [len(e) for e in encoded], 0, decs, flags=dflags)
         ok = r == 0 and all(decs[i].tobytes() == texs[i] for i in range(nf)) and ORA.decode(encoded[0], 0, n) == (0, texs[0], fmt)
     # the checker's frames: block scan path (several blocks per chunk when the texture is large)
     if ok:
         foreign = [ORA.encode([t], [fmt], [1], [chunks])[1] for t in texs]
         decs = [np.zeros(n, dtype=np.uint8) for _ in range(nf)]
-        r, du, df, dr = ctx.decode_frames(foreign, [len(e) for e in foreign], 0, decs)
+        r, du, df, dr = ctx.decode_frames(foreign, [len(e) for e in foreign], 0, decs, flags=dflags)
         ok = r == 0 and all(decs[i].tobytes() == texs[i] for i in range(nf))
     # pictures: blocks made inside the compressor (DXT5 / YCoCg), or by the block encoder's own pass; noise pictures
     # give chunks that do not shrink (frames encoded again through slots when the fragments were placed)
@@ -87,6 +93,6 @@ while time.time() - t0 < budget:
     rounds += 1; frames += nf
     if not ok:
         fails += 1
-        print("FAIL round", rounds, "fmt", hex(fmt), "blocks", nblocks, "chunks", chunks, "frames", nf, "flags", flags)
+        print("FAIL round", rounds, "fmt", hex(fmt), "blocks", nblocks, "chunks", chunks, "frames", nf, "flags", flags, "dflags", dflags)
 print("stress: %d rounds, %d frames, %d failures, fallbacks %d, placement retries %d, %.0f s" % (
     rounds, frames, fails, ctx.table_fallbacks(), ctx.placement_retries(), time.time() - t0))
