@@ -640,9 +640,18 @@ unsigned hapb_encode_complete(HapGpuContext *ctx, HapbEncodePending *pd)
                     }
                 ctx->block_encode_job = NULL;
                 if (pd->has_job) {
+                    /* the table goes where the first pass's was: pinned memory at an address that stays -- a recorded
+                       launch sequence (HAP_AMD_GRAPHS) copies from THAT address again when it is replayed (found by
+                       tools/stress.py: a table in malloc'd memory was gone by then) */
+                    uint64_t *pinned = (uint64_t *)hapgpu_rt_pinned_scratch(rt, P_BC_PTRS, sizeof(uint64_t) * (size_t)(1u + pd->job.count) * again);
                     rjob = pd->job;
-                    rjob.host_table = rtable;
                     rjob.frame_count = again;
+                    if (pinned) {
+                        memcpy(pinned, rtable, sizeof(uint64_t) * (size_t)(1u + pd->job.count) * again);
+                        rjob.host_table = pinned;
+                    } else {
+                        rjob.host_table = rtable;
+                    }
                     ctx->block_encode_job = &rjob;
                 }
                 ctx->no_placing = 1u;

@@ -2373,6 +2373,19 @@ def test_a_placed_call_from_pictures_encodes_unshrinkable_frames_again_from_the_
         r, used, res = placed.encode_frames_rgba(pics, w, h, w * 4, [fmt], [1], [chunks], houts, flags=flags)
         assert r == 0 and res == [0] * len(pics)
         assert [o[:u].tobytes() for o, u in zip(houts, used)] == got["gathered"]
+        # the same call again and again with launch sequences recorded (HAP_AMD_GRAPHS): the second pass of the frames
+        # that were not placed is a recorded sequence too, and its picture table must still be there when it is replayed
+        # (tools/stress.py found a GPU memory fault: the first cut kept that table in malloc'd memory)
+        recorded = _context_with(hap, HAP_AMD_PLACING_MIN_FRAMES="1", HAP_AMD_PLACING_HOLDOFF="0", HAP_AMD_GRAPHS="1")
+        dpics = [torch.from_numpy(p).cuda() for p in pics]
+        for rep in range(5):
+            douts = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in pics]
+            order = list(range(len(pics))) if rep % 2 == 0 else list(reversed(range(len(pics))))
+            torch.cuda.synchronize()
+            r, used, res = recorded.encode_frames_rgba([dpics[i] for i in order], w, h, w * 4, [fmt], [1], [chunks], douts, flags=flags)
+            assert r == 0 and res == [0] * len(pics), rep
+            assert [o[:u].cpu().numpy().tobytes() for o, u in zip(douts, used)] == [got["gathered"][i] for i in order], rep
+        recorded.close()
     placed.close()
     gathered.close()
 
