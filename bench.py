@@ -107,12 +107,15 @@ def frames_of_rank(total, rank, world, scaling):
 class Stream:
     """One rank's share of a synthetic stream with every buffer resident in HBM, and the timed step over it."""
 
-    def __init__(self, hap_amd, ctx, dev, config, frame_ids, flags, ctx_dec=None):
+    def __init__(self, hap_amd, ctx, dev, config, frame_ids, flags, ctx_dec=None, ctx_enc2=None):
         from hap_amd import synth
         self.hap, self.ctx = hap_amd, ctx
         # pipelined steps: the decode calls go to a context of their own (own stream, own scratch), and the frames of
         # consecutive batches to alternating buffers -- batch k + 1 is being written while batch k is read
         self.ctx_dec = ctx_dec
+        # a second ENCODE context (optional): batches alternate between the two, so that one batch's encode kernel starts
+        # while the other's is in its tail -- what small batches lose to the last, partly filled round of workgroups
+        self.ctx_enc2 = ctx_enc2
         self.w, self.h, self.fmts, self.chunks, _n = CONFIGS[config]
         self.nf = len(frame_ids)
         self.flags = flags
@@ -126,6 +129,8 @@ class Stream:
         self.frames = hap_amd.BufferList([torch.empty(self.cap, dtype=torch.uint8, device=dev) for _ in frame_ids])
         self.frames_b = hap_amd.BufferList([torch.empty(self.cap, dtype=torch.uint8, device=dev) for _ in frame_ids]) \
             if ctx_dec is not None else None
+        self.frames_c = hap_amd.BufferList([torch.empty(self.cap, dtype=torch.uint8, device=dev) for _ in frame_ids]) \
+            if ctx_enc2 is not None else None
         self.dec = [hap_amd.BufferList([torch.empty(tb, dtype=torch.uint8, device=dev) for _ in frame_ids])
                     for tb in self.tex_bytes]
         # entry f * T + t = texture t of frame f: the order HapGpuDecodeFrameTextures takes
@@ -154,14 +159,14 @@ class Stream:
         if r != 0 or dused[0] != self.tex_bytes[0]:
             raise RuntimeError("decode failed: %r %r" % (r, dres[:4]))
 
-    def begin(self, frames):
-        r = self.ctx.encode_frames_rgba_begin(self.rgba, self.w, self.h, self.w * 4, self.fmts, self.comps, self.chunks, frames,
-                                              flags=self.flags)
+    def begin(self, frames, ctx=None):
+        r = (ctx or self.ctx).encode_frames_rgba_begin(self.rgba, self.w, self.h, self.w * 4, self.fmts, self.comps, self.chunks, frames,
+                                                       flags=self.flags)
         if r != 0:
             raise RuntimeError("encode (first half) failed: %r" % r)
 
-    def finish(self):
-        r, used, results = self.ctx.encode_finish()
+    def finish(self, ctx=None):
+        r, used, results = (ctx or self.ctx).encode_finish()
         if r != 0:
             raise RuntimeError("encode failed: %r %r" % (r, results[:4]))
         return used
@@ -181,7 +186,7 @@ class Stream:
             self.step()
         if pipelined and self.nf:
             self.decode(self.used, self.ctx_dec)                # the decode context's scratch and code, untimed
-        ctxs = [self.ctx] + ([self.ctx_dec] if pipelined else [])
+        ctxs = [self.ctx] + ([self.ctx_dec] if pipelined else []) + ([self.ctx_enc2] if pipelined and self.ctx_enc2 is not None else [])
         for c in ctxs:
             c.set_profiling(True)
             c.collect_profile()            # drop anything recorded so far
@@ -190,6 +195,18 @@ class Stream:
         if not pipelined:
             for _ in range(steps):
                 self.step()
+        elif self.nf and self.ctx_enc2 is not None:
+            # two encode contexts: batches k and k + 1 are both on the GPU's queues while batch k - 1 is decoded
+            sets = [self.frames, self.frames_b, self.frames_c]
+            encs = [self.ctx, self.ctx_enc2]
+            for k in range(min(2, steps)):
+                self.begin(sets[k % 3], encs[k & 1])
+            for k in range(steps):
+                self.used = self.finish(encs[k & 1])
+                if k + 2 < steps:
+                    self.begin(sets[(k + 2) % 3], encs[k & 1])
+                self.decode(self.used, self.ctx_dec, sets[k % 3])
+            self.last_frames = sets[(steps - 1) % 3]
         elif self.nf:
             sets = [self.frames, self.frames_b]
             self.begin(sets[0])
@@ -477,12 +494,12 @@ def main():
             torch.cuda.empty_cache()
             try:
                 line["c5"] = side_config(hap_amd, ctx, dev, "C5", args.c5_frames, flags, fence,
-                                         reference_frames=0 if args.no_cpu_baseline else 1)
+                                         reference_frames=0 if args.no_cpu_baseline else 1, ctx_dec=ctx_dec)
             except Exception as exc:
                 line["c5"] = {"error": repr(exc)}
             for small in ("C2", "C3"):
                 try:
-                    line[small.lower()] = side_config(hap_amd, ctx, dev, small, CONFIGS[small][4], flags, fence)
+                    line[small.lower()] = side_config(hap_amd, ctx, dev, small, CONFIGS[small][4], flags, fence, ctx_dec=ctx_dec)
                 except Exception as exc:
                     line[small.lower()] = {"error": repr(exc)}
             for name, fn in (("c1", lambda: c1_object(hap_amd, ctx, dev)), ("bc7_opaque", lambda: opaque_object(hap_amd, ctx, dev, fence))):
@@ -780,13 +797,20 @@ def _section_bytes(head, idx, count):
     return _l0 - (h1 + l1) - 8
 
 
-def side_config(hap_amd, ctx, dev, config, frames, flags, fence, steps=6, reference_frames=0):
+def side_config(hap_amd, ctx, dev, config, frames, flags, fence, steps=6, reference_frames=0, ctx_dec=None):
     """The other BASELINE.json configs beside the headline, same step and timing rules: C5 = the north-star's target,
-    16384x16384 Hap Q Alpha (YCoCg-DXT5 + RGTC1, 64 + 64 chunks, two-texture frame); C2 / C3 = the 4K configs."""
-    s = Stream(hap_amd, ctx, dev, config, list(range(frames)), flags)
+    16384x16384 Hap Q Alpha (YCoCg-DXT5 + RGTC1, 64 + 64 chunks, two-texture frame); C2 / C3 = the 4K configs.
+    `value` is the pipelined step's when a decode context is given (as for the headline), the per-kernel events and the
+    roofline those of the serial region."""
+    s = Stream(hap_amd, ctx, dev, config, list(range(frames)), flags, ctx_dec=ctx_dec)
     # (two timed regions of `steps` steps, the faster one reported: with a few milliseconds per region one stall of
     # the box -- seen once: 15 ms -- would otherwise be the number)
     elapsed, prof = min((s.timed(steps, 2, fence), s.timed(steps, 0, fence)), key=lambda r: r[0])
+    serial_elapsed = elapsed
+    if ctx_dec is not None:
+        pipe_ok = True
+        elapsed = min(s.timed(steps, 1, fence, pipelined=True)[0] for _ in range(2))
+        pipe_ok = s.bit_exact()
     kernels, ratio = s.kernel_table(prof, steps, config)
     enc_ms, dec_ms = s.split_rates()
     total = frames * steps
@@ -795,7 +819,10 @@ def side_config(hap_amd, ctx, dev, config, frames, flags, fence, steps=6, refere
             "value": round(total * s.rgba_bytes / elapsed / 1e9, 2), "unit": "GB/s", "fps": round(total / elapsed, 2),
             "steps": steps, "timed_regions": 2, "ms_per_step": round(elapsed / steps * 1e3, 3), "snappy_ratio": round(ratio, 4),
             "compressed_bytes_per_step": int(sum(s.used)),
-            "bit_exact": s.bit_exact(),
+            "bit_exact": bool(s.bit_exact() and (ctx_dec is None or pipe_ok)),
+            "step": "pipelined" if ctx_dec is not None else "serial",
+            "serial_step": {"ms_per_step": round(serial_elapsed / steps * 1e3, 3),
+                            "value": round(total * s.rgba_bytes / serial_elapsed / 1e9, 2)},
             "encode_only": {"rgba_GBps": round(frames * s.rgba_bytes / (enc_ms * 1e-3) / 1e9, 2), "ms": round(enc_ms, 3)},
             "decode_only": {"rgba_GBps": round(frames * s.rgba_bytes / (dec_ms * 1e-3) / 1e9, 2), "ms": round(dec_ms, 3),
                             "texture_GBps": round(frames * sum(s.tex_bytes) / (dec_ms * 1e-3) / 1e9, 2)},
