@@ -53,6 +53,7 @@ constexpr unsigned kFragBytes = 8192u;
 constexpr unsigned kHalf = 128u;                       // bytes of output per half-tile
 constexpr unsigned kHalves = kFragBytes / kHalf;       // 64: one parse lane each
 constexpr unsigned kMaxFragCompressed = kFragBytes + 320u;
+constexpr int kGuessLdsBytes = 0;          // (see hapgpu_launch_guess_group_tables)
 // Switches of the measurement builds (tools/build_variants.sh, which defines HAP_MEASUREMENT_BUILD and writes to
 // hap_amd/variants/; measurement_guard.h refuses them in any other build): LDS per wave up or down (occupancy
 // studies), the set of DPP hops, one layout's code alone.  None changes what the kernel writes.  (The ablations of
@@ -600,187 +601,114 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
 // ---- group tables for field streams that come without one ------------------------------------------------------------
 // Frames written with HAPGPU_ENCODE_FINE_CHUNKS carry no private section: every 8 KiB fragment is a chunk of its own in
 // the tables every Hap parser reads, so its boundaries are known -- but not the 64 places inside it from which the
-// kernel above starts its lanes.  This kernel finds them: one LANE per fragment walks the fragment's tags (twice: count
-// the elements and check the promises, then note where every G-th element begins) and writes the table of version 4 into
-// scratch; the fragment's unit becomes a FIELDS unit that points there.  What is not a field stream -- another
-// encoder's chunk of the same size, an element off a field boundary -- stays a STREAM unit for the generic kernel.
-// (The kernel above checks every promise again; its verdict, not this one's, is what protects memory.)
-//
-// The tags are not read from memory lane by lane: 64 lanes each following their own stream is 64 cache lines per
-// wave-instruction, and the memory system serves about 100 G such requests a second whatever the occupancy (first
-// version of this kernel: 2.1 ms for the 243 000 fragments of 60 8K frames, three times the decode itself).  The wave
-// STAGES its 64 fragments through LDS in slices instead: 256 bytes of every fragment per slice, fetched 16 bytes a lane
-// with 16 lanes to a fragment (four fragments, sixteen 64-byte lines per wave-instruction, every byte of them used),
-// then every lane walks the elements that begin in its slice out of LDS.
-constexpr unsigned kCoopAdvance = 240u;      // stream bytes a slice advances (16 bytes of overlap: an element's tag bytes)
-constexpr unsigned kCoopStride = 66u;        // dwords per fragment row in LDS: 64 of data + 2 (rows stay 8-byte aligned)
-
-struct tag_step {
-    unsigned len, adv;
-    bool ok;
-};
-
-// one element at output position p, from the four bytes at its tag: bytes produced, bytes of the element, and whether it
-// keeps the promises of a field stream (whole blocks back, inside the fragment, on a field boundary, inside its half-tile)
-__device__ __forceinline__ tag_step read_tag(unsigned w, unsigned p, unsigned block, unsigned starts)
+// kernel above starts its lanes.  This kernel finds them: ONE LANE per fragment walks the fragment's tags (twice: count
+// the elements, then note where every G-th begins) and writes the table of version 4 into scratch; the fragment's unit
+// becomes a FIELDS unit that points there.  A lane's walk is ~450 dependent loads from memory -- 64 different cache lines
+// per wave-instruction, which the memory system serves at about 100 G requests a second whatever the occupancy: 2.1 ms
+// for the 243 000 fragments of 60 8K frames, three times the decode itself (the host takes this road from a few thousand
+// fragments on; fewer are decoded by the generic kernel, one wavefront per fragment).  A cooperative form -- the wave
+// stages its 64 fragments through LDS in coalesced 256-byte slices and the lanes walk out of LDS -- was built in round 5
+// and is NO faster (2.2 ms): every slice is a load / barrier / walk / barrier round trip, and a wave runs as long as the
+// busiest of its 64 fragments has elements.  This is the simpler of the two.
+// What is not a field stream -- another encoder's chunk of the same size, an element off a field boundary -- stays a
+// STREAM unit for the generic kernel: the walk checks the promises the table would have made.  (The kernel above checks
+// them all again; its verdict, not this one's, is what protects memory.)
+__device__ __forceinline__ unsigned load_tag32(gin_t src, unsigned cp, unsigned n)
 {
-    tag_step t;
-    const unsigned kind = w & 3u, up = (w >> 2) & 63u;
-    if (kind == 0u) {
-        t.ok = up <= 60u;
-        t.len = (up == 60u ? ((w >> 8) & 255u) : up) + 1u;
-        t.adv = t.len + (up == 60u ? 2u : 1u);
-    } else {
-        t.len = kind == 1u ? ((w >> 2) & 7u) + 4u : up + 1u;
-        t.adv = kind + 1u;
-        const unsigned off = kind == 1u ? (((w >> 5) & 7u) << 8) | ((w >> 8) & 255u) : (w >> 8) & 0xFFFFu;
-        t.ok = kind != 3u && off >= block && (off % block) == 0u && off <= p;
-    }
-    t.ok = t.ok && ((starts >> (p % block)) & 1u) != 0u && (p & (kHalf - 1u)) + t.len <= kHalf;
-    return t;
+    // bytes cp .. cp + 3 of the stream (zero beyond its end); unaligned dword loads are fine in global memory
+    struct __attribute__((packed)) unaligned32 { uint32_t v; };
+    if (cp + 4u <= n)
+        return reinterpret_cast<const unaligned32 __attribute__((address_space(1))) *>(src + cp)->v;
+    unsigned w = 0;
+    for (unsigned k = 0; k < 4u && cp + k < n; k++)
+        w |= (unsigned)src[cp + k] << (8u * k);
+    return w;
 }
 
 __global__ __launch_bounds__(64) void guess_group_tables_kernel(HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t rows[64u * kCoopStride];
-    const unsigned lane = threadIdx.x;
-    const unsigned idx = blockIdx.x * 64u + lane;
-    // ---- the lane's fragment, if it has one that qualifies ----
-    HapGpuDecodeUnit u = {};
-    bool cand = idx < unit_count;
-    if (cand)
-        u = units[idx];
-    cand = cand && u.kind == HAPGPU_UNIT_SNAPPY_STREAM && u.aux == 0u && u.reserved == 0u;
-    const HapGpuDecodeJob *job = &jobs[cand ? u.job : 0u];
-    cand = cand && ((job->reserved >> 16) & 1u) != 0u && job->group_tables != 0u && job->status == 0u;
-    if (__builtin_amdgcn_ballot_w64(cand) == 0ull)
+    const unsigned idx = blockIdx.x * 64u + threadIdx.x;
+    if (idx >= unit_count)
         return;
-    const unsigned layout = cand ? job->fields_period : 4u;
+    HapGpuDecodeUnit u = units[idx];
+    if (u.kind != HAPGPU_UNIT_SNAPPY_STREAM || u.aux != 0u || u.reserved != 0u)
+        return;
+    const HapGpuDecodeJob *job = &jobs[u.job];
+    if (!((job->reserved >> 16) & 1u) || job->group_tables == 0u || job->status != 0u)
+        return;
+    const unsigned layout = job->fields_period;
     const unsigned block = (layout == 4u || layout == 8u) ? 16u : 8u;
     // field starts inside a block, as a mask over its bytes: [2,6,4,4]: 0, 2, 8, 12; [4,4]: 0, 4; [2,6]: 0, 2; [4,4,4,4]: 0, 4, 8, 12
     const unsigned starts = layout == 4u ? 0x1105u : layout == 2u ? 0x11u : layout == 6u ? 0x05u : 0x1111u;
-    // the stream's length prefix (a byte at a time: once per fragment)
+    const gin_t base = (gin_t)u.src;
+    // the stream's length prefix
     unsigned hdr = 0, out_len = 0;
-    if (cand) {
-        const gin_t base = (gin_t)u.src;
-        for (unsigned k = 0; k < 5u && k < u.src_len; k++) {
-            const unsigned b = base[k];
-            out_len |= (b & 0x7Fu) << (7u * k);
-            if (!(b & 0x80u)) {
-                hdr = k + 1u;
-                break;
-            }
+    for (unsigned k = 0; k < 5u && k < u.src_len; k++) {
+        const unsigned b = base[k];
+        out_len |= (b & 0x7Fu) << (7u * k);
+        if (!(b & 0x80u)) {
+            hdr = k + 1u;
+            break;
         }
     }
-    cand = cand && hdr != 0u && out_len == u.dst_len && out_len != 0u && out_len <= kFragBytes && (out_len % block) == 0u &&
-           u.src_len - hdr <= kMaxFragCompressed;
-    const unsigned n = cand ? u.src_len - hdr : 0u;
-    // coordinates: x counts bytes from the 16-byte aligned address at or below the first element; the stream is [shift, shift + n)
-    const uint64_t first = cand ? u.src + hdr : 0u;
-    const uint64_t origin = first & ~(uint64_t)15u;
-    const unsigned shift = (unsigned)(first & 15u), end_x = shift + n;
-    // bytes behind the stream that may be fetched with its last piece: what follows inside the texture section
-    unsigned readable_x = end_x;
-    if (cand) {
-        const uint64_t stream_end = u.src + u.src_len, section_end = job->payload + job->payload_len;
-        readable_x += section_end > stream_end ? (unsigned)(section_end - stream_end < 15u ? section_end - stream_end : 15u) : 0u;
-    }
-    unsigned max_end = end_x;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1)
-        max_end = max(max_end, (unsigned)__shfl_xor((int)max_end, d));
-    const unsigned slices = (max_end + kCoopAdvance - 1u) / kCoopAdvance;
-    const unsigned origin_lo = (unsigned)origin, origin_hi = (unsigned)(origin >> 32);
-    const uint32_t *row = rows + lane * kCoopStride;
-
-    // stages slice k of all 64 fragments: lanes 16 q .. 16 q + 15 fetch the 256 bytes of fragment 4 j + q
-    auto stage = [&](unsigned k) {
-#pragma unroll 4
-        for (unsigned j = 0; j < 16u; j++) {
-            const unsigned f = 4u * j + (lane >> 4), piece = lane & 15u;
-            const uint64_t org = ((uint64_t)(unsigned)__shfl((int)origin_hi, (int)f) << 32) | (unsigned)__shfl((int)origin_lo, (int)f);
-            const unsigned fend = (unsigned)__shfl((int)end_x, (int)f), fread = (unsigned)__shfl((int)readable_x, (int)f);
-            const unsigned x = k * kCoopAdvance + piece * 16u;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (x < fend) {
-                const gin_t at = (gin_t)(org + x);
-                if (x + 16u <= fread) {
-                    v = gload16(at);
-                } else {
-                    unsigned wds[4] = {0, 0, 0, 0};
-                    for (unsigned b = 0; b < 16u && x + b < fend; b++)
-                        wds[b >> 2] |= (unsigned)at[b] << (8u * (b & 3u));
-                    v = make_uint4(wds[0], wds[1], wds[2], wds[3]);
-                }
-            }
-            uint2 *dst = reinterpret_cast<uint2 *>(rows + f * kCoopStride + piece * 4u);
-            dst[0] = make_uint2(v.x, v.y);
-            dst[1] = make_uint2(v.z, v.w);
-        }
-    };
-    // the four bytes at stream position cp (slice k is staged: cp lies in it)
-    auto tag_at = [&](unsigned cp, unsigned k) {
-        const unsigned rel = shift + cp - k * kCoopAdvance;                 // 0 .. 239: bytes rel .. rel + 3 are staged
-        return __builtin_amdgcn_alignbyte(row[(rel >> 2) + 1u], row[rel >> 2], rel);
-    };
-
-    // ---- first walk: count the elements, check what the table would promise ----
+    if (hdr == 0u || out_len != u.dst_len || out_len == 0u || out_len > kFragBytes || (out_len % block) != 0u)
+        return;
+    const gin_t src = base + hdr;
+    const unsigned n = u.src_len - hdr;
+    if (n > kMaxFragCompressed)
+        return;
+    // first walk: count the elements, check what the table promises
     unsigned cp = 0, p = 0, count = 0;
-    bool ok = cand;
-    for (unsigned k = 0; k < slices; k++) {
-        stage(k);
-        __syncthreads();
-        const unsigned lim = min(end_x, (k + 1u) * kCoopAdvance);
-        while (__builtin_amdgcn_ballot_w64(ok && shift + cp < lim) != 0ull) {
-            if (ok && shift + cp < lim) {
-                const tag_step t = read_tag(tag_at(cp, k), p, block, starts);
-                ok = t.ok;
-                p += t.len;
-                cp += t.adv;
-                count += 1u;
-            }
+    bool ok = true;
+    while (cp < n && ok) {
+        const unsigned w = load_tag32(src, cp, n);
+        const unsigned kind = w & 3u, up = (w >> 2) & 63u;
+        unsigned len, adv;
+        if (kind == 0u) {
+            ok = up <= 60u;
+            len = (up == 60u ? ((w >> 8) & 255u) : up) + 1u;
+            adv = len + (up == 60u ? 2u : 1u);
+        } else {
+            len = kind == 1u ? ((w >> 2) & 7u) + 4u : up + 1u;
+            adv = kind + 1u;
+            const unsigned off = kind == 1u ? (((w >> 5) & 7u) << 8) | ((w >> 8) & 255u) : (w >> 8) & 0xFFFFu;
+            ok = kind != 3u && off >= block && (off % block) == 0u && off <= p;
         }
-        __syncthreads();
+        ok = ok && ((starts >> (p % block)) & 1u) != 0u && (p & (kHalf - 1u)) + len <= kHalf;
+        p += len;
+        cp += adv;
+        count += 1u;
     }
     // (an element that ends off a field boundary shows as the next one's start, or as the total)
-    ok = ok && cp == n && p == out_len && 4u * count <= out_len;
-    if (__builtin_amdgcn_ballot_w64(ok) == 0ull)
+    if (!ok || cp != n || p != out_len || 4u * count > out_len)
         return;
-
-    // ---- second walk: where every G-th element begins ----
+    // second walk: where every G-th element begins
     const unsigned G = (count + 63u) >> 6;
     gout_t table = (gout_t)(job->group_tables + (uint64_t)idx * HAP_GROUP_TABLE_BYTES);
     unsigned g = 0, left = G, cp0 = 0, p0 = 0;
-    bool fits = true;
     cp = 0;
     p = 0;
-    for (unsigned k = 0; k < slices; k++) {
-        stage(k);
-        __syncthreads();
-        const unsigned lim = min(end_x, (k + 1u) * kCoopAdvance);
-        while (__builtin_amdgcn_ballot_w64(ok && shift + cp < lim) != 0ull) {
-            if (ok && shift + cp < lim) {
-                const tag_step t = read_tag(tag_at(cp, k), p, block, starts);
-                p += t.len;
-                cp += t.adv;
-                if (--left == 0u || cp >= n) {
-                    const unsigned cs = cp - cp0, os = p - p0;
-                    fits = fits && cs < 4096u && os < 4096u;
-                    const unsigned entry = cs | (os << 12);
-                    table[3u * g] = (uint8_t)entry;
-                    table[3u * g + 1u] = (uint8_t)(entry >> 8);
-                    table[3u * g + 2u] = (uint8_t)(entry >> 16);
-                    g += 1u;
-                    left = G;
-                    cp0 = cp;
-                    p0 = p;
-                }
-            }
+    bool fits = true;
+    while (cp < n) {
+        const unsigned w = load_tag32(src, cp, n);
+        const unsigned kind = w & 3u, up = (w >> 2) & 63u;
+        const unsigned len = kind == 0u ? (up == 60u ? ((w >> 8) & 255u) : up) + 1u : kind == 1u ? ((w >> 2) & 7u) + 4u : up + 1u;
+        const unsigned adv = kind == 0u ? len + (up == 60u ? 2u : 1u) : kind + 1u;
+        p += len;
+        cp += adv;
+        if (--left == 0u || cp >= n) {
+            const unsigned cs = cp - cp0, os = p - p0;
+            fits = fits && cs < 4096u && os < 4096u;
+            const unsigned entry = cs | (os << 12);
+            table[3u * g] = (uint8_t)entry;
+            table[3u * g + 1u] = (uint8_t)(entry >> 8);
+            table[3u * g + 2u] = (uint8_t)(entry >> 16);
+            g += 1u;
+            left = G;
+            cp0 = cp;
+            p0 = p;
         }
-        __syncthreads();
     }
-    if (!ok)
-        return;
     for (; g < 64u; g++) {
         table[3u * g] = 0;
         table[3u * g + 1u] = 0;
@@ -793,12 +721,13 @@ __global__ __launch_bounds__(64) void guess_group_tables_kernel(HapGpuDecodeUnit
     if (!fits)
         return;
     // the unit becomes a field-stream fragment: bare elements, its table, the readable bytes behind it
+    const uint64_t end = u.src + u.src_len, section_end = job->payload + job->payload_len;
     u.src += hdr;
     u.src_len = n;
     u.kind = layout == 4u ? HAPGPU_UNIT_SNAPPY_FIELDS4 : layout == 2u ? HAPGPU_UNIT_SNAPPY_FIELDS2
            : layout == 8u ? HAPGPU_UNIT_SNAPPY_FIELDS44 : HAPGPU_UNIT_SNAPPY_FIELDS26;
     u.aux = (uint64_t)(uintptr_t)table;
-    u.reserved = readable_x - end_x;
+    u.reserved = section_end > end ? (section_end - end < 15u ? section_end - end : 15u) : 0u;
     units[idx] = u;
 }
 
@@ -808,7 +737,17 @@ extern "C" int hapgpu_launch_guess_group_tables(HapGpuDecodeUnit *units, unsigne
 {
     if (unit_count == 0)
         return 0;
-    hipLaunchKernelGGL(guess_group_tables_kernel, dim3((unit_count + 63u) / 64u), dim3(64), 0, stream, units, unit_count, jobs);
+    // Every lane reads its own stream, a few bytes per turn: a wavefront's 64 lanes keep 64 cache lines alive, and with
+    // sixteen wavefronts on a CU none of them survives in its 32 KiB L1 until the lane's next element (every turn then
+    // comes from the L2).  Dynamic LDS the kernel never touches keeps the wavefronts per CU down to what the L1 holds.
+    static int lds_bytes = -1;
+    if (lds_bytes < 0) {
+        const char *e = HAP_AB_ENV("HAP_AMD_GUESS_LDS");
+        lds_bytes = e ? atoi(e) : kGuessLdsBytes;
+        if (lds_bytes > 65536)
+            lds_bytes = 65536;
+    }
+    hipLaunchKernelGGL(guess_group_tables_kernel, dim3((unit_count + 63u) / 64u), dim3(64), (unsigned)lds_bytes, stream, units, unit_count, jobs);
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 
