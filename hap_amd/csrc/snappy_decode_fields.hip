@@ -203,12 +203,8 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
     const unsigned elements_lo = group_table[192], elements_hi = group_table[193];
     uint4 early[4];
 #pragma unroll
-    for (unsigned i = 0; i < 4u; i++) {
-        // (a kilobyte row the fragment does not reach is not asked for at all: the alpha plane's fragments are one row long)
-        early[i] = make_uint4(0, 0, 0, 0);
-        if (i * 1024u < in_end)
-            early[i] = load_input16(src_al, i * 1024u + lane * 16u, shift, in_end, readable_end);
-    }
+    for (unsigned i = 0; i < 4u; i++)
+        early[i] = load_input16(src_al, i * 1024u + lane * 16u, shift, in_end, readable_end);
     if (job_status != 0u)
         return;
 
@@ -281,7 +277,7 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
         int max_reach = 0;                                 // how far before the fragment the farthest copy reaches
         unsigned min_off = 0xFFFFFu, max_up = 0;           // smallest copy offset, largest literal length code
         unsigned crossed = 0;                              // an element that leaves its half-tile
-        int slack = 0x7FFFFFFF;                            // least room between an element's bytes and the output of earlier steps
+        unsigned overrun = 0;                              // an element whose bytes the output of earlier steps would reach
         uint32_t *const mask_words = reinterpret_cast<uint32_t *>(masks);
         // (two typed pointers and a uniform branch at the store: one pointer chosen between LDS and memory would make
         // every record a flat store)
@@ -310,8 +306,8 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
                 max_up = max(max_up, is_lit ? up : 0u);
                 max_kind = max(max_kind, kind);
                 max_reach = max(max_reach, (int)(offx & 0xFFFFu) - (int)p);     // > 0: a copy from before the fragment
-                crossed |= hp + lm1;                                            // (bit 7 or 8: the element leaves its half-tile)
-                slack = min(slack, (int)cp - (int)(p & ~(kStepBytes - 1u)));   // < 0: the steps before this one write up to there
+                crossed |= (hp + lm1) >> 7;
+                overrun |= (p & ~(kStepBytes - 1u)) > cp ? 1u : 0u;            // the steps before this one write up to there
                 {
                     const unsigned from = (is_lit ? cp + 1u + lngv : p - off) - (p & (kStepBytes - 1u));
                     const unsigned record = (from & 0xFFFFFFu) | (min(offx >> kRecShift, 255u) << 24);
@@ -332,7 +328,7 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
         // leaves cp or p off the mark; starts off a field boundary show in the masks (checked below, per half-tile)
         const bool bad = max_kind == 3u || max_reach > 0 || (acc_or & (kBlock - 1u)) != 0u ||
                          ((acc_or >> 17) & ((1u << kPosShift) - 1u)) != 0u || min_off < kBlock || max_up > 60u ||
-                         (crossed & 0x180u) != 0u || slack < 0 ||
+                         crossed != 0u || overrun != 0u ||
                          cp != cend || p != obegin + gout;
         if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
             fail_unit(job, lane);
