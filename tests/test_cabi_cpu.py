@@ -333,3 +333,33 @@ def test_every_environment_switch_is_documented_and_tested():
         body = body[: body.index("\ndef ", 1) if "\ndef " in body[1:] else len(body)]
         assert name in body or name == "HAP_AMD_LIBRARY", "%s does not mention %s" % (test, name)
     assert set(ENVIRONMENT_SWITCHES) == product, set(ENVIRONMENT_SWITCHES) ^ product
+
+
+def test_round5_entry_points_without_a_gpu(hap):
+    """The integer side of the round-5 additions needs no GPU: HapGpuFineChunkCount is hap.c:277-300's limiting of
+    bytes / 8 KiB chunks to a divisor of the block count (0 for arguments HapEncode would refuse), and the
+    several-context calls and the two-halves calls refuse missing contexts before they touch a device."""
+    lib = hap._lib.lib
+    u, ul, vp = C.c_uint, C.c_ulong, C.c_void_p
+    # 8K Hap Q: 33 177 600 bytes = 4050 x 8 KiB; 4K DXT1: 518 400 blocks, 507 asked, 480 is the largest divisor below
+    assert hap.fine_chunk_count(7680 * 4320, L.FMT_YCOCG) == 4050
+    assert hap.fine_chunk_count(3840 * 2160 // 2, L.FMT_DXT1) == 480
+    for n, fmt in ((16, L.FMT_YCOCG), (8, L.FMT_DXT1), (8192, L.FMT_RGTC1), (8192 + 16, L.FMT_DXT5), (1 << 20, L.FMT_BC7)):
+        k = hap.fine_chunk_count(n, fmt)
+        block = D.BLOCK_BYTES[fmt]
+        assert k >= 1 and (n // block) % k == 0 and k <= (n + 8191) // 8192
+        assert hap.HapMaxEncodedLength([n], [fmt], [k]) > 0
+    assert hap.fine_chunk_count(0, L.FMT_DXT1) == 0 and hap.fine_chunk_count(4096, 0x1234) == 0
+    assert hap.fine_chunk_count(1 << 33, L.FMT_DXT1) == 0
+    res = (u * 2)(7, 7)
+    used = (ul * 2)()
+    one = (vp * 1)(None)
+    assert lib.HapGpuEncodeFramesRGBAOnDevices(None, 0, 2, None, 8, 8, 32, 1, None, None, None, None, None, used, res, 0) == hap.HapResult.Bad_Arguments
+    assert lib.HapGpuEncodeFramesRGBAOnDevices(one, 1, 2, None, 8, 8, 32, 1, None, None, None, None, None, used, res, 0) == hap.HapResult.Bad_Arguments
+    assert lib.HapGpuDecodeFramesOnDevices(None, 3, 2, None, None, 0, None, None, None, None, res, 0) == hap.HapResult.Bad_Arguments
+    assert lib.HapGpuEncodeFramesOnDevices(one, 1, 2, 3, None, None, None, None, None, None, None, used, res, 0) == hap.HapResult.Bad_Arguments
+    assert list(res) == [hap.HapResult.Bad_Arguments] * 2                       # (count 3: every frame says so)
+    assert lib.HapGpuEncodeFramesFinish(None) == hap.HapResult.Bad_Arguments
+    assert lib.HapGpuEncodeFramesRGBABegin(None, 1, None, 8, 8, 32, 1, None, None, None, None, None, used, res, 0) == hap.HapResult.Bad_Arguments
+    assert lib.HapGpuPlacementTimeoutCount(None) == 0
+    assert lib.HapGpuCollectProfileN(None, 9, None, None) == hap.HapResult.Bad_Arguments
