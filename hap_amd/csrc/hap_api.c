@@ -56,14 +56,16 @@ unsigned int HapGpuCreate(int device, HapGpuContext **context)
     return HapResult_No_Error;
 }
 
-unsigned int HapGpuEncodeFramesFinish(HapGpuContext *context);
-
 void HapGpuDestroy(HapGpuContext *context)
 {
     if (!context)
         return;
-    if (context->pending_encode)
-        HapGpuEncodeFramesFinish(context);
+    /* an encode call begun and never finished: its launches are waited for (hapgpu_rt_destroy synchronises), its results
+       are NOT written -- the client's arrays may be gone by now */
+    if (context->pending_encode) {
+        hapb_encode_abandon(context, context->pending_encode);
+        context->pending_encode = NULL;
+    }
     hapgpu_rt_destroy(context->rt);
     free(context);
 }

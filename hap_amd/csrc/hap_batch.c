@@ -689,6 +689,14 @@ done:
     return first_error;
 }
 
+void hapb_encode_abandon(HapGpuContext *ctx, HapbEncodePending *pd)
+{
+    (void)hapgpu_rt_sync(ctx->rt);
+    free(pd->live_index); free(pd->stage_off_out);
+    free(pd->inputs); free(pd->outputs); free(pd->output_bytes);
+    free(pd);
+}
+
 unsigned hapb_compress_rgba(HapGpuContext *ctx, const void *rgba, unsigned width, unsigned height,
                             unsigned long row_bytes, unsigned format, void *output,
                             unsigned long output_bytes, unsigned long *used, int synchronise)

@@ -73,6 +73,8 @@ typedef struct HapbEncodePending {
     HapbBlockEncodeJob job;           /* a call that started from pictures (has_job) */
 } HapbEncodePending;
 unsigned hapb_encode_complete(HapGpuContext *ctx, HapbEncodePending *pending);
+/* ... or lets go of it without touching the client's arrays (the context is being destroyed): waits for the launches, frees `pending` */
+void hapb_encode_abandon(HapGpuContext *ctx, HapbEncodePending *pending);
 
 /* inputs_are_device != 0: every input pointer is known to be device memory (skips classification) */
 unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,

@@ -208,7 +208,8 @@ unsigned int HapGpuEncodeFramesRGBA(HapGpuContext *context, unsigned int frameCo
  * decodes the previous batch on ANOTHER context, parses, reads the next pictures: the encode kernels run under it
  * and the GPU never idles between calls (bench.py's step, DESIGN.md "Pipelined step").  Begin returns errors that are
  * known at once (then nothing is pending and Finish has nothing to do); Finish returns what the one-call form
- * returns.  At most 32768 frames per Begin.  The reference has no counterpart: HapEncode returns when its frame is
+ * returns.  At most 32768 frames per Begin.  A context destroyed between the halves waits for the launches and writes
+ * no results.  The reference has no counterpart: HapEncode returns when its frame is
  * written (hap.h:98-104). */
 unsigned int HapGpuEncodeFramesRGBABegin(HapGpuContext *context, unsigned int frameCount,
                                          const void *const *rgbaFrames,
