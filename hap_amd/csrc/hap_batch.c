@@ -1021,7 +1021,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     unsigned f, live = 0, first_error = HapResult_No_Error, total_units = 0, total_chunks = 0;
     unsigned frag_log2_seen = 0, frag_kinds = 0, max_chunks = 0, max_stream_src = 0, guess_units = 0;
     unsigned char *guess_frame = NULL;                         /* frames whose chunks may be field-stream fragments without a table */
-    int use_guess = 0;
+    int use_guess = 0, use_scan_guess = 0;
     uint8_t *dguess = NULL;
     int any_stream = 0, need_retry = 0;
     unsigned scan_chunks = 0, scan_segs = 0, scan_words = 0;   /* streams with BLOCK slots; their segments; bpos words */
@@ -1299,7 +1299,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
         unsigned units = 0;
         int c;
         /* (the chunks of a frame on that road are not looked over for 64 KiB blocks: one unit each) */
-        const int frame_scan = block_scan && !(use_guess && guess_frame[f]);
+        const int frame_scan = block_scan && !(use_guess && (guess_frame[f] & 1));
         if (results[f] != HapResult_No_Error)
             continue;
         if (p->mode == HAPGPU_JOB_COMPLEX) {
@@ -1348,6 +1348,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
             if (!p->frag_table_offset)
                 for (c = 0; c < p->chunk_count; c++)
                     if ((p->chunks[c].codec & 0xFFu) == HAP_NIBBLE_SNAPPY && p->chunks[c].unit_count > 1u) {
+                        guess_frame[f] |= 2;
                         scan_chunks += 1u;
                         scan_segs += stream_scan_segments(p->chunks[c].src_len);
                         scan_words += stream_mark_words(p->chunks[c].src_len, output_bytes[f]);
@@ -1364,6 +1365,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                 max_stream_src = p->section_length;
             units = 1u + (block_scan ? stream_block_slots(p->section_length, output_bytes[f]) : 0u);
             if (units > 1u) {
+                guess_frame[f] |= 2;
                 scan_chunks += 1u;
                 scan_segs += stream_scan_segments(p->section_length);
                 scan_words += stream_mark_words(p->section_length, output_bytes[f]);
@@ -1382,6 +1384,15 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     }
     if (live == 0)
         goto finish;
+    /* streams without a table that the block scan cuts into 8 KiB pieces (plain hap.h frames of this library: one or a
+       few chunks of many fragments): the same pre-pass can find the starting points inside every piece the scan lists,
+       and the block-per-lane decoder then takes the pieces that are field-stream fragments; the others (another
+       encoder's) stay with the generic kernel.  A lane's two walks over its piece take 0.45 ms however few the
+       pieces; the generic kernel's wavefront per piece costs 13 ns a piece more than the block-per-lane one's + the
+       pre-pass's 8 ns: even at 32 thousand pieces (8 8K frames: 1.18 ms against 1.13), 14 % ahead at 243 thousand
+       (60 frames: 5.93 ms against 6.87). */
+    use_scan_guess = fine_total && !(flags & HAPGPU_DECODE_NO_FIELD_GUESS) &&
+                     (fine_total >= 65536u || (flags & HAPGPU_DECODE_GUESS_FIELDS));
 
     /* 3. device descriptors */
     hjobs = (HapGpuDecodeJob *)hapgpu_rt_pinned_scratch(rt, P_JOBS, sizeof(HapGpuDecodeJob) * live);
@@ -1419,8 +1430,10 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
         djoins = arena + o_joins;
         drecs = arena + o_recs;
     }
-    if (use_guess) {
-        dguess = (uint8_t *)hapgpu_rt_device_scratch(rt, D_GUESS, (size_t)HAP_GROUP_TABLE_BYTES * ((size_t)total_units + 1u));
+    if (use_guess || use_scan_guess) {
+        /* (a table per unit slot; the scan's pieces are the slots behind the ordinary ones) */
+        dguess = (uint8_t *)hapgpu_rt_device_scratch(rt, D_GUESS, (size_t)HAP_GROUP_TABLE_BYTES *
+                                                     ((size_t)total_units + (use_scan_guess ? fine_total : 0u) + 1u));
         if (!dguess) {
             rc = 1;
             goto fail_alloc;
@@ -1475,7 +1488,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                     else
                         frag_kinds |= 1u << p->frag_gran_log2;
                 }
-                if (dguess && guess_frame[f]) {
+                if (dguess && use_guess && (guess_frame[f] & 1)) {
                     const unsigned layout = field_layout_of_format(p->format);
                     job->fields_period = layout;
                     job->group_tables = (uint64_t)(uintptr_t)dguess;
@@ -1501,6 +1514,14 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                 if (scan_chunks && p->mode == HAPGPU_JOB_SNAPPY && units > 1u)
                     scan_entry(&hscan[scan_cursor++], unit_cursor, p->section_length, output_bytes[f], dbpos, &seg_cursor,
                                &word_cursor, total_units, &fine_cursor);
+            }
+            if (dguess && use_scan_guess && (guess_frame[f] & 2) && field_layout_of_format(p->format) && !job->fields_period) {
+                const unsigned layout = field_layout_of_format(p->format);
+                job->fields_period = layout;
+                job->group_tables = (uint64_t)(uintptr_t)dguess;
+                job->reserved |= 1u << 16;
+                /* 0x1000: units for the block-per-lane decoder may appear among the scan's pieces as well */
+                frag_kinds |= (layout == 4u ? 0x100u : layout == 2u ? 0x200u : 0x400u) | 0x1000u;
             }
             unit_cursor += units;
         }
@@ -1568,11 +1589,19 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
         if (scan_chunks && scan_cursor == scan_chunks) {
             rc |= hapgpu_rt_h2d(rt, dscan, hscan, sizeof(HapGpuScanChunk) * scan_chunks);
             rc |= hapgpu_rt_zero(rt, dwork, sizeof(uint32_t));
+            if (frag_kinds & 0x1000u)       /* (the decoder below walks all the pieces' slots, not only the listed ones) */
+                rc |= hapgpu_rt_zero(rt, dunits + total_units, sizeof(HapGpuDecodeUnit) * (size_t)fine_total);
             rc |= hapgpu_k_scan_blocks(rt, dunits, djobs, dscan, scan_chunks, dsegs, drecs, djoins, scan_segs,
                                        fine_total ? dwork : NULL);
         }
-        if (dguess)
-            rc |= hapgpu_k_guess_group_tables(rt, dunits, total_units, djobs);
+        if (dguess && use_guess)
+            rc |= hapgpu_k_guess_group_tables(rt, dunits, total_units, djobs, NULL, 0u);
+        if (dguess && (frag_kinds & 0x1000u)) {
+            if (scan_chunks && scan_cursor == scan_chunks)
+                rc |= hapgpu_k_guess_group_tables(rt, dunits, total_units + fine_total, djobs, dwork, fine_total);
+            else
+                frag_kinds &= ~0x1000u;
+        }
         rc |= hapgpu_k_snappy_decode(rt, dunits, total_units, djobs, frag_log2_seen, frag_kinds,
                                      /* 3: every stream is as short as one 8 KiB fragment (frames written with
                                         HAPGPU_ENCODE_FINE_CHUNKS): the 2 KiB ring of the block-scan launches instead of the 32 KiB one, 30 wavefronts per CU instead of 4 */

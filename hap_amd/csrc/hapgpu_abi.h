@@ -344,7 +344,10 @@ void hapgpu_rt_set_profiling(hapgpu_rt *rt, int enable);
 int hapgpu_rt_collect_profile(hapgpu_rt *rt, unsigned long *launches, double *ms, unsigned classes);
 /* group tables for the STREAM units of jobs whose reserved bit 16 is set (fragments that came as chunks of their own,
    without a private table): units that turn out to be field streams become FIELDS units (snappy_decode_fields.hip) */
-int hapgpu_k_guess_group_tables(hapgpu_rt *rt, HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs);
+/* (work != NULL: only the units the block scan listed there -- the 8 KiB pieces of table-less streams of this library;
+   unit_count then spans the fine region behind the ordinary units as well) */
+int hapgpu_k_guess_group_tables(hapgpu_rt *rt, HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs,
+                                const uint32_t *work, unsigned work_slots);
 int hapgpu_rt_timer_start(hapgpu_rt *rt);
 int hapgpu_rt_timer_stop(hapgpu_rt *rt, double *ms);
 

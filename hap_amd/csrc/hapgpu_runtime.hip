@@ -682,11 +682,13 @@ extern "C" int hapgpu_k_scan_blocks(hapgpu_rt *rt, HapGpuDecodeUnit *units, cons
     return hapgpu_launch_scan_blocks(units, jobs, chunks, chunk_count, segs, recs, joins, seg_total, fine_work, rt->stream);
 }
 
-extern "C" int hapgpu_launch_guess_group_tables(HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs, hipStream_t stream);
-extern "C" int hapgpu_k_guess_group_tables(hapgpu_rt *rt, HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs)
+extern "C" int hapgpu_launch_guess_group_tables(HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs,
+                                                const uint32_t *work, unsigned work_slots, hipStream_t stream);
+extern "C" int hapgpu_k_guess_group_tables(hapgpu_rt *rt, HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs,
+                                           const uint32_t *work, unsigned work_slots)
 {
     scoped_timing st(rt, 7);          // (with the block scan: finding where wavefronts may start in streams that do not say)
-    return hapgpu_launch_guess_group_tables(units, unit_count, jobs, rt->stream);
+    return hapgpu_launch_guess_group_tables(units, unit_count, jobs, work, work_slots, rt->stream);
 }
 
 extern "C" int hapgpu_k_snappy_decode(hapgpu_rt *rt, const HapGpuDecodeUnit *units, unsigned unit_count,

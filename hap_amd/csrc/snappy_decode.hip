@@ -1462,8 +1462,10 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
     if (unit_count == 0)
         return 0;
     // field streams (fragment table version 3): the block-per-lane decoder of snappy_decode_fields.hip
+    // (bit 12: the pre-pass may have turned 8 KiB pieces of scanned streams into such units: they lie behind the ordinary ones)
     if ((fragment_kinds >> 8) & 15u) {
-        if (hapgpu_launch_snappy_decode_fields(units, unit_count, jobs, (fragment_kinds >> 8) & 15u, stream) != 0)
+        if (hapgpu_launch_snappy_decode_fields(units, unit_count + (((fragment_kinds >> 12) & 1u) ? fine_slots : 0u), jobs,
+                                               (fragment_kinds >> 8) & 15u, stream) != 0)
             return 4;
         fragment_kinds &= 0xFFu;
         if (fragment_kinds == 0u)

@@ -609,7 +609,10 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
 // fragments on; fewer are decoded by the generic kernel, one wavefront per fragment).  A cooperative form -- the wave
 // stages its 64 fragments through LDS in coalesced 256-byte slices and the lanes walk out of LDS -- was built in round 5
 // and is NO faster (2.2 ms): every slice is a load / barrier / walk / barrier round trip, and a wave runs as long as the
-// busiest of its 64 fragments has elements.  This is the simpler of the two.
+// busiest of its 64 fragments has elements.  Nor is a private 64-byte window per lane in LDS (four aligned 16-byte loads
+// per refill, tags read from the slot, no barrier): some lane of the 64 needs its refill at almost every turn, so the
+// wave waits for global loads as often as before -- 2.17 ms at 243 000 fragments, and 0.92 ms instead of 0.45 at 8 000,
+// where nothing but a lane's own latency counts.  This is the simplest of the three.
 // What is not a field stream -- another encoder's chunk of the same size, an element off a field boundary -- stays a
 // STREAM unit for the generic kernel: the walk checks the promises the table would have made.  (The kernel above checks
 // them all again; its verdict, not this one's, is what protects memory.)
@@ -625,14 +628,22 @@ __device__ __forceinline__ unsigned load_tag32(gin_t src, unsigned cp, unsigned 
     return w;
 }
 
-__global__ __launch_bounds__(64) void guess_group_tables_kernel(HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs)
+// `work` == nullptr: the lane's unit is units[blockIdx.x * 64 + lane] -- a STREAM unit of a frame whose chunks are single
+// fragments (length prefix + elements).  `work` != nullptr: the units the block scan listed ([0]: how many, then their
+// indices) -- the 8 KiB pieces of a table-less stream of this library (plain hap.h frames), bare elements between two of
+// the scan's marks.
+__global__ __launch_bounds__(64) void guess_group_tables_kernel(HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs,
+                                                                const uint32_t *work)
 {
-    const unsigned idx = blockIdx.x * 64u + threadIdx.x;
+    unsigned idx = blockIdx.x * 64u + threadIdx.x;
+    if (work) {
+        if (idx >= work[0])
+            return;
+        idx = work[1u + idx];
+    }
     if (idx >= unit_count)
         return;
     HapGpuDecodeUnit u = units[idx];
-    if (u.kind != HAPGPU_UNIT_SNAPPY_STREAM || u.aux != 0u || u.reserved != 0u)
-        return;
     const HapGpuDecodeJob *job = &jobs[u.job];
     if (!((job->reserved >> 16) & 1u) || job->group_tables == 0u || job->status != 0u)
         return;
@@ -640,22 +651,42 @@ __global__ __launch_bounds__(64) void guess_group_tables_kernel(HapGpuDecodeUnit
     const unsigned block = (layout == 4u || layout == 8u) ? 16u : 8u;
     // field starts inside a block, as a mask over its bytes: [2,6,4,4]: 0, 2, 8, 12; [4,4]: 0, 4; [2,6]: 0, 2; [4,4,4,4]: 0, 4, 8, 12
     const unsigned starts = layout == 4u ? 0x1105u : layout == 2u ? 0x11u : layout == 6u ? 0x05u : 0x1111u;
-    const gin_t base = (gin_t)u.src;
-    // the stream's length prefix
-    unsigned hdr = 0, out_len = 0;
-    for (unsigned k = 0; k < 5u && k < u.src_len; k++) {
-        const unsigned b = base[k];
-        out_len |= (b & 0x7Fu) << (7u * k);
-        if (!(b & 0x80u)) {
-            hdr = k + 1u;
-            break;
+    unsigned hdr = 0, out_len = 0, n = 0;
+    gin_t src;
+    if (!work) {
+        if (u.kind != HAPGPU_UNIT_SNAPPY_STREAM || u.aux != 0u || u.reserved != 0u)
+            return;
+        const gin_t base = (gin_t)u.src;
+        // the stream's length prefix
+        for (unsigned k = 0; k < 5u && k < u.src_len; k++) {
+            const unsigned b = base[k];
+            out_len |= (b & 0x7Fu) << (7u * k);
+            if (!(b & 0x80u)) {
+                hdr = k + 1u;
+                break;
+            }
         }
+        if (hdr == 0u || out_len != u.dst_len)
+            return;
+        src = base + hdr;
+        n = u.src_len - hdr;
+    } else {
+        // (what snappy_decode_fragment_kernel does with such a unit: the piece lies between marks b and b + 1 of its stream)
+        if (u.kind != HAPGPU_UNIT_SNAPPY_BLOCK || !(u.reserved & HAPGPU_BLOCK_FINE))
+            return;
+        const HapGpuScanChunk *scan = (const HapGpuScanChunk *)u.aux;
+        const unsigned b = (unsigned)u.reserved, marks = scan->expected_fine;
+        if (!scan->ok || marks == 0u || scan->found_fine != marks || b + 1u > marks)
+            return;
+        const uint32_t *bpos = (const uint32_t *)scan->bpos;
+        const unsigned from = bpos[b], to = bpos[b + 1u];
+        if (from > to || to > bpos[marks])
+            return;
+        src = (gin_t)u.src + from;
+        n = to - from;
+        out_len = u.dst_len;
     }
-    if (hdr == 0u || out_len != u.dst_len || out_len == 0u || out_len > kFragBytes || (out_len % block) != 0u)
-        return;
-    const gin_t src = base + hdr;
-    const unsigned n = u.src_len - hdr;
-    if (n > kMaxFragCompressed)
+    if (out_len == 0u || out_len > kFragBytes || (out_len % block) != 0u || n > kMaxFragCompressed)
         return;
     // first walk: count the elements, check what the table promises
     unsigned cp = 0, p = 0, count = 0;
@@ -685,6 +716,10 @@ __global__ __launch_bounds__(64) void guess_group_tables_kernel(HapGpuDecodeUnit
     // second walk: where every G-th element begins
     const unsigned G = (count + 63u) >> 6;
     gout_t table = (gout_t)(job->group_tables + (uint64_t)idx * HAP_GROUP_TABLE_BYTES);
+    // (the table's 3-byte entries leave as dwords: the arena and 196 are multiples of 4)
+    uint32_t __attribute__((address_space(1))) *table32 = (uint32_t __attribute__((address_space(1))) *)table;
+    unsigned long long pending = 0;
+    unsigned pending_bytes = 0, words = 0;
     unsigned g = 0, left = G, cp0 = 0, p0 = 0;
     cp = 0;
     p = 0;
@@ -699,30 +734,31 @@ __global__ __launch_bounds__(64) void guess_group_tables_kernel(HapGpuDecodeUnit
         if (--left == 0u || cp >= n) {
             const unsigned cs = cp - cp0, os = p - p0;
             fits = fits && cs < 4096u && os < 4096u;
-            const unsigned entry = cs | (os << 12);
-            table[3u * g] = (uint8_t)entry;
-            table[3u * g + 1u] = (uint8_t)(entry >> 8);
-            table[3u * g + 2u] = (uint8_t)(entry >> 16);
+            const unsigned entry = (cs | (os << 12)) & 0xFFFFFFu;
+            pending |= (unsigned long long)entry << (8u * pending_bytes);
+            pending_bytes += 3u;
+            if (pending_bytes >= 4u) {
+                table32[words++] = (uint32_t)pending;
+                pending >>= 32;
+                pending_bytes -= 4u;
+            }
             g += 1u;
             left = G;
             cp0 = cp;
             p0 = p;
         }
     }
-    for (; g < 64u; g++) {
-        table[3u * g] = 0;
-        table[3u * g + 1u] = 0;
-        table[3u * g + 2u] = 0;
+    if (pending_bytes != 0u || g < 64u) {
+        table32[words++] = (uint32_t)pending;           // (the entries of the groups that do not exist are zero)
+        for (; words < 48u; words++)
+            table32[words] = 0u;
     }
-    table[192] = (uint8_t)count;
-    table[193] = (uint8_t)(count >> 8);
-    table[194] = 0;
-    table[195] = 0;
+    table32[48] = count;                                // bytes 192, 193: the element count; 194, 195: zero
     if (!fits)
         return;
     // the unit becomes a field-stream fragment: bare elements, its table, the readable bytes behind it
-    const uint64_t end = u.src + u.src_len, section_end = job->payload + job->payload_len;
-    u.src += hdr;
+    const uint64_t end = (uint64_t)(uintptr_t)src + n, section_end = job->payload + job->payload_len;
+    u.src = (uint64_t)(uintptr_t)src;
     u.src_len = n;
     u.kind = layout == 4u ? HAPGPU_UNIT_SNAPPY_FIELDS4 : layout == 2u ? HAPGPU_UNIT_SNAPPY_FIELDS2
            : layout == 8u ? HAPGPU_UNIT_SNAPPY_FIELDS44 : HAPGPU_UNIT_SNAPPY_FIELDS26;
@@ -733,9 +769,13 @@ __global__ __launch_bounds__(64) void guess_group_tables_kernel(HapGpuDecodeUnit
 
 } // namespace
 
-extern "C" int hapgpu_launch_guess_group_tables(HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs, hipStream_t stream)
+// work == nullptr: every unit of the call is looked at (frames whose chunks are single fragments); else the `work_slots`
+// units the block scan may have listed in `work` (the count is on the device)
+extern "C" int hapgpu_launch_guess_group_tables(HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs,
+                                                const uint32_t *work, unsigned work_slots, hipStream_t stream)
 {
-    if (unit_count == 0)
+    const unsigned lanes = work ? work_slots : unit_count;
+    if (unit_count == 0 || lanes == 0)
         return 0;
     // Every lane reads its own stream, a few bytes per turn: a wavefront's 64 lanes keep 64 cache lines alive, and with
     // sixteen wavefronts on a CU none of them survives in its 32 KiB L1 until the lane's next element (every turn then
@@ -747,7 +787,7 @@ extern "C" int hapgpu_launch_guess_group_tables(HapGpuDecodeUnit *units, unsigne
         if (lds_bytes > 65536)
             lds_bytes = 65536;
     }
-    hipLaunchKernelGGL(guess_group_tables_kernel, dim3((unit_count + 63u) / 64u), dim3(64), (unsigned)lds_bytes, stream, units, unit_count, jobs);
+    hipLaunchKernelGGL(guess_group_tables_kernel, dim3((lanes + 63u) / 64u), dim3(64), (unsigned)lds_bytes, stream, units, unit_count, jobs, work);
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 

@@ -98,8 +98,11 @@ typedef struct HapGpuContext HapGpuContext;
                                                     and carry no private table: do not look for the block-per-lane decoder's
                                                     starting points (one lane per chunk walks its tags, then the chunk
                                                     decodes like a fragment with a table), decode every chunk with the
-                                                    generic kernel -- what calls of fewer than 4096 such chunks do anyway */
-#define HAPGPU_DECODE_GUESS_FIELDS 0x10u         /* ... do it however few the chunks are (tests) */
+                                                    generic kernel -- what calls of fewer than 4096 such chunks do anyway.
+                                                    The same for table-less frames whose chunks are many fragments long
+                                                    (plain hap.h frames of this library): calls with 65536 or more 8 KiB
+                                                    pieces found by the block scan run the pre-pass over the pieces */
+#define HAPGPU_DECODE_GUESS_FIELDS 0x10u         /* ... do it however few the chunks / pieces are (tests) */
 #define HAPGPU_DECODE_NO_BLOCK_SCAN 0x4u         /* decode other encoders' Snappy streams with one wavefront per
                                                     stream instead of looking for their 64 KiB blocks first: for A/B
                                                     measurements (environment HAP_AMD_NO_BLOCK_SCAN does the same) */

@@ -2675,3 +2675,66 @@ def test_fine_chunk_frames_decode_through_the_block_per_lane_kernel_without_a_ta
     r, du, df, dr = ctx.decode_frames([ours], [len(ours)], 0, [dec], flags=hap.DECODE_GUESS_FIELDS)
     assert (r, dr) == (0, [0]) and dec.tobytes() == tex
     assert hap.HapDecode(ours, 0, outputBufferBytes=len(tex)) == (0, tex, fmt)
+
+
+@pytest.mark.parametrize("fmt,shape,chunks", [(L.FMT_YCOCG, (1024, 512), 1), (L.FMT_DXT5, (1000, 516), 4), (L.FMT_DXT1, (2048, 1024), 2),
+                                              (L.FMT_RGTC1, (4096, 1024), 3)])
+def test_plain_frames_decode_through_the_block_per_lane_kernel_by_the_scans_pieces(ctx, hap, monkeypatch, fmt, shape, chunks):
+    """Plain hap.h frames of this library carry no private table and their chunks are many fragments long.  The block
+    scan finds the 8 KiB pieces of such streams; from a few thousand pieces on (forced here with
+    HAPGPU_DECODE_GUESS_FIELDS) the pre-pass walks every listed piece with one lane, writes its group table into scratch
+    and hands it to the block-per-lane decoder.  Pieces that are not field-stream fragments -- the reference encoder's
+    stream of the same texture, whose 8 KiB marks fall where libsnappy put them -- stay with the generic kernel in the
+    same call; a frame that came with its table does not notice.  Same bytes on every road, no second pass."""
+    w, h = shape
+    tex = D.oracle_bc_encode(D.rgba(w, h, frame=41), fmt)
+    monkeypatch.delenv("HAP_AMD_FRAGMENT_INDEX", raising=False)
+    r, plain = hap.HapEncode([tex], [fmt], [1], [chunks])
+    assert r == 0 and find_fragment_table(plain, 0, 4000)[0] < 0
+    rng = np.random.RandomState(5)
+    noisy = bytearray(tex)
+    third = (len(tex) // 3) // 8192 * 8192
+    noisy[third: 2 * third] = rng.randint(0, 256, third, dtype=np.uint8).tobytes()
+    noisy = bytes(noisy)
+    r, plain_noisy = hap.HapEncode([noisy], [fmt], [1], [chunks])
+    assert r == 0
+    theirs = _encode_with(ORA, tex, fmt, L.COMP_SNAPPY, chunks)
+    cap = hap.HapMaxEncodedLength([len(tex)], [fmt], [chunks])
+    out = np.zeros(cap, dtype=np.uint8)
+    r, used, res = ctx.encode_frames([[tex]], [fmt], [1], [chunks], [out], flags=hap.ENCODE_FRAGMENT_INDEX)
+    assert r == 0 and res == [0]
+    tabled = out[: used[0]].tobytes()
+    assert find_fragment_table(tabled, 0, 4000)[0] > 0
+    frames = [plain, theirs, plain_noisy, tabled, plain]
+    wants = [tex, tex, noisy, tex, tex]
+    n0 = ctx.table_fallbacks()
+    scans = {}
+    for flags in (hap.DECODE_GUESS_FIELDS, hap.DECODE_NO_FIELD_GUESS, 0, hap.DECODE_GUESS_FIELDS):
+        dframes = [torch.from_numpy(np.frombuffer(f, dtype=np.uint8).copy()).cuda() for f in frames]
+        decs = [torch.full((len(tex),), 0x5A, dtype=torch.uint8, device="cuda") for _ in frames]
+        torch.cuda.synchronize()
+        ctx.set_profiling(True)
+        ctx.collect_profile()
+        r, du, df, dr = ctx.decode_frames(dframes, [len(f) for f in frames], 0, decs, flags=flags)
+        prof = ctx.collect_profile()
+        ctx.set_profiling(False)
+        assert (r, dr, df) == (0, [0] * len(frames), [fmt] * len(frames)), flags
+        for i, (d, want) in enumerate(zip(decs, wants)):
+            assert d.cpu().numpy().tobytes() == want, (flags, i)
+        scans[flags] = prof.get("block_scan", (0, 0.0))[0]
+    # (the pre-pass is timed with the block scan, "finding where wavefronts may start": one more launch when it ran)
+    assert scans[hap.DECODE_GUESS_FIELDS] == scans[hap.DECODE_NO_FIELD_GUESS] + 1, scans
+    assert scans[0] == scans[hap.DECODE_NO_FIELD_GUESS], scans
+    assert ctx.table_fallbacks() == n0
+    # host buffers; a damaged piece (one tag turned into a copy that reaches before the stream) fails the frame alone
+    dec = np.zeros(len(tex), dtype=np.uint8)
+    r, du, df, dr = ctx.decode_frames([plain], [len(plain)], 0, [dec], flags=hap.DECODE_GUESS_FIELDS)
+    assert (r, dr) == (0, [0]) and dec.tobytes() == tex
+    bad = bytearray(plain)
+    at = len(bad) - len(bad) // 3
+    bad[at: at + 64] = bytes([0xFE]) * 64
+    decs = [np.zeros(len(tex), dtype=np.uint8) for _ in range(2)]
+    r, du, df, dr = ctx.decode_frames([bytes(bad), plain], [len(bad), len(plain)], 0, decs, flags=hap.DECODE_GUESS_FIELDS)
+    want_bad = ORA.decode(bytes(bad), 0, len(tex))[0]
+    assert dr[1] == 0 and decs[1].tobytes() == tex
+    assert (dr[0] == 0) == (want_bad == 0), (dr, want_bad)
