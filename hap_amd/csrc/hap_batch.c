@@ -263,6 +263,12 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
        its wavefronts learn the sizes of what lies before them from each other (snappy_compress_blocks.hip) */
     /* (up to 64 chunks: their totals are one load per wavefront.  16 8K frames of 400 chunks: 0.966 ms placed against 0.880
        gathered; of 1 chunk -- 4050 fragments to look back over -- 1.110 against 1.111) */
+    /* (frames of two textures -- Hap Q Alpha -- with their FIRST texture placed and the second one gathered behind it:
+       measured in round 5 and slower at every chunk count, because such calls run the compressor that reads finished
+       textures, whose wavefronts are short: what a placed one waits for -- every fragment before it compressed -- is a
+       larger share of its life than in the kernel that makes its blocks itself.  16 8K Hap Q Alpha frames, 24 + 24
+       chunks: compress 0.493 -> 0.722 ms for a gather of 0.106 -> 0.036; 4 16K frames, 64 + 64: 0.922 -> 1.537 for
+       0.219 -> 0.082.  One texture per frame.) */
     placed = (!ctx->no_placing && !ctx->placing_off && count == 1u && g[0].compressor == HapCompressorSnappy && g[0].field_period != 0u && frag_log2 == 13u &&
               g[0].chunk_count <= 64u) ? 1u : 0u;
     slot_stride = (unsigned)align_up(frag_bytes + frag_bytes / 32u + 64u + HAPGPU_SLOT_SCRATCH_BYTES, 16);

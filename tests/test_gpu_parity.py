@@ -865,6 +865,27 @@ def test_fragments_placed_by_the_compressor_give_the_same_frames(hap):
         r, used, res = placed.encode_frames([[t] for t in tex], [fmt], [1], [chunks], houts, flags=flags)
         assert r == 0 and res == [0] * nf
         assert [o[:u].tobytes() for o, u in zip(houts, used)] == frames["gathered"]
+    # frames of two textures (Hap Q Alpha) are never placed (measured slower, hap_batch.c): the switches must not change their bytes
+    fmts2 = [L.FMT_YCOCG, L.FMT_RGTC1]
+    sizes2 = [nb * 16, nb * 8]
+    for chunks2, flags in (([5, 2], hap.ENCODE_FRAGMENT_INDEX), ([1, 1], 0), ([64, 3], hap.ENCODE_FRAGMENT_INDEX)):
+        cap = hap.HapMaxEncodedLength(sizes2, fmts2, chunks2)
+        frames = {}
+        for name, c in (("placed", placed), ("gathered", gathered), ("unfused", unfused)):
+            outs = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(nf)]
+            torch.cuda.synchronize()
+            r, used, res = c.encode_frames_rgba(rgba, w, h, w * 4, fmts2, [1, 1], chunks2, outs, flags=flags)
+            assert r == 0 and res == [0] * nf, (name, chunks2)
+            frames[name] = [o[:u].cpu().numpy().tobytes() for o, u in zip(outs, used)]
+        assert frames["placed"] == frames["gathered"] and frames["unfused"] == frames["gathered"], chunks2
+        tex2 = [[D.oracle_bc_encode(rgba[i].cpu().numpy(), f) for f in fmts2] for i in (0, nf - 1)]
+        for k, i in enumerate((0, nf - 1)):
+            for t in range(2):
+                assert REF.decode(frames["placed"][i], t, sizes2[t]) == (0, tex2[k][t], fmts2[t])
+        houts = [np.zeros(cap, dtype=np.uint8) for _ in range(2)]
+        r, used, res = placed.encode_frames(tex2, fmts2, [1, 1], chunks2, houts, flags=flags)
+        assert r == 0 and res == [0, 0]
+        assert [o[:u].tobytes() for o, u in zip(houts, used)] == [frames["gathered"][0], frames["gathered"][nf - 1]]
     # opaque 16-byte blocks under the size-for-speed option (layout [4,4,4,4])
     tex7 = [np.frombuffer(D.oracle_bc_encode(rgba[i].cpu().numpy(), L.FMT_YCOCG), dtype=np.uint8).copy() for i in range(nf)]
     cap = hap.HapMaxEncodedLength([nb * 16], [L.FMT_BC7], [4])
