@@ -1006,8 +1006,9 @@ static void scan_entry(HapGpuScanChunk *e, unsigned unit, unsigned long src_len,
     e->seg_first = *seg_cursor;
     e->seg_count = stream_scan_segments(src_len);
     e->slots = coarse;
-    e->fine_slots = fine;
-    e->fine_unit_first = fine_region_first + *fine_cursor;
+    e->fine_slots = fine;              /* (its words of block positions; the unit slots come from the call's pool, on the device) */
+    e->fine_unit_first = 0;
+    (void)fine_region_first;
     e->bpos = (uint64_t)(uintptr_t)(dbpos + *word_cursor);
     *seg_cursor += e->seg_count;
     *word_cursor += stream_mark_words(src_len, dst_cap);
@@ -1351,15 +1352,23 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                     frag_log2_seen = p->frag_log2;
                 }
             }
-            if (!p->frag_table_offset)
+            if (!p->frag_table_offset) {
+                /* the 8 KiB blocks of all the frame's streams together: what each could expand to, but no more than the
+                   texture holds (+ a ragged last block per stream) -- the slots are handed out on the device */
+                unsigned long long fine_sum = 0, streams = 0;
                 for (c = 0; c < p->chunk_count; c++)
                     if ((p->chunks[c].codec & 0xFFu) == HAP_NIBBLE_SNAPPY && p->chunks[c].unit_count > 1u) {
                         guess_frame[f] |= 2;
                         scan_chunks += 1u;
                         scan_segs += stream_scan_segments(p->chunks[c].src_len);
                         scan_words += stream_mark_words(p->chunks[c].src_len, output_bytes[f]);
-                        fine_total += stream_fine_slots(p->chunks[c].src_len, output_bytes[f]);
+                        fine_sum += stream_fine_slots(p->chunks[c].src_len, output_bytes[f]);
+                        streams += 1u;
                     }
+                if (fine_sum > output_bytes[f] / HAPGPU_SCAN_FINE + streams)
+                    fine_sum = output_bytes[f] / HAPGPU_SCAN_FINE + streams;
+                fine_total += (unsigned)fine_sum;
+            }
             total_chunks += (unsigned)p->chunk_count;
             if ((unsigned)p->chunk_count > max_chunks)
                 max_chunks = (unsigned)p->chunk_count;
@@ -1394,11 +1403,11 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
        few chunks of many fragments): the same pre-pass can find the starting points inside every piece the scan lists,
        and the block-per-lane decoder then takes the pieces that are field-stream fragments; the others (another
        encoder's) stay with the generic kernel.  A lane's two walks over its piece take 0.45 ms however few the
-       pieces; the generic kernel's wavefront per piece costs 13 ns a piece more than the block-per-lane one's + the
-       pre-pass's 8 ns: even at 32 thousand pieces (8 8K frames: 1.18 ms against 1.13), 14 % ahead at 243 thousand
-       (60 frames: 5.93 ms against 6.87). */
+       pieces, and the generic kernel's wavefront per piece is 8 ns a piece dearer than pre-pass + block-per-lane
+       decode: even at 32 thousand pieces (8 8K frames: 1.09 ms against 1.13), 17 % ahead at 65 thousand, 25 % at 243
+       thousand (60 frames: 4.98 ms against 6.67). */
     use_scan_guess = fine_total && !(flags & HAPGPU_DECODE_NO_FIELD_GUESS) &&
-                     (fine_total >= 65536u || (flags & HAPGPU_DECODE_GUESS_FIELDS));
+                     (fine_total >= 32768u || (flags & HAPGPU_DECODE_GUESS_FIELDS));
 
     /* 3. device descriptors */
     hjobs = (HapGpuDecodeJob *)hapgpu_rt_pinned_scratch(rt, P_JOBS, sizeof(HapGpuDecodeJob) * live);
@@ -1421,7 +1430,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
         const size_t o_segs = align_up(sizeof(HapGpuScanChunk) * scan_chunks, 64);
         const size_t o_bpos = o_segs + sizeof(HapGpuScanSegment) * scan_segs;
         const size_t o_work = align_up(o_bpos + sizeof(uint32_t) * scan_words, 64);
-        const size_t o_joins = align_up(o_work + sizeof(uint32_t) * ((size_t)fine_total + 1u), 64);
+        const size_t o_joins = align_up(o_work + sizeof(uint32_t) * ((size_t)fine_total + 2u), 64);   /* count | list | pool cursor */
         const size_t o_recs = align_up(o_joins + (size_t)8u * scan_segs, 64);
         uint8_t *arena = (uint8_t *)hapgpu_rt_device_scratch(rt, D_SCAN, o_recs + (size_t)512u * scan_segs);
         hscan = (HapGpuScanChunk *)hapgpu_rt_pinned_scratch(rt, P_SCAN, sizeof(HapGpuScanChunk) * scan_chunks);
@@ -1595,10 +1604,12 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
         if (scan_chunks && scan_cursor == scan_chunks) {
             rc |= hapgpu_rt_h2d(rt, dscan, hscan, sizeof(HapGpuScanChunk) * scan_chunks);
             rc |= hapgpu_rt_zero(rt, dwork, sizeof(uint32_t));
+            if (fine_total)
+                rc |= hapgpu_rt_zero(rt, dwork + 1u + fine_total, sizeof(uint32_t));
             if (frag_kinds & 0x1000u)       /* (the decoder below walks all the pieces' slots, not only the listed ones) */
                 rc |= hapgpu_rt_zero(rt, dunits + total_units, sizeof(HapGpuDecodeUnit) * (size_t)fine_total);
             rc |= hapgpu_k_scan_blocks(rt, dunits, djobs, dscan, scan_chunks, dsegs, drecs, djoins, scan_segs,
-                                       fine_total ? dwork : NULL);
+                                       fine_total ? dwork : NULL, total_units, fine_total);
         }
         if (dguess && use_guess)
             rc |= hapgpu_k_guess_group_tables(rt, dunits, total_units, djobs, NULL, 0u);

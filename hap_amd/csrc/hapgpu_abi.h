@@ -217,7 +217,7 @@ typedef struct HapGpuScanChunk {
     uint32_t fine_failed;    /* ... and one of them met a copy that reaches before its block (marks on element boundaries
                                 do not make a stream's 8 KiB pieces independent): the 64 KiB blocks / the stream unit
                                 of the launch's second phase decode the stream instead */
-    uint32_t fine_unit_first; /* host: index of the stream's first fine unit slot in the call's unit array */
+    uint32_t fine_unit_first; /* device: index of the stream's first fine unit slot in the call's unit array (from the pool) */
     uint32_t reserved;
     uint32_t probe_found;    /* of the first two 8 KiB marks (output positions 8192 and 16384): the rest of the fine
                                 marks are only looked for when both fall on element boundaries -- in a libsnappy
@@ -329,7 +329,10 @@ int hapgpu_k_decode_plan(hapgpu_rt *rt, HapGpuDecodeJob *jobs, unsigned job_coun
  * seg_total * 64 words of 8 bytes / seg_total * 8 bytes */
 int hapgpu_k_scan_blocks(hapgpu_rt *rt, HapGpuDecodeUnit *units, const HapGpuDecodeJob *jobs, HapGpuScanChunk *chunks,
                          unsigned chunk_count, HapGpuScanSegment *segs, void *recs, void *joins, unsigned seg_total,
-                         uint32_t *fine_work /* [0]: count (zero on entry), then the unit indices of the 8 KiB blocks to decode */);
+                         uint32_t *fine_work /* [0]: count (zero on entry), then the unit indices of the 8 KiB blocks to decode
+                                                (room for fine_pool of them), then the pool's cursor (zero on entry) */,
+                         unsigned fine_first, unsigned fine_pool /* the 8 KiB blocks' unit slots: units[fine_first .. + fine_pool),
+                                                                    handed out to the streams on the device */);
 /* frag_log2: fragment size of the batch's FRAGMENT units (0: none present);
  * fragment_kinds: bit g set = fragments of granularity_log2 g present */
 /* fragment_kinds bits 8 / 9 / 10: field-stream units of [2,6,4,4] / [4,4] / [2,6] blocks present */

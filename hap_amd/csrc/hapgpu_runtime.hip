@@ -33,7 +33,7 @@ int hapgpu_launch_frame_gather(const HapGpuCopyEntry *copies, unsigned count, hi
 int hapgpu_launch_decode_plan(HapGpuDecodeJob *jobs, unsigned job_count, unsigned max_chunks, hipStream_t stream);
 int hapgpu_launch_scan_blocks(HapGpuDecodeUnit *units, const HapGpuDecodeJob *jobs, HapGpuScanChunk *chunks, unsigned chunk_count,
                               HapGpuScanSegment *segs, void *recs, void *joins, unsigned seg_total, uint32_t *fine_work,
-                              hipStream_t stream);
+                              unsigned fine_first, unsigned fine_pool, hipStream_t stream);
 int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsigned unit_count, HapGpuDecodeJob *jobs,
                                 unsigned frag_log2, unsigned fragment_kinds, int any_stream_or_copy_units,
                                 const uint32_t *fine_work, unsigned fine_slots, hipStream_t stream);
@@ -676,10 +676,11 @@ extern "C" int hapgpu_k_decode_plan(hapgpu_rt *rt, HapGpuDecodeJob *jobs, unsign
 
 extern "C" int hapgpu_k_scan_blocks(hapgpu_rt *rt, HapGpuDecodeUnit *units, const HapGpuDecodeJob *jobs, HapGpuScanChunk *chunks,
                                     unsigned chunk_count, HapGpuScanSegment *segs, void *recs, void *joins, unsigned seg_total,
-                                    uint32_t *fine_work)
+                                    uint32_t *fine_work, unsigned fine_first, unsigned fine_pool)
 {
     scoped_timing st(rt, 7);
-    return hapgpu_launch_scan_blocks(units, jobs, chunks, chunk_count, segs, recs, joins, seg_total, fine_work, rt->stream);
+    return hapgpu_launch_scan_blocks(units, jobs, chunks, chunk_count, segs, recs, joins, seg_total, fine_work, fine_first, fine_pool,
+                                     rt->stream);
 }
 
 extern "C" int hapgpu_launch_guess_group_tables(HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs,

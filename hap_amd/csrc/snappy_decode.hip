@@ -1093,7 +1093,8 @@ __device__ __forceinline__ void scan_window_bytes(const uint8_t *src_al, unsigne
 __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units, const HapGpuDecodeJob *jobs,
                                                         HapGpuScanChunk *chunks, unsigned chunk_count,
                                                         const HapGpuScanSegment *__restrict__ segs,
-                                                        const unsigned long long *__restrict__ recs, uint2 *__restrict__ joins)
+                                                        const unsigned long long *__restrict__ recs, uint2 *__restrict__ joins,
+                                                        uint32_t *fine_cursor, unsigned fine_first, unsigned fine_pool)
 {
     const unsigned lane = threadIdx.x, c = blockIdx.x;
     if (c >= chunk_count)
@@ -1106,7 +1107,20 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
     if (!scan_unit_wanted(u, jobs) || nblk > sc.slots)
         return;                                   // (ok stays 0: the host sent zeros)
     // marks every 8 KiB of output when the host reserved a unit slot for each (else every 64 KiB, as for any stream)
-    const bool fine_on = sc.fine_slots != 0u && nfine <= sc.fine_slots;
+    bool fine_on = sc.fine_slots != 0u && nfine <= sc.fine_slots && fine_cursor != nullptr;
+    // The 8 KiB blocks' unit slots come out of a pool behind the call's ordinary units, handed out here: the host knows
+    // what all the streams of a frame can produce together (its texture), not how the chunks share it (r05: a slot range
+    // per stream sized by what ITS bytes could expand to made the pool of 60 8K frames of 24 chunks 2.07 M slots for
+    // 243 000 blocks -- and two launches of 2 M wavefronts that found nothing to do, 0.7 ms).  A stream that finds the
+    // pool empty -- lengths that lie -- goes on with its 64 KiB blocks.
+    unsigned fine_at = 0;
+    if (fine_on) {
+        if (lane == 0)
+            fine_at = atomicAdd(fine_cursor, nfine);
+        fine_at = uniform(fine_at);
+        fine_on = fine_at <= fine_pool && nfine <= fine_pool - fine_at;
+        fine_at += fine_first;
+    }
     const unsigned mark = fine_on ? kFine : kBlockOut;
     const unsigned shift = (unsigned)(u.src & 15u);
     const uint8_t *src_al = (const uint8_t *)u.src - shift;
@@ -1275,7 +1289,7 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
         w.job = u.job;
         w.aux = (uint64_t)state;
         w.reserved = (uint64_t)b | HAPGPU_BLOCK_FINE;
-        units[sc.fine_unit_first + b] = w;
+        units[fine_at + b] = w;
     }
     for (unsigned b = lane; b < nblk; b += 64u) {
         HapGpuDecodeUnit w;
@@ -1294,6 +1308,7 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
         units[sc.unit].reserved = (uint64_t)state;
         state->expected = nblk;
         state->expected_fine = fine_on ? nfine : 0u;
+        state->fine_unit_first = fine_at;
         atomicAdd(&state->found, found);
         atomicAdd(&state->found_fine, found_fine);
         atomicAdd(&state->probe_found, found_probe);
@@ -1438,14 +1453,16 @@ extern "C" int hapgpu_launch_snappy_decode_fields(const HapGpuDecodeUnit *units,
 // BLOCK units; the decode launch that follows must include the stream kernel.
 extern "C" int hapgpu_launch_scan_blocks(HapGpuDecodeUnit *units, const HapGpuDecodeJob *jobs, HapGpuScanChunk *chunks,
                                          unsigned chunk_count, HapGpuScanSegment *segs, void *recs, void *joins,
-                                         unsigned seg_total, uint32_t *fine_work, hipStream_t stream)
+                                         unsigned seg_total, uint32_t *fine_work, unsigned fine_first, unsigned fine_pool,
+                                         hipStream_t stream)
 {
     if (chunk_count == 0 || seg_total == 0)
         return 0;
     hipLaunchKernelGGL(scan_walk_kernel, dim3(seg_total), dim3(64), 0, stream, units, jobs, chunks, chunk_count, segs,
                        (unsigned long long *)recs, (uint2 *)joins, seg_total);
+    // (fine_work: [0] the list's length, then the list -- fine_pool entries --, then the pool's cursor)
     hipLaunchKernelGGL(scan_merge_kernel, dim3(chunk_count), dim3(64), 0, stream, units, jobs, chunks, chunk_count, segs,
-                       (const unsigned long long *)recs, (uint2 *)joins);
+                       (const unsigned long long *)recs, (uint2 *)joins, fine_work ? fine_work + 1u + fine_pool : nullptr, fine_first, fine_pool);
     hipLaunchKernelGGL(scan_find_kernel, dim3(seg_total), dim3(64), 0, stream, units, chunks, chunk_count, segs,
                        (const unsigned long long *)recs, (const uint2 *)joins, seg_total, 0u);
     hipLaunchKernelGGL(scan_find_kernel, dim3(seg_total), dim3(64), 0, stream, units, chunks, chunk_count, segs,

@@ -100,7 +100,7 @@ typedef struct HapGpuContext HapGpuContext;
                                                     decodes like a fragment with a table), decode every chunk with the
                                                     generic kernel -- what calls of fewer than 4096 such chunks do anyway.
                                                     The same for table-less frames whose chunks are many fragments long
-                                                    (plain hap.h frames of this library): calls with 65536 or more 8 KiB
+                                                    (plain hap.h frames of this library): calls with 32768 or more 8 KiB
                                                     pieces found by the block scan run the pre-pass over the pieces */
 #define HAPGPU_DECODE_GUESS_FIELDS 0x10u         /* ... do it however few the chunks / pieces are (tests) */
 #define HAPGPU_DECODE_NO_BLOCK_SCAN 0x4u         /* decode other encoders' Snappy streams with one wavefront per
