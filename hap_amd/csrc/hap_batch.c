@@ -1457,6 +1457,9 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     {
         unsigned chunk_cursor = 0, unit_cursor = 0, scan_cursor = 0, seg_cursor = 0, word_cursor = 0, fine_cursor = 0;
         request_marks marks;
+        const void *staged_src = NULL;
+        unsigned long staged_len = 0;
+        const uint8_t *staged_dev = NULL;
         marks.count = 0;
         marks.requested = NULL;
         for (f = 0; f < frame_count; f++) {
@@ -1469,10 +1472,17 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
             units = p->unit_count;
             job = &hjobs[job_of_frame[f]];
             memset(job, 0, sizeof(*job));
-            if (in_off[f]) {
+            if (in_off[f] && inputs[f] == staged_src && input_bytes[f] == staged_len) {
+                /* (the entry before this one was the same host frame -- HapGpuDecodeFramesRGBA asks for both textures of a
+                   frame in one call: one upload serves both) */
+                frame_dev = staged_dev;
+            } else if (in_off[f]) {
                 uint8_t *d = in_stage + (in_off[f] - 1);
                 rc |= hapgpu_rt_h2d(rt, d, inputs[f], input_bytes[f]);
                 frame_dev = d;
+                staged_src = inputs[f];
+                staged_len = input_bytes[f];
+                staged_dev = d;
             } else {
                 frame_dev = (const uint8_t *)inputs[f];
             }

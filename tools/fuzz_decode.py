@@ -43,6 +43,21 @@ if "--blocks" in sys.argv:
             r, used, _ = ctx.encode_frames([[tex]], [fmt], [1], [chunks], [out], flags=flags)
             assert r == 0
             bases = [(out[:used[0]].tobytes(), len(tex))] + bases
+# --guess (round 5): table-less frames of this library -- plain (the block scan's 8 KiB pieces) and with a chunk per
+# fragment -- through the batched call with the group-table pre-pass forced (HAPGPU_DECODE_GUESS_FIELDS): corrupted
+# pieces must be refused by the pre-pass or caught by the block-per-lane kernel, never decoded differently
+GUESS = "--guess" in sys.argv
+if GUESS:
+    wide = D.rgba(1024, 512, 4)
+    bases = []
+    for fmt, chunks in ((L.FMT_DXT5, 2), (L.FMT_YCOCG, 1), (L.FMT_DXT1, 3), (L.FMT_RGTC1, 1)):
+        tex = D.oracle_bc_encode(wide, fmt)
+        bases.append((ORA.encode([tex], [fmt], [1], [chunks])[1], len(tex)))
+        for flags, n_chunks in ((0, chunks), (hap_amd.ENCODE_FINE_CHUNKS, hap_amd.fine_chunk_count(len(tex), fmt))):
+            out = np.zeros(hap_amd.HapMaxEncodedLength([len(tex)], [fmt], [n_chunks]) + 65536, dtype=np.uint8)
+            r, used, _ = ctx.encode_frames([[tex]], [fmt], [1], [n_chunks], [out], flags=flags)
+            assert r == 0
+            bases += [(out[:used[0]].tobytes(), len(tex))] * 2
 a = D.oracle_bc_encode(img, L.FMT_YCOCG); b = D.oracle_bc_encode(img, L.FMT_RGTC1)
 bases.append((ORA.encode([a, b], [L.FMT_YCOCG, L.FMT_RGTC1], [1, 1], [2, 2])[1], len(a)))
 def oracle_in_child(frame, idx, cap):
@@ -93,8 +108,15 @@ for it in range(N):
         f[i:i] = bytes(rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8))
     f = bytes(f)
     for idx in (0, 1):
-        got = hap_amd.HapDecode(f, idx, outputBufferBytes=n + 16)
+        if GUESS:
+            buf = np.zeros(n + 16, dtype=np.uint8)
+            r_, du_, df_, dr_ = ctx.decode_frames([f], [len(f)], idx, [buf], flags=hap_amd.DECODE_GUESS_FIELDS)
+            got = (dr_[0], buf[: du_[0]].tobytes() if dr_[0] == 0 else None, df_[0] if dr_[0] == 0 else 0)
+        else:
+            got = hap_amd.HapDecode(f, idx, outputBufferBytes=n + 16)
         want = oracle_in_child(f, idx, n + 16)
+        if GUESS and got[0] != 0 and want[0] == got[0]:
+            got = want                                     # (the batched call reports no format for a frame that failed)
         if want[0] == -1:
             crashed += 1                                   # the reference algorithm read out of bounds
             assert got[0] != 0 or True
