@@ -198,9 +198,11 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
     const unsigned job_status = __builtin_nontemporal_load(&job->status);
     // fragment table version 4: 64 groups x 24 bits little endian (compressed bytes | bytes produced << 12), then the
     // number of elements (LE16)
-    const unsigned gat = 3u * lane;
-    const unsigned gentry = (unsigned)group_table[gat] | ((unsigned)group_table[gat + 1u] << 8) | ((unsigned)group_table[gat + 2u] << 16);
-    const unsigned elements_lo = group_table[192], elements_hi = group_table[193];
+    // (one dword at any byte address per lane -- lane 63's reaches into the element count, inside the table -- and one 16-bit load)
+    struct __attribute__((packed)) any32 { uint32_t v; };
+    struct __attribute__((packed)) any16 { uint16_t v; };
+    const unsigned gentry = reinterpret_cast<const any32 __attribute__((address_space(1))) *>(group_table + 3u * lane)->v & 0xFFFFFFu;
+    const unsigned elements_raw = reinterpret_cast<const any16 __attribute__((address_space(1))) *>(group_table + 192)->v;
     uint4 early[4];
 #pragma unroll
     for (unsigned i = 0; i < 4u; i++)
@@ -216,7 +218,7 @@ __device__ __forceinline__ void decode_fields_unit(const HapGpuDecodeUnit &u, Ha
     const unsigned oincl = (unsigned)fwave_scan_add((int)gout);
     const unsigned coff = gincl - gsz;
     const unsigned obegin = oincl - gout;                          // output position of the group's first element
-    const unsigned elements = (unsigned)__builtin_amdgcn_readfirstlane((int)(elements_lo | (elements_hi << 8)));
+    const unsigned elements = (unsigned)__builtin_amdgcn_readfirstlane((int)elements_raw);
     // every element is at least two bytes (a field) and every field belongs to one element: at most out_len / 4 of them
     // (the records, 4 bytes each, then fit the unit's own output range if they have to go to memory)
     if ((unsigned)__builtin_amdgcn_readlane((int)gincl, 63) != total || (unsigned)__builtin_amdgcn_readlane((int)oincl, 63) != out_len ||
