@@ -75,6 +75,9 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true",
                     help="the timed pipeline only: no size-for-speed option, texture->RGBA, host-pointer, foreign-frame, CPU "
                          "or C5 legs (what tools/prof_bench.sh profiles, so that every dispatch belongs to the headline)")
+    ap.add_argument("--extras-deadline", type=int, default=240,
+                    help="N > 1: seconds the legs beside the headline (other scaling mode, chunk groups with the RCCL gather) may take "
+                         "before rank 0 prints the line without them")
     ap.add_argument("--one-gpu-ranks", action="store_true",
                     help="dry run of the multi-rank path on ONE GPU (tests): every rank uses device 0 and the collectives "
                          "run over gloo (host copies) instead of RCCL; the codec is the real one.  Never a measurement")
@@ -373,27 +376,62 @@ def main():
     value = total_frames * rgba_bytes / elapsed / 1e9
 
     other = None
+    watchdog = None
     if world > 1:
-        # the other scaling mode beside the headline (same kernels, same step; a second timed region)
-        mode = "weak" if args.scaling == "strong" else "strong"
-        del stream.rgba, stream.frames, stream.dec, stream.dec_all
-        torch.cuda.empty_cache()
-        del stream.frames_b
-        s2 = Stream(hap_amd, ctx, dev, args.config, frames_of_rank(nf_total, rank, world, mode), flags, ctx_dec=ctx_dec)
-        e2, _p2 = s2.timed(args.steps, 1, fence, pipelined=pipelined)
-        e2 = max_over_ranks(e2)
-        f2 = (nf_total if mode == "strong" else nf_total * world) * args.steps
-        other = {"scaling": mode, "value": round(f2 * rgba_bytes / e2 / 1e9, 2), "unit": "GB/s", "fps": round(f2 / e2, 1),
-                 "ms_per_step": round(e2 / args.steps * 1e3, 3), "frames_per_step": f2 // args.steps}
-        del s2
-        torch.cuda.empty_cache()
-        groups = c5_chunk_groups(hap_amd, ctx, dist, dev, rank, world, fence)
+        # What follows is reported beside the headline, never required for it -- and it is the only part of this file
+        # with collectives on the data path (the optional RCCL gather of the chunk-group leg).  The headline is safe
+        # from it: an exception in a leg is reported in its place, and if a leg has not come back after
+        # --extras-deadline seconds (a rank that failed alone leaves the others waiting in a collective) rank 0 prints
+        # the line as it stands and every rank leaves.
+        import threading
+        core = {"metric": "RGBA GB/s + frames/sec, 8K Hap Q encode+decode" if args.config == "C4"
+                          else "RGBA GB/s + frames/sec, %s encode+decode" % args.config,
+                "value": round(value, 2), "unit": "GB/s", "fps": round(total_frames / elapsed, 1), "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                "config": {"workload": "%s, %d-frame stream, device-resident" % (args.config, nf_total),
+                           "parallelism": "frame f -> GPU f mod %d, no data-path collective" % world},
+                "bit_exact": bool(timed_bit_exact),
+                "extras": "not finished within %d s: the line was printed without them" % args.extras_deadline}
+
+        def give_up():
+            if rank == 0:
+                print(json.dumps(core))
+                sys.stdout.flush()
+            os._exit(0)
+
+        watchdog = threading.Timer(args.extras_deadline, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        groups = None
+        try:
+            # the other scaling mode beside the headline (same kernels, same step; a second timed region)
+            mode = "weak" if args.scaling == "strong" else "strong"
+            del stream.rgba, stream.frames, stream.dec, stream.dec_all
+            torch.cuda.empty_cache()
+            del stream.frames_b
+            s2 = Stream(hap_amd, ctx, dev, args.config, frames_of_rank(nf_total, rank, world, mode), flags, ctx_dec=ctx_dec)
+            e2, _p2 = s2.timed(args.steps, 1, fence, pipelined=pipelined)
+            e2 = max_over_ranks(e2)
+            f2 = (nf_total if mode == "strong" else nf_total * world) * args.steps
+            other = {"scaling": mode, "value": round(f2 * rgba_bytes / e2 / 1e9, 2), "unit": "GB/s", "fps": round(f2 / e2, 1),
+                     "ms_per_step": round(e2 / args.steps * 1e3, 3), "frames_per_step": f2 // args.steps}
+            del s2
+            torch.cuda.empty_cache()
+        except Exception as exc:
+            other = {"error": repr(exc)}
+        try:
+            groups = c5_chunk_groups(hap_amd, ctx, dist, dev, rank, world, fence)
+        except Exception as exc:
+            groups = {"error": repr(exc)}
     else:
         groups = None
 
     if rank != 0:
         if dist is not None:
             dist.barrier()
+            if watchdog is not None:
+                watchdog.cancel()
             dist.destroy_process_group()
         return
 
@@ -526,10 +564,21 @@ def main():
         line["roofline"] = stream.roofline(kernels, args.config)
         line["roofline"]["note"] = "rank 0's launches (%d frames per step)" % stream.nf
         line["cpu_baseline"] = None
+    if watchdog is not None:
+        watchdog.cancel()
     print(json.dumps(line))
     sys.stdout.flush()
     if dist is not None:
+        # (the line is out: a rank that never arrives must not keep this one from leaving)
+        leave = None
+        if world > 1:
+            import threading
+            leave = threading.Timer(60.0, lambda: os._exit(0))
+            leave.daemon = True
+            leave.start()
         dist.barrier()
+        if leave is not None:
+            leave.cancel()
         dist.destroy_process_group()
 
 

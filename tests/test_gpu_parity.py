@@ -2315,6 +2315,16 @@ def test_bench_multi_rank_path_runs_with_two_ranks_on_one_gpu():
     assert groups["bit_exact"] is True and groups["frame_bytes"] > 0
     assert set(groups["ms"]) >= {"encode_bands_ms", "gather_band_frames_ms", "join_on_device_ms", "decode_groups_tex0_ms",
                                  "decode_groups_tex1_ms", "gather_slices_tex0_ms", "gather_slices_tex1_ms"}
+    # The legs beside the headline are the only ones with collectives on the data path: when they do not come back in
+    # time (here: a deadline of no time at all) rank 0 prints the headline without them and every rank leaves -- one line,
+    # exit code 0.
+    done = subprocess.run([sys.executable, bench, "--gpus", "2", "--one-gpu-ranks", "--steps", "2", "--warmup", "1", "--frames", "6",
+                           "--extras-deadline", "0"], capture_output=True, text=True, timeout=900, env=env)
+    assert done.returncode == 0, done.stderr[-3000:]
+    lines = [json.loads(x) for x in done.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1
+    assert lines[0]["n_gpus"] == 2 and lines[0]["value"] > 0 and lines[0]["bit_exact"] is True and "not finished" in lines[0]["extras"]
+    assert lines[0]["scaling"] == "strong" and lines[0]["unit"] == "GB/s" and lines[0]["steps"] == 2
 
 
 @pytest.mark.parametrize("fmt,chunks", [(L.FMT_YCOCG, 3), (L.FMT_DXT1, 1), (L.FMT_RGTC1, 2), (L.FMT_BC7, 5)])
