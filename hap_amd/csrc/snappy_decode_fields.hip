@@ -59,6 +59,9 @@ constexpr int kGuessLdsBytes = 0;          // (see hapgpu_launch_guess_group_tab
 // studies), the set of DPP hops, one layout's code alone.  None changes what the kernel writes.  (The ablations of
 // round 4 that broke the output on purpose -- no rounds, no ring store, no overrun check -- are gone from the source.)
 // ring + parked input (at the end of the buffer: see the S computation below) + alignment slack
+// (The least an honest stream needs is 16 + 8320 + alignment: with 8416 + 32 bytes buffer + masks + offsets are 9216
+// bytes and a CU holds 17 wavefronts instead of 16 -- tried late in r05: C4 decode 0.640 -> 0.651 ms, C5 0.518 -> 0.528,
+// SLOWER; fragments that compress badly keep their records in memory sooner, and one more wavefront buys nothing.)
 #ifndef SDF_BUF_BYTES
 #define SDF_BUF_BYTES (9344u + 32u)
 #endif
