@@ -617,7 +617,9 @@ __global__ __launch_bounds__(64) void snappy_decode_fields_kernel(const HapGpuDe
 // busiest of its 64 fragments has elements.  Nor is a private 64-byte window per lane in LDS (four aligned 16-byte loads
 // per refill, tags read from the slot, no barrier): some lane of the 64 needs its refill at almost every turn, so the
 // wave waits for global loads as often as before -- 2.17 ms at 243 000 fragments, and 0.92 ms instead of 0.45 at 8 000,
-// where nothing but a lane's own latency counts.  This is the simplest of the three.
+// where nothing but a lane's own latency counts.  Cache hints on the tag loads do not help either: streaming (`nt`) loads
+// make the pre-pass 1.9 ms SLOWER per 60 frames (the lines a lane comes back to are gone), loads past the L1 change nothing.
+// This is the simplest of the three.
 // What is not a field stream -- another encoder's chunk of the same size, an element off a field boundary -- stays a
 // STREAM unit for the generic kernel: the walk checks the promises the table would have made.  (The kernel above checks
 // them all again; its verdict, not this one's, is what protects memory.)
