@@ -2,7 +2,7 @@
 //
 // Replaces the snappy_compress call-out of the reference's chunk loop (hap.c:448-476, call at hap.c:453) for DXT5 /
 // YCoCg-DXT5 / DXT1 / RGTC1 textures.  The output is ordinary Snappy (literal / copy-1 / copy-2 elements: the
-// reference decodes it unchanged) that keeps the promises of the private fragment table version 3
+// reference decodes it unchanged) that keeps the promises of the private fragment table version 4
 // (include/hap_gpu.h, snappy_decode_fields.hip): 8 KiB fragments, no element crosses a 128-byte half-tile, every
 // element starts and ends on a block-field boundary, copy offsets are whole blocks; and a table of the bytes of 64
 // groups of equally many elements per fragment, the decoder's starting points.  Its bytes are DEFINED by the
@@ -29,8 +29,9 @@
 //      of the fields start an element: a tag per field, predicated away, was half the kernel): phase 2 left a list
 //      of (half-tile, field) per element; the half-tile's masks give stream offset, length and kind; one to three tag
 //      bytes per element.
-//   4. GROUP TABLE: the N elements of the fragment in 64 groups of ceil(N / 64); the first element of every group
-//      leaves its stream offset behind during 3b; differences of neighbours are the 12-bit entries.
+//   4. GROUP TABLE (version 4): the N elements of the fragment in 64 groups of ceil(N / 64); the first element of every
+//      group leaves its stream offset and its output position behind during 3b; differences of neighbours are the
+//      24-bit entries (compressed bytes | bytes produced << 12), N follows.
 //
 // HBM traffic: texture read once (the neighbour loads hit L1 / L2), compressed bytes written once.
 #include <hip/hip_runtime.h>
@@ -55,6 +56,7 @@ template <> struct unit_layout<4u> {
     static constexpr unsigned block = 16u, code = 4u;
     static constexpr unsigned small32 = 0x11111111u;     // 2-byte fields of a half-tile
     static constexpr unsigned big32 = 0x22222222u;       // 6-byte fields
+    static constexpr unsigned four32 = 0xCCCCCCCCu;      // 4-byte fields
     static constexpr unsigned run3_12 = 0xBBBBBBBBu;     // starts whose 3-field run has >= 12 bytes
     static constexpr unsigned run15_61 = 0x22222222u;    // starts whose 15-field run has > 60 bytes
     __device__ static constexpr unsigned fo(unsigned k) { return k == 0u ? 0u : k == 1u ? 2u : k == 2u ? 8u : 12u; }
@@ -63,21 +65,21 @@ template <> struct unit_layout<4u> {
 };
 template <> struct unit_layout<2u> {
     static constexpr unsigned block = 8u, code = 10u;
-    static constexpr unsigned small32 = 0u, big32 = 0u, run3_12 = 0xFFFFFFFFu, run15_61 = 0u;
+    static constexpr unsigned small32 = 0u, big32 = 0u, four32 = 0xFFFFFFFFu, run3_12 = 0xFFFFFFFFu, run15_61 = 0u;
     __device__ static constexpr unsigned fo(unsigned k) { return 4u * k; }
     __device__ static constexpr unsigned fs(unsigned) { return 4u; }
     __device__ static constexpr unsigned cls(unsigned k) { return (k & 1u) ? 1u : 0u; }
 };
 template <> struct unit_layout<8u> {     // opaque 16-byte blocks (BC7, BC6H): four dwords, distances in whole blocks
     static constexpr unsigned block = 16u, code = 12u;
-    static constexpr unsigned small32 = 0u, big32 = 0u, run3_12 = 0xFFFFFFFFu, run15_61 = 0u;
+    static constexpr unsigned small32 = 0u, big32 = 0u, four32 = 0xFFFFFFFFu, run3_12 = 0xFFFFFFFFu, run15_61 = 0u;
     __device__ static constexpr unsigned fo(unsigned k) { return 4u * k; }
     __device__ static constexpr unsigned fs(unsigned) { return 4u; }
     __device__ static constexpr unsigned cls(unsigned k) { return k == 1u ? 1u : k == 3u ? 3u : 0u; }
 };
 template <> struct unit_layout<6u> {
     static constexpr unsigned block = 8u, code = 2u;
-    static constexpr unsigned small32 = 0x55555555u, big32 = 0xAAAAAAAAu, run3_12 = 0xAAAAAAAAu,
+    static constexpr unsigned small32 = 0x55555555u, big32 = 0xAAAAAAAAu, four32 = 0u, run3_12 = 0xAAAAAAAAu,
                               run15_61 = 0xAAAAAAAAu;
     __device__ static constexpr unsigned fo(unsigned k) { return k == 0u ? 0u : k == 1u ? 2u : k == 2u ? 8u : 10u; }
     __device__ static constexpr unsigned fs(unsigned k) { return (k & 1u) ? 6u : 2u; }
@@ -505,8 +507,19 @@ __global__ __launch_bounds__(64, SCB_MIN_WAVES) void snappy_compress_blocks_kern
             front = ends & U;
         }
         const unsigned cov = A[0] | A[1] | A[2] | A[3];
-        const unsigned Hm = mb.x & ~cov;
+        unsigned Hm = mb.x & ~cov;
         unsigned L = valid & ~(cov | Hm);
+        if (UL::four32 != 0u) {
+            // a copy of ONE 4-byte field with literal fields on both sides becomes literal bytes: one byte more, two
+            // elements fewer (the decoder's lanes walk ceil(elements / 64) of them each; phase 3b a pass per 64)
+            const unsigned cpy = cov | Hm;
+            const unsigned lone4 = cpy & ~(cpy << 1) & ~(cpy >> 1) & UL::four32 & (L << 1) & (L >> 1);
+            L |= lone4;
+            Hm &= ~lone4;
+#pragma unroll
+            for (unsigned d = 0; d < kDistances; d++)
+                A[d] &= ~lone4;
+        }
         unsigned S = 0;
 #pragma unroll
         for (int pass = 0; pass < 2; pass++) {

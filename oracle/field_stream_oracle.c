@@ -28,7 +28,8 @@
  *   c. per half-tile: copies are chosen left to right -- at the first uncovered matching position the NEAREST
  *      matching distance starts a copy that runs to the end of its match ("sticky"), the next one starts where it
  *      ends; a copy longer than 64 bytes is cut at field 16 (byte 64); fields no distance covers are single-field copies from their
- *      table candidate if they have one, literals otherwise;
+ *      table candidate if they have one, literals otherwise; a copy of one 4-byte field between two literal fields becomes
+ *      literal bytes too (one byte more, two elements fewer);
  *   d. literal runs take a 1-byte header up to 60 bytes and (0xF0, len - 1) above; copies are copy-1 when shorter
  *      than 12 bytes and nearer than 2048 bytes, else copy-2.
  */
@@ -122,10 +123,11 @@ unsigned ofs_compress_fragment(const uint8_t *src, unsigned n, unsigned layout, 
                 }
     }
     /* c. + d. per half-tile */
-    uint32_t small32 = 0, cls32 = 0;
+    uint32_t small32 = 0, cls32 = 0, four32 = 0;
     for (unsigned i = 0; i < 32; i++) {
         small32 |= (uint32_t)(L->fs[i & 3u] == 2u) << i;
         cls32 |= (uint32_t)(L->cls[i & 3u] != 0u) << i;
+        four32 |= (uint32_t)(L->fs[i & 3u] == 4u) << i;
     }
     for (unsigned h = 0; h * 32u < fields; h++) {
         const unsigned f0 = h * 32u;
@@ -166,6 +168,17 @@ unsigned ofs_compress_fragment(const uint8_t *src, unsigned n, unsigned layout, 
             cov |= A[d];
         H &= ~cov & cls32;
         uint32_t lit = valid & ~(cov | H), S = 0;
+        {
+            /* a copy of ONE 4-byte field with literal fields on both sides is not worth its two elements: as a copy it
+               costs 2 bytes and a second literal header, as literal bytes 4 -- one byte more for two elements fewer
+               (the decoder's lanes walk ceil(elements / 64) of them each) */
+            const uint32_t cpy = cov | H;
+            const uint32_t lone4 = cpy & ~(cpy << 1) & ~(cpy >> 1) & four32 & (lit << 1) & (lit >> 1);
+            lit |= lone4;
+            H &= ~lone4;
+            for (unsigned d = 0; d < OFS_DISTANCES; d++)
+                A[d] &= ~lone4;
+        }
         for (int pass = 0; pass < 2; pass++) {
             S = H | (lit & ~(lit << 1));
             for (unsigned d = 0; d < OFS_DISTANCES; d++)
