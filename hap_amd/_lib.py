@@ -44,6 +44,7 @@ def _load():
         "HapGpuFineChunkCount": (u, [ul, u]),
         "HapGpuTableFallbackCount": (ul, [vp]),
         "HapGpuPlacementRetryCount": (ul, [vp]),
+        "HapGpuResolvedBlockCount": (ul, [vp]),
         "HapGpuPlacementTimeoutCount": (ul, [vp]),
         "HapGpuCompressRGBA": (u, [vp, vp, u, u, ul, u, vp, ul, P(ul)]),
         "HapGpuDecompressRGBA": (u, [vp, vp, ul, u, vp, ul, u, u, vp, ul]),

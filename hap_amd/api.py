@@ -261,6 +261,10 @@ class Context:
     def synchronize(self):
         return lib.HapGpuSynchronize(self.handle)
 
+    def resolved_blocks(self):
+        """64 KiB blocks of other encoders' streams decoded by a workgroup each (HapGpuResolvedBlockCount)"""
+        return int(lib.HapGpuResolvedBlockCount(self.handle))
+
     def placement_retries(self):
         """frames encoded a second time because one of their chunks did not shrink (HapGpuPlacementRetryCount)"""
         return int(lib.HapGpuPlacementRetryCount(self.handle))

@@ -189,6 +189,17 @@ unsigned long HapGpuTableFallbackCount(HapGpuContext *context)
     return n;
 }
 
+unsigned long HapGpuResolvedBlockCount(HapGpuContext *context)
+{
+    unsigned long n;
+    if (!context)
+        return 0;
+    hapgpu_rt_lock(context->rt);
+    n = hapgpu_rt_resolved_blocks(context->rt);
+    hapgpu_rt_unlock(context->rt);
+    return n;
+}
+
 unsigned long HapGpuPlacementRetryCount(HapGpuContext *context)
 {
     unsigned long n;

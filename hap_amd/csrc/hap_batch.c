@@ -39,6 +39,7 @@ static double hapb_now_us(void) { struct timespec ts; clock_gettime(CLOCK_MONOTO
 #define HAPB_MARK(name) do { } while (0)
 #endif
 #define PREFIX_BYTES 2048u   /* headers + tables of a frame with up to ~400 chunks; larger ones are fetched on demand */
+#define PREFIX_BATCH_MAX_BYTES ((size_t)32u << 20)   /* the longer second prefix, all frames of a call together (x2: a far window each) */
 #define COPY_PIECE 65536u
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -1104,6 +1105,15 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
            on demand per frame and table) */
         for (prefix_pass = 0; prefix_pass < 2u; prefix_pass++) {
             size_t need_max = 0;
+            if (device_frames && prefix_pass == 1u) {
+                /* the longer prefix is a convenience, never a reason to fail the batch: if its scratch cannot
+                   be had, the call goes on with the short prefixes it already holds the sizes for, and tables beyond them
+                   are fetched on demand, frame by frame */
+                const size_t block = (size_t)prefix_bytes * frame_count;
+                if (!hapgpu_rt_device_scratch(rt, D_PREFIX, 2u * block + sizeof(uint64_t) * frame_count) ||
+                    !hapgpu_rt_pinned_scratch(rt, P_PREFIX, 2u * block + sizeof(uint64_t) * frame_count))
+                    prefix_bytes = PREFIX_BYTES;
+            }
             if (device_frames) {
                 /* one gather kernel + one copy bring every device frame's header prefix to the host -- and, for a later
                    texture of a multi-texture frame (which begins where the first one ends, far beyond the prefix), the
@@ -1243,11 +1253,17 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                     }
                     if (need > ins_end)
                         need = ins_end;
+                    /* (a table that claims to run past the end of its frame is a Bad_Frame for the planner; it does not
+                       get to size anybody's scratch) */
+                    if (need > input_bytes[f])
+                        need = input_bytes[f];
                     if (need > have && need > need_max)
                         need_max = need;
                 }
             }
-            if (need_max <= prefix_bytes || need_max > ((size_t)4u << 20))
+            /* (bounded per frame AND for the batch: one frame's claim decides the prefix of all of them) */
+            if (need_max <= prefix_bytes || need_max > ((size_t)4u << 20) ||
+                align_up(need_max, 256) * (size_t)frame_count > PREFIX_BATCH_MAX_BYTES)
                 break;
             prefix_bytes = align_up(need_max, 256);
             for (f = 0; f < frame_count; f++)

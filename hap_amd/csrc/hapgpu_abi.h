@@ -268,6 +268,8 @@ int hapgpu_rt_zero(hapgpu_rt *rt, void *dst, size_t bytes);
 /* 1: kernels may be handed pinned-scratch addresses directly (no copy in front of or behind them) */
 int hapgpu_rt_pinned_is_mapped(hapgpu_rt *rt);
 int hapgpu_rt_sync(hapgpu_rt *rt);
+/* 64 KiB blocks of other encoders' streams decoded by a workgroup each since the runtime was made (waits for the stream) */
+unsigned hapgpu_rt_resolved_blocks(hapgpu_rt *rt);
 void hapgpu_rt_lock(hapgpu_rt *rt);
 void hapgpu_rt_unlock(hapgpu_rt *rt);
 /* 0: the lock was free and is now held by the caller */

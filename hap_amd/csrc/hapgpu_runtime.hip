@@ -36,7 +36,8 @@ int hapgpu_launch_scan_blocks(HapGpuDecodeUnit *units, const HapGpuDecodeJob *jo
                               unsigned fine_first, unsigned fine_pool, hipStream_t stream);
 int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsigned unit_count, HapGpuDecodeJob *jobs,
                                 unsigned frag_log2, unsigned fragment_kinds, int any_stream_or_copy_units,
-                                const uint32_t *fine_work, unsigned fine_slots, hipStream_t stream);
+                                const uint32_t *fine_work, unsigned fine_slots, const void *scan_recs, const void *scan_joins,
+                                uint32_t *resolved, hipStream_t stream);
 }
 
 namespace {
@@ -71,6 +72,8 @@ struct hapgpu_rt {
     uint64_t generation;
     int graphs_off;      // unless HAP_AMD_GRAPHS=1
     int recording;
+    const void *scan_recs, *scan_joins;      // the block scan's records of the call in progress (for its decode launch)
+    uint32_t *resolved_blocks;               // device counter: 64 KiB blocks a workgroup decoded
 };
 
 #define HIP_OK(expr) ((expr) == hipSuccess)
@@ -127,6 +130,10 @@ extern "C" int hapgpu_rt_create(int device, hapgpu_rt **out)
         delete rt;
         return 4;
     }
+    if (hipMalloc((void **)&rt->resolved_blocks, 64u * sizeof(uint32_t)) != hipSuccess || hipMemset(rt->resolved_blocks, 0, 64u * sizeof(uint32_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        rt->resolved_blocks = nullptr;       // (a statistic: the decoder runs without it)
+    }
     *out = rt;
     return 0;
 }
@@ -149,6 +156,8 @@ extern "C" void hapgpu_rt_destroy(hapgpu_rt *rt)
         (void)hipEventDestroy(ev);
     for (auto &g : rt->graphs)
         (void)hipGraphExecDestroy(g.exec);
+    if (rt->resolved_blocks)
+        (void)hipFree(rt->resolved_blocks);
     (void)hipEventDestroy(rt->t0);
     (void)hipEventDestroy(rt->t1);
     (void)hipStreamDestroy(rt->stream);
@@ -679,6 +688,9 @@ extern "C" int hapgpu_k_scan_blocks(hapgpu_rt *rt, HapGpuDecodeUnit *units, cons
                                     uint32_t *fine_work, unsigned fine_first, unsigned fine_pool)
 {
     scoped_timing st(rt, 7);
+    // (the decode launch of the same call reads the scan's records again: the 64 KiB blocks as workgroups)
+    rt->scan_recs = recs;
+    rt->scan_joins = joins;
     return hapgpu_launch_scan_blocks(units, jobs, chunks, chunk_count, segs, recs, joins, seg_total, fine_work, fine_first, fine_pool,
                                      rt->stream);
 }
@@ -697,6 +709,29 @@ extern "C" int hapgpu_k_snappy_decode(hapgpu_rt *rt, const HapGpuDecodeUnit *uni
                                       int any_stream_or_copy_units, const uint32_t *fine_work, unsigned fine_slots)
 {
     scoped_timing st(rt, 5);
+    const void *recs = rt->scan_recs, *joins = rt->scan_joins;
+    rt->scan_recs = nullptr;                 // (one call's records: never another's)
+    rt->scan_joins = nullptr;
     return hapgpu_launch_snappy_decode(units, unit_count, jobs, frag_log2, fragment_kinds, any_stream_or_copy_units,
-                                       fine_work, fine_slots, rt->stream);
+                                       fine_work, fine_slots, any_stream_or_copy_units == 2 ? recs : nullptr,
+                                       any_stream_or_copy_units == 2 ? joins : nullptr, rt->resolved_blocks, rt->stream);
+}
+
+// 64 KiB blocks of other encoders' streams that a workgroup decoded (snappy_decode_block_resolve_kernel) since the runtime
+// was made; waits for the stream
+extern "C" unsigned hapgpu_rt_resolved_blocks(hapgpu_rt *rt)
+{
+    uint32_t v = 0;
+    if (!rt->resolved_blocks)
+        return 0;
+    if (hipStreamSynchronize(rt->stream) != hipSuccess || hipMemcpy(&v, rt->resolved_blocks, sizeof v, hipMemcpyDeviceToHost) != hipSuccess)
+        return 0;
+#ifdef BRK_TIMING
+    {
+        uint32_t d[16];
+        if (hipMemcpy(d, rt->resolved_blocks, sizeof d, hipMemcpyDeviceToHost) == hipSuccess && getenv("BRK_PRINT"))
+            fprintf(stderr, "brk: blocks %u  ticks records %u windows %u verify %u jump %u fetch %u  rounds %u windows %u\n", d[0], d[2], d[3], d[4], d[5], d[6], d[8], d[9]);
+    }
+#endif
+    return v;
 }

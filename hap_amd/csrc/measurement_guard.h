@@ -11,7 +11,7 @@
 #define HAP_AMD_MEASUREMENT_GUARD_H
 
 #if !defined(HAP_MEASUREMENT_BUILD) && ( \
-    defined(SDF_BUF_BYTES) || defined(SDF_DYN_LDS) || defined(SDF_HOPS) || defined(SDF_ONLY) || \
+    defined(SDF_BUF_BYTES) || defined(SDF_DYN_LDS) || defined(SDF_HOPS) || defined(BRK_TIMING) || defined(SDF_ONLY) || \
     defined(SDF_UNSAFE) || defined(SDF_ABL_NOROUNDS) || defined(SDF_ABL_NOPRODREADS) || defined(SDF_ABL_NORINGSTORE) || \
     defined(SCB_MIN_WAVES) || defined(SCB_PREFETCH) || defined(SCB_ONLY_FUSED_YCOCG) || defined(PLC_ABL) || defined(PLC_NO_INTERLEAVE) || \
     defined(HAP_BLK_FAR_FIRST) || defined(HAP_WG_WAVES) || defined(HAP_WG_SUBS) || defined(HAP_WG_HASH_BITS) || \

@@ -1430,6 +1430,469 @@ __global__ __launch_bounds__(64) void scan_decide_kernel(const HapGpuScanChunk *
         work[1u + base + b] = sc.fine_unit_first + b;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// 64 KiB blocks of other encoders' streams, a WORKGROUP each: pointers first, bytes last
+// ------------------------------------------------------------------------------------------
+//
+// The kernel above decodes a libsnappy block (hap.c:606-642's snappy_uncompress, for frames the reference's own HapEncode
+// wrote, hap.c:448-476) with ONE wavefront that takes its ~330 windows of 64 compressed bytes one after the other: 0.8 ms
+// for a block however idle the GPU is, and a whole 8K frame is only 506 blocks.  What is serial about a Snappy stream is
+// (a) where its elements begin and (b) that copies read what earlier elements wrote.  (a) is on record: the block scan
+// left, for every window of compressed bytes, the byte at which the element chain enters it and the output position
+// there (scan_walk's records, joined to the true chain by scan_merge).  (b) is a forest: every output byte either IS a
+// literal byte or EQUALS one earlier output byte of its block.  So sixteen wavefronts take a block together:
+//
+//   A. every window with a record is parsed speculatively (all 64 byte positions, chain membership by pointer doubling
+//      from the recorded entry -- the parser of the kernels above) and notes where its chain leaves it;
+//   B. the records are VERIFIED, not trusted: each window's exit must be the recorded entry (byte and output position)
+//      of the window it lands in, the block's first window is entered at the block's mark, exactly one chain ends at the
+//      next mark with the block's length, and no window is entered twice.  Windows the true chain enters without a usable
+//      record (the start of the one segment in a hundred whose guessed chain had not joined the true one yet) are
+//      walked by one wavefront from the exit of the window before them;
+//   C. the windows are parsed again, now with verified entries, and every output byte gets a 16-bit POINTER in LDS:
+//      a literal byte points to itself (and goes to memory at once), a copy byte to the byte it copies -- inside an
+//      overlapping copy to the pattern's first period, so that an element never chains through itself;
+//   D. pointer jumping, ptr[i] = ptr[ptr[i]], until nothing moves: as many rounds as the logarithm of the longest
+//      chain of copies of copies (3 to 5 for Hap textures), every round over all 64 Ki pointers by all 1024 lanes;
+//   E. every copy byte fetches the literal byte its pointer names from memory and is stored.
+//
+// Anything unexpected -- a record that does not verify, an element the window parser does not take, a copy that reaches
+// before its block -- and the kernel returns without a word: the unit is still there for the wavefront-per-block kernel
+// of the launch that follows, which decides what the stream's fault is called.  A block that went through becomes a SKIP
+// unit.  One 8K frame of the reference encoder: two blocks per CU instead of two wavefronts per CU.
+constexpr unsigned kBrkWaves = 16u, kBrkThreads = 64u * kBrkWaves;
+constexpr unsigned kBrkMaxWindows = 1024u;          // compressed bytes of a block this kernel takes: 64 KiB (libsnappy's blocks: ~21 KiB of a Hap Q texture)
+constexpr unsigned kBrkOwner = 512u;                // output bytes of one production pass of a wavefront
+constexpr unsigned kBrkStage = 512u;                // compressed bytes a wavefront stages per window: the window and the longest short literal behind it
+constexpr unsigned kBrkMaxRounds = 18u;
+
+struct BrkLds {
+    uint16_t ptr[kBlockOut];
+    uint32_t w_op[kBrkMaxWindows];                  // output position (inside the block) at the window's entry
+    uint32_t w_exit_p[kBrkMaxWindows];              // where the chain leaves the window (stream coordinate)
+    uint32_t w_exit_op[kBrkMaxWindows];             // ... and the output position there
+    uint8_t w_entry[kBrkMaxWindows];                // byte of the window at which the chain enters it; 0xFF: not on record
+    uint8_t w_in[kBrkMaxWindows];                   // windows whose chain leaves into this one
+    uint8_t owner[kBrkWaves][kBrkOwner];
+    uint8_t stage[kBrkWaves][kBrkStage + 16u];
+    uint32_t fail;
+    uint32_t ends;                                  // chains that end at the block's end
+};
+
+// eight bytes of the stream at the 8-byte aligned coordinate c; nothing at or beyond `end` is touched
+__device__ __forceinline__ uint2 brk_load8(const uint8_t *src_al, unsigned c, unsigned end)
+{
+    uint2 v = make_uint2(0u, 0u);
+    if (c + 8u <= end) {
+        v = *reinterpret_cast<const uint2 *>(src_al + c);
+    } else if (c < end) {
+        unsigned w[2] = {0u, 0u};
+#pragma unroll 1
+        for (unsigned k = 0; k < 8u && c + k < end; k++)
+            w[k >> 2] |= (unsigned)src_al[c + k] << (8u * (k & 3u));
+        v = make_uint2(w[0], w[1]);
+    }
+    return v;
+}
+
+// One window of one wavefront: the elements that begin in [ws + e, ws + 64) -- and the long literal the chain may stop at --
+// get their pointers (and the literal bytes go to memory); where the chain leaves the window comes back.  `bytes`: the
+// lane's eight of the 512 bytes from ws on.  false: something this kernel does not read.
+__device__ __forceinline__ bool brk_do_window(BrkLds &L, unsigned wave, unsigned lane, const uint8_t *src_al, uint8_t *dst, unsigned ws,
+                                              unsigned e, unsigned op, unsigned to, unsigned out_len, const uint2 bytes,
+                                              unsigned *exit_p, unsigned *exit_op)
+{
+    uint8_t *stage = L.stage[wave], *owner = L.owner[wave];
+    *reinterpret_cast<uint2 *>(stage + lane * 8u) = bytes;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // (stored as 8 bytes, read as dwords: no reordering by the compiler)
+    const unsigned x = ws + lane;
+    const uint32_t *st32 = reinterpret_cast<const uint32_t *>(stage);
+    const unsigned w0 = st32[lane >> 2], w1 = st32[(lane >> 2) + 1u];      // (a wave's LDS accesses complete in order)
+    const unsigned lo = __builtin_amdgcn_alignbyte(w1, w0, lane);          // bytes x .. x + 3 (the shift is lane & 3)
+    const unsigned hi = (w1 >> (8u * (lane & 3u))) & 0xFFu;                // byte x + 4
+    const unsigned tag = lo & 0xFFu, kind = tag & 3u;
+    unsigned len, off = 0, hdr;
+    bool special = false;
+    if (kind == 0u) {
+        len = (tag >> 2) + 1u;
+        hdr = 1u;
+        if (len == 61u) {
+            len = ((lo >> 8) & 0xFFu) + 1u;
+            hdr = 2u;
+        } else if (len > 61u) {
+            special = true;
+            hdr = 1u + (len - 60u);
+        }
+    } else if (kind == 1u) {
+        len = 4u + ((tag >> 2) & 7u);
+        off = ((tag >> 5) << 8) | ((lo >> 8) & 0xFFu);
+        hdr = 2u;
+    } else if (kind == 2u) {
+        len = (tag >> 2) + 1u;
+        off = (lo >> 8) & 0xFFFFu;
+        hdr = 3u;
+    } else {
+        len = (tag >> 2) + 1u;
+        off = (lo >> 8) | (hi << 24);
+        hdr = 5u;
+    }
+    const unsigned tokbytes = hdr + (kind == 0u ? len : 0u);
+    const bool stopper = special || x >= to || tokbytes > to - x;
+    const unsigned nxt = stopper ? 64u : min(lane + tokbytes, 64u);
+    while (e < 64u && ws + e < to) {
+        unsigned long long T = window_chain(stopper, nxt, lane, e);
+        if (T == 0ull) {
+            // a literal with 2..4 length bytes: the wavefront moves it, 64 bytes a turn, straight from memory
+            unsigned h = 0, llen = 0;
+            if (!scan_long_literal((unsigned)__builtin_amdgcn_readlane((int)lo, (int)e), (unsigned)__builtin_amdgcn_readlane((int)hi, (int)e),
+                                   ws + e, to, &h, &llen) || op > out_len || llen > out_len - op)
+                return false;
+            const unsigned at = ws + e + h;
+            for (unsigned done = lane; done < llen; done += 64u) {
+                L.ptr[op + done] = (uint16_t)(op + done);
+                dst[op + done] = src_al[at + done];
+            }
+            op += llen;
+            e += h + llen;                           // (far beyond this window)
+            break;
+        }
+        bool is_tok = __builtin_amdgcn_inverse_ballot_w64(T);
+        const int incl = wave_scan_add(is_tok ? (int)len : 0);
+        const unsigned o_t = (unsigned)incl - (is_tok ? len : 0u);
+        T &= ballot64(o_t + len <= kBrkOwner);                   // (prefix-closed: o_t is monotone; an element is at most 256 bytes)
+        is_tok = __builtin_amdgcn_inverse_ballot_w64(T);
+        const unsigned last = 63u - (unsigned)__builtin_clzll(T);
+        const unsigned N = (unsigned)__builtin_amdgcn_readlane(incl, (int)last);
+        const unsigned adv = last + (unsigned)__builtin_amdgcn_readlane((int)tokbytes, (int)last);
+        const bool bad = is_tok && ((kind != 0u && (off == 0u || off > op + o_t)) || len > out_len - op - o_t || o_t > out_len - op);
+        if (op > out_len || ballot64(bad) != 0ull)
+            return false;                            // (a copy from before the block among them: not this kernel's business)
+        for (unsigned k4 = lane * 4u; k4 < N; k4 += 256u)
+            *reinterpret_cast<uint32_t *>(owner + k4) = 0u;
+        if (is_tok)
+            owner[o_t] = (uint8_t)(lane + 1u);
+        // element attributes for the byte lanes: a0 = o_t (10 bits) | len (9) << 10 | literal << 19 | offset, saturated
+        // at 511, << 20 (it only matters where it is shorter than the copy); a1 = where the bytes come from: the
+        // literal's place in the staged bytes, or the copy's source position in the block
+        const int a0 = (int)(o_t | (len << 10) | (kind == 0u ? (1u << 19) : 0u) | (min(off, 511u) << 20));
+        const int a1 = (int)(kind == 0u ? lane + hdr : op + o_t - off);
+        unsigned carry = 0;
+        for (unsigned B = 0; B < N; B += 64u) {
+            const unsigned bb = B + lane;
+            const bool active = bb < N;
+            int m = active ? (int)owner[bb] : 0;
+            m = wave_scan_max(m);
+            m = max(m, (int)carry);
+            carry = (unsigned)__builtin_amdgcn_readlane(m, 63);
+            const unsigned sl = (unsigned)(m - 1) & 63u;
+            const unsigned g0 = (unsigned)lane_gather(a0, sl);
+            const unsigned g1 = (unsigned)lane_gather(a1, sl);
+            const unsigned rel = bb - (g0 & 0x3FFu);
+            const unsigned elen = (g0 >> 10) & 0x1FFu, eoff = g0 >> 20;
+            const bool lit = ((g0 >> 19) & 1u) != 0u;
+            if (active) {
+                const unsigned o = op + bb;
+                if (lit) {
+                    L.ptr[o] = (uint16_t)o;
+                    dst[o] = stage[(g1 + rel) & (kBrkStage - 1u)];          // (63 + 2 + 256 bytes from ws at most)
+                } else {
+                    unsigned r = rel;
+                    if (eoff < elen) {               // overlapping copy: every byte names the pattern's first period
+                        const unsigned mm = (unsigned)(65536.0f * __builtin_amdgcn_rcpf((float)eoff)) + 1u;
+                        r = rel - __umul24(__umul24(rel, mm) >> 16, eoff);
+                    }
+                    const unsigned src_pos = g1 + r;
+                    const unsigned there = L.ptr[src_pos];
+                    L.ptr[o] = (uint16_t)(there != 0xFFFFu ? there : src_pos);
+                }
+            }
+        }
+        op += N;
+        e = adv;
+    }
+    *exit_p = ws + e;
+    *exit_op = op;
+    return true;
+}
+
+__global__ __launch_bounds__(kBrkThreads) void snappy_decode_block_resolve_kernel(HapGpuDecodeUnit *units, unsigned unit_count,
+                                                                                  const HapGpuDecodeJob *jobs,
+                                                                                  const unsigned long long *__restrict__ recs,
+                                                                                  const uint2 *__restrict__ joins,
+                                                                                  uint32_t *resolved_counter)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
+    BrkLds &L = *reinterpret_cast<BrkLds *>(dynamic_lds);
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (blockIdx.x >= unit_count)
+        return;
+    const HapGpuDecodeUnit u = units[blockIdx.x];
+    if (u.kind != HAPGPU_UNIT_SNAPPY_BLOCK || (u.reserved & HAPGPU_BLOCK_FINE) != 0ull || jobs[u.job].status != 0u)
+        return;
+    // (the same decision the wavefront-per-block kernel takes: 64 KiB blocks run when every 64 KiB mark was found and
+    // the stream's 8 KiB pieces, if it has any, did not all check out)
+    const HapGpuScanChunk *scan = (const HapGpuScanChunk *)u.aux;
+    const bool fine_on = scan->expected_fine != 0u;
+    const bool fine_ok = fine_on && scan->found_fine == scan->expected_fine &&
+                         __hip_atomic_load(&scan->fine_failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+    if (scan->ok == 0u || fine_ok || scan->found != scan->expected)
+        return;
+    const uint32_t *bpos = (const uint32_t *)scan->bpos;
+    const unsigned b = (unsigned)u.reserved;
+    const unsigned marks = fine_on ? scan->expected_fine : scan->expected;
+    const unsigned first = fine_on ? 8u * b : b, last_mark = fine_on ? min(8u * b + 8u, marks) : b + 1u;
+    if (!(first < marks && last_mark <= marks))
+        return;
+    const unsigned from = bpos[first], to = bpos[last_mark], stream_end = bpos[marks];
+    const unsigned out_len = u.dst_len;
+    if (from >= to || to > stream_end || out_len == 0u || out_len > kBlockOut)
+        return;
+    const unsigned w0 = from >> 6, nw = ((to - 1u) >> 6) - w0 + 1u;
+    if (nw > kBrkMaxWindows)
+        return;
+    const uint8_t *src_al = (const uint8_t *)u.src;
+    uint8_t *dst = (uint8_t *)u.dst;
+    const unsigned blk_op = b * kBlockOut;
+#ifdef BRK_TIMING
+    unsigned long long tstamp[8];
+    unsigned rounds_done = 0;
+    tstamp[0] = wall_clock64();
+#define BRK_STAMP(k) tstamp[k] = wall_clock64()
+#else
+#define BRK_STAMP(k)
+#endif
+
+    // ---- the records of the block's windows: where the element chain enters each, and with how much output behind it ----
+    for (unsigned i = tid; i < nw; i += kBrkThreads) {
+        const unsigned ws = (w0 + i) << 6;
+        const unsigned seg = ws / kScanSegment, k = (ws % kScanSegment) >> 6;
+        unsigned e = 0xFFu, op = 0;
+        if (i == 0u) {
+            e = from & 63u;                          // the block's mark: an element begins there, with nothing of the block behind it
+        } else if (seg < scan->seg_count) {
+            const unsigned long long rec = recs[(size_t)(scan->seg_first + seg) * 64u + k];
+            const uint2 join = joins[scan->seg_first + seg];
+            const unsigned abs_op = join.y + (unsigned)(rec >> 8);
+            if (join.x < 64u && k >= join.x && ((unsigned)rec & 0xFFu) < 64u && abs_op - blk_op <= out_len && ws + ((unsigned)rec & 0xFFu) < to) {
+                e = (unsigned)rec & 0xFFu;
+                op = abs_op - blk_op;
+            }
+        }
+        L.w_entry[i] = (uint8_t)e;
+        L.w_op[i] = op;
+        L.w_in[i] = 0u;
+    }
+    // every pointer "not written yet": a copy byte whose source already has its pointer takes that one instead of the
+    // source's position -- the windows are worked through roughly in order, so most chains are short before the
+    // jumping starts (6.3 rounds without this).  (0xFFFF is no pointer a source can hold: a pointer is below its byte.)
+    for (unsigned i = tid * 8u; i < kBlockOut; i += kBrkThreads * 8u)
+        *reinterpret_cast<uint4 *>(&L.ptr[i]) = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    if (tid == 0) {
+        L.fail = 0u;
+        L.ends = 0u;
+    }
+    __syncthreads();
+    BRK_STAMP(1);
+
+    // ---- A. pointers for every output byte of the windows on record (literal bytes to memory); where their chains leave ----
+    // (a wavefront's next window is on its way from memory while it works on this one)
+    {
+        unsigned i = wave;
+        uint2 ahead = make_uint2(0u, 0u);
+        if (i < nw)
+            ahead = brk_load8(src_al, ((w0 + i) << 6) + lane * 8u, stream_end);
+        for (; i < nw; i += kBrkWaves) {
+            const uint2 bytes = ahead;
+            if (i + kBrkWaves < nw)
+                ahead = brk_load8(src_al, ((w0 + i + kBrkWaves) << 6) + lane * 8u, stream_end);
+            const unsigned e = L.w_entry[i];
+            if (e == 0xFFu)
+                continue;
+            unsigned xp = 0, xo = 0;
+            if (!brk_do_window(L, wave, lane, src_al, dst, (w0 + i) << 6, e, L.w_op[i], to, out_len, bytes, &xp, &xo)) {
+                L.fail = 1u;
+                break;
+            }
+            if (lane == 0) {
+                L.w_exit_p[i] = xp;
+                L.w_exit_op[i] = xo;
+            }
+        }
+    }
+    __syncthreads();
+    if (L.fail != 0u)
+        return;
+    BRK_STAMP(2);
+
+    // ---- B. verify the chain; walk what is not on record ----
+    if (wave == 0u) {
+        // (one wavefront: a window per lane finds out whether its exit is on record; the gaps are walked one after the
+        // other -- a handful of windows in one block of twenty)
+        for (unsigned base = 0; base < nw; base += 64u) {
+            const unsigned i = base + lane;
+            bool gap = false;
+            unsigned xp = 0, xo = 0;
+            if (i < nw && L.w_entry[i] != 0xFFu) {
+                xp = L.w_exit_p[i];
+                xo = L.w_exit_op[i];
+                if (xp < to) {
+                    const unsigned j = (xp >> 6) - w0;
+                    gap = !(j < nw && L.w_entry[j] == (xp & 63u) && L.w_op[j] == xo);
+                }
+            }
+            unsigned long long gaps = ballot64(gap);
+            while (gaps != 0ull) {
+                const unsigned g = (unsigned)__builtin_ctzll(gaps);
+                gaps &= gaps - 1ull;
+                unsigned p = (unsigned)__builtin_amdgcn_readlane((int)xp, (int)g), op = (unsigned)__builtin_amdgcn_readlane((int)xo, (int)g);
+                for (unsigned guard = 0; guard <= nw && p < to; guard++) {
+                    const unsigned j = (p >> 6) - w0;
+                    if (j >= nw) {
+                        L.fail = 1u;
+                        break;
+                    }
+                    if (L.w_entry[j] == (p & 63u) && L.w_op[j] == op)
+                        break;                       // on record from here on
+                    unsigned np = 0, nop = 0;
+                    const unsigned ws = (w0 + j) << 6;
+                    if (!brk_do_window(L, 0u, lane, src_al, dst, ws, p & 63u, op, to, out_len, brk_load8(src_al, ws + lane * 8u, stream_end), &np, &nop)) {
+                        L.fail = 1u;
+                        break;
+                    }
+                    if (lane == 0) {
+                        L.w_entry[j] = (uint8_t)(p & 63u);
+                        L.w_op[j] = op;
+                        L.w_exit_p[j] = np;
+                        L.w_exit_op[j] = nop;
+                    }
+                    p = np;
+                    op = nop;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (L.fail != 0u)
+        return;
+    // every window on the chain is entered exactly once (the first: by nobody), and one chain ends the block
+    for (unsigned i = tid; i < nw; i += kBrkThreads) {
+        if (L.w_entry[i] == 0xFFu)
+            continue;
+        const unsigned xp = L.w_exit_p[i], xo = L.w_exit_op[i];
+        if (xp == to && xo == out_len) {
+            atomicAdd(&L.ends, 1u);
+        } else if (xp < to && (xp >> 6) - w0 < nw && (xp >> 6) - w0 > i && xo <= out_len) {
+            const unsigned j = (xp >> 6) - w0;
+            if (L.w_entry[j] == (xp & 63u) && L.w_op[j] == xo) {
+                // (byte counters: four windows share a word)
+                atomicAdd(reinterpret_cast<uint32_t *>(L.w_in) + (j >> 2), 1u << (8u * (j & 3u)));
+            } else {
+                L.fail = 1u;
+            }
+        } else {
+            L.fail = 1u;
+        }
+    }
+    __syncthreads();
+    for (unsigned i = tid; i < nw; i += kBrkThreads)
+        if (L.w_entry[i] != 0xFFu && L.w_in[i] != (i == 0u ? 0u : 1u))
+            L.fail = 1u;
+    __syncthreads();
+    if (L.fail != 0u || L.ends != 1u || L.w_entry[0] == 0xFFu)
+        return;
+    BRK_STAMP(3);
+
+    // ---- C. pointer jumping: a group of four whose pointers have stopped moving is left alone from then on ----
+    {
+        unsigned pending = 0xFFFFu;                  // bit it: the thread's group (it * 1024 + tid) * 4 is not final yet
+        unsigned round = 0;
+        for (; round < kBrkMaxRounds; round++) {
+            int changed = 0;
+#pragma unroll 1
+            for (unsigned it = 0; it < 16u; it++) {
+                if (!((pending >> it) & 1u))
+                    continue;
+                const unsigned base = (it * kBrkThreads + tid) * 4u;
+                if (base >= out_len) {
+                    pending &= ~(1u << it);
+                    continue;
+                }
+                const uint2 v = *reinterpret_cast<const uint2 *>(&L.ptr[base]);
+                unsigned p[4] = {v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16};
+                const unsigned n = min(4u, out_len - base);
+#pragma unroll
+                for (unsigned k = 0; k < 4u; k++)
+                    if (k >= n)
+                        p[k] = base + k;             // (beyond a short block's end: nobody's bytes)
+                unsigned q[4];
+#pragma unroll
+                for (unsigned k = 0; k < 4u; k++)
+                    q[k] = L.ptr[p[k]];
+                if (q[0] == p[0] && q[1] == p[1] && q[2] == p[2] && q[3] == p[3]) {
+                    pending &= ~(1u << it);          // (what they point at points at itself: literal bytes)
+                } else {
+                    *reinterpret_cast<uint2 *>(&L.ptr[base]) = make_uint2(q[0] | (q[1] << 16), q[2] | (q[3] << 16));
+                    changed = 1;
+                }
+            }
+            if (!__syncthreads_or(changed))
+                break;
+        }
+        if (round == kBrkMaxRounds)
+            return;                                  // (never seen: 2^18 links; the other kernel writes the block again)
+#ifdef BRK_TIMING
+        rounds_done = round;
+#endif
+    }
+    BRK_STAMP(4);
+    // ---- D. every copy byte fetches the literal byte its pointer names ----
+    // (Ordinary cached loads: the literal bytes were written -- by whichever wavefront -- before the fence and the barrier
+    // below, this kernel has not read a byte of the block until now, and a CU's L1 starts a kernel empty; the copy bytes
+    // stored meanwhile may or may not show in a line that is already here, and nobody reads THEM.  Loads past the L1,
+    // one request per lane, took 72 us a block; sixteen loads of a lane are in flight together.)
+    // (a fence of WORKGROUP scope: the readers sit on this CU.  One of agent scope writes the XCD's L2 back and
+    // invalidates it -- 26 us a block)
+    __threadfence_block();
+    __syncthreads();
+#pragma unroll 1
+    for (unsigned base = tid; base < out_len; base += kBrkThreads * 16u) {
+        unsigned r[16], v[16];
+#pragma unroll
+        for (unsigned k = 0; k < 16u; k++) {
+            const unsigned o = base + k * kBrkThreads;
+            r[k] = o < out_len ? L.ptr[o] : o;
+        }
+#pragma unroll
+        for (unsigned k = 0; k < 16u; k++) {
+            const unsigned o = base + k * kBrkThreads;
+            v[k] = 0u;
+            if (r[k] != o)
+                v[k] = dst[r[k]];
+        }
+#pragma unroll
+        for (unsigned k = 0; k < 16u; k++) {
+            const unsigned o = base + k * kBrkThreads;
+            if (r[k] != o)
+                dst[o] = (uint8_t)v[k];
+        }
+    }
+    BRK_STAMP(5);
+    if (tid == 0) {
+        units[blockIdx.x].kind = HAPGPU_UNIT_SKIP;
+        if (resolved_counter)
+            atomicAdd(resolved_counter, 1u);
+#ifdef BRK_TIMING
+        if (resolved_counter) {
+            for (unsigned k = 0; k < 5u; k++)
+                atomicAdd(resolved_counter + 2u + k, (unsigned)(tstamp[k + 1u] - tstamp[k]));
+            atomicAdd(resolved_counter + 8u, rounds_done);
+            atomicAdd(resolved_counter + 9u, nw);
+        }
+#endif
+    }
+}
+
 } // namespace
 
 extern "C" int hapgpu_launch_decode_plan(HapGpuDecodeJob *jobs, unsigned job_count, unsigned max_chunks, hipStream_t stream)
@@ -1472,9 +1935,13 @@ extern "C" int hapgpu_launch_scan_blocks(HapGpuDecodeUnit *units, const HapGpuDe
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 
+// scan_recs / scan_joins: what the block scan of THIS call left (hapgpu_launch_scan_blocks), or null: the 64 KiB blocks
+// it found are then taken by a workgroup each first (snappy_decode_block_resolve_kernel); resolved: a counter of the
+// blocks that went through
 extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsigned unit_count, HapGpuDecodeJob *jobs,
                                            unsigned frag_log2, unsigned fragment_kinds, int any_stream_or_copy_units,
-                                           const uint32_t *fine_work, unsigned fine_slots, hipStream_t stream)
+                                           const uint32_t *fine_work, unsigned fine_slots, const void *scan_recs,
+                                           const void *scan_joins, uint32_t *resolved, hipStream_t stream)
 {
     if (unit_count == 0)
         return 0;
@@ -1507,8 +1974,37 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
         // device), then the ordinary units (phase 2) -- a stream whose 8 KiB pieces turned out not to be independent is
         // decoded by its 64 KiB blocks or whole in the second launch
         const bool two = any_stream_or_copy_units == 2 && fine_work != nullptr && fine_slots != 0u;
+        // A workgroup per 64 KiB block shortens the CALL -- a block takes 0.1 ms instead of 0.8 -- at about twice the work
+        // per block (the block scan's records are verified, the pointers jump): it pays while the blocks are few enough for
+        // the wavefront-per-block kernel to leave most of the GPU idle.  Measured on an MI355X (8K frames of the reference
+        // encoder, 528 blocks each): 1 frame 0.82 -> 0.26 ms, 2 frames 0.89 -> 0.49, 4 frames 1.00 -> 1.21: up to six
+        // units per CU (the units of a call are its streams and their blocks).
+        static int resolve_on = -1;
+        static unsigned resolve_max_units = 0;
+        if (resolve_on < 0) {
+            const char *e = HAP_AB_ENV("HAP_AMD_BLOCK_RESOLVE");
+            int dev = 0;
+            hipDeviceProp_t prop;
+            resolve_on = e ? atoi(e) : 1;
+            resolve_max_units = 6u * 256u;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                resolve_max_units = 6u * (unsigned)prop.multiProcessorCount;
+            if (resolve_on > 1)
+                resolve_max_units = 0xFFFFFFFFu;         // (measurement builds: every call)
+            if (hipFuncSetAttribute((const void *)snappy_decode_block_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)sizeof(BrkLds)) != hipSuccess) {
+                (void)hipGetLastError();
+                resolve_on = 0;
+            }
+        }
         for (unsigned phase = two ? 1u : any_stream_or_copy_units == 2 ? 2u : 0u; phase <= (any_stream_or_copy_units == 2 ? 2u : 0u); phase++) {
             const dim3 grid(phase == 1u ? fine_slots : unit_count);
+            // the 64 KiB blocks of the scanned streams, a workgroup each -- after the 8 KiB pieces of phase 1 (whose failures
+            // decide which units run), in front of the wavefront-per-unit launch that takes whatever is left
+            if (phase == 2u && resolve_on && scan_recs && scan_joins && unit_count <= resolve_max_units)
+                hipLaunchKernelGGL(snappy_decode_block_resolve_kernel, dim3(unit_count), dim3(kBrkThreads), sizeof(BrkLds), stream,
+                                   const_cast<HapGpuDecodeUnit *>(units), unit_count, jobs, (const unsigned long long *)scan_recs,
+                                   (const uint2 *)scan_joins, resolved);
             if (ring_log2 == 11)
                 hipLaunchKernelGGL((snappy_decode_fragment_kernel<2048u, true, 1u>), grid, dim3(64), 0, stream, units, grid.x, jobs, phase, fine_work);
             else if (ring_log2 == 12)

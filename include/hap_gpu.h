@@ -144,6 +144,12 @@ unsigned long HapGpuPlacementRetryCount(HapGpuContext *context);
  * context's life (its calls gather from then on); 0 in every run so far.  For tests and tools. */
 unsigned long HapGpuPlacementTimeoutCount(HapGpuContext *context);
 
+/* Number of 64 KiB blocks of OTHER encoders' Snappy streams (frames without this library's private table, e.g. what the
+ * reference's HapEncode writes: hap.c:448-476) that this context decoded with a whole workgroup each -- sixteen wavefronts
+ * resolving the block's copies by pointer jumping -- instead of one wavefront walking its elements.  Which of the two
+ * decodes a block changes nothing but the time it takes.  Waits for the context's stream.  For tests and tools. */
+unsigned long HapGpuResolvedBlockCount(HapGpuContext *context);
+
 /* RGBA8 (row-major, rowBytes stride, width/height multiples of 4) -> block
  * compressed texture.  textureFormat is one of RGB_DXT1, RGBA_DXT5,
  * YCoCg_DXT5, A_RGTC1 (A_RGTC1 compresses the alpha channel).  rgba and

@@ -688,6 +688,36 @@ def test_device_resident_batch_round_trip(ctx, hap):
             assert r == 0 and all(torch.equal(x, y) for x, y in zip(dec, dec2))
 
 
+def test_a_tiny_frame_that_claims_huge_tables_does_not_reach_its_neighbours(ctx, hap):
+    """the second, longer header read-back of a batch was sized by ONE frame's untrusted section lengths.  A
+    64-byte device frame whose Decode Instructions Container claims 3 MiB of tables is a Bad_Frame for itself (the
+    reference: hap.c:137-212 section lengths are checked against the buffer) and nothing for the valid frames around it."""
+    w, h = 512, 256
+    tex = [D.oracle_bc_encode(D.rgba(w, h, frame=i), L.FMT_YCOCG) for i in range(2)]
+    frames = []
+    for t in tex:
+        r, f = hap.HapEncode([t], [L.FMT_YCOCG], [1], [4])
+        assert r == 0
+        frames.append(f)
+    claim = 3 << 20
+    bad = bytearray(64)
+    bad[0:4] = (60).to_bytes(3, "little") + b"\xcf"                      # complex, scaled YCoCg-DXT5
+    bad[4:8] = (claim).to_bytes(3, "little") + b"\x01"                   # decode instructions container: 3 MiB
+    bad[8:12] = (claim - 8).to_bytes(3, "little") + b"\x02"              # compressor table: nearly all of it
+    batch = [frames[0], bytes(bad), frames[1], bytes(bad), frames[0]]
+    want = [tex[0], None, tex[1], None, tex[0]]
+    dframes = [torch.from_numpy(np.frombuffer(f, dtype=np.uint8).copy()).cuda() for f in batch]
+    decs = [torch.zeros(len(tex[0]), dtype=torch.uint8, device="cuda") for _ in batch]
+    torch.cuda.synchronize()
+    for _ in range(2):
+        r, du, df, dr = ctx.decode_frames(dframes, [len(f) for f in batch], 0, decs)
+        assert dr == [0, hap.HapResult.Bad_Frame, 0, hap.HapResult.Bad_Frame, 0] and r == hap.HapResult.Bad_Frame
+        for d, t in zip(decs, want):
+            assert t is None or d.cpu().numpy().tobytes() == t
+    for name, api in CHECKERS:
+        assert api.decode(bytes(bad), 0, len(tex[0]))[0] == hap.HapResult.Bad_Frame, name
+
+
 def test_both_textures_of_a_batch_decode_in_one_call(ctx, hap):
     """HapGpuDecodeFrameTextures: entry f * T + t is what HapDecode(frame f, index t) gives -- frames in HBM (second
     section located by the prefix gather itself), on the host, from a checker's encoder, and a single-texture frame
@@ -2055,6 +2085,49 @@ def test_smaller_files_flag_round_trips(ctx, hap):
                 assert ctx.table_fallbacks() == n0                     # every block start found: no second pass
         assert sizes[hap.ENCODE_SMALLER_FILES] < 0.97 * sizes[hap.ENCODE_FRAGMENT_INDEX], sizes
         assert sizes[hap.ENCODE_SMALLER_FILES] == sizes[hap.ENCODE_SMALLER_FILES | hap.ENCODE_FRAGMENT_INDEX]
+
+
+@pytest.mark.parametrize("kind", ["synthetic", "random", "flat", "stripes"])
+def test_blocks_of_reference_made_frames_go_through_a_workgroup_each(ctx, hap, kind):
+    """Round 6: in calls of few blocks the 64 KiB blocks the scan finds in another encoder's stream (hap.c:448-476 wrote
+    it, hap.c:606-642 would decode it) are decoded by a workgroup each -- records verified, pointers jumped, copy bytes
+    fetched -- instead of one wavefront walking the elements.  Same bytes as the checker's decoder, for textures that make
+    the stream all copies, all long literals, long overlapping runs and everything at once; and the counter says that
+    the workgroups did the work (a block they decline is decoded by the other kernel: that would pass unnoticed)."""
+    w, h, fmt = 2048, 1024, L.FMT_DXT5
+    if kind == "synthetic":
+        tex = D.oracle_bc_encode(D.rgba(w, h, frame=17), fmt)
+    elif kind == "random":
+        # (noise with a quarter of every 64 KiB repeated: literals of tens of kilobytes -- 2..4 length bytes -- between copies)
+        rnd = np.random.default_rng(5).integers(0, 256, (w // 4) * (h // 4) * 16, dtype=np.uint8)
+        for at in range(0, rnd.size, 65536):
+            rnd[at + 49152: at + 65536] = rnd[at + 1000: at + 1000 + 16384]
+        tex = rnd.tobytes()
+    elif kind == "flat":
+        tex = (b"\x10\x20" + bytes(6) + b"\x12\x34\x12\x34" + bytes(4)) * ((w // 4) * (h // 4))
+    else:
+        pat = np.random.default_rng(6).integers(0, 256, 4 * 16, dtype=np.uint8).tobytes()
+        tex = (pat * ((w // 4) * (h // 4) // 4 + 1))[: (w // 4) * (h // 4) * 16]
+    name, api = CHECKERS[-1]
+    for chunks in (1, 4):
+        r, frame = api.encode([tex], [fmt], [1], [chunks])
+        assert r == 0
+        blocks = chunks * ((len(tex) // chunks + 65535) // 65536)
+        dframe = torch.from_numpy(np.frombuffer(frame, dtype=np.uint8).copy()).cuda()
+        for where in ("device", "host"):
+            n0, f0 = ctx.resolved_blocks(), ctx.table_fallbacks()
+            if where == "device":
+                out = torch.full((len(tex),), 0x5A, dtype=torch.uint8, device="cuda")
+                torch.cuda.synchronize()
+                r, du, df, dr = ctx.decode_frames([dframe], [len(frame)], 0, [out])
+                got = out.cpu().numpy().tobytes()
+            else:
+                out = np.full(len(tex), 0x5A, dtype=np.uint8)
+                r, du, df, dr = ctx.decode_frames([frame], [len(frame)], 0, [out])
+                got = out.tobytes()
+            assert (r, du, df, dr) == (0, [len(tex)], [fmt], [0]) and got == tex, (kind, chunks, where)
+            assert ctx.table_fallbacks() == f0
+            assert ctx.resolved_blocks() - n0 == blocks, (kind, chunks, where, blocks)
 
 
 def test_block_scan_on_corrupted_streams_matches_the_checker(ctx, hap):

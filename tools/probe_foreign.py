@@ -48,6 +48,13 @@ for count in sorted({1, n}):
         ctx.decode_frames(fr, lens, 0, ou, flags)
         wall = ctx.timer_stop()
         ok = all(torch.equal(ou[i], tex[i]) for i in range(count))
-        print("%2d frame(s) %-13s: scan %.3f ms  decode %.3f ms  plan %.3f ms  call %.3f ms  %s" % (
+        blocks = sum((nbytes // chunks + 65535) // 65536 * chunks for _ in range(count))
+        r0 = ctx.resolved_blocks()
+        for o in ou:
+            o.zero_()
+        torch.cuda.synchronize()
+        ctx.decode_frames(fr, lens, 0, ou, flags)
+        ok = ok and all(torch.equal(ou[i], tex[i]) for i in range(count))
+        print("%2d frame(s) %-13s: scan %.3f ms  decode %.3f ms  plan %.3f ms  call %.3f ms  %s  (64 KiB blocks %d, by a workgroup each %d)" % (
             count, name, prof["block_scan"][1] / reps, prof["snappy_decode"][1] / reps, prof["decode_plan"][1] / reps,
-            wall, "ok" if ok else "MISMATCH"))
+            wall, "ok" if ok else "MISMATCH", blocks, ctx.resolved_blocks() - r0))
