@@ -47,7 +47,7 @@ CONFIGS = {
     "C5": (16384, 16384, [0x01, 0x8DBB], [64, 64], 4),
 }
 BLOCK_BYTES = {0x83F0: 8, 0x8DBB: 8, 0x83F3: 16, 0x01: 16}
-ROUND_TAG = "r05"        # profiles/<round>_traffic_<cfg>.json is what roofline.traffic quotes
+ROUND_TAG = "r06"        # profiles/<round>_traffic_<cfg>.json is what roofline.traffic quotes
 
 
 def parse_args():
@@ -303,10 +303,18 @@ class Stream:
         dom = kernel or max(cands, key=lambda k: kernels[k]["ms_total"])
         achieved = kernels[dom]["algorithmic_GBps"]
         traffic, source = measured_traffic(config, dom, self.nf)
-        return {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": source,
-                "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_launch"],
-                "avg_launch_ms": kernels[dom]["ms_avg"]}
+        r = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": source,
+             "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_launch"],
+             "avg_launch_ms": kernels[dom]["ms_avg"]}
+        # what these kernels actually sit on: vector instruction issue.  SQ_INSTS_VALU (the round's PMC pass over this
+        # command) x 4 cycles / (1024 SIMDs x 2.4 GHz) = the time the launch's vector instructions take issued back to
+        # back on every SIMD of the chip; as a share of the measured launch time
+        valu = measured_valu(config, dom, self.nf)
+        if valu and kernels[dom]["ms_avg"]:
+            r["issue_bound"] = round(valu * 4.0 / (1024 * 2.4e9) / (kernels[dom]["ms_avg"] * 1e-3), 4)
+            r["issue_bound_note"] = "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz) / avg_launch_ms"
+        return r
 
 
 def main():
@@ -503,7 +511,7 @@ def main():
         line["roofline"]["events_from"] = ("the serial region of the same K steps (each kernel runs by itself there; in the pipelined region the "
                                            "encode kernel of one batch and the decode kernels of the other share the GPU)") if serial is not None \
             else "the timed region"
-        line["roofline"]["profiled_as"] = "python bench.py --config %s --steps 2 --warmup 1 --frames %d --no-extras --serial (tools/prof_bench.sh -> profiles/%s_kernel_stats_%s.csv)" % (
+        line["roofline"]["profiled_as"] = "python bench.py --config %s --steps 20 --warmup 5 --frames %d --no-extras --serial (tools/prof_bench.sh -> profiles/%s_kernel_stats_%s.csv)" % (
             args.config, nf_total, ROUND_TAG, args.config.lower())
         line["kernels"] = kernels
         if not args.no_extras:
@@ -566,6 +574,8 @@ def main():
         line["cpu_baseline"] = None
     if watchdog is not None:
         watchdog.cancel()
+    if world == 1:
+        line["summary"] = summary_of(line)
     print(json.dumps(line))
     sys.stdout.flush()
     if dist is not None:
@@ -580,6 +590,47 @@ def main():
         if leave is not None:
             leave.cancel()
         dist.destroy_process_group()
+
+
+def summary_of(line):
+    """The numbers a reader of the line's LAST two thousand characters must find (the driver's record keeps the parsed
+    core and a tail of that length): per-kernel milliseconds of the headline config, the serial step, the small batch,
+    frames without the private table, frames of the reference encoder, and the other configs' headline figures."""
+    def g(o, *path):
+        for k in path:
+            o = o.get(k) if isinstance(o, dict) else None
+        return o
+    def r(v, n=4):
+        return round(v, n) if isinstance(v, (int, float)) else v
+    k = line.get("kernels") or {}
+    c5 = line.get("c5") or {}
+    ref, ref5 = line.get("decode_of_reference_encoded_frames") or {}, c5.get("decode_of_reference_encoded_frames") or {}
+    out = {
+        "c4": {"ms_step": line.get("ms_per_step"), "ms_step_serial": g(line, "serial_step", "ms_per_step"),
+               "kernels_ms": {n: r(v.get("ms_avg")) for n, v in k.items()},
+               "encode_only_ms": g(line, "encode_only", "ms"), "decode_only_ms": g(line, "decode_only", "ms"),
+               "ratio": g(line, "config", "snappy_ratio"), "roofline_frac": g(line, "roofline", "frac"),
+               "issue_bound": g(line, "roofline", "issue_bound"),
+               "decode_frac": r((g(k, "snappy_decode", "algorithmic_GBps") or 0) / HBM_PEAK_GBPS)},
+        "small_batch": {"ms_step": g(line, "small_batch", "pipelined", "ms_per_step"),
+                        "implied_strong_scaling_at_8": g(line, "small_batch", "implied_strong_scaling_at_8")},
+        "plain_frames_batched": {"decode_ms": g(line, "plain_frames_batched", "decode_ms"),
+                                 "encode_ms": g(line, "plain_frames_batched", "encode_ms")},
+        "per_call_hap_h": {"plain_decode_ms": g(line, "per_call_hap_h", "plain_frames", "decode_ms_per_call"),
+                           "table_decode_ms": g(line, "per_call_hap_h", "with_private_table", "decode_ms_per_call")},
+        "reference_frames": {"frames": ref.get("frames"), "ms": ref.get("ms"), "one_frame_ms": ref.get("one_frame_ms"),
+                             "frac": ref.get("frac_of_hbm_peak"), "bit_exact": ref.get("bit_exact")},
+        "c5": {"value": c5.get("value"), "ms_step": c5.get("ms_per_step"), "ms_step_serial": g(c5, "serial_step", "ms_per_step"),
+               "ratio": c5.get("snappy_ratio"), "decode_frac": g(c5, "roofline", "frac"), "decode_ms": g(c5, "roofline", "avg_launch_ms"),
+               "issue_bound": g(c5, "roofline", "issue_bound"),
+               "decode_by_layout_frac": {n: v.get("frac") for n, v in (c5.get("decode_by_layout") or {}).items() if isinstance(v, dict)},
+               "encode_only_ms": g(c5, "encode_only", "ms"), "kernels_ms": {n: r(v.get("ms_avg")) for n, v in (c5.get("kernels") or {}).items()},
+               "reference_frame_ms": ref5.get("ms"), "bit_exact": c5.get("bit_exact")},
+        "c2": {"value": g(line, "c2", "value"), "ratio": g(line, "c2", "snappy_ratio"), "decode_frac": g(line, "c2", "roofline", "frac")},
+        "c3": {"value": g(line, "c3", "value"), "ratio": g(line, "c3", "snappy_ratio"), "decode_frac": g(line, "c3", "roofline", "frac")},
+        "bit_exact": line.get("bit_exact"), "value": line.get("value"),
+    }
+    return out
 
 
 def selftest_cpu(args, dist, rank, world):
@@ -1390,6 +1441,18 @@ def measured_traffic(config, kernel, frames):
         return None, None
     scale = frames / float(t["frames_per_launch"])
     return int((2.0 * k["fetch_kib"] + k["write_kib"]) * 1024 * scale), "profiles/" + name
+
+
+def measured_valu(config, kernel, frames):
+    """Vector instructions per launch of `kernel` (SQ_INSTS_VALU of the same rocprofv3 PMC passes, scaled to this run's
+    frames per launch), or None."""
+    path = os.path.join(ROOT, "profiles", "%s_traffic_%s.json" % (ROUND_TAG, config.lower()))
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return float(t["kernels"][kernel]["valu_insts"]) * frames / float(t["frames_per_launch"])
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
 
 
 def cpu_baseline(w, h, fmts, chunks, rgba, dec, tex_bytes, cap, budget_s):

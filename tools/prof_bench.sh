@@ -13,7 +13,10 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 rm -rf $OUT; mkdir -p $OUT
 # (--serial: blocking calls on one context, so that every kernel runs by itself and its duration is its own -- the
 # region the bench line takes its per-kernel events and roofline from; frames per launch = the bench line's)
-CMD="python bench.py --config $CFG --steps 2 --warmup 1 --frames $FRAMES --no-extras --serial"
+# (r06: the bench's own step counts -- r05 profiled 2 steps after 1 warm-up and got launches 8-13 % slower than the
+# events of a 20-step region: cold clocks)
+STEPS=${STEPS:-20}; WARMUP=${WARMUP:-5}
+CMD="python bench.py --config $CFG --steps $STEPS --warmup $WARMUP --frames $FRAMES --no-extras --serial"
 echo "${3:+HAP_AMD_NO_FUSION=1 HAP_AMD_NO_PLACING=1 }$CMD" > $OUT/command.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb_trace -o r -- $CMD > $OUT/bench_trace.json 2> /tmp/pb_trace.err
 cp $(find /tmp/pb_trace -name "*kernel_stats.csv") $OUT/kernel_stats.csv

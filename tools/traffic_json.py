@@ -20,6 +20,18 @@ for line in open(src + "/traffic_summary.txt"):
     m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE)\s+mean/dispatch\s+([\d.]+)", line)
     if m:
         vals.setdefault(cur, {})[m.group(1)] = float(m.group(2))
+# vector instructions per dispatch, from the SQ pass of the same command (bench.py's roofline.issue_bound)
+valu = {}
+try:
+    for line in open(src + "/pmc_summary.txt"):
+        if not line.startswith(" "):
+            cur = line.strip()
+            continue
+        m = re.match(r"\s+SQ_INSTS_VALU\s+mean/dispatch\s+([\d.]+)", line)
+        if m:
+            valu[cur] = float(m.group(1))
+except OSError:
+    pass
 out = {"config": cfg, "frames_per_launch": frames, "command": open(src + "/command.txt").read().strip(),
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), tools/prof_bench.sh; raw per-kernel means in %s_traffic_summary_%s.txt" % (rnd, cfg.lower()),
        "kernels": {}, "per_kernel": vals}
@@ -31,5 +43,8 @@ for cls, pats in classes.items():
     per_step = max(1, round(line["kernels"].get(cls, {}).get("launches", line["steps"]) / line["steps"]))
     if f or w:
         out["kernels"][cls] = {"fetch_kib": round(f / per_step, 1), "write_kib": round(w / per_step, 1), "launches_per_step": per_step}
+        vi = sum(v for k, v in valu.items() if any(re.search(p, k) for p in pats))
+        if vi:
+            out["kernels"][cls]["valu_insts"] = round(vi / per_step, 1)
 json.dump(out, open("profiles/%s_traffic_%s.json" % (rnd, cfg.lower()), "w"), indent=1)
 print(json.dumps(out["kernels"]))
