@@ -81,6 +81,10 @@ def parse_args():
     ap.add_argument("--one-gpu-ranks", action="store_true",
                     help="dry run of the multi-rank path on ONE GPU (tests): every rank uses device 0 and the collectives "
                          "run over gloo (host copies) instead of RCCL; the codec is the real one.  Never a measurement")
+    ap.add_argument("--devices-from-c", type=int, default=0, metavar="N",
+                    help="the stream dealt out over N contexts on min(N, visible) GPUs by ONE process through the C entry points "
+                         "HapGpuEncodeFramesRGBAOnDevices / HapGpuDecodeFramesOnDevices (frame f -> context f mod N, a host thread "
+                         "per context, no collective): the multi-GPU road of a C client, same line shape as --gpus N")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="launch / rank / reduction logic only, gloo on CPU, a sleep in place of the codec (tests)")
     return ap.parse_args()
@@ -317,8 +321,81 @@ class Stream:
         return r
 
 
+def devices_from_c(args):
+    """One process, N contexts: frame f -> context f mod N (hap_devices.c).  The timed step is one
+    HapGpuEncodeFramesRGBAOnDevices call + one HapGpuDecodeFramesOnDevices call over the whole stream; `value` counts every
+    frame of every step, the clock is this process's (the calls return when every context has finished)."""
+    import time
+    import hap_amd
+    from hap_amd import synth
+    from hap_amd.api import encode_frames_rgba_on_devices, decode_frames_on_devices
+    w, h, fmts, chunks, nf_default = CONFIGS[args.config]
+    nf = args.frames or nf_default
+    n_ctx = args.devices_from_c
+    visible = torch.cuda.device_count()
+    devices = [c % visible for c in range(n_ctx)]
+    ctxs = [hap_amd.Context(d) for d in devices]
+    flags = 0 if args.no_fragment_index else hap_amd.ENCODE_FRAGMENT_INDEX
+    tex_bytes = [(w // 4) * (h // 4) * (8 if f in (0x83F0, 0x8DBB) else 16) for f in fmts]
+    cap = hap_amd.HapMaxEncodedLength(tex_bytes, fmts, chunks) + (1 << 20)
+    rgba, frames, decs = [], [], []
+    for f in range(nf):
+        dev = torch.device("cuda", devices[f % n_ctx])
+        rgba.append(synth.rgba_frame(w, h, f, device=dev))
+        frames.append(torch.zeros(cap, dtype=torch.uint8, device=dev))
+        decs.append([torch.zeros(b, dtype=torch.uint8, device=dev) for b in tex_bytes])
+    for d in range(visible):
+        torch.cuda.synchronize(d)
+
+    def step():
+        r, used, res = encode_frames_rgba_on_devices(ctxs, rgba, w, h, w * 4, fmts, [1] * len(fmts), chunks, frames, flags=flags)
+        assert r == 0 and res == [0] * nf, (r, res)
+        for t in range(len(fmts)):
+            r, du, df, dr = decode_frames_on_devices(ctxs, frames, used, t, [d[t] for d in decs])
+            assert r == 0 and dr == [0] * nf, (r, dr)
+        return used
+
+    for _ in range(args.warmup):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        used = step()
+    elapsed = time.perf_counter() - t0
+    # the last step's textures against the block encoder's (each on its own device)
+    ok = True
+    for f in range(0, nf, max(1, nf // 8)):
+        for t, fmt in enumerate(fmts):
+            want = torch.zeros(tex_bytes[t], dtype=torch.uint8, device=rgba[f].device)
+            torch.cuda.synchronize(rgba[f].device)
+            assert ctxs[f % n_ctx].compress_rgba(rgba[f], w, h, w * 4, fmt, want) == (0, tex_bytes[t])
+            ok = ok and bool(torch.equal(want, decs[f][t]))
+    rgba_bytes = w * h * 4
+    total = nf * args.steps
+    line = {"metric": "RGBA GB/s + frames/sec, 8K Hap Q encode+decode" if args.config == "C4"
+                      else "RGBA GB/s + frames/sec, %s encode+decode" % args.config,
+            "value": round(total * rgba_bytes / elapsed / 1e9, 2), "unit": "GB/s", "fps": round(total / elapsed, 1),
+            "n_gpus": min(n_ctx, visible), "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "step": "one HapGpuEncodeFramesRGBAOnDevices call + one HapGpuDecodeFramesOnDevices call per texture over the whole stream "
+                    "(blocking: the calls return when every context has finished)",
+            "config": {"workload": "%s: %dx%d %s, %s chunks, Snappy, %d-frame stream, device-resident" % (
+                           args.config, w, h, "+".join("%#x" % f for f in fmts), "+".join(map(str, chunks)), nf),
+                       "frames_per_step": nf, "contexts": n_ctx, "devices": sorted(set(devices)), "fragment_index": not args.no_fragment_index,
+                       "snappy_ratio": round(sum(used) / nf / sum(tex_bytes), 4),
+                       "parallelism": "one process: frame f -> context f mod %d (hap_devices.c), a host thread per context, "
+                                      "no data-path collective" % n_ctx},
+            "bit_exact": ok, "roofline": None, "cpu_baseline": None}
+    if min(n_ctx, visible) < n_ctx:
+        line["dry_run"] = "%d contexts share %d GPU(s): a functional check of the C road, not a scaling measurement" % (n_ctx, visible)
+    print(json.dumps(line))
+    sys.stdout.flush()
+
+
 def main():
     args = parse_args()
+    if args.devices_from_c:
+        return devices_from_c(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(respawn_under_torchrun(args))
 

@@ -37,7 +37,7 @@ int hapgpu_launch_scan_blocks(HapGpuDecodeUnit *units, const HapGpuDecodeJob *jo
 int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsigned unit_count, HapGpuDecodeJob *jobs,
                                 unsigned frag_log2, unsigned fragment_kinds, int any_stream_or_copy_units,
                                 const uint32_t *fine_work, unsigned fine_slots, const void *scan_recs, const void *scan_joins,
-                                uint32_t *resolved, hipStream_t stream);
+                                unsigned scan_blocks_hint, uint32_t *resolved, hipStream_t stream);
 }
 
 namespace {
@@ -73,6 +73,7 @@ struct hapgpu_rt {
     int graphs_off;      // unless HAP_AMD_GRAPHS=1
     int recording;
     const void *scan_recs, *scan_joins;      // the block scan's records of the call in progress (for its decode launch)
+    unsigned scan_blocks_hint;
     uint32_t *resolved_blocks;               // device counter: 64 KiB blocks a workgroup decoded
 };
 
@@ -691,6 +692,9 @@ extern "C" int hapgpu_k_scan_blocks(hapgpu_rt *rt, HapGpuDecodeUnit *units, cons
     // (the decode launch of the same call reads the scan's records again: the 64 KiB blocks as workgroups)
     rt->scan_recs = recs;
     rt->scan_joins = joins;
+    // (about how many 64 KiB blocks the scanned streams hold: an eighth of the 8 KiB pieces the host made room for -- what
+    // the frames' textures hold -- or, without those, what the compressed bytes would be at three to one)
+    rt->scan_blocks_hint = fine_pool ? fine_pool / 8u + 1u : seg_total / 5u + 1u;
     return hapgpu_launch_scan_blocks(units, jobs, chunks, chunk_count, segs, recs, joins, seg_total, fine_work, fine_first, fine_pool,
                                      rt->stream);
 }
@@ -714,7 +718,7 @@ extern "C" int hapgpu_k_snappy_decode(hapgpu_rt *rt, const HapGpuDecodeUnit *uni
     rt->scan_joins = nullptr;
     return hapgpu_launch_snappy_decode(units, unit_count, jobs, frag_log2, fragment_kinds, any_stream_or_copy_units,
                                        fine_work, fine_slots, any_stream_or_copy_units == 2 ? recs : nullptr,
-                                       any_stream_or_copy_units == 2 ? joins : nullptr, rt->resolved_blocks, rt->stream);
+                                       any_stream_or_copy_units == 2 ? joins : nullptr, rt->scan_blocks_hint, rt->resolved_blocks, rt->stream);
 }
 
 // 64 KiB blocks of other encoders' streams that a workgroup decoded (snappy_decode_block_resolve_kernel) since the runtime

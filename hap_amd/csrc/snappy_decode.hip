@@ -1935,13 +1935,13 @@ extern "C" int hapgpu_launch_scan_blocks(HapGpuDecodeUnit *units, const HapGpuDe
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 
-// scan_recs / scan_joins: what the block scan of THIS call left (hapgpu_launch_scan_blocks), or null: the 64 KiB blocks
-// it found are then taken by a workgroup each first (snappy_decode_block_resolve_kernel); resolved: a counter of the
-// blocks that went through
+// scan_recs / scan_joins: what the block scan of THIS call left (hapgpu_launch_scan_blocks), or null; scan_blocks_hint: about
+// how many 64 KiB blocks its streams hold: few enough, and a workgroup each takes them first
+// (snappy_decode_block_resolve_kernel); resolved: a counter of the blocks that went through
 extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsigned unit_count, HapGpuDecodeJob *jobs,
                                            unsigned frag_log2, unsigned fragment_kinds, int any_stream_or_copy_units,
                                            const uint32_t *fine_work, unsigned fine_slots, const void *scan_recs,
-                                           const void *scan_joins, uint32_t *resolved, hipStream_t stream)
+                                           const void *scan_joins, unsigned scan_blocks_hint, uint32_t *resolved, hipStream_t stream)
 {
     if (unit_count == 0)
         return 0;
@@ -1978,7 +1978,7 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
         // per block (the block scan's records are verified, the pointers jump): it pays while the blocks are few enough for
         // the wavefront-per-block kernel to leave most of the GPU idle.  Measured on an MI355X (8K frames of the reference
         // encoder, 528 blocks each): 1 frame 0.82 -> 0.26 ms, 2 frames 0.89 -> 0.49, 4 frames 1.00 -> 1.21: up to six
-        // units per CU (the units of a call are its streams and their blocks).
+        // blocks per CU (the host's estimate: what the scanned streams' textures hold).
         static int resolve_on = -1;
         static unsigned resolve_max_units = 0;
         if (resolve_on < 0) {
@@ -2001,7 +2001,7 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
             const dim3 grid(phase == 1u ? fine_slots : unit_count);
             // the 64 KiB blocks of the scanned streams, a workgroup each -- after the 8 KiB pieces of phase 1 (whose failures
             // decide which units run), in front of the wavefront-per-unit launch that takes whatever is left
-            if (phase == 2u && resolve_on && scan_recs && scan_joins && unit_count <= resolve_max_units)
+            if (phase == 2u && resolve_on && scan_recs && scan_joins && scan_blocks_hint <= resolve_max_units)
                 hipLaunchKernelGGL(snappy_decode_block_resolve_kernel, dim3(unit_count), dim3(kBrkThreads), sizeof(BrkLds), stream,
                                    const_cast<HapGpuDecodeUnit *>(units), unit_count, jobs, (const unsigned long long *)scan_recs,
                                    (const uint2 *)scan_joins, resolved);

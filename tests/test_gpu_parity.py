@@ -2401,6 +2401,26 @@ def test_bench_multi_rank_path_runs_with_two_ranks_on_one_gpu():
     assert lines[0]["scaling"] == "strong" and lines[0]["unit"] == "GB/s" and lines[0]["steps"] == 2
 
 
+def test_bench_times_the_c_road_over_several_contexts():
+    """`bench.py --devices-from-c N` deals the stream out over N contexts through the C entry points
+    (HapGpuEncodeFramesRGBAOnDevices / HapGpuDecodeFramesOnDevices, hap_devices.c) and prints the line shape of `--gpus N`.
+    With one GPU here the three contexts share it: the line says so (`dry_run`); the bytes are checked either way."""
+    import json
+    import os
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    done = subprocess.run([sys.executable, bench, "--devices-from-c", "3", "--steps", "2", "--warmup", "1", "--frames", "7", "--config", "C3"],
+                          capture_output=True, text=True, timeout=900)
+    assert done.returncode == 0, done.stderr[-3000:]
+    lines = [json.loads(x) for x in done.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["bit_exact"] is True and line["value"] > 0 and line["steps"] == 2 and line["unit"] == "GB/s"
+    assert line["config"]["contexts"] == 3 and line["config"]["frames_per_step"] == 7 and line["scaling"] == "strong"
+    assert line["n_gpus"] == min(3, torch.cuda.device_count()) and (("dry_run" in line) == (torch.cuda.device_count() < 3))
+
+
 @pytest.mark.parametrize("fmt,chunks", [(L.FMT_YCOCG, 3), (L.FMT_DXT1, 1), (L.FMT_RGTC1, 2), (L.FMT_BC7, 5)])
 def test_table_less_frames_of_this_library_decode_as_their_8k_fragments(ctx, hap, fmt, chunks):
     """What plain hap.h HapEncode writes by default: no private section, chunks that are concatenations of independent
