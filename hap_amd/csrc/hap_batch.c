@@ -950,11 +950,13 @@ static void mark_chunk(void *p, unsigned index)
    The output length is on the device (the stream's varint); bound it by the client's buffer and by the format's
    largest expansion (a 3-byte copy element produces 64 bytes).  Streams of one block need none. */
 static void scan_entry(HapGpuScanChunk *e, unsigned unit, unsigned long src_len, unsigned long dst_cap, uint32_t *dbpos,
-                       unsigned *seg_cursor, unsigned *word_cursor, unsigned fine_region_first, unsigned *fine_cursor);
+                       unsigned *seg_cursor, unsigned *word_cursor, unsigned seg_bytes, unsigned *fine_cursor);
 
-static unsigned stream_scan_segments(unsigned long src_len)
+/* seg_bytes: the call's segment size -- HAPGPU_SCAN_SEGMENT, or half of it in calls of few compressed bytes (r06): the scan's
+   first kernel walks a segment's windows one after the other, 64 + 12 of them at 4 KiB */
+static unsigned stream_scan_segments(unsigned long src_len, unsigned seg_bytes)
 {
-    return (unsigned)(((unsigned long long)src_len + 15u + HAPGPU_SCAN_SEGMENT - 1u) / HAPGPU_SCAN_SEGMENT);
+    return (unsigned)(((unsigned long long)src_len + 15u + seg_bytes - 1u) / seg_bytes);
 }
 
 static unsigned long long stream_output_bound(unsigned long src_len, unsigned long dst_cap)
@@ -999,17 +1001,17 @@ static unsigned stream_mark_words(unsigned long src_len, unsigned long dst_cap)
 }
 
 static void scan_entry(HapGpuScanChunk *e, unsigned unit, unsigned long src_len, unsigned long dst_cap, uint32_t *dbpos,
-                       unsigned *seg_cursor, unsigned *word_cursor, unsigned fine_region_first, unsigned *fine_cursor)
+                       unsigned *seg_cursor, unsigned *word_cursor, unsigned seg_bytes, unsigned *fine_cursor)
 {
     const unsigned coarse = stream_coarse_slots(src_len, dst_cap), fine = coarse ? stream_fine_slots(src_len, dst_cap) : 0u;
     memset(e, 0, sizeof(*e));
     e->unit = unit;
     e->seg_first = *seg_cursor;
-    e->seg_count = stream_scan_segments(src_len);
+    e->seg_count = stream_scan_segments(src_len, seg_bytes);
+    e->seg_bytes = seg_bytes;
     e->slots = coarse;
     e->fine_slots = fine;              /* (its words of block positions; the unit slots come from the call's pool, on the device) */
     e->fine_unit_first = 0;
-    (void)fine_region_first;
     e->bpos = (uint64_t)(uintptr_t)(dbpos + *word_cursor);
     *seg_cursor += e->seg_count;
     *word_cursor += stream_mark_words(src_len, dst_cap);
@@ -1033,6 +1035,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     uint8_t *dguess = NULL;
     int any_stream = 0, need_retry = 0;
     unsigned scan_chunks = 0, scan_segs = 0, scan_words = 0;   /* streams with BLOCK slots; their segments; bpos words */
+    unsigned scan_seg_bytes = HAPGPU_SCAN_SEGMENT;             /* (below: a quarter in calls of few compressed bytes) */
     unsigned fine_total = 0;                                   /* unit slots for the 8 KiB blocks of scanned streams */
     uint32_t *dwork = NULL;                                    /* [0]: count, then the fine units the scan listed */
     unsigned far_seen = 0;
@@ -1275,6 +1278,17 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     }
 
     HAPB_MARK("prefixes");
+    {
+        /* the block scan's segment size for this call: a wavefront of its first kernel walks a segment's windows one after
+           the other, and the merge kernel -- one wavefront per stream -- walks where a segment's guessed chain had not
+           joined the true one: halves shorten the first and lengthen the second (one reference-made 8K frame, walk + merge:
+           4 KiB ~175 us, 2 KiB 56 + 80, 1 KiB 60 + 122); batches keep 4 KiB (a warm-up of twelve windows per segment) */
+        unsigned long long total_in = 0;
+        for (f = 0; f < frame_count; f++)
+            total_in += input_bytes[f];
+        if (total_in <= ((unsigned long long)24u << 20))
+            scan_seg_bytes = HAPGPU_SCAN_SEGMENT / 2u;
+    }
     /* 2. plan on the host: sections and tables only (hap_frame.c) */
     for (f = 0; f < frame_count; f++) {
         hapf_texture_plan *p = &plans[f];
@@ -1376,7 +1390,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                     if ((p->chunks[c].codec & 0xFFu) == HAP_NIBBLE_SNAPPY && p->chunks[c].unit_count > 1u) {
                         guess_frame[f] |= 2;
                         scan_chunks += 1u;
-                        scan_segs += stream_scan_segments(p->chunks[c].src_len);
+                        scan_segs += stream_scan_segments(p->chunks[c].src_len, scan_seg_bytes);
                         scan_words += stream_mark_words(p->chunks[c].src_len, output_bytes[f]);
                         fine_sum += stream_fine_slots(p->chunks[c].src_len, output_bytes[f]);
                         streams += 1u;
@@ -1398,7 +1412,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
             if (units > 1u) {
                 guess_frame[f] |= 2;
                 scan_chunks += 1u;
-                scan_segs += stream_scan_segments(p->section_length);
+                scan_segs += stream_scan_segments(p->section_length, scan_seg_bytes);
                 scan_words += stream_mark_words(p->section_length, output_bytes[f]);
                 fine_total += stream_fine_slots(p->section_length, output_bytes[f]);
             }
@@ -1546,7 +1560,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                         if ((ch->codec & 0xFFu) != HAP_NIBBLE_SNAPPY || ch->unit_count <= 1u)
                             continue;
                         scan_entry(&hscan[scan_cursor++], unit_cursor + ch->unit_first, ch->src_len, output_bytes[f],
-                                   dbpos, &seg_cursor, &word_cursor, total_units, &fine_cursor);
+                                   dbpos, &seg_cursor, &word_cursor, scan_seg_bytes, &fine_cursor);
                     }
                 }
             } else {
@@ -1554,7 +1568,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
                 job->payload_len = p->section_length;
                 if (scan_chunks && p->mode == HAPGPU_JOB_SNAPPY && units > 1u)
                     scan_entry(&hscan[scan_cursor++], unit_cursor, p->section_length, output_bytes[f], dbpos, &seg_cursor,
-                               &word_cursor, total_units, &fine_cursor);
+                               &word_cursor, scan_seg_bytes, &fine_cursor);
             }
             if (dguess && use_scan_guess && (guess_frame[f] & 2) && field_layout_of_format(p->format) && !job->fields_period) {
                 const unsigned layout = field_layout_of_format(p->format);

@@ -218,7 +218,7 @@ typedef struct HapGpuScanChunk {
                                 do not make a stream's 8 KiB pieces independent): the 64 KiB blocks / the stream unit
                                 of the launch's second phase decode the stream instead */
     uint32_t fine_unit_first; /* device: index of the stream's first fine unit slot in the call's unit array (from the pool) */
-    uint32_t reserved;
+    uint32_t seg_bytes;      /* host: the call's segment size, HAPGPU_SCAN_SEGMENT or half of it (0: HAPGPU_SCAN_SEGMENT) */
     uint32_t probe_found;    /* of the first two 8 KiB marks (output positions 8192 and 16384): the rest of the fine
                                 marks are only looked for when both fall on element boundaries -- in a libsnappy
                                 stream they hardly ever do, and its scan then costs what it did with 64 KiB marks only */

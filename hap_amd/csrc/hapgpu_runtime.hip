@@ -732,9 +732,11 @@ extern "C" unsigned hapgpu_rt_resolved_blocks(hapgpu_rt *rt)
         return 0;
 #ifdef BRK_TIMING
     {
-        uint32_t d[16];
-        if (hipMemcpy(d, rt->resolved_blocks, sizeof d, hipMemcpyDeviceToHost) == hipSuccess && getenv("BRK_PRINT"))
+        uint32_t d[24];
+        if (hipMemcpy(d, rt->resolved_blocks, sizeof d, hipMemcpyDeviceToHost) == hipSuccess && getenv("BRK_PRINT")) {
+            fprintf(stderr, "brk: declined: too long %u, window %u, gap walk %u, links %u, ends %u, first %u\n", d[16], d[17], d[18], d[19], d[20], d[21]);
             fprintf(stderr, "brk: blocks %u  ticks records %u windows %u verify %u jump %u fetch %u  rounds %u windows %u\n", d[0], d[2], d[3], d[4], d[5], d[6], d[8], d[9]);
+        }
     }
 #endif
     return v;

@@ -870,7 +870,11 @@ __global__ __launch_bounds__(64) void snappy_decode_fragment_kernel(const HapGpu
 // hardly ever do: its scan costs what it did); scan_decide_kernel lists the fine units of the streams whose marks were
 // ALL found, and the decode launch runs that list as a first phase.  Marks on element boundaries do not make pieces
 // independent: a fine unit that fails hands its stream to the 64 KiB blocks / the stream unit of the second phase.
-constexpr unsigned kScanSegment = HAPGPU_SCAN_SEGMENT;
+constexpr unsigned kScanSegment = HAPGPU_SCAN_SEGMENT;       // the longest segment (LDS is sized for it); a call of few compressed bytes uses half
+__device__ __forceinline__ unsigned scan_segment_bytes(const HapGpuScanChunk &sc)
+{
+    return (sc.seg_bytes == kScanSegment / 2u) ? kScanSegment / 2u : kScanSegment;
+}
 // (5 windows -- longer than the longest element that is not a "long literal", 258 bytes -- let libsnappy's streams
 // join; the streams of this library's block compressor, with their long literal runs in noisy areas, need more: with 5
 // the merge kernel walked enough windows itself to take 0.22 ms for one 8K frame, with 12 it takes 0.05)
@@ -1007,7 +1011,8 @@ __global__ __launch_bounds__(64) void scan_walk_kernel(const HapGpuDecodeUnit *u
     const unsigned shift = (unsigned)(u.src & 15u);
     const uint8_t *src_al = (const uint8_t *)u.src - shift;
     const unsigned in_end = shift + u.src_len;
-    const unsigned seg_begin = s * kScanSegment, seg_end = seg_begin + kScanSegment;
+    const unsigned seg_bytes = scan_segment_bytes(sc);
+    const unsigned seg_begin = s * seg_bytes, seg_end = seg_begin + seg_bytes;
     unsigned long long rec = kRecNone;
     unsigned flags = 1u, cum = 0, p = 0;
     if (scan_unit_wanted(u, jobs) && s < sc.seg_count && seg_begin < in_end) {
@@ -1147,7 +1152,8 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
     __shared__ uint32_t l_exit[kMergeSegments];             // where segment i's recorded chain leaves it
     __shared__ uint32_t l_before[kMergeSegments + 1u];      // output of the good segments before i (entry to exit each)
     __shared__ unsigned long long l_good[kMergeSegments / 64u];
-    const unsigned nseg = (in_end + kScanSegment - 1u) / kScanSegment;
+    const unsigned seg_bytes = scan_segment_bytes(sc);
+    const unsigned nseg = (in_end + seg_bytes - 1u) / seg_bytes;
     const unsigned first_element = p;
     const bool tabled = nseg <= sc.seg_count && nseg <= kMergeSegments;
     if (tabled) {
@@ -1165,9 +1171,9 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
             unsigned long long r = kRecNone;
             if (mine)
                 here = segs[sc.seg_first + i];
-            const bool inside = mine && flags_prev == 0u && entry / kScanSegment == i && entry < in_end;
+            const bool inside = mine && flags_prev == 0u && entry / seg_bytes == i && entry < in_end;
             if (inside)
-                r = recs[(size_t)(sc.seg_first + i) * 64u + ((entry % kScanSegment) >> 6)];
+                r = recs[(size_t)(sc.seg_first + i) * 64u + ((entry % seg_bytes) >> 6)];
             const bool good = inside && ((unsigned)r & 0xFFu) == (entry & 63u) && (here.flags & 1u) == 0u;
             const unsigned delta = good ? here.cum_total - (unsigned)(r >> 8) : 0u;
             const unsigned incl = (unsigned)wave_scan_add((int)delta);
@@ -1185,7 +1191,7 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
         __syncthreads();
     }
     while (p < in_end) {
-        const unsigned s = p / kScanSegment, wi = (p % kScanSegment) >> 6, e = p & 63u;
+        const unsigned s = p / seg_bytes, wi = (p % seg_bytes) >> 6, e = p & 63u;
         if (tabled && p == (s == 0u ? first_element : l_exit[s - 1u]) && ((l_good[s / 64u] >> (s & 63u)) & 1ull)) {
             // a run of good segments [s, t): all their joins at once, then on to where the last one's chain leaves
             unsigned t = s + 1u;
@@ -1194,7 +1200,7 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
             const unsigned before_run = l_before[s];
             for (unsigned i = s + lane; i < t; i += 64u) {
                 const unsigned entry = i == 0u ? first_element : l_exit[i - 1u];
-                const unsigned w = (entry % kScanSegment) >> 6;
+                const unsigned w = (entry % seg_bytes) >> 6;
                 const unsigned at_entry = (unsigned)(recs[(size_t)(sc.seg_first + i) * 64u + w] >> 8);
                 joins[sc.seg_first + i] = make_uint2(w, op + (l_before[i] - before_run) - at_entry);
             }
@@ -1340,7 +1346,7 @@ __global__ __launch_bounds__(64) void scan_find_kernel(const HapGpuDecodeUnit *u
     const uint8_t *src_al = (const uint8_t *)u.src - shift;
     const unsigned in_end = shift + u.src_len, out_len = u.dst_len;
     uint32_t *bpos = (uint32_t *)sc.bpos;
-    const unsigned seg_begin = (g - sc.seg_first) * kScanSegment;
+    const unsigned seg_begin = (g - sc.seg_first) * scan_segment_bytes(sc);
     const unsigned long long rec = recs[(size_t)g * 64u + lane];
     const unsigned entry = (unsigned)rec & 0xFFu;
     const unsigned abs_op = base_op + (unsigned)(rec >> 8);              // output position at this window's entry
@@ -1649,8 +1655,15 @@ __global__ __launch_bounds__(kBrkThreads) void snappy_decode_block_resolve_kerne
     if (from >= to || to > stream_end || out_len == 0u || out_len > kBlockOut)
         return;
     const unsigned w0 = from >> 6, nw = ((to - 1u) >> 6) - w0 + 1u;
-    if (nw > kBrkMaxWindows)
+#ifdef BRK_TIMING
+#define BRK_WHY(k) do { if (tid == 0 && resolved_counter) atomicAdd(resolved_counter + 16u + (k), 1u); } while (0)
+#else
+#define BRK_WHY(k)
+#endif
+    if (nw > kBrkMaxWindows) {
+        BRK_WHY(0);
         return;
+    }
     const uint8_t *src_al = (const uint8_t *)u.src;
     uint8_t *dst = (uint8_t *)u.dst;
     const unsigned blk_op = b * kBlockOut;
@@ -1664,9 +1677,10 @@ __global__ __launch_bounds__(kBrkThreads) void snappy_decode_block_resolve_kerne
 #endif
 
     // ---- the records of the block's windows: where the element chain enters each, and with how much output behind it ----
+    const unsigned seg_bytes = scan_segment_bytes(*scan);
     for (unsigned i = tid; i < nw; i += kBrkThreads) {
         const unsigned ws = (w0 + i) << 6;
-        const unsigned seg = ws / kScanSegment, k = (ws % kScanSegment) >> 6;
+        const unsigned seg = ws / seg_bytes, k = (ws % seg_bytes) >> 6;
         unsigned e = 0xFFu, op = 0;
         if (i == 0u) {
             e = from & 63u;                          // the block's mark: an element begins there, with nothing of the block behind it
@@ -1721,8 +1735,10 @@ __global__ __launch_bounds__(kBrkThreads) void snappy_decode_block_resolve_kerne
         }
     }
     __syncthreads();
-    if (L.fail != 0u)
+    if (L.fail != 0u) {
+        BRK_WHY(1);
         return;
+    }
     BRK_STAMP(2);
 
     // ---- B. verify the chain; walk what is not on record ----
@@ -1773,8 +1789,10 @@ __global__ __launch_bounds__(kBrkThreads) void snappy_decode_block_resolve_kerne
         }
     }
     __syncthreads();
-    if (L.fail != 0u)
+    if (L.fail != 0u) {
+        BRK_WHY(2);
         return;
+    }
     // every window on the chain is entered exactly once (the first: by nobody), and one chain ends the block
     for (unsigned i = tid; i < nw; i += kBrkThreads) {
         if (L.w_entry[i] == 0xFFu)
@@ -1799,8 +1817,10 @@ __global__ __launch_bounds__(kBrkThreads) void snappy_decode_block_resolve_kerne
         if (L.w_entry[i] != 0xFFu && L.w_in[i] != (i == 0u ? 0u : 1u))
             L.fail = 1u;
     __syncthreads();
-    if (L.fail != 0u || L.ends != 1u || L.w_entry[0] == 0xFFu)
+    if (L.fail != 0u || L.ends != 1u || L.w_entry[0] == 0xFFu) {
+        BRK_WHY(L.fail != 0u ? 3 : L.ends != 1u ? 4 : 5);
         return;
+    }
     BRK_STAMP(3);
 
     // ---- C. pointer jumping: a group of four whose pointers have stopped moving is left alone from then on ----
@@ -1975,10 +1995,12 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
         // decoded by its 64 KiB blocks or whole in the second launch
         const bool two = any_stream_or_copy_units == 2 && fine_work != nullptr && fine_slots != 0u;
         // A workgroup per 64 KiB block shortens the CALL -- a block takes 0.1 ms instead of 0.8 -- at about twice the work
-        // per block (the block scan's records are verified, the pointers jump): it pays while the blocks are few enough for
-        // the wavefront-per-block kernel to leave most of the GPU idle.  Measured on an MI355X (8K frames of the reference
-        // encoder, 528 blocks each): 1 frame 0.82 -> 0.26 ms, 2 frames 0.89 -> 0.49, 4 frames 1.00 -> 1.21: up to six
-        // blocks per CU (the host's estimate: what the scanned streams' textures hold).
+        // per block (the block scan's records are verified, the pointers jump) and with one workgroup per CU: it pays while
+        // the blocks are few enough for the wavefront-per-block kernel to leave most of the GPU idle.  Measured on an
+        // MI355X, decode kernels of a call, 8K frames of the reference encoder (528 blocks each): DXT5 1 frame 0.82 -> 0.26 ms,
+        // 2 frames 0.89 -> 0.49, 3 frames 0.95 -> 0.91, 4 frames 1.00 -> 1.21; Hap Q (more elements per block) 1 frame 0.38,
+        // 2 frames 0.68, 3 frames 1.11 against 1.12 for FOUR frames the other way: up to four blocks per CU (the host's
+        // estimate: what the scanned streams' textures hold).
         static int resolve_on = -1;
         static unsigned resolve_max_units = 0;
         if (resolve_on < 0) {
@@ -1986,9 +2008,9 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
             int dev = 0;
             hipDeviceProp_t prop;
             resolve_on = e ? atoi(e) : 1;
-            resolve_max_units = 6u * 256u;
+            resolve_max_units = 4u * 256u;
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                resolve_max_units = 6u * (unsigned)prop.multiProcessorCount;
+                resolve_max_units = 4u * (unsigned)prop.multiProcessorCount;
             if (resolve_on > 1)
                 resolve_max_units = 0xFFFFFFFFu;         // (measurement builds: every call)
             if (hipFuncSetAttribute((const void *)snappy_decode_block_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
