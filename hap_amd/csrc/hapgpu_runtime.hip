@@ -37,7 +37,8 @@ int hapgpu_launch_scan_blocks(HapGpuDecodeUnit *units, const HapGpuDecodeJob *jo
 int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsigned unit_count, HapGpuDecodeJob *jobs,
                                 unsigned frag_log2, unsigned fragment_kinds, int any_stream_or_copy_units,
                                 const uint32_t *fine_work, unsigned fine_slots, const void *scan_recs, const void *scan_joins,
-                                unsigned scan_blocks_hint, uint32_t *resolved, hipStream_t stream);
+                                const HapGpuScanChunk *scan_chunks, unsigned scan_chunk_count, unsigned scan_blocks_hint,
+                                uint32_t *resolved, hipStream_t stream);
 }
 
 namespace {
@@ -74,6 +75,8 @@ struct hapgpu_rt {
     int recording;
     const void *scan_recs, *scan_joins;      // the block scan's records of the call in progress (for its decode launch)
     unsigned scan_blocks_hint;
+    const HapGpuScanChunk *scan_chunks;
+    unsigned scan_chunk_count;
     uint32_t *resolved_blocks;               // device counter: 64 KiB blocks a workgroup decoded
 };
 
@@ -692,6 +695,8 @@ extern "C" int hapgpu_k_scan_blocks(hapgpu_rt *rt, HapGpuDecodeUnit *units, cons
     // (the decode launch of the same call reads the scan's records again: the 64 KiB blocks as workgroups)
     rt->scan_recs = recs;
     rt->scan_joins = joins;
+    rt->scan_chunks = chunks;
+    rt->scan_chunk_count = chunk_count;
     // (about how many 64 KiB blocks the scanned streams hold: an eighth of the 8 KiB pieces the host made room for -- what
     // the frames' textures hold -- or, without those, what the compressed bytes would be at three to one)
     rt->scan_blocks_hint = fine_pool ? fine_pool / 8u + 1u : seg_total / 5u + 1u;
@@ -718,7 +723,8 @@ extern "C" int hapgpu_k_snappy_decode(hapgpu_rt *rt, const HapGpuDecodeUnit *uni
     rt->scan_joins = nullptr;
     return hapgpu_launch_snappy_decode(units, unit_count, jobs, frag_log2, fragment_kinds, any_stream_or_copy_units,
                                        fine_work, fine_slots, any_stream_or_copy_units == 2 ? recs : nullptr,
-                                       any_stream_or_copy_units == 2 ? joins : nullptr, rt->scan_blocks_hint, rt->resolved_blocks, rt->stream);
+                                       any_stream_or_copy_units == 2 ? joins : nullptr, rt->scan_chunks, rt->scan_chunk_count,
+                                       rt->scan_blocks_hint, rt->resolved_blocks, rt->stream);
 }
 
 // 64 KiB blocks of other encoders' streams that a workgroup decoded (snappy_decode_block_resolve_kernel) since the runtime

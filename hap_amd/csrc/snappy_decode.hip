@@ -1484,6 +1484,8 @@ struct BrkLds {
     uint8_t stage[kBrkWaves][kBrkStage + 16u];
     uint32_t fail;
     uint32_t ends;                                  // chains that end at the block's end
+    uint32_t work;                                  // the block the workgroup has just taken
+    uint32_t stream_first[256u + 1u];               // blocks of the call's scanned streams before stream c (kBrkMaxStreams)
 };
 
 // eight bytes of the stream at the 8-byte aligned coordinate c; nothing at or beyond `end` is touched
@@ -1622,19 +1624,16 @@ __device__ __forceinline__ bool brk_do_window(BrkLds &L, unsigned wave, unsigned
     return true;
 }
 
-__global__ __launch_bounds__(kBrkThreads) void snappy_decode_block_resolve_kernel(HapGpuDecodeUnit *units, unsigned unit_count,
-                                                                                  const HapGpuDecodeJob *jobs,
-                                                                                  const unsigned long long *__restrict__ recs,
-                                                                                  const uint2 *__restrict__ joins,
-                                                                                  uint32_t *resolved_counter)
+// One block: units[unit_index].  only_full: the first sweep of a launch takes the whole 64 KiB blocks, the second the short
+// ones at the ends of their streams -- the last workgroups to finish then finish soon.
+__device__ __forceinline__ void brk_block(BrkLds &L, HapGpuDecodeUnit *units, unsigned unit_index, bool only_full, const HapGpuDecodeJob *jobs,
+                                          const unsigned long long *__restrict__ recs, const uint2 *__restrict__ joins,
+                                          uint32_t *resolved_counter)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
-    BrkLds &L = *reinterpret_cast<BrkLds *>(dynamic_lds);
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    if (blockIdx.x >= unit_count)
-        return;
-    const HapGpuDecodeUnit u = units[blockIdx.x];
-    if (u.kind != HAPGPU_UNIT_SNAPPY_BLOCK || (u.reserved & HAPGPU_BLOCK_FINE) != 0ull || jobs[u.job].status != 0u)
+    const HapGpuDecodeUnit u = units[unit_index];
+    if (u.kind != HAPGPU_UNIT_SNAPPY_BLOCK || (u.reserved & HAPGPU_BLOCK_FINE) != 0ull || jobs[u.job].status != 0u ||
+        (u.dst_len == kBlockOut) != only_full)
         return;
     // (the same decision the wavefront-per-block kernel takes: 64 KiB blocks run when every 64 KiB mark was found and
     // the stream's 8 KiB pieces, if it has any, did not all check out)
@@ -1899,7 +1898,7 @@ __global__ __launch_bounds__(kBrkThreads) void snappy_decode_block_resolve_kerne
     }
     BRK_STAMP(5);
     if (tid == 0) {
-        units[blockIdx.x].kind = HAPGPU_UNIT_SKIP;
+        units[unit_index].kind = HAPGPU_UNIT_SKIP;
         if (resolved_counter)
             atomicAdd(resolved_counter, 1u);
 #ifdef BRK_TIMING
@@ -1910,6 +1909,62 @@ __global__ __launch_bounds__(kBrkThreads) void snappy_decode_block_resolve_kerne
             atomicAdd(resolved_counter + 9u, nw);
         }
 #endif
+    }
+}
+
+// As many workgroups as the GPU has CUs (each fills one: 158 KiB of LDS), every one taking blocks off a counter until there
+// are none: block after block without a dispatch in between (a grid of one workgroup per block took 350 us for the 528
+// blocks of an 8K frame, this takes 258), full blocks first.  The blocks are those of the call's scanned streams (scan_merge
+// wrote their units behind each stream's own): stream c's block b is units[chunks[c].unit + 1 + b].
+constexpr unsigned kBrkMaxStreams = 256u;
+__global__ __launch_bounds__(kBrkThreads) void snappy_decode_block_resolve_kernel(HapGpuDecodeUnit *units, unsigned unit_count,
+                                                                                  const HapGpuScanChunk *chunks, unsigned chunk_count,
+                                                                                  const HapGpuDecodeJob *jobs,
+                                                                                  const unsigned long long *__restrict__ recs,
+                                                                                  const uint2 *__restrict__ joins,
+                                                                                  uint32_t *resolved_counter, uint32_t *work_counter)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
+    BrkLds &L = *reinterpret_cast<BrkLds *>(dynamic_lds);
+    const unsigned tid = threadIdx.x;
+    if (chunk_count == 0u || chunk_count > kBrkMaxStreams)
+        return;
+    if (tid < chunk_count) {
+        const HapGpuScanChunk sc = chunks[tid];
+        // (what scan_merge wrote: `expected` blocks behind the stream's unit, inside the slots the host reserved)
+        L.stream_first[tid + 1u] = (sc.ok != 0u && sc.expected <= sc.slots && (unsigned long long)sc.unit + 1u + sc.expected <= unit_count) ? sc.expected : 0u;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned run = 0;
+        L.stream_first[0] = 0u;
+        for (unsigned c = 1; c <= chunk_count; c++) {
+            run += L.stream_first[c];
+            L.stream_first[c] = run;
+        }
+    }
+    __syncthreads();
+    const unsigned total = L.stream_first[chunk_count];
+    for (;;) {
+        if (tid == 0)
+            L.work = atomicAdd(work_counter, 1u);
+        __syncthreads();
+        const unsigned idx = L.work;
+        __syncthreads();
+        if (idx >= 2u * total)
+            break;
+        const bool only_full = idx < total;
+        const unsigned j = only_full ? idx : idx - total;
+        unsigned lo = 0, hi = chunk_count;          // stream c: stream_first[c] <= j < stream_first[c + 1]
+        while (hi - lo > 1u) {
+            const unsigned mid = (lo + hi) >> 1;
+            if (L.stream_first[mid] <= j)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        brk_block(L, units, chunks[lo].unit + 1u + (j - L.stream_first[lo]), only_full, jobs, recs, joins, resolved_counter);
+        __syncthreads();
     }
 }
 
@@ -1961,7 +2016,8 @@ extern "C" int hapgpu_launch_scan_blocks(HapGpuDecodeUnit *units, const HapGpuDe
 extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsigned unit_count, HapGpuDecodeJob *jobs,
                                            unsigned frag_log2, unsigned fragment_kinds, int any_stream_or_copy_units,
                                            const uint32_t *fine_work, unsigned fine_slots, const void *scan_recs,
-                                           const void *scan_joins, unsigned scan_blocks_hint, uint32_t *resolved, hipStream_t stream)
+                                           const void *scan_joins, const HapGpuScanChunk *scan_chunks, unsigned scan_chunk_count,
+                                           unsigned scan_blocks_hint, uint32_t *resolved, hipStream_t stream)
 {
     if (unit_count == 0)
         return 0;
@@ -2002,15 +2058,17 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
         // 2 frames 0.68, 3 frames 1.11 against 1.12 for FOUR frames the other way: up to four blocks per CU (the host's
         // estimate: what the scanned streams' textures hold).
         static int resolve_on = -1;
-        static unsigned resolve_max_units = 0;
+        static unsigned resolve_max_units = 0, resolve_workgroups = 256u;
         if (resolve_on < 0) {
             const char *e = HAP_AB_ENV("HAP_AMD_BLOCK_RESOLVE");
             int dev = 0;
             hipDeviceProp_t prop;
             resolve_on = e ? atoi(e) : 1;
             resolve_max_units = 4u * 256u;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                resolve_max_units = 4u * (unsigned)prop.multiProcessorCount;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) {
+                resolve_workgroups = (unsigned)prop.multiProcessorCount;
+                resolve_max_units = 4u * resolve_workgroups;
+            }
             if (resolve_on > 1)
                 resolve_max_units = 0xFFFFFFFFu;         // (measurement builds: every call)
             if (hipFuncSetAttribute((const void *)snappy_decode_block_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2023,10 +2081,14 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
             const dim3 grid(phase == 1u ? fine_slots : unit_count);
             // the 64 KiB blocks of the scanned streams, a workgroup each -- after the 8 KiB pieces of phase 1 (whose failures
             // decide which units run), in front of the wavefront-per-unit launch that takes whatever is left
-            if (phase == 2u && resolve_on && scan_recs && scan_joins && scan_blocks_hint <= resolve_max_units)
-                hipLaunchKernelGGL(snappy_decode_block_resolve_kernel, dim3(unit_count), dim3(kBrkThreads), sizeof(BrkLds), stream,
-                                   const_cast<HapGpuDecodeUnit *>(units), unit_count, jobs, (const unsigned long long *)scan_recs,
-                                   (const uint2 *)scan_joins, resolved);
+            if (phase == 2u && resolve_on && scan_recs && scan_joins && scan_chunks && resolved && scan_chunk_count <= kBrkMaxStreams &&
+                scan_blocks_hint <= resolve_max_units) {
+                // (resolved[0]: blocks that went through, ever; [1]: this launch's work counter)
+                (void)hipMemsetAsync(resolved + 1, 0, sizeof(uint32_t), stream);
+                hipLaunchKernelGGL(snappy_decode_block_resolve_kernel, dim3(resolve_workgroups), dim3(kBrkThreads), sizeof(BrkLds), stream,
+                                   const_cast<HapGpuDecodeUnit *>(units), unit_count, scan_chunks, scan_chunk_count, jobs,
+                                   (const unsigned long long *)scan_recs, (const uint2 *)scan_joins, resolved, resolved + 1);
+            }
             if (ring_log2 == 11)
                 hipLaunchKernelGGL((snappy_decode_fragment_kernel<2048u, true, 1u>), grid, dim3(64), 0, stream, units, grid.x, jobs, phase, fine_work);
             else if (ring_log2 == 12)
