@@ -317,7 +317,10 @@ class Stream:
         valu = measured_valu(config, dom, self.nf)
         if valu and kernels[dom]["ms_avg"]:
             r["issue_bound"] = round(valu * 4.0 / (1024 * 2.4e9) / (kernels[dom]["ms_avg"] * 1e-3), 4)
-            r["issue_bound_note"] = "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz) / avg_launch_ms"
+            r["issue_bound_note"] = ("SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz) / avg_launch_ms; above 1: the kernel's mix issues "
+                                     "faster than 4 cycles an instruction (tools/micro/valu_rates.hip: add / and / mov 2.7, the rest 3.4-4.3; "
+                                     "3.6 on average -> issue_bound_at_3p6)")
+            r["issue_bound_at_3p6"] = round(valu * 3.6 / (1024 * 2.4e9) / (kernels[dom]["ms_avg"] * 1e-3), 4)
         return r
 
 

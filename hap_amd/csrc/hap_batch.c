@@ -952,8 +952,6 @@ static void mark_chunk(void *p, unsigned index)
 static void scan_entry(HapGpuScanChunk *e, unsigned unit, unsigned long src_len, unsigned long dst_cap, uint32_t *dbpos,
                        unsigned *seg_cursor, unsigned *word_cursor, unsigned seg_bytes, unsigned *fine_cursor);
 
-/* seg_bytes: the call's segment size -- HAPGPU_SCAN_SEGMENT, or half of it in calls of few compressed bytes (r06): the scan's
-   first kernel walks a segment's windows one after the other, 64 + 12 of them at 4 KiB */
 static unsigned stream_scan_segments(unsigned long src_len, unsigned seg_bytes)
 {
     return (unsigned)(((unsigned long long)src_len + 15u + seg_bytes - 1u) / seg_bytes);
@@ -1035,7 +1033,10 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     uint8_t *dguess = NULL;
     int any_stream = 0, need_retry = 0;
     unsigned scan_chunks = 0, scan_segs = 0, scan_words = 0;   /* streams with BLOCK slots; their segments; bpos words */
-    unsigned scan_seg_bytes = HAPGPU_SCAN_SEGMENT;             /* (below: a quarter in calls of few compressed bytes) */
+    /* (r06 measured shorter segments for calls of few streams -- a wavefront of the scan's first kernel walks a segment's
+       windows one after the other -- and found nothing: one reference-made 8K frame, walk + merge 56 + 80 us at 2 KiB,
+       60 + 122 at 1 KiB, the whole scan 0.088 ms at 2 KiB and at 4 KiB) */
+    const unsigned scan_seg_bytes = HAPGPU_SCAN_SEGMENT;
     unsigned fine_total = 0;                                   /* unit slots for the 8 KiB blocks of scanned streams */
     uint32_t *dwork = NULL;                                    /* [0]: count, then the fine units the scan listed */
     unsigned far_seen = 0;
@@ -1278,17 +1279,6 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     }
 
     HAPB_MARK("prefixes");
-    {
-        /* the block scan's segment size for this call: a wavefront of its first kernel walks a segment's windows one after
-           the other, and the merge kernel -- one wavefront per stream -- walks where a segment's guessed chain had not
-           joined the true one: halves shorten the first and lengthen the second (one reference-made 8K frame, walk + merge:
-           4 KiB ~175 us, 2 KiB 56 + 80, 1 KiB 60 + 122); batches keep 4 KiB (a warm-up of twelve windows per segment) */
-        unsigned long long total_in = 0;
-        for (f = 0; f < frame_count; f++)
-            total_in += input_bytes[f];
-        if (total_in <= ((unsigned long long)24u << 20))
-            scan_seg_bytes = HAPGPU_SCAN_SEGMENT / 2u;
-    }
     /* 2. plan on the host: sections and tables only (hap_frame.c) */
     for (f = 0; f < frame_count; f++) {
         hapf_texture_plan *p = &plans[f];
