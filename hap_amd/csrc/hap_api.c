@@ -219,6 +219,22 @@ unsigned int HapGpuFineChunkCount(unsigned long textureBytes, unsigned int textu
     want = (textureBytes + 8191ul) / 8192ul;
     if (textureBytes < 16ul)
         return 1;
+    {
+        /* The SMALLEST divisor of the block count that is at least bytes / 8 KiB: chunks of at most one fragment (ADVICE r05:
+           walking DOWN to a divisor gave 1080p DXT5 240 chunks of 8640 bytes -- two fragments each, which the table-less
+           road into the block-per-lane decoder does not take).  Where the block count has no divisor up to four times that
+           many chunks (a prime number of blocks), the largest one below it, as for any chunk count (hap.c:277-300). */
+        const unsigned long block = (textureFormat == HapTextureFormat_RGB_DXT1 || textureFormat == HapTextureFormat_A_RGTC1) ? 8ul : 16ul;
+        const unsigned long blocks = textureBytes / block;
+        unsigned long c, top = want * 4ul;
+        if (top > 3355431ul)
+            top = 3355431ul;
+        if (top > blocks)
+            top = blocks;
+        for (c = want; c <= top; c++)
+            if (c != 0ul && blocks % c == 0ul)
+                return (unsigned)c;
+    }
     return hapf_limit_chunk_count(textureBytes, textureFormat, want > 3355431ul ? 3355431u : (unsigned)want);
 }
 
@@ -836,7 +852,8 @@ unsigned int HapGpuCollectProfileN(HapGpuContext *context, unsigned int classCou
    eight.  New code says how many entries its arrays have (HapGpuCollectProfileN). */
 unsigned int HapGpuCollectProfile(HapGpuContext *context, unsigned long *launches, double *milliseconds)
 {
-    return HapGpuCollectProfileN(context, 8u, launches, milliseconds);
+    /* (the class count of the header this entry point was last released with: nine, encode_fused included -- ADVICE r05) */
+    return HapGpuCollectProfileN(context, 9u, launches, milliseconds);
 }
 
 unsigned int HapGpuTimerStart(HapGpuContext *context)

@@ -114,8 +114,9 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
         if (count == 0 || count > 2 || !inputs || !input_bytes || !formats || !compressors || !chunk_counts ||
             !outputs || !output_bytes || !output_used)
             rc = HapResult_Bad_Arguments;
+        /* (with HAPGPU_ENCODE_FINE_CHUNKS the call's chunk counts are replaced below: whatever they say is not looked at) */
         for (i = 0; rc == HapResult_No_Error && i < count; i++)
-            if (chunk_counts[i] == 0)
+            if (chunk_counts[i] == 0 && !((flags & HAPGPU_ENCODE_FINE_CHUNKS) && !smaller && compressors[i] == HapCompressorSnappy))
                 rc = HapResult_Bad_Arguments;
         if (rc == HapResult_No_Error && count == 2 &&
             formats[0] != HapTextureFormat_YCoCg_DXT5 && formats[1] != HapTextureFormat_YCoCg_DXT5 &&
@@ -357,6 +358,8 @@ unsigned hapb_encode(HapGpuContext *ctx, unsigned frame_count, unsigned count,
         ctx->placing_holdoff -= 1u;
         placed = 0u;
     }
+    if (ctx->placing_off)                            /* (after a timeout: counted down call by call, then placing is back) */
+        ctx->placing_off -= 1u;
 
     /* scratch */
     hframes = (HapGpuFrameEnc *)hapgpu_rt_pinned_scratch(rt, P_FRAMES, sizeof(HapGpuFrameEnc) * live);
@@ -590,7 +593,10 @@ unsigned hapb_encode_complete(HapGpuContext *ctx, HapbEncodePending *pd)
                 /* a wavefront gave up waiting for its predecessors (snappy_compress_blocks.hip): something keeps the
                    grid from advancing in order -- this context gathers from now on */
                 ctx->placement_timeouts += 1u;
-                ctx->placing_off = 1u;
+                if (!ctx->placing_off)
+                    fprintf(stderr, "hap_amd: a placed encode waited too long for its predecessors (another kernel, a profiler, CU "
+                                    "masking?): this context gathers for its next 64 encode calls\n");
+                ctx->placing_off = 64u;              /* calls that gather before placing is tried again */
             }
             if (fe->status == HapResult_No_Error) {
                 output_used[f] = (unsigned long)fe->bytes_used;

@@ -31,7 +31,7 @@ struct HapGpuContext {
        table turned out wrong: the callback is invoked exactly once per HapDecode, as in the reference */
     unsigned long placement_retries; /* frames encoded a second time, through slots (a chunk of theirs was stored raw) */
     unsigned long placement_timeouts; /* ... of which: a wavefront waited for its predecessors' sizes longer than the bound */
-    unsigned placing_off;     /* set by the first such timeout: this context gathers from then on */
+    unsigned placing_off;     /* after such a timeout: encode calls left that gather before placing is tried again */
     unsigned long table_fallbacks;   /* frames decoded again without their fragment table (it did not match) */
     const unsigned char *preset_marks;
     unsigned preset_count;

@@ -120,8 +120,10 @@ HapGpuContext *HapGpuDefaultContext(void);
  * 13 = 8 KiB).  Fragments are compressed independently of each other. */
 unsigned int HapGpuSetFragmentLog2(HapGpuContext *context, unsigned int log2_bytes);
 
-/* The chunk count HAPGPU_ENCODE_FINE_CHUNKS gives a texture: bytes / 8 KiB rounded up, limited like every chunk count
- * to a divisor of the block count (hap.c:277-300).  0 for arguments HapEncode would refuse.  Needs no GPU. */
+/* The chunk count HAPGPU_ENCODE_FINE_CHUNKS gives a texture: the smallest divisor of its block count (hap.c:277-300: every
+ * chunk count must be one) that is at least bytes / 8 KiB rounded up -- chunks of at most 8 KiB, one Snappy fragment each;
+ * where the block count has no divisor up to four times that number, the largest one below it (chunks of two fragments
+ * and more: such frames decode like plain ones).  0 for arguments HapEncode would refuse.  Needs no GPU. */
 unsigned int HapGpuFineChunkCount(unsigned long textureBytes, unsigned int textureFormat);
 
 /* Blocks until everything enqueued on the context's stream has finished. */
@@ -140,8 +142,9 @@ unsigned long HapGpuPlacementRetryCount(HapGpuContext *context);
 
 /* ... and how many of those were retried because a wavefront waited longer than its bound (about two milliseconds)
  * for the sizes of the fragments in front of its own: placing relies on the workgroups of a grid starting in index
- * order, which gfx950 does but HIP does not promise.  The first such frame switches placing off for the rest of the
- * context's life (its calls gather from then on); 0 in every run so far.  For tests and tools. */
+ * order, which gfx950 does but HIP does not promise.  Such a frame switches placing off for the context's next 64 encode
+ * calls, which gather (r06; until r05 for the rest of its life: one late neighbour under a profiler or on a shared GPU was a
+ * permanent, nearly invisible change); 0 in every run so far.  For tests and tools. */
 unsigned long HapGpuPlacementTimeoutCount(HapGpuContext *context);
 
 /* Number of 64 KiB blocks of OTHER encoders' Snappy streams (frames without this library's private table, e.g. what the

@@ -2666,6 +2666,12 @@ def test_fine_chunks_put_every_fragment_into_the_tables_every_parser_reads(ctx, 
         r, du, df, dr = ctx.decode_frames(dframes, [len(frame)] * 5, 0, decs)
         assert (r, dr, df, du) == (0, [0] * 5, [fmt] * 5, [len(tex)] * 5)
         assert all(d.cpu().numpy().tobytes() == tex for d in decs) and ctx.table_fallbacks() == n0
+    #  the count is the SMALLEST divisor of the block count that makes chunks of at most one fragment -- 1080p
+    # DXT5: 270 chunks of 7680 bytes, not 240 of 8640 --, and the caller's own counts, being replaced, are not looked at
+    assert hap.fine_chunk_count(1920 * 1080, L.FMT_DXT5) == 270 and hap.fine_chunk_count(8192 * 16, L.FMT_DXT5) == 16
+    assert hap.fine_chunk_count(16 * 8191, L.FMT_DXT5) == 1           # (a prime number of blocks: no divisor anywhere near)
+    r, used0, res = ctx.encode_frames([[tex]], [fmt], [1], [0], [np.zeros(cap, dtype=np.uint8)], flags=hap.ENCODE_FINE_CHUNKS)
+    assert (r, res) == (0, [0])
     # the same picture with the client's own chunk count is a different frame of the same texture; too small a buffer for
     # the fine tables is refused like any other (hap.c:386-389)
     small = np.zeros(hap.HapMaxEncodedLength([len(tex)], [fmt], [1]), dtype=np.uint8)
