@@ -341,13 +341,18 @@ def test_round5_entry_points_without_a_gpu(hap):
     several-context calls and the two-halves calls refuse missing contexts before they touch a device."""
     lib = hap._lib.lib
     u, ul, vp = C.c_uint, C.c_ulong, C.c_void_p
-    # 8K Hap Q: 33 177 600 bytes = 4050 x 8 KiB; 4K DXT1: 518 400 blocks, 507 asked, 480 is the largest divisor below
+    # 8K Hap Q: 33 177 600 bytes = 4050 x 8 KiB; 4K DXT1: 518 400 blocks, 507 chunks would be 8 KiB each: 540 is the smallest
+    # divisor from there up (chunks of 7680 bytes: one fragment each; until r05 the largest divisor BELOW, 480 chunks of 8640
+    # bytes, two fragments each -- ADVICE r05); 1080p DXT5: 270, not 240
     assert hap.fine_chunk_count(7680 * 4320, L.FMT_YCOCG) == 4050
-    assert hap.fine_chunk_count(3840 * 2160 // 2, L.FMT_DXT1) == 480
-    for n, fmt in ((16, L.FMT_YCOCG), (8, L.FMT_DXT1), (8192, L.FMT_RGTC1), (8192 + 16, L.FMT_DXT5), (1 << 20, L.FMT_BC7)):
+    assert hap.fine_chunk_count(3840 * 2160 // 2, L.FMT_DXT1) == 540
+    assert hap.fine_chunk_count(1920 * 1080, L.FMT_DXT5) == 270
+    for n, fmt in ((16, L.FMT_YCOCG), (8, L.FMT_DXT1), (8192, L.FMT_RGTC1), (8192 + 16, L.FMT_DXT5), (1 << 20, L.FMT_BC7), (16 * 8191, L.FMT_DXT5)):
         k = hap.fine_chunk_count(n, fmt)
         block = D.BLOCK_BYTES[fmt]
-        assert k >= 1 and (n // block) % k == 0 and k <= (n + 8191) // 8192
+        want = (n + 8191) // 8192
+        # a divisor of the block count; chunks of at most 8 KiB unless the block count has no divisor up to four times as many
+        assert k >= 1 and (n // block) % k == 0 and (want <= k <= 4 * want or (k < want and not any((n // block) % c == 0 for c in range(want, min(4 * want, n // block) + 1))))
         assert hap.HapMaxEncodedLength([n], [fmt], [k]) > 0
     assert hap.fine_chunk_count(0, L.FMT_DXT1) == 0 and hap.fine_chunk_count(4096, 0x1234) == 0
     assert hap.fine_chunk_count(1 << 33, L.FMT_DXT1) == 0
