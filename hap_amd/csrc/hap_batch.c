@@ -1457,7 +1457,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
         const size_t o_bpos = o_segs + sizeof(HapGpuScanSegment) * scan_segs;
         const size_t o_work = align_up(o_bpos + sizeof(uint32_t) * scan_words, 64);
         const size_t o_joins = align_up(o_work + sizeof(uint32_t) * ((size_t)fine_total + 2u), 64);   /* count | list | pool cursor */
-        const size_t o_recs = align_up(o_joins + (size_t)8u * scan_segs, 64);
+        const size_t o_recs = align_up(o_joins + (size_t)16u * scan_segs, 64);
         uint8_t *arena = (uint8_t *)hapgpu_rt_device_scratch(rt, D_SCAN, o_recs + (size_t)512u * scan_segs);
         hscan = (HapGpuScanChunk *)hapgpu_rt_pinned_scratch(rt, P_SCAN, sizeof(HapGpuScanChunk) * scan_chunks);
         if (!arena || !hscan) {

@@ -228,10 +228,12 @@ typedef struct HapGpuScanSegment {   /* device only */
     uint32_t exit_coord;     /* where the segment's (guessed) chain left the segment */
     uint32_t cum_total;      /* output bytes that chain produced from its start to there */
     uint32_t flags;          /* 1: the chain met something that is not an element; 2: it reached the end of the input */
-    uint32_t reserved;
+    uint32_t elements;       /* elements of that chain from its start to there */
 } HapGpuScanSegment;
-/* (per segment, in an array of its own: the window in which the true chain joined the recorded one -- 0xFFFFFFFF:
-   never -- and the absolute output position of the recorded chain's zero, 2 x uint32) */
+/* (per segment, in an array of its own, 4 x uint32: the window in which the true chain joined the recorded one --
+   0xFFFFFFFF: never --, the absolute output position and the absolute element number of the recorded chain's zero, and
+   1 where the true chain may have entered the segment in front of that window.  A window's record, 64 bits: byte of the
+   window at which the chain entered it | output bytes of the chain so far << 8 | its elements so far << 40) */
 
 /* [device] one wavefront's worth of decode work */
 typedef struct HapGpuDecodeUnit {

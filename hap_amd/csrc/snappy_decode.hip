@@ -998,7 +998,7 @@ __device__ __forceinline__ bool scan_unit_wanted(const HapGpuDecodeUnit &u, cons
 __global__ __launch_bounds__(64) void scan_walk_kernel(const HapGpuDecodeUnit *units, const HapGpuDecodeJob *jobs,
                                                        const HapGpuScanChunk *chunks, unsigned chunk_count,
                                                        HapGpuScanSegment *__restrict__ segs, unsigned long long *__restrict__ recs,
-                                                       uint2 *__restrict__ joins, unsigned seg_total)
+                                                       uint4 *__restrict__ joins, unsigned seg_total)
 {
     __shared__ __attribute__((aligned(16))) uint8_t smem[kScanLds];
     const uint32_t *inw = reinterpret_cast<const uint32_t *>(smem);
@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(64) void scan_walk_kernel(const HapGpuDecodeUnit *u
     const unsigned seg_bytes = scan_segment_bytes(sc);
     const unsigned seg_begin = s * seg_bytes, seg_end = seg_begin + seg_bytes;
     unsigned long long rec = kRecNone;
-    unsigned flags = 1u, cum = 0, p = 0;
+    unsigned flags = 1u, cum = 0, cum_e = 0, p = 0;           // (cum_e: elements, as cum counts their output bytes)
     if (scan_unit_wanted(u, jobs) && s < sc.seg_count && seg_begin < in_end) {
         const unsigned warm = s == 0 ? 0u : kScanWarmWindows;
         const unsigned stage_begin = seg_begin - 64u * warm;
@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(64) void scan_walk_kernel(const HapGpuDecodeUnit *u
             }
             const unsigned wi = (p - stage_begin) >> 6, ws = stage_begin + wi * 64u, e = p - ws;
             if (wi != seen && wi >= warm && lane == wi - warm)
-                rec = ((unsigned long long)cum << 8) | e;
+                rec = ((unsigned long long)cum_e << 40) | ((unsigned long long)cum << 8) | e;
             seen = wi;
             const unsigned x = ws + lane, xi = (x - stage_begin) >> 2, sh = x & 3u;
             const unsigned w0 = inw[xi], w1 = inw[xi + 1u];
@@ -1063,12 +1063,14 @@ __global__ __launch_bounds__(64) void scan_walk_kernel(const HapGpuDecodeUnit *u
                 }
                 p += h + llen;
                 cum += llen;
+                cum_e += 1u;
                 continue;
             }
             const bool is_tok = __builtin_amdgcn_inverse_ballot_w64(T);
             const int incl = wave_scan_add(is_tok ? (int)el.len : 0);
             const unsigned last = 63u - (unsigned)__builtin_clzll(T);
             cum += (unsigned)__builtin_amdgcn_readlane(incl, 63);
+            cum_e += (unsigned)__builtin_popcountll(T);
             p = ws + last + (unsigned)__builtin_amdgcn_readlane((int)el.tokbytes, (int)last);
         }
         if (flags == 0u && p >= in_end)
@@ -1080,9 +1082,9 @@ __global__ __launch_bounds__(64) void scan_walk_kernel(const HapGpuDecodeUnit *u
         sg.exit_coord = p;
         sg.cum_total = cum;
         sg.flags = flags;
-        sg.reserved = 0;
+        sg.elements = cum_e;
         segs[g] = sg;
-        joins[g] = make_uint2(0xFFFFFFFFu, 0u);          // (window, output position of the record's zero): not joined yet
+        joins[g] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);  // (window, output position and element number of the record's zero, late): not joined yet
     }
 }
 
@@ -1098,7 +1100,7 @@ __device__ __forceinline__ void scan_window_bytes(const uint8_t *src_al, unsigne
 __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units, const HapGpuDecodeJob *jobs,
                                                         HapGpuScanChunk *chunks, unsigned chunk_count,
                                                         const HapGpuScanSegment *__restrict__ segs,
-                                                        const unsigned long long *__restrict__ recs, uint2 *__restrict__ joins,
+                                                        const unsigned long long *__restrict__ recs, uint4 *__restrict__ joins,
                                                         uint32_t *fine_cursor, unsigned fine_first, unsigned fine_pool)
 {
     const unsigned lane = threadIdx.x, c = blockIdx.x;
@@ -1140,7 +1142,7 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
         } while ((b & 0x80u) && p < in_end);
         p = uniform(p);
     }
-    unsigned op = 0, found = 0, found_fine = 0, found_probe = 0, cur = 0xFFFFFFFFu;
+    unsigned op = 0, oe = 0, found = 0, found_fine = 0, found_probe = 0, cur = 0xFFFFFFFFu;   // (oe: elements so far, as op counts output bytes)
     unsigned long long rec = kRecNone, rec_ahead = kRecNone;
     HapGpuScanSegment sg = {}, sg_ahead = {};
     bool ok = true;
@@ -1151,13 +1153,14 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
     // parses windows itself only in the segments that are not good (about one in a hundred).
     __shared__ uint32_t l_exit[kMergeSegments];             // where segment i's recorded chain leaves it
     __shared__ uint32_t l_before[kMergeSegments + 1u];      // output of the good segments before i (entry to exit each)
+    __shared__ uint32_t l_before_e[kMergeSegments + 1u];    // ... and their elements
     __shared__ unsigned long long l_good[kMergeSegments / 64u];
     const unsigned seg_bytes = scan_segment_bytes(sc);
     const unsigned nseg = (in_end + seg_bytes - 1u) / seg_bytes;
     const unsigned first_element = p;
     const bool tabled = nseg <= sc.seg_count && nseg <= kMergeSegments;
     if (tabled) {
-        unsigned run = 0;
+        unsigned run = 0, run_e = 0;
         for (unsigned base = 0; base < nseg; base += 64u) {
             const unsigned i = base + lane;
             const bool mine = i < nseg;
@@ -1176,18 +1179,24 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
                 r = recs[(size_t)(sc.seg_first + i) * 64u + ((entry % seg_bytes) >> 6)];
             const bool good = inside && ((unsigned)r & 0xFFu) == (entry & 63u) && (here.flags & 1u) == 0u;
             const unsigned delta = good ? here.cum_total - (unsigned)(r >> 8) : 0u;
+            const unsigned delta_e = good ? here.elements - (unsigned)(r >> 40) : 0u;
             const unsigned incl = (unsigned)wave_scan_add((int)delta);
+            const unsigned incl_e = (unsigned)wave_scan_add((int)delta_e);
             if (mine) {
                 l_exit[i] = here.exit_coord;
                 l_before[i] = run + incl - delta;
+                l_before_e[i] = run_e + incl_e - delta_e;
             }
             const unsigned long long goods = ballot64(good);
             if (lane == 0)
                 l_good[base / 64u] = goods;
             run += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+            run_e += (unsigned)__builtin_amdgcn_readlane((int)incl_e, 63);
         }
-        if (lane == 0)
+        if (lane == 0) {
             l_before[nseg] = run;
+            l_before_e[nseg] = run_e;
+        }
         __syncthreads();
     }
     while (p < in_end) {
@@ -1197,14 +1206,17 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
             unsigned t = s + 1u;
             while (t < nseg && ((l_good[t / 64u] >> (t & 63u)) & 1ull))
                 t++;
-            const unsigned before_run = l_before[s];
+            const unsigned before_run = l_before[s], before_run_e = l_before_e[s];
             for (unsigned i = s + lane; i < t; i += 64u) {
                 const unsigned entry = i == 0u ? first_element : l_exit[i - 1u];
                 const unsigned w = (entry % seg_bytes) >> 6;
-                const unsigned at_entry = (unsigned)(recs[(size_t)(sc.seg_first + i) * 64u + w] >> 8);
-                joins[sc.seg_first + i] = make_uint2(w, op + (l_before[i] - before_run) - at_entry);
+                const unsigned long long r = recs[(size_t)(sc.seg_first + i) * 64u + w];
+                // (w = 0 in the last word: the chain enters no window of this segment in front of the one on record)
+                joins[sc.seg_first + i] = make_uint4(w, op + (l_before[i] - before_run) - (unsigned)(r >> 8),
+                                                     oe + (l_before_e[i] - before_run_e) - (unsigned)(r >> 40), 0u);
             }
             op += l_before[t] - before_run;
+            oe += l_before_e[t] - before_run_e;
             p = l_exit[t - 1u];
             cur = 0xFFFFFFFFu;
             continue;
@@ -1233,11 +1245,14 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
                 break;
             }
             const unsigned at_entry = (r_lo >> 8) | (r_hi << 24);
-            const unsigned base_op = op - at_entry;
+            const unsigned base_op = op - at_entry, base_e = oe - (r_hi >> 8);
+            // (last word: 1 = the true chain may have entered this segment in front of window wi -- those windows' records
+            // are not its own)
             if (lane == 0)
-                joins[sc.seg_first + s] = make_uint2(wi, base_op);
+                joins[sc.seg_first + s] = make_uint4(wi, base_op, base_e, 1u);
             p = sg.exit_coord;
             op = base_op + sg.cum_total;
+            oe = base_e + sg.elements;
             continue;
         }
         // not yet: one window of the true chain, parsed here
@@ -1262,10 +1277,12 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
             }
             p += h + llen;
             op += llen;
+            oe += 1u;
             continue;
         }
         const bool is_tok = __builtin_amdgcn_inverse_ballot_w64(T);
         const int incl = wave_scan_add(is_tok ? (int)el.len : 0);
+        oe += (unsigned)__builtin_popcountll(T);
         const unsigned at = op + (unsigned)incl - (is_tok ? el.len : 0u);
         const bool starts_mark = is_tok && (at & (mark - 1u)) == 0u && at < out_len;
         if (starts_mark)
@@ -1326,7 +1343,7 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
 // streams whose probe marks both fell on element boundaries
 __global__ __launch_bounds__(64) void scan_find_kernel(const HapGpuDecodeUnit *units, HapGpuScanChunk *chunks, unsigned chunk_count,
                                                        const HapGpuScanSegment *__restrict__ segs,
-                                                       const unsigned long long *__restrict__ recs, const uint2 *__restrict__ joins,
+                                                       const unsigned long long *__restrict__ recs, const uint4 *__restrict__ joins,
                                                        unsigned seg_total, unsigned pass)
 {
     const unsigned lane = threadIdx.x, g = blockIdx.x;
@@ -1335,7 +1352,7 @@ __global__ __launch_bounds__(64) void scan_find_kernel(const HapGpuDecodeUnit *u
     const unsigned c = scan_chunk_of(chunks, chunk_count, g);
     const HapGpuScanChunk sc = chunks[c];
     const HapGpuScanSegment sg = segs[g];
-    const uint2 join = joins[g];
+    const uint4 join = joins[g];
     const unsigned merge_window = join.x, base_op = join.y;
     if (!sc.ok || merge_window >= 64u)
         return;
@@ -1349,7 +1366,7 @@ __global__ __launch_bounds__(64) void scan_find_kernel(const HapGpuDecodeUnit *u
     const unsigned seg_begin = (g - sc.seg_first) * scan_segment_bytes(sc);
     const unsigned long long rec = recs[(size_t)g * 64u + lane];
     const unsigned entry = (unsigned)rec & 0xFFu;
-    const unsigned abs_op = base_op + (unsigned)(rec >> 8);              // output position at this window's entry
+    const unsigned abs_op = base_op + (unsigned)(rec >> 8);              // output position at this window's entry (bits 8..39)
     const bool usable = lane >= merge_window && entry != kRecNone;
     const unsigned first_op = (unsigned)__builtin_amdgcn_readlane((int)abs_op, (int)merge_window);
     const unsigned exit_op = base_op + sg.cum_total;
@@ -1627,7 +1644,7 @@ __device__ __forceinline__ bool brk_do_window(BrkLds &L, unsigned wave, unsigned
 // One block: units[unit_index].  only_full: the first sweep of a launch takes the whole 64 KiB blocks, the second the short
 // ones at the ends of their streams -- the last workgroups to finish then finish soon.
 __device__ __forceinline__ void brk_block(BrkLds &L, HapGpuDecodeUnit *units, unsigned unit_index, bool only_full, const HapGpuDecodeJob *jobs,
-                                          const unsigned long long *__restrict__ recs, const uint2 *__restrict__ joins,
+                                          const unsigned long long *__restrict__ recs, const uint4 *__restrict__ joins,
                                           uint32_t *resolved_counter)
 {
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -1685,7 +1702,7 @@ __device__ __forceinline__ void brk_block(BrkLds &L, HapGpuDecodeUnit *units, un
             e = from & 63u;                          // the block's mark: an element begins there, with nothing of the block behind it
         } else if (seg < scan->seg_count) {
             const unsigned long long rec = recs[(size_t)(scan->seg_first + seg) * 64u + k];
-            const uint2 join = joins[scan->seg_first + seg];
+            const uint4 join = joins[scan->seg_first + seg];
             const unsigned abs_op = join.y + (unsigned)(rec >> 8);
             if (join.x < 64u && k >= join.x && ((unsigned)rec & 0xFFu) < 64u && abs_op - blk_op <= out_len && ws + ((unsigned)rec & 0xFFu) < to) {
                 e = (unsigned)rec & 0xFFu;
@@ -1921,7 +1938,7 @@ __global__ __launch_bounds__(kBrkThreads) void snappy_decode_block_resolve_kerne
                                                                                   const HapGpuScanChunk *chunks, unsigned chunk_count,
                                                                                   const HapGpuDecodeJob *jobs,
                                                                                   const unsigned long long *__restrict__ recs,
-                                                                                  const uint2 *__restrict__ joins,
+                                                                                  const uint4 *__restrict__ joins,
                                                                                   uint32_t *resolved_counter, uint32_t *work_counter)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
@@ -1997,14 +2014,14 @@ extern "C" int hapgpu_launch_scan_blocks(HapGpuDecodeUnit *units, const HapGpuDe
     if (chunk_count == 0 || seg_total == 0)
         return 0;
     hipLaunchKernelGGL(scan_walk_kernel, dim3(seg_total), dim3(64), 0, stream, units, jobs, chunks, chunk_count, segs,
-                       (unsigned long long *)recs, (uint2 *)joins, seg_total);
+                       (unsigned long long *)recs, (uint4 *)joins, seg_total);
     // (fine_work: [0] the list's length, then the list -- fine_pool entries --, then the pool's cursor)
     hipLaunchKernelGGL(scan_merge_kernel, dim3(chunk_count), dim3(64), 0, stream, units, jobs, chunks, chunk_count, segs,
-                       (const unsigned long long *)recs, (uint2 *)joins, fine_work ? fine_work + 1u + fine_pool : nullptr, fine_first, fine_pool);
+                       (const unsigned long long *)recs, (uint4 *)joins, fine_work ? fine_work + 1u + fine_pool : nullptr, fine_first, fine_pool);
     hipLaunchKernelGGL(scan_find_kernel, dim3(seg_total), dim3(64), 0, stream, units, chunks, chunk_count, segs,
-                       (const unsigned long long *)recs, (const uint2 *)joins, seg_total, 0u);
+                       (const unsigned long long *)recs, (const uint4 *)joins, seg_total, 0u);
     hipLaunchKernelGGL(scan_find_kernel, dim3(seg_total), dim3(64), 0, stream, units, chunks, chunk_count, segs,
-                       (const unsigned long long *)recs, (const uint2 *)joins, seg_total, 1u);
+                       (const unsigned long long *)recs, (const uint4 *)joins, seg_total, 1u);
     if (fine_work)
         hipLaunchKernelGGL(scan_decide_kernel, dim3(chunk_count), dim3(64), 0, stream, chunks, chunk_count, fine_work);
     return hipGetLastError() == hipSuccess ? 0 : 4;
@@ -2087,7 +2104,7 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
                 (void)hipMemsetAsync(resolved + 1, 0, sizeof(uint32_t), stream);
                 hipLaunchKernelGGL(snappy_decode_block_resolve_kernel, dim3(resolve_workgroups), dim3(kBrkThreads), sizeof(BrkLds), stream,
                                    const_cast<HapGpuDecodeUnit *>(units), unit_count, scan_chunks, scan_chunk_count, jobs,
-                                   (const unsigned long long *)scan_recs, (const uint2 *)scan_joins, resolved, resolved + 1);
+                                   (const unsigned long long *)scan_recs, (const uint4 *)scan_joins, resolved, resolved + 1);
             }
             if (ring_log2 == 11)
                 hipLaunchKernelGGL((snappy_decode_fragment_kernel<2048u, true, 1u>), grid, dim3(64), 0, stream, units, grid.x, jobs, phase, fine_work);
