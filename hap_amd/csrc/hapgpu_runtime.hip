@@ -706,10 +706,17 @@ extern "C" int hapgpu_k_scan_blocks(hapgpu_rt *rt, HapGpuDecodeUnit *units, cons
 
 extern "C" int hapgpu_launch_guess_group_tables(HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs,
                                                 const uint32_t *work, unsigned work_slots, hipStream_t stream);
+extern "C" int hapgpu_launch_group_tables_from_records(HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs,
+                                                       const uint32_t *work, unsigned work_slots, const void *recs, const void *joins,
+                                                       hipStream_t stream);
 extern "C" int hapgpu_k_guess_group_tables(hapgpu_rt *rt, HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs,
                                            const uint32_t *work, unsigned work_slots)
 {
     scoped_timing st(rt, 7);          // (with the block scan: finding where wavefronts may start in streams that do not say)
+    // the pieces the scan of this call listed: from its records, a wavefront per piece (r06); fragments that are chunks of
+    // their own (no scan): a lane per fragment walks it
+    if (work && rt->scan_recs && rt->scan_joins)
+        return hapgpu_launch_group_tables_from_records(units, unit_count, jobs, work, work_slots, rt->scan_recs, rt->scan_joins, rt->stream);
     return hapgpu_launch_guess_group_tables(units, unit_count, jobs, work, work_slots, rt->stream);
 }
 

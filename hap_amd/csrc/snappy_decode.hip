@@ -1985,6 +1985,201 @@ __global__ __launch_bounds__(kBrkThreads) void snappy_decode_block_resolve_kerne
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// group tables for the 8 KiB pieces of this library's table-less streams, from the block scan's records
+// ------------------------------------------------------------------------------------------
+//
+// A plain hap.h frame of this library (hap.c:448-476's layout, no private section) is decoded fastest by the block-per-lane
+// kernel of snappy_decode_fields.hip, which wants 64 starting points inside every 8 KiB fragment.  Until round 5 a lane
+// per fragment walked the fragment's ~400 elements twice to find them (guess_group_tables_kernel: 1.95 ms per 60 8K
+// frames, bound by scattered loads).  But the block scan has already walked every element of the stream: its records say,
+// for every window of 64 compressed bytes, at which byte the element chain enters it, how many output bytes and -- since
+// round 6 -- how many ELEMENTS the chain has behind it there.  So a wavefront per fragment now: the fragment's bytes staged
+// in LDS, the records of its windows in a list; lane 0 counts the elements of the first window that lie in front of the
+// fragment, lane 1 those of the last window up to the fragment's end (N = the difference); then lane g looks up the window
+// that holds element g * ceil(N / 64) and walks the few elements from that window's entry to it.  A dozen element steps per
+// lane instead of eight hundred.  The table is a HINT, as every table is: the block-per-lane kernel verifies all it says
+// while it decodes, and a piece this kernel declines (a window without a record of the true chain, an element that is no
+// field-stream element) stays a unit of the other kernel.
+constexpr unsigned kGtMaxCompressed = HAPGPU_SCAN_FINE + 320u;                  // what a field-stream fragment compresses to at most
+constexpr unsigned kGtMaxWindows = (kGtMaxCompressed + 63u) / 64u + 2u;
+constexpr unsigned kGtStage = kGtMaxWindows * 64u + 16u;
+
+// the element at byte x of the staged fragment: output bytes and stream bytes; false: none a field stream has
+__device__ __forceinline__ bool gt_element(const uint8_t *stage, unsigned x, unsigned *len, unsigned *adv)
+{
+    const uint32_t *st32 = reinterpret_cast<const uint32_t *>(stage);
+    const unsigned w = __builtin_amdgcn_alignbyte(st32[(x >> 2) + 1u], st32[x >> 2], x);
+    const unsigned kind = w & 3u, up = (w >> 2) & 63u;
+    if (kind == 0u) {
+        *len = (up == 60u ? ((w >> 8) & 255u) : up) + 1u;
+        *adv = *len + (up == 60u ? 2u : 1u);
+        return up <= 60u;
+    }
+    *len = kind == 1u ? ((w >> 2) & 7u) + 4u : up + 1u;
+    *adv = kind + 1u;
+    return kind != 3u;
+}
+
+__global__ __launch_bounds__(64) void group_tables_from_records_kernel(HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs,
+                                                                       const uint32_t *__restrict__ work,
+                                                                       const unsigned long long *__restrict__ recs,
+                                                                       const uint4 *__restrict__ joins)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kGtStage];
+    __shared__ uint32_t w_pos[kGtMaxWindows + 1u], w_e[kGtMaxWindows + 1u], w_op[kGtMaxWindows + 1u];
+    __shared__ uint32_t g_c[65], g_o[65];
+    const unsigned lane = threadIdx.x;
+    if (blockIdx.x >= work[0])
+        return;
+    const unsigned idx = work[1u + blockIdx.x];
+    if (idx >= unit_count)
+        return;
+    HapGpuDecodeUnit u = units[idx];
+    const HapGpuDecodeJob *job = &jobs[u.job];
+    if (u.kind != HAPGPU_UNIT_SNAPPY_BLOCK || !(u.reserved & HAPGPU_BLOCK_FINE) || !((job->reserved >> 16) & 1u) || job->group_tables == 0u ||
+        job->status != 0u)
+        return;
+    const unsigned layout = job->fields_period;
+    const unsigned block = (layout == 4u || layout == 8u) ? 16u : 8u;
+    const HapGpuScanChunk *scan = (const HapGpuScanChunk *)u.aux;
+    const unsigned b = (unsigned)u.reserved, marks = scan->expected_fine;
+    if (!scan->ok || marks == 0u || scan->found_fine != marks || b + 1u > marks)
+        return;
+    const uint32_t *bpos = (const uint32_t *)scan->bpos;
+    const unsigned from = bpos[b], to = bpos[b + 1u], stream_end = bpos[marks];
+    const unsigned out_len = u.dst_len;
+    if (from >= to || to > stream_end || to - from > kGtMaxCompressed || out_len == 0u || out_len > HAPGPU_SCAN_FINE || (out_len % block) != 0u)
+        return;
+    const unsigned n = to - from;
+    const unsigned w0 = from >> 6, nw = ((to - 1u) >> 6) - w0 + 1u;          // <= kGtMaxWindows - 1
+    const uint8_t *src_al = (const uint8_t *)u.src;
+    const unsigned base = w0 << 6;                                            // stream coordinate of stage[0]
+    const unsigned seg_bytes = scan_segment_bytes(*scan);
+    const unsigned blk_op = b * HAPGPU_SCAN_FINE;
+
+    // the fragment's bytes (and eight more: an element's tag is read as a dword)
+    for (unsigned c = lane * 16u; c < nw * 64u + 16u; c += 1024u)
+        *reinterpret_cast<uint4 *>(stage + c) = scan_load16(src_al, base + c, stream_end);
+    // the windows on record, in order: where the chain enters, its element number and output position there
+    unsigned m = 0;
+    bool decline = false;
+    for (unsigned i0 = 0; i0 < nw; i0 += 64u) {
+        const unsigned i = i0 + lane;
+        bool usable = false;
+        unsigned pos = 0, e = 0, op = 0;
+        if (i < nw) {
+            const unsigned ws = base + (i << 6);
+            const unsigned seg = ws / seg_bytes, k = (ws % seg_bytes) >> 6;
+            if (seg < scan->seg_count) {
+                const unsigned long long rec = recs[(size_t)(scan->seg_first + seg) * 64u + k];
+                const uint4 join = joins[scan->seg_first + seg];
+                const unsigned entry = (unsigned)rec & 0xFFu;
+                if (join.x < 64u && k >= join.x && entry < 64u && ws + entry < to) {
+                    usable = true;
+                    pos = ws + entry;
+                    e = join.z + (unsigned)(rec >> 40);
+                    op = join.y + (unsigned)(rec >> 8) - blk_op;
+                } else if (join.x >= 64u || (join.w != 0u && k < join.x)) {
+                    decline = true;                  // (the true chain may enter this window where no record of it is)
+                }
+            } else {
+                decline = true;
+            }
+        }
+        const unsigned long long mask = ballot64(usable);
+        if (usable) {
+            const unsigned at = m + (unsigned)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            w_pos[at] = pos;
+            w_e[at] = e;
+            w_op[at] = op;
+        }
+        m += (unsigned)__builtin_popcountll(mask);
+    }
+    if (ballot64(decline) != 0ull || m == 0u)
+        return;
+    __syncthreads();
+    if (w_pos[0] > from)
+        return;                                      // (the fragment begins with an element: its window has a record at or in front of it)
+    // ---- N: lane 0 counts up to the fragment's first element, lane 1 from the last window on record to its end ----
+    unsigned cnt = 0, ok = 1u;
+    {
+        unsigned pos = lane == 0u ? w_pos[0] : w_pos[m - 1u], op = lane == 0u ? w_op[0] : w_op[m - 1u];
+        const unsigned stop = lane == 0u ? from : to;
+        for (unsigned step = 0; step < 80u && lane < 2u && pos < stop; step++) {
+            unsigned len, adv;
+            if (!gt_element(stage, pos - base, &len, &adv))
+                ok = 0u;
+            pos += adv;
+            op += len;
+            cnt += 1u;
+        }
+        if (lane < 2u && (pos != stop || op != (lane == 0u ? 0u : out_len)))
+            ok = 0u;
+    }
+    const unsigned e0 = w_e[0] + (unsigned)__builtin_amdgcn_readlane((int)cnt, 0);
+    const unsigned e1 = w_e[m - 1u] + (unsigned)__builtin_amdgcn_readlane((int)cnt, 1);
+    const unsigned N = e1 - e0;
+    if (ballot64(ok == 0u) != 0ull || e1 <= e0 || 4u * N > out_len)
+        return;
+    const unsigned G = (N + 63u) >> 6;
+    // ---- lane g: where element g * G begins ----
+    unsigned cpos = n, opos = out_len;
+    if (lane * G < N) {
+        const unsigned T = e0 + lane * G;
+        unsigned lo = 0, hi = m;                     // the last window on record with w_e <= T (w_e[0] <= e0 <= T)
+        while (hi - lo > 1u) {
+            const unsigned mid = (lo + hi) >> 1;
+            if (w_e[mid] <= T)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        unsigned pos = w_pos[lo], e = w_e[lo], op = w_op[lo];
+        for (unsigned step = 0; step < 80u && e < T && pos < to; step++) {
+            unsigned len, adv;
+            if (!gt_element(stage, pos - base, &len, &adv))
+                ok = 0u;
+            pos += adv;
+            op += len;
+            e += 1u;
+        }
+        if (e != T || pos < from || pos > to || op > out_len)
+            ok = 0u;
+        cpos = pos - from;
+        opos = op;
+    }
+    g_c[lane] = cpos;
+    g_o[lane] = opos;
+    if (lane == 0) {
+        g_c[64] = n;
+        g_o[64] = out_len;
+    }
+    __syncthreads();
+    const unsigned gsz = g_c[lane + 1u] - cpos, gout = g_o[lane + 1u] - opos;
+    if (g_c[lane + 1u] < cpos || g_o[lane + 1u] < opos || gsz >= 4096u || gout >= 4096u)
+        ok = 0u;
+    if (ballot64(ok == 0u) != 0ull)
+        return;
+    // fragment table version 4: 64 x 24 bits (compressed bytes | bytes produced << 12), then the element count
+    uint8_t *table = (uint8_t *)(uintptr_t)(job->group_tables + (uint64_t)idx * HAP_GROUP_TABLE_BYTES);
+    const unsigned entry = gsz | (gout << 12);
+    table[3u * lane] = (uint8_t)entry;
+    table[3u * lane + 1u] = (uint8_t)(entry >> 8);
+    table[3u * lane + 2u] = (uint8_t)(entry >> 16);
+    if (lane == 0) {
+        *reinterpret_cast<uint32_t *>(table + 192) = N;          // (bytes 192, 193: the count; 194, 195: zero.  The arena and 196 are multiples of 4)
+        const uint64_t begin = (uint64_t)(uintptr_t)src_al + from, end = begin + n, section_end = job->payload + job->payload_len;
+        u.src = begin;
+        u.src_len = n;
+        u.kind = layout == 4u ? HAPGPU_UNIT_SNAPPY_FIELDS4 : layout == 2u ? HAPGPU_UNIT_SNAPPY_FIELDS2
+               : layout == 8u ? HAPGPU_UNIT_SNAPPY_FIELDS44 : HAPGPU_UNIT_SNAPPY_FIELDS26;
+        u.aux = (uint64_t)(uintptr_t)table;
+        u.reserved = section_end > end ? (section_end - end < 15u ? section_end - end : 15u) : 0u;
+        units[idx] = u;
+    }
+}
+
 } // namespace
 
 extern "C" int hapgpu_launch_decode_plan(HapGpuDecodeJob *jobs, unsigned job_count, unsigned max_chunks, hipStream_t stream)
@@ -2003,6 +2198,20 @@ static constexpr unsigned fragment_dynamic_lds(unsigned ring) { return ring + kF
 
 extern "C" int hapgpu_launch_snappy_decode_fields(const HapGpuDecodeUnit *units, unsigned unit_count, HapGpuDecodeJob *jobs,
                                                   unsigned fields_kinds, hipStream_t stream);
+
+// The pieces the block scan listed in `work` ([0]: how many; room for work_slots): their group tables from the scan's records.
+extern "C" int hapgpu_launch_group_tables_from_records(HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs,
+                                                       const uint32_t *work, unsigned work_slots, const void *recs, const void *joins,
+                                                       hipStream_t stream)
+{
+    if (unit_count == 0 || work_slots == 0 || !work || !recs || !joins)
+        return 0;
+    hipLaunchKernelGGL(group_tables_from_records_kernel, dim3(work_slots), dim3(64), 0, stream, units, unit_count, jobs, work,
+                       (const unsigned long long *)recs, (const uint4 *)joins);
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}
+
+
 
 // Finds the 64 KiB blocks of the whole-stream units listed in `chunks` (see the block scan above) and writes their
 // BLOCK units; the decode launch that follows must include the stream kernel.
