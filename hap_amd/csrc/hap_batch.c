@@ -1426,14 +1426,14 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
     if (live == 0)
         goto finish;
     /* streams without a table that the block scan cuts into 8 KiB pieces (plain hap.h frames of this library: one or a
-       few chunks of many fragments): the same pre-pass can find the starting points inside every piece the scan lists,
-       and the block-per-lane decoder then takes the pieces that are field-stream fragments; the others (another
-       encoder's) stay with the generic kernel.  A lane's two walks over its piece take 0.45 ms however few the
-       pieces, and the generic kernel's wavefront per piece is 8 ns a piece dearer than pre-pass + block-per-lane
-       decode: even at 32 thousand pieces (8 8K frames: 1.09 ms against 1.13), 17 % ahead at 65 thousand, 25 % at 243
-       thousand (60 frames: 4.98 ms against 6.67). */
+       few chunks of many fragments): the starting points inside every piece the scan lists can be had from the scan's own
+       records (r06: a wavefront per piece looks up the windows that hold every ceil(N / 64)-th element and walks a dozen
+       elements each; until r05 a lane per piece walked its ~400 elements twice: 1.95 ms per 60 8K frames, 0.87 now), and
+       the block-per-lane decoder then takes the pieces that are field-stream fragments; the others (another encoder's)
+       stay with the generic kernel.  Calls, plain 8K frames: 1 frame 0.435 ms against 0.412 through the generic kernel
+       alone, 8 frames 0.84 against 1.09, 60 frames 4.03 against 6.30 (r05, lane per piece: 4.98): from two frames' pieces on. */
     use_scan_guess = fine_total && !(flags & HAPGPU_DECODE_NO_FIELD_GUESS) &&
-                     (fine_total >= 32768u || (flags & HAPGPU_DECODE_GUESS_FIELDS));
+                     (fine_total >= 8192u || (flags & HAPGPU_DECODE_GUESS_FIELDS));
 
     /* 3. device descriptors */
     hjobs = (HapGpuDecodeJob *)hapgpu_rt_pinned_scratch(rt, P_JOBS, sizeof(HapGpuDecodeJob) * live);

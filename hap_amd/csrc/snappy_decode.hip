@@ -2036,17 +2036,21 @@ __global__ __launch_bounds__(64) void group_tables_from_records_kernel(HapGpuDec
     if (idx >= unit_count)
         return;
     HapGpuDecodeUnit u = units[idx];
+    if (u.kind != HAPGPU_UNIT_SNAPPY_BLOCK || !(u.reserved & HAPGPU_BLOCK_FINE) || u.aux == 0u)
+        return;
+    // (the job's and the stream's words in one round of loads: a wavefront of this kernel is a chain of trips to memory)
     const HapGpuDecodeJob *job = &jobs[u.job];
-    if (u.kind != HAPGPU_UNIT_SNAPPY_BLOCK || !(u.reserved & HAPGPU_BLOCK_FINE) || !((job->reserved >> 16) & 1u) || job->group_tables == 0u ||
-        job->status != 0u)
-        return;
-    const unsigned layout = job->fields_period;
-    const unsigned block = (layout == 4u || layout == 8u) ? 16u : 8u;
     const HapGpuScanChunk *scan = (const HapGpuScanChunk *)u.aux;
-    const unsigned b = (unsigned)u.reserved, marks = scan->expected_fine;
-    if (!scan->ok || marks == 0u || scan->found_fine != marks || b + 1u > marks)
-        return;
+    const unsigned job_flags = job->reserved, job_status = job->status, layout = job->fields_period;
+    const uint64_t job_tables = job->group_tables;
+    const unsigned marks = scan->expected_fine, scan_ok = scan->ok, scan_found = scan->found_fine;
     const uint32_t *bpos = (const uint32_t *)scan->bpos;
+    if (!((job_flags >> 16) & 1u) || job_tables == 0u || job_status != 0u)
+        return;
+    const unsigned block = (layout == 4u || layout == 8u) ? 16u : 8u;
+    const unsigned b = (unsigned)u.reserved;
+    if (!scan_ok || marks == 0u || scan_found != marks || b + 1u > marks)
+        return;
     const unsigned from = bpos[b], to = bpos[b + 1u], stream_end = bpos[marks];
     const unsigned out_len = u.dst_len;
     if (from >= to || to > stream_end || to - from > kGtMaxCompressed || out_len == 0u || out_len > HAPGPU_SCAN_FINE || (out_len % block) != 0u)
@@ -2058,6 +2062,18 @@ __global__ __launch_bounds__(64) void group_tables_from_records_kernel(HapGpuDec
     const unsigned seg_bytes = scan_segment_bytes(*scan);
     const unsigned blk_op = b * HAPGPU_SCAN_FINE;
 
+    // the records of the fragment's first 64 windows are asked for in front of its bytes: both are on their way together
+    const unsigned seg_first = scan->seg_first, seg_count = scan->seg_count;
+    unsigned long long rec0 = kRecNone;
+    uint4 join0 = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+    if (lane < nw) {
+        const unsigned ws = base + (lane << 6);
+        const unsigned seg = ws / seg_bytes;
+        if (seg < seg_count) {
+            rec0 = recs[(size_t)(seg_first + seg) * 64u + ((ws % seg_bytes) >> 6)];
+            join0 = joins[seg_first + seg];
+        }
+    }
     // the fragment's bytes (and eight more: an element's tag is read as a dword)
     for (unsigned c = lane * 16u; c < nw * 64u + 16u; c += 1024u)
         *reinterpret_cast<uint4 *>(stage + c) = scan_load16(src_al, base + c, stream_end);
@@ -2071,9 +2087,9 @@ __global__ __launch_bounds__(64) void group_tables_from_records_kernel(HapGpuDec
         if (i < nw) {
             const unsigned ws = base + (i << 6);
             const unsigned seg = ws / seg_bytes, k = (ws % seg_bytes) >> 6;
-            if (seg < scan->seg_count) {
-                const unsigned long long rec = recs[(size_t)(scan->seg_first + seg) * 64u + k];
-                const uint4 join = joins[scan->seg_first + seg];
+            if (seg < seg_count) {
+                const unsigned long long rec = i0 == 0u ? rec0 : recs[(size_t)(seg_first + seg) * 64u + k];
+                const uint4 join = i0 == 0u ? join0 : joins[seg_first + seg];
                 const unsigned entry = (unsigned)rec & 0xFFu;
                 if (join.x < 64u && k >= join.x && entry < 64u && ws + entry < to) {
                     usable = true;
@@ -2162,7 +2178,7 @@ __global__ __launch_bounds__(64) void group_tables_from_records_kernel(HapGpuDec
     if (ballot64(ok == 0u) != 0ull)
         return;
     // fragment table version 4: 64 x 24 bits (compressed bytes | bytes produced << 12), then the element count
-    uint8_t *table = (uint8_t *)(uintptr_t)(job->group_tables + (uint64_t)idx * HAP_GROUP_TABLE_BYTES);
+    uint8_t *table = (uint8_t *)(uintptr_t)(job_tables + (uint64_t)idx * HAP_GROUP_TABLE_BYTES);
     const unsigned entry = gsz | (gout << 12);
     table[3u * lane] = (uint8_t)entry;
     table[3u * lane + 1u] = (uint8_t)(entry >> 8);
