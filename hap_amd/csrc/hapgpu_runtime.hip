@@ -706,6 +706,9 @@ extern "C" int hapgpu_k_scan_blocks(hapgpu_rt *rt, HapGpuDecodeUnit *units, cons
 
 extern "C" int hapgpu_launch_guess_group_tables(HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs,
                                                 const uint32_t *work, unsigned work_slots, hipStream_t stream);
+#ifdef BRK_TIMING
+extern "C" void hapgpu_debug_merge_counters(unsigned *out);
+#endif
 extern "C" int hapgpu_launch_group_tables_from_records(HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs,
                                                        const uint32_t *work, unsigned work_slots, const void *recs, const void *joins,
                                                        hipStream_t stream);
@@ -747,6 +750,11 @@ extern "C" unsigned hapgpu_rt_resolved_blocks(hapgpu_rt *rt)
     {
         uint32_t d[24];
         if (hipMemcpy(d, rt->resolved_blocks, sizeof d, hipMemcpyDeviceToHost) == hipSuccess && getenv("BRK_PRINT")) {
+            {
+                unsigned m[8] = {0};
+                hapgpu_debug_merge_counters(m);
+                fprintf(stderr, "merge: streams %u segments %u good %u windows parsed by the merge %u record joins %u ticks %u\n", m[0], m[1], m[2], m[3], m[4], m[5]);
+            }
             fprintf(stderr, "brk: declined: too long %u, window %u, gap walk %u, links %u, ends %u, first %u\n", d[16], d[17], d[18], d[19], d[20], d[21]);
             fprintf(stderr, "brk: blocks %u  ticks records %u windows %u verify %u jump %u fetch %u  rounds %u windows %u\n", d[0], d[2], d[3], d[4], d[5], d[6], d[8], d[9]);
         }

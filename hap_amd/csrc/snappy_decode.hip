@@ -1097,6 +1097,12 @@ __device__ __forceinline__ void scan_window_bytes(const uint8_t *src_al, unsigne
     *hi = (w1 >> (8u * sh)) & 0xFFu;
 }
 
+#ifdef BRK_TIMING
+__device__ unsigned g_merge_dbg[8];       // [0] streams, [1] segments, [2] good segments, [3] windows parsed here, [4] record joins, [5] clock ticks
+#define MERGE_DBG(k, v) do { if (lane == 0) atomicAdd(&g_merge_dbg[k], (unsigned)(v)); } while (0)
+#else
+#define MERGE_DBG(k, v)
+#endif
 __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units, const HapGpuDecodeJob *jobs,
                                                         HapGpuScanChunk *chunks, unsigned chunk_count,
                                                         const HapGpuScanSegment *__restrict__ segs,
@@ -1159,6 +1165,11 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
     const unsigned nseg = (in_end + seg_bytes - 1u) / seg_bytes;
     const unsigned first_element = p;
     const bool tabled = nseg <= sc.seg_count && nseg <= kMergeSegments;
+#ifdef BRK_TIMING
+    const unsigned long long t_begin = wall_clock64();
+#endif
+    MERGE_DBG(0, 1);
+    MERGE_DBG(1, nseg);
     if (tabled) {
         unsigned run = 0, run_e = 0;
         for (unsigned base = 0; base < nseg; base += 64u) {
@@ -1188,6 +1199,7 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
                 l_before_e[i] = run_e + incl_e - delta_e;
             }
             const unsigned long long goods = ballot64(good);
+            MERGE_DBG(2, __builtin_popcountll(goods));
             if (lane == 0)
                 l_good[base / 64u] = goods;
             run += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
@@ -1244,6 +1256,7 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
                 ok = false;
                 break;
             }
+            MERGE_DBG(4, 1);
             const unsigned at_entry = (r_lo >> 8) | (r_hi << 24);
             const unsigned base_op = op - at_entry, base_e = oe - (r_hi >> 8);
             // (last word: 1 = the true chain may have entered this segment in front of window wi -- those windows' records
@@ -1256,6 +1269,7 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
             continue;
         }
         // not yet: one window of the true chain, parsed here
+        MERGE_DBG(3, 1);
         const unsigned ws = p - e, x = ws + lane;
         unsigned lo, hi;
         scan_window_bytes(src_al, x, in_end, &lo, &hi);
@@ -1298,6 +1312,9 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(HapGpuDecodeUnit *units,
             break;
         }
     }
+#ifdef BRK_TIMING
+    MERGE_DBG(5, wall_clock64() - t_begin);
+#endif
     if (!ok || p != in_end || op != out_len)
         return;
     HapGpuScanChunk *state = chunks + c;
@@ -1948,8 +1965,12 @@ __global__ __launch_bounds__(kBrkThreads) void snappy_decode_block_resolve_kerne
         return;
     if (tid < chunk_count) {
         const HapGpuScanChunk sc = chunks[tid];
-        // (what scan_merge wrote: `expected` blocks behind the stream's unit, inside the slots the host reserved)
-        L.stream_first[tid + 1u] = (sc.ok != 0u && sc.expected <= sc.slots && (unsigned long long)sc.unit + 1u + sc.expected <= unit_count) ? sc.expected : 0u;
+        // (what scan_merge wrote: `expected` blocks behind the stream's unit, inside the slots the host reserved; none for a
+        // stream whose 64 KiB blocks do not run at all: marks not all found, or -- this library's own plain frames -- decoded
+        // by its 8 KiB pieces)
+        const bool pieces = sc.expected_fine != 0u && sc.found_fine == sc.expected_fine && sc.fine_failed == 0u;
+        L.stream_first[tid + 1u] = (sc.ok != 0u && !pieces && sc.found == sc.expected && sc.expected <= sc.slots &&
+                                    (unsigned long long)sc.unit + 1u + sc.expected <= unit_count) ? sc.expected : 0u;
     }
     __syncthreads();
     if (tid == 0) {
@@ -2197,6 +2218,13 @@ __global__ __launch_bounds__(64) void group_tables_from_records_kernel(HapGpuDec
 }
 
 } // namespace
+
+#ifdef BRK_TIMING
+extern "C" void hapgpu_debug_merge_counters(unsigned *out)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_merge_dbg), sizeof(unsigned) * 8u);
+}
+#endif
 
 extern "C" int hapgpu_launch_decode_plan(HapGpuDecodeJob *jobs, unsigned job_count, unsigned max_chunks, hipStream_t stream)
 {
