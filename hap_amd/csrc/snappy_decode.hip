@@ -879,7 +879,13 @@ __device__ __forceinline__ unsigned scan_segment_bytes(const HapGpuScanChunk &sc
 // join; the streams of this library's block compressor, with their long literal runs in noisy areas, need more: with 5
 // the merge kernel walked enough windows itself to take 0.22 ms for one 8K frame, with 12 it takes 0.05)
 constexpr unsigned kScanWarmWindows = 12u;
-constexpr unsigned kScanLds = kScanSegment + 64u * kScanWarmWindows + 128u;
+// (r06: calls of few segments warm up over twice as many windows.  The segments whose guess has not joined the true chain by
+// the time it enters them are walked by scan_merge, ONE wavefront per stream: in a single plain 8K frame of this library 5 % of
+// the segments -- the ones that begin in noise, where elements are 130-byte literals and a guess inside one hops through
+// texture bytes -- cost the merge 833 windows, 139 us for the slowest stream, more than the walk itself (59 us).  A batch has
+// streams enough to hide that, and pays for every warm-up window in the walk.)
+constexpr unsigned kScanWarmWindowsShortCall = 24u;
+constexpr unsigned kScanLdsFor(unsigned warm) { return kScanSegment + 64u * warm + 128u; }
 constexpr unsigned kBlockOut = 65536u;
 constexpr unsigned kFine = HAPGPU_SCAN_FINE;                  // 8 KiB: the fragments of this library's own streams
 constexpr unsigned kRecNone = 0xFFu;
@@ -998,9 +1004,9 @@ __device__ __forceinline__ bool scan_unit_wanted(const HapGpuDecodeUnit &u, cons
 __global__ __launch_bounds__(64) void scan_walk_kernel(const HapGpuDecodeUnit *units, const HapGpuDecodeJob *jobs,
                                                        const HapGpuScanChunk *chunks, unsigned chunk_count,
                                                        HapGpuScanSegment *__restrict__ segs, unsigned long long *__restrict__ recs,
-                                                       uint4 *__restrict__ joins, unsigned seg_total)
+                                                       uint4 *__restrict__ joins, unsigned seg_total, unsigned warm_windows)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t smem[kScanLds];
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];        // kScanLdsFor(warm_windows) bytes
     const uint32_t *inw = reinterpret_cast<const uint32_t *>(smem);
     const unsigned lane = threadIdx.x, g = blockIdx.x;
     if (g >= seg_total)
@@ -1016,7 +1022,7 @@ __global__ __launch_bounds__(64) void scan_walk_kernel(const HapGpuDecodeUnit *u
     unsigned long long rec = kRecNone;
     unsigned flags = 1u, cum = 0, cum_e = 0, p = 0;           // (cum_e: elements, as cum counts their output bytes)
     if (scan_unit_wanted(u, jobs) && s < sc.seg_count && seg_begin < in_end) {
-        const unsigned warm = s == 0 ? 0u : kScanWarmWindows;
+        const unsigned warm = s == 0 ? 0u : warm_windows;
         const unsigned stage_begin = seg_begin - 64u * warm;
         const unsigned stage_end = min(seg_end + 64u, (in_end + 15u) & ~15u);
         for (unsigned c = stage_begin + lane * 16u; c < stage_end; c += 1024u)
@@ -2266,8 +2272,10 @@ extern "C" int hapgpu_launch_scan_blocks(HapGpuDecodeUnit *units, const HapGpuDe
 {
     if (chunk_count == 0 || seg_total == 0)
         return 0;
-    hipLaunchKernelGGL(scan_walk_kernel, dim3(seg_total), dim3(64), 0, stream, units, jobs, chunks, chunk_count, segs,
-                       (unsigned long long *)recs, (uint4 *)joins, seg_total);
+    // (a single 8K frame is ~3 000 segments; the GPU holds 8 192 wavefronts)
+    const unsigned warm = seg_total <= 8192u ? kScanWarmWindowsShortCall : kScanWarmWindows;
+    hipLaunchKernelGGL(scan_walk_kernel, dim3(seg_total), dim3(64), kScanLdsFor(warm), stream, units, jobs, chunks, chunk_count, segs,
+                       (unsigned long long *)recs, (uint4 *)joins, seg_total, warm);
     // (fine_work: [0] the list's length, then the list -- fine_pool entries --, then the pool's cursor)
     hipLaunchKernelGGL(scan_merge_kernel, dim3(chunk_count), dim3(64), 0, stream, units, jobs, chunks, chunk_count, segs,
                        (const unsigned long long *)recs, (uint4 *)joins, fine_work ? fine_work + 1u + fine_pool : nullptr, fine_first, fine_pool);
