@@ -1432,8 +1432,7 @@ unsigned hapb_decode(HapGpuContext *ctx, unsigned frame_count, const void *const
        the block-per-lane decoder then takes the pieces that are field-stream fragments; the others (another encoder's)
        stay with the generic kernel.  Calls, plain 8K frames: 1 frame 0.435 ms against 0.412 through the generic kernel
        alone, 8 frames 0.84 against 1.09, 60 frames 4.03 against 6.30 (r05, lane per piece: 4.98): from two frames' pieces on. */
-    use_scan_guess = fine_total && !(flags & HAPGPU_DECODE_NO_FIELD_GUESS) &&
-                     (fine_total >= 8192u || (flags & HAPGPU_DECODE_GUESS_FIELDS));
+    use_scan_guess = fine_total && !(flags & HAPGPU_DECODE_NO_FIELD_GUESS);
 
     /* 3. device descriptors */
     hjobs = (HapGpuDecodeJob *)hapgpu_rt_pinned_scratch(rt, P_JOBS, sizeof(HapGpuDecodeJob) * live);

@@ -2031,21 +2031,30 @@ __global__ __launch_bounds__(kBrkThreads) void snappy_decode_block_resolve_kerne
 constexpr unsigned kGtMaxCompressed = HAPGPU_SCAN_FINE + 320u;                  // what a field-stream fragment compresses to at most
 constexpr unsigned kGtMaxWindows = (kGtMaxCompressed + 63u) / 64u + 2u;
 constexpr unsigned kGtStage = kGtMaxWindows * 64u + 16u;
+constexpr unsigned kGtMaxSteps = 384u;              // elements a lane walks at most: a window holds up to 32, a dozen on average
 
-// the element at byte x of the staged fragment: output bytes and stream bytes; false: none a field stream has
-__device__ __forceinline__ bool gt_element(const uint8_t *stage, unsigned x, unsigned *len, unsigned *adv)
+// the element at byte x of the staged fragment, which begins at output position p of the fragment: output bytes and stream
+// bytes; false: none a field stream has (the promises of the fragment table: it starts on a field boundary -- `starts`: a bit
+// per byte of a block --, stays inside its 128-byte half-tile, a copy comes a whole number of blocks from inside the fragment).
+// What the walks below do not pass over goes unchecked here: the block-per-lane kernel checks everything again.
+__device__ __forceinline__ bool gt_element(const uint8_t *stage, unsigned x, unsigned p, unsigned block, unsigned starts, unsigned *len, unsigned *adv)
 {
     const uint32_t *st32 = reinterpret_cast<const uint32_t *>(stage);
     const unsigned w = __builtin_amdgcn_alignbyte(st32[(x >> 2) + 1u], st32[x >> 2], x);
     const unsigned kind = w & 3u, up = (w >> 2) & 63u;
+    bool ok;
     if (kind == 0u) {
         *len = (up == 60u ? ((w >> 8) & 255u) : up) + 1u;
         *adv = *len + (up == 60u ? 2u : 1u);
-        return up <= 60u;
+        ok = up <= 60u;
+    } else {
+        const unsigned off = kind == 1u ? (((w >> 5) & 7u) << 8) | ((w >> 8) & 255u) : (w >> 8) & 0xFFFFu;
+        *len = kind == 1u ? ((w >> 2) & 7u) + 4u : up + 1u;
+        *adv = kind + 1u;
+        ok = kind != 3u && off >= block && (off % block) == 0u && (int)p >= 0 && off <= p;
     }
-    *len = kind == 1u ? ((w >> 2) & 7u) + 4u : up + 1u;
-    *adv = kind + 1u;
-    return kind != 3u;
+    // (an element in front of the fragment -- the first window's -- has a "negative" p: only its size matters)
+    return (int)p < 0 || (ok && ((starts >> (p % block)) & 1u) != 0u && (p & 127u) + *len <= 128u);
 }
 
 __global__ __launch_bounds__(64) void group_tables_from_records_kernel(HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs,
@@ -2075,6 +2084,8 @@ __global__ __launch_bounds__(64) void group_tables_from_records_kernel(HapGpuDec
     if (!((job_flags >> 16) & 1u) || job_tables == 0u || job_status != 0u)
         return;
     const unsigned block = (layout == 4u || layout == 8u) ? 16u : 8u;
+    // field starts inside a block, a bit per byte: [2,6,4,4]: 0, 2, 8, 12; [4,4]: 0, 4; [2,6]: 0, 2; [4,4,4,4]: 0, 4, 8, 12
+    const unsigned starts = layout == 4u ? 0x1105u : layout == 2u ? 0x11u : layout == 6u ? 0x05u : 0x1111u;
     const unsigned b = (unsigned)u.reserved;
     if (!scan_ok || marks == 0u || scan_found != marks || b + 1u > marks)
         return;
@@ -2106,7 +2117,6 @@ __global__ __launch_bounds__(64) void group_tables_from_records_kernel(HapGpuDec
         *reinterpret_cast<uint4 *>(stage + c) = scan_load16(src_al, base + c, stream_end);
     // the windows on record, in order: where the chain enters, its element number and output position there
     unsigned m = 0;
-    bool decline = false;
     for (unsigned i0 = 0; i0 < nw; i0 += 64u) {
         const unsigned i = i0 + lane;
         bool usable = false;
@@ -2123,11 +2133,11 @@ __global__ __launch_bounds__(64) void group_tables_from_records_kernel(HapGpuDec
                     pos = ws + entry;
                     e = join.z + (unsigned)(rec >> 40);
                     op = join.y + (unsigned)(rec >> 8) - blk_op;
-                } else if (join.x >= 64u || (join.w != 0u && k < join.x)) {
-                    decline = true;                  // (the true chain may enter this window where no record of it is)
                 }
-            } else {
-                decline = true;
+                // (A window the true chain enters without a record of its own -- the first windows of a segment whose
+                // guessed chain joined late -- is simply not on the list: the walks below start at the last listed window in
+                // front of what they look for and pass through it.  A whole segment of such windows makes a walk longer
+                // than kGtMaxSteps, and the piece is left to the other kernel.)
             }
         }
         const unsigned long long mask = ballot64(usable);
@@ -2139,7 +2149,7 @@ __global__ __launch_bounds__(64) void group_tables_from_records_kernel(HapGpuDec
         }
         m += (unsigned)__builtin_popcountll(mask);
     }
-    if (ballot64(decline) != 0ull || m == 0u)
+    if (m == 0u)
         return;
     __syncthreads();
     if (w_pos[0] > from)
@@ -2149,9 +2159,9 @@ __global__ __launch_bounds__(64) void group_tables_from_records_kernel(HapGpuDec
     {
         unsigned pos = lane == 0u ? w_pos[0] : w_pos[m - 1u], op = lane == 0u ? w_op[0] : w_op[m - 1u];
         const unsigned stop = lane == 0u ? from : to;
-        for (unsigned step = 0; step < 80u && lane < 2u && pos < stop; step++) {
+        for (unsigned step = 0; step < kGtMaxSteps && lane < 2u && pos < stop; step++) {
             unsigned len, adv;
-            if (!gt_element(stage, pos - base, &len, &adv))
+            if (!gt_element(stage, pos - base, op, block, starts, &len, &adv))
                 ok = 0u;
             pos += adv;
             op += len;
@@ -2167,7 +2177,7 @@ __global__ __launch_bounds__(64) void group_tables_from_records_kernel(HapGpuDec
         return;
     const unsigned G = (N + 63u) >> 6;
     // ---- lane g: where element g * G begins ----
-    unsigned cpos = n, opos = out_len;
+    unsigned cpos = n, opos = out_len, end_c = n, end_o = out_len;
     if (lane * G < N) {
         const unsigned T = e0 + lane * G;
         unsigned lo = 0, hi = m;                     // the last window on record with w_e <= T (w_e[0] <= e0 <= T)
@@ -2179,9 +2189,9 @@ __global__ __launch_bounds__(64) void group_tables_from_records_kernel(HapGpuDec
                 hi = mid;
         }
         unsigned pos = w_pos[lo], e = w_e[lo], op = w_op[lo];
-        for (unsigned step = 0; step < 80u && e < T && pos < to; step++) {
+        for (unsigned step = 0; step < kGtMaxSteps && e < T && pos < to; step++) {
             unsigned len, adv;
-            if (!gt_element(stage, pos - base, &len, &adv))
+            if (!gt_element(stage, pos - base, op, block, starts, &len, &adv))
                 ok = 0u;
             pos += adv;
             op += len;
@@ -2191,6 +2201,22 @@ __global__ __launch_bounds__(64) void group_tables_from_records_kernel(HapGpuDec
             ok = 0u;
         cpos = pos - from;
         opos = op;
+        // ... and on through the group's own G elements: between them the lanes pass over every element of the fragment, so
+        // a piece that is no field stream (another compressor's bytes with marks in the right places) is declined HERE, for
+        // the price of a few steps -- not by the block-per-lane kernel, whose verdict sends the whole frame round again
+        const unsigned T1 = min(T + G, e1);
+        for (unsigned step = 0; step < G && e < T1 && pos < to; step++) {
+            unsigned len, adv;
+            if (!gt_element(stage, pos - base, op, block, starts, &len, &adv))
+                ok = 0u;
+            pos += adv;
+            op += len;
+            e += 1u;
+        }
+        if (e != T1 || pos > to || op > out_len)
+            ok = 0u;
+        end_c = pos - from;
+        end_o = op;
     }
     g_c[lane] = cpos;
     g_o[lane] = opos;
@@ -2200,8 +2226,8 @@ __global__ __launch_bounds__(64) void group_tables_from_records_kernel(HapGpuDec
     }
     __syncthreads();
     const unsigned gsz = g_c[lane + 1u] - cpos, gout = g_o[lane + 1u] - opos;
-    if (g_c[lane + 1u] < cpos || g_o[lane + 1u] < opos || gsz >= 4096u || gout >= 4096u)
-        ok = 0u;
+    if (g_c[lane + 1u] != end_c || g_o[lane + 1u] != end_o || end_c < cpos || end_o < opos || gsz >= 4096u || gout >= 4096u)
+        ok = 0u;                                     // (a group ends where the next one begins)
     if (ballot64(ok == 0u) != 0ull)
         return;
     // fragment table version 4: 64 x 24 bits (compressed bytes | bytes produced << 12), then the element count

@@ -2812,9 +2812,9 @@ def test_fine_chunk_frames_decode_through_the_block_per_lane_kernel_without_a_ta
                                               (L.FMT_RGTC1, (4096, 1024), 3)])
 def test_plain_frames_decode_through_the_block_per_lane_kernel_by_the_scans_pieces(ctx, hap, monkeypatch, fmt, shape, chunks):
     """Plain hap.h frames of this library carry no private table and their chunks are many fragments long.  The block
-    scan finds the 8 KiB pieces of such streams; from a few thousand pieces on (forced here with
-    HAPGPU_DECODE_GUESS_FIELDS) the pre-pass walks every listed piece with one lane, writes its group table into scratch
-    and hands it to the block-per-lane decoder.  Pieces that are not field-stream fragments -- the reference encoder's
+    scan finds the 8 KiB pieces of such streams, and a wavefront per listed piece makes its group table from the scan's own
+    records (round 6; until round 5 a lane per piece walked it, from a few thousand pieces on), writes it into scratch
+    and hands the piece to the block-per-lane decoder.  Pieces that are not field-stream fragments -- the reference encoder's
     stream of the same texture, whose 8 KiB marks fall where libsnappy put them -- stay with the generic kernel in the
     same call; a frame that came with its table does not notice.  Same bytes on every road, no second pass."""
     w, h = shape
@@ -2853,9 +2853,11 @@ def test_plain_frames_decode_through_the_block_per_lane_kernel_by_the_scans_piec
         for i, (d, want) in enumerate(zip(decs, wants)):
             assert d.cpu().numpy().tobytes() == want, (flags, i)
         scans[flags] = prof.get("block_scan", (0, 0.0))[0]
-    # (the pre-pass is timed with the block scan, "finding where wavefronts may start": one more launch when it ran)
+    # (the table maker is timed with the block scan, "finding where wavefronts may start": one more launch when it ran --
+    # which since round 6 it does in every call that has such pieces: a wavefront per piece makes the table from the scan's
+    # records, and that pays for a single frame too)
     assert scans[hap.DECODE_GUESS_FIELDS] == scans[hap.DECODE_NO_FIELD_GUESS] + 1, scans
-    assert scans[0] == scans[hap.DECODE_NO_FIELD_GUESS], scans
+    assert scans[0] == scans[hap.DECODE_GUESS_FIELDS], scans
     assert ctx.table_fallbacks() == n0
     # host buffers; a damaged piece (one tag turned into a copy that reaches before the stream) fails the frame alone
     dec = np.zeros(len(tex), dtype=np.uint8)
