@@ -2031,12 +2031,15 @@ __global__ __launch_bounds__(kBrkThreads) void snappy_decode_block_resolve_kerne
 constexpr unsigned kGtMaxCompressed = HAPGPU_SCAN_FINE + 320u;                  // what a field-stream fragment compresses to at most
 constexpr unsigned kGtMaxWindows = (kGtMaxCompressed + 63u) / 64u + 2u;
 constexpr unsigned kGtStage = kGtMaxWindows * 64u + 16u;
+constexpr unsigned kGtBatchPieces = 16384u;         // calls with room for that many pieces and more (four 8K frames) decline pieces with unrecorded windows
 constexpr unsigned kGtMaxSteps = 384u;              // elements a lane walks at most: a window holds up to 32, a dozen on average
 
-// the element at byte x of the staged fragment, which begins at output position p of the fragment: output bytes and stream
-// bytes; false: none a field stream has (the promises of the fragment table: it starts on a field boundary -- `starts`: a bit
-// per byte of a block --, stays inside its 128-byte half-tile, a copy comes a whole number of blocks from inside the fragment).
-// What the walks below do not pass over goes unchecked here: the block-per-lane kernel checks everything again.
+// the element at byte x of the staged fragment: output bytes and stream bytes.  CHECK: is it one a field stream has -- the
+// promises of the fragment table: it begins at output position p of the fragment on a field boundary (`starts`: a bit per
+// byte of a block), stays inside its 128-byte half-tile, a copy comes a whole number of blocks from inside the fragment?
+// The walks that only look for a place do not ask (they pass over elements twice and over some in front of the fragment); the
+// walk over a lane's own group does, and between them the groups are the whole fragment.
+template <bool CHECK>
 __device__ __forceinline__ bool gt_element(const uint8_t *stage, unsigned x, unsigned p, unsigned block, unsigned starts, unsigned *len, unsigned *adv)
 {
     const uint32_t *st32 = reinterpret_cast<const uint32_t *>(stage);
@@ -2048,13 +2051,17 @@ __device__ __forceinline__ bool gt_element(const uint8_t *stage, unsigned x, uns
         *adv = *len + (up == 60u ? 2u : 1u);
         ok = up <= 60u;
     } else {
-        const unsigned off = kind == 1u ? (((w >> 5) & 7u) << 8) | ((w >> 8) & 255u) : (w >> 8) & 0xFFFFu;
         *len = kind == 1u ? ((w >> 2) & 7u) + 4u : up + 1u;
         *adv = kind + 1u;
-        ok = kind != 3u && off >= block && (off % block) == 0u && (int)p >= 0 && off <= p;
+        ok = kind != 3u;
+        if (CHECK) {
+            const unsigned off = kind == 1u ? (((w >> 5) & 7u) << 8) | ((w >> 8) & 255u) : (w >> 8) & 0xFFFFu;
+            ok = ok && off >= block && (off & (block - 1u)) == 0u && off <= p;                       // (blocks are 8 or 16 bytes)
+        }
     }
-    // (an element in front of the fragment -- the first window's -- has a "negative" p: only its size matters)
-    return (int)p < 0 || (ok && ((starts >> (p % block)) & 1u) != 0u && (p & 127u) + *len <= 128u);
+    if (CHECK)
+        ok = ok && ((starts >> (p & (block - 1u))) & 1u) != 0u && (p & 127u) + *len <= 128u;
+    return ok;
 }
 
 __global__ __launch_bounds__(64) void group_tables_from_records_kernel(HapGpuDecodeUnit *units, unsigned unit_count, const HapGpuDecodeJob *jobs,
@@ -2117,6 +2124,7 @@ __global__ __launch_bounds__(64) void group_tables_from_records_kernel(HapGpuDec
         *reinterpret_cast<uint4 *>(stage + c) = scan_load16(src_al, base + c, stream_end);
     // the windows on record, in order: where the chain enters, its element number and output position there
     unsigned m = 0;
+    bool gap = false;
     for (unsigned i0 = 0; i0 < nw; i0 += 64u) {
         const unsigned i = i0 + lane;
         bool usable = false;
@@ -2133,11 +2141,17 @@ __global__ __launch_bounds__(64) void group_tables_from_records_kernel(HapGpuDec
                     pos = ws + entry;
                     e = join.z + (unsigned)(rec >> 40);
                     op = join.y + (unsigned)(rec >> 8) - blk_op;
+                } else if (join.x >= 64u || (join.w != 0u && k < join.x)) {
+                    // A window the true chain may enter without a record of its own (the first windows of a segment whose
+                    // guessed chain joined late) is not on the list: the walks below start at the last listed window in
+                    // front of what they look for and pass through it -- a lane then walks dozens of elements while 63
+                    // wait.  In a call of few pieces that beats leaving the piece to the other kernel (one plain 8K frame:
+                    // its generic launch 90 us -> 7); in a batch it does not (60 frames: this kernel 0.78 -> 1.14 ms for
+                    // 0.09 ms less of the other), and the piece is declined.
+                    gap = true;
                 }
-                // (A window the true chain enters without a record of its own -- the first windows of a segment whose
-                // guessed chain joined late -- is simply not on the list: the walks below start at the last listed window in
-                // front of what they look for and pass through it.  A whole segment of such windows makes a walk longer
-                // than kGtMaxSteps, and the piece is left to the other kernel.)
+            } else {
+                gap = true;
             }
         }
         const unsigned long long mask = ballot64(usable);
@@ -2149,7 +2163,7 @@ __global__ __launch_bounds__(64) void group_tables_from_records_kernel(HapGpuDec
         }
         m += (unsigned)__builtin_popcountll(mask);
     }
-    if (m == 0u)
+    if (m == 0u || (gridDim.x >= kGtBatchPieces && ballot64(gap) != 0ull))
         return;
     __syncthreads();
     if (w_pos[0] > from)
@@ -2161,7 +2175,7 @@ __global__ __launch_bounds__(64) void group_tables_from_records_kernel(HapGpuDec
         const unsigned stop = lane == 0u ? from : to;
         for (unsigned step = 0; step < kGtMaxSteps && lane < 2u && pos < stop; step++) {
             unsigned len, adv;
-            if (!gt_element(stage, pos - base, op, block, starts, &len, &adv))
+            if (!gt_element<false>(stage, pos - base, op, block, starts, &len, &adv))
                 ok = 0u;
             pos += adv;
             op += len;
@@ -2191,7 +2205,7 @@ __global__ __launch_bounds__(64) void group_tables_from_records_kernel(HapGpuDec
         unsigned pos = w_pos[lo], e = w_e[lo], op = w_op[lo];
         for (unsigned step = 0; step < kGtMaxSteps && e < T && pos < to; step++) {
             unsigned len, adv;
-            if (!gt_element(stage, pos - base, op, block, starts, &len, &adv))
+            if (!gt_element<false>(stage, pos - base, op, block, starts, &len, &adv))
                 ok = 0u;
             pos += adv;
             op += len;
@@ -2207,7 +2221,7 @@ __global__ __launch_bounds__(64) void group_tables_from_records_kernel(HapGpuDec
         const unsigned T1 = min(T + G, e1);
         for (unsigned step = 0; step < G && e < T1 && pos < to; step++) {
             unsigned len, adv;
-            if (!gt_element(stage, pos - base, op, block, starts, &len, &adv))
+            if (!gt_element<true>(stage, pos - base, op, block, starts, &len, &adv))
                 ok = 0u;
             pos += adv;
             op += len;
