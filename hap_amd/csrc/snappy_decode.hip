@@ -2406,6 +2406,10 @@ extern "C" int hapgpu_launch_snappy_decode(const HapGpuDecodeUnit *units, unsign
                 hipLaunchKernelGGL(snappy_decode_block_resolve_kernel, dim3(resolve_workgroups), dim3(kBrkThreads), sizeof(BrkLds), stream,
                                    const_cast<HapGpuDecodeUnit *>(units), unit_count, scan_chunks, scan_chunk_count, jobs,
                                    (const unsigned long long *)scan_recs, (const uint4 *)scan_joins, resolved, resolved + 1);
+                // (an accelerator only: a launch the runtime refuses -- 159 KiB of LDS is nearly all a CU has -- must not fail
+                // the call: the wavefront-per-block launch below decodes every block then, as it did before)
+                if (hipGetLastError() != hipSuccess)
+                    resolve_on = 0;
             }
             if (ring_log2 == 11)
                 hipLaunchKernelGGL((snappy_decode_fragment_kernel<2048u, true, 1u>), grid, dim3(64), 0, stream, units, grid.x, jobs, phase, fine_work);
