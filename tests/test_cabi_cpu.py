@@ -367,4 +367,5 @@ def test_round5_entry_points_without_a_gpu(hap):
     assert lib.HapGpuEncodeFramesFinish(None) == hap.HapResult.Bad_Arguments
     assert lib.HapGpuEncodeFramesRGBABegin(None, 1, None, 8, 8, 32, 1, None, None, None, None, None, used, res, 0) == hap.HapResult.Bad_Arguments
     assert lib.HapGpuPlacementTimeoutCount(None) == 0
+    assert lib.HapGpuResolvedBlockCount(None) == 0           # (round 6: blocks of other encoders' streams a workgroup decoded)
     assert lib.HapGpuCollectProfileN(None, 9, None, None) == hap.HapResult.Bad_Arguments
